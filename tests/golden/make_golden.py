@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""Builds the golden fixtures under tests/golden/ from the reference's own DATA files.
+
+Run in the build container only (needs /root/reference):  python tests/golden/make_golden.py
+
+What is read (data files, no reference source is imported, executed or copied):
+  output files/<model>.vtk   mesh (points, tet10 cells in fcVM's internal node order: exportVTK,
+                             fcVM.py:2907-2912 writes elNodes-1 verbatim) and the final nodal
+                             result fields in f64
+  output files/<model>.out   the load / displacement / peeq / csr table (3 significant digits)
+  control files/<model>.inp  the 21-line analysis control file
+  freeCAD files/<model>.FCStd (zip) Document.xml: material card and the constraint objects
+
+The FreeCAD geometry kernel is not available, so the node sets of the constrained CAD faces are
+resolved geometrically (faces of the Embankment extrusion are the planes of its bounding box) and
+cross-checked against the exact-zero pattern of the reference's own displacement result: both must
+give the same sets, otherwise the script aborts.
+"""
+import json
+import os
+import re
+import sys
+import zipfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(REPO, "fcvm-workbench_amd"))
+from fcvm_hip.vtkio import read_vtk  # noqa: E402
+
+REF = "/root/reference"
+
+
+def parse_out(path):
+    rows, head = [], {}
+    for ln in open(path):
+        if ln.startswith("No. of elements"):
+            head["ne"] = int(ln.split(":")[1])
+        elif ln.startswith("No. of Degrees"):
+            head["nn"] = int(ln.split(":")[1])
+        elif ln.startswith("Sum of loads"):
+            head.setdefault("loadsum", []).append(float(ln.split(":")[1]))
+        else:
+            t = ln.split()
+            if len(t) == 12 and re.match(r"^-?\d+$", t[0]):
+                rows.append([float(v) for v in t])
+    return head, np.array(rows)
+
+
+def material_from_fcstd(path):
+    xml = zipfile.ZipFile(path).read("Document.xml").decode("utf8", "replace")
+
+    def item(key):
+        return re.search(r'<Item key="%s" value="([^"]*)"' % key, xml).group(1)
+
+    def qty(s, units):
+        v, u = s.split()
+        return float(v) * units[u]
+
+    E = qty(item("YoungsModulus"), {"MPa": 1.0, "kPa": 1e-3, "GPa": 1e3, "Pa": 1e-6})
+    nu = float(item("PoissonRatio"))
+    rho = qty(item("Density"), {"kg/m^3": 1e-9, "kg/mm^3": 1.0})
+    return E, nu, rho, xml
+
+
+def embankment():
+    name = "Embankment_with_Ditch_Example"
+    pts, cells, data = read_vtk(os.path.join(REF, "output files", name + ".vtk"))
+    head, table = parse_out(os.path.join(REF, "output files", name + ".out"))
+    inp = [ln.strip() for ln in open(os.path.join(REF, "control files", name + ".inp"))]
+    inp = [s for s in inp if s != ""][:21]
+    E, nu, rho, xml = material_from_fcstd(os.path.join(REF, "freeCAD files", name + ".FCStd"))
+    assert head["ne"] == len(cells) and head["nn"] == len(pts)
+    # constraints in the FreeCAD document: ConstraintFixed on 3 faces (bottom + the two x-ends),
+    # ConstraintDisplacement (yFree = false, value 0) on the two extrusion caps (plane strain)
+    assert xml.count('<Object type="Fem::ConstraintFixed"') == 1
+    assert xml.count('<Object type="Fem::ConstraintDisplacement"') == 1
+    lo, hi = pts.min(0), pts.max(0)
+    tol = 1e-6
+    on = lambda ax, v: np.abs(pts[:, ax] - v) < tol  # noqa: E731
+    fixed_nodes = np.where(on(0, lo[0]) | on(0, hi[0]) | on(2, lo[2]))[0]
+    ycap_nodes = np.where(on(1, lo[1]) | on(1, hi[1]))[0]
+    fix = {}
+    for n in fixed_nodes:
+        for k in range(3):
+            fix[3 * int(n) + k] = 0.0
+    for n in ycap_nodes:
+        fix[3 * int(n) + 1] = 0.0
+    # cross-check with the reference's own result: fixed dofs are exactly the dofs whose
+    # displacement is exactly 0.0 in the exported field
+    u = data["Displacement"].reshape(-1)
+    assert set(np.where(u == 0.0)[0].tolist()) == set(fix.keys()), "BC inference mismatch"
+    fixed_dofs = np.array(sorted(fix.keys()), dtype=np.int64)
+    np.savez_compressed(
+        os.path.join(HERE, "embankment.npz"),
+        nocoord=pts,
+        elNodes=(cells + 1).astype(np.int64),
+        fixed_dofs=fixed_dofs,
+        fixed_vals=np.zeros(len(fixed_dofs)),
+        material=np.array([E, nu, rho]),
+        out_table=table,
+        out_loadsum=np.array(head["loadsum"]),
+        **{"vtk_" + re.sub(r"\W", "", k): v for k, v in data.items()},
+    )
+    json.dump({"name": name, "inp": inp, "source": "reference output files/*.vtk,*.out; control files/*.inp; freeCAD files/*.FCStd"},
+              open(os.path.join(HERE, "embankment.json"), "w"), indent=1)
+    print(name, "ne", len(cells), "nn", len(pts), "fixed dofs", len(fixed_dofs), "E nu rho", E, nu, rho)
+
+
+def vtk_only(name, key):
+    """Mesh + final fields of a reference result file (no boundary conditions): used for the
+    checks that need none (principal stresses; stress recovery + nodal mapping of elastic runs;
+    equilibrium K u = 0 at unloaded free nodes)."""
+    pts, cells, data = read_vtk(os.path.join(REF, "output files", name + ".vtk"))
+    E, nu, rho, _ = material_from_fcstd(os.path.join(REF, "freeCAD files", name + ".FCStd"))
+    inp = [ln.strip() for ln in open(os.path.join(REF, "control files", name + ".inp"))]
+    inp = [s for s in inp if s != ""][:21]
+    head, table = parse_out(os.path.join(REF, "output files", name + ".out"))
+    np.savez_compressed(
+        os.path.join(HERE, key + ".npz"),
+        nocoord=pts, elNodes=(cells + 1).astype(np.int64), material=np.array([E, nu, rho]),
+        out_table=table, out_loadsum=np.array(head.get("loadsum", [])),
+        **{"vtk_" + re.sub(r"\W", "", k): v for k, v in data.items()},
+    )
+    json.dump({"name": name, "inp": inp}, open(os.path.join(HERE, key + ".json"), "w"), indent=1)
+    print(name, "ne", len(cells), "nn", len(pts), "E nu rho", E, nu, rho, "fields", list(data))
+
+
+if __name__ == "__main__":
+    embankment()
+    vtk_only("tensile", "tensile")
+    vtk_only("Buckling", "buckling")
+    vtk_only("Lug_Pressure_Example", "lug")
