@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): Newton iterations/s and elements*GP/s of the elastoplastic
+tet10 solver on the synthetic 1M-tet10 cube, SpMV GB/s against the HBM roofline.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--cells C]
+
+A "step" is one Newton (Riks-corrected, modified-Newton) iteration of the reference's calcDisp
+inner loop (fcVM.py:1346-1455): PCG solve of K due = relax*r (replacing the CHOLMOD back
+substitution), arc-length correction, update_stress_load over all elements, out-of-balance norm.
+The one-time work of an analysis (pattern, K assembly = calcGSM, elastic solve) is done before the
+timed region, exactly where the reference does it (it factorises once, fcVM.py:1121), and is
+reported separately in the same JSON line.
+
+N > 1 (one process per GPU under torch.distributed.run): elements are range-partitioned in z-slabs,
+one slab of `cells`^3 cells per rank (weak scaling), RCCL all-reduce for the PCG scalars and an
+interface exchange of the shared-node values per SpMV.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "fcvm-workbench_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+CTL = dict(sig_yield=120.0, grav_x=0.0, grav_y=0.0, grav_z=0.0, nstep=2, iterat_max=10 ** 9, error_max=0.0, relax=1.2,
+           scale_re=2.0, scale_up=1.2, scale_dn=1.2, disp_output="total", ultimate_strain=0.25, Et_E=0.0,
+           target_LF=1.0e9, csr_option="PEEQ", averaged_option="unaveraged", gnl="GNLN", maxImp="0.0", ev1="1.0",
+           ev2="0.0")
+MATERIAL = (210000.0, 0.3, 7.8e-6)
+TRACTION = (20.0, 0.0, 200.0)
+RTOL = 1.0e-10
+
+
+def cpu_baseline(cells=14, iters=3):
+    """The oracle (C restatement + SuperLU in place of CHOLMOD) on this host: one Newton iteration =
+    back substitution + update_stress_load, factorisation outside (as in the reference)."""
+    from fcvm_hip import meshgen
+    from oracle import oracle as orc
+    case = meshgen.cube_case(cells, l=100.0, traction=TRACTION)
+    el, xyz = case["elNodes"], case["nocoord"]
+    loads = orc.Loads(ufaces=case["ufaces"], uloads=case["uloads"])
+    mat = np.array(MATERIAL)
+    ne, nn = len(el), len(xyz)
+    t0 = time.perf_counter()
+    stm, row, col, glv, modf, *_ = orc.calcGSM(el, xyz, mat, case["fix"], (0, 0, 0), loads)
+    t_asm = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    factor = orc._Direct(stm, row, col, 3 * nn)
+    t_fac = time.perf_counter() - t0
+    fixdof = np.ones(3 * nn)
+    fixdof[list(case["fix"].keys())] = 0.0
+    ue = factor(fixdof * glv + modf)
+    du = 0.5 * ue
+    sig_old, sig_new, sig_test = np.zeros(24 * ne), np.zeros(24 * ne), np.zeros(24 * ne)
+    sy = np.full(4 * ne, CTL["sig_yield"])
+    pgp = np.zeros(4 * ne, np.uint8)
+    disp = np.zeros(3 * nn)
+    qin = np.zeros(3 * nn)
+    orc.update_stress_load(el, xyz, mat, sy, disp, du, sig_old, sig_new, sig_test, qin, 0.0, False, pgp)
+    r = fixdof * (0.5 * glv - qin)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        due = factor(CTL["relax"] * r)
+        du = du + due
+        qin = np.zeros(3 * nn)
+        orc.update_stress_load(el, xyz, mat, sy, disp, du, sig_old, sig_new, sig_test, qin, 0.0, False, pgp)
+        r = fixdof * (0.5 * glv - qin)
+        np.linalg.norm(r)
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": ne * 4 / dt, "unit": "elements*GP/s", "cores": 1, "kind": "port",
+            "newton_iterations_per_s": 1.0 / dt,
+            "sample": "%d^3-cell cube = %d tet10 / %d dof, %d Newton iterations (SuperLU back-substitution + "
+                      "update_stress_load); one-time calcGSM %.1fs and factorisation %.1fs excluded" %
+                      (cells, ne, 3 * nn, iters, t_asm, t_fac)}
+
+
+def run_single(args):
+    from fcvm_hip import _lib, meshgen
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import GpuModel, RiksDriver
+    if _lib.device_count() < 1:
+        raise SystemExit("bench.py: no HIP device / libfcvm_hip.so -- there is no CPU fallback")
+    n = args.cells
+    t0 = time.perf_counter()
+    case = meshgen.cube_case(n, l=100.0, traction=TRACTION)
+    t_mesh = time.perf_counter() - t0
+    model = GpuModel(case["elNodes"], case["nocoord"], MATERIAL, case["fix"],
+                     Loads(ufaces=case["ufaces"], uloads=case["uloads"]))
+    c = model.ctx
+    info = c.pattern_info()
+    # calcGSM on the GPU, timed on its own (one-time work of an analysis)
+    c.sync()
+    t0 = time.perf_counter()
+    model.calc_gsm((0.0, 0.0, 0.0), want_x=False)
+    c.sync()
+    t_asm = time.perf_counter() - t0
+    stats = {}
+    drv = RiksDriver(model, CTL, rtol=RTOL, stats=stats)  # assembly + elastic solve
+    drv.start_step()
+    for _ in range(args.warmup):
+        drv.iteration()
+    c.sync()
+    s0 = dict(stats)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        drv.iteration()
+    c.sync()
+    dt = time.perf_counter() - t0
+    spmv_launches = stats["spmv_launches"] - s0["spmv_launches"]
+    spmv_ms = stats["spmv_ms"] - s0["spmv_ms"]
+    pcg_its = stats["pcg_iterations"] - s0["pcg_iterations"]
+    # algorithmic bytes of one SpMV launch: every 3x3 block once (72 B values + 4 B column), x read
+    # once, y written once (DESIGN.md "Roofline accounting")
+    ndof = info["ndof"]
+    alg_bytes = info["nnz_blocks"] * 76 + 2 * ndof * 8
+    avg_ms = spmv_ms / max(spmv_launches, 1)
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    plastic = int(drv.pgp.get().sum())
+    ne = model.ne
+    out = {
+        "metric": "elements*GP/s over Newton iterations (Newton iterations/s x elements x 4 GP), 1M tet10",
+        "value": ne * 4 * args.steps / dt, "unit": "elements*GP/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "synthetic cube %d^3 cells = %d tet10, %d dof, clamped base, top traction, von Mises "
+                               "plasticity (%d of %d Gauss points plastic), one Newton/Riks iteration per step" %
+                               (n, ne, ndof, plastic, 4 * ne), "pcg_rtol": RTOL, "preconditioner": "block-Jacobi 3x3"},
+        "newton_iterations_per_s": args.steps / dt,
+        "pcg_iterations_per_step": pcg_its / args.steps,
+        "assembly": {"ms": t_asm * 1e3, "elements_gp_per_s": ne * 4 / t_asm},
+        "setup_s": {"mesh": t_mesh, "pattern_host": model.t_pattern},
+        "roofline": {"bound": "hbm", "kernel": "k_spmv<true> (sliced-ELL 3x3-block SpMV + p.Ap partials)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
+                     "launches_timed": spmv_launches, "padded_matrix_bytes": info["matrix_bytes"],
+                     "csr_equivalent_GBs": (info["nnz_blocks"] * 9 * 12 + 2 * ndof * 8) / (avg_ms * 1e-3) / 1e9},
+    }
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cells", type=int, default=55, help="cells per cube edge (55 -> 998,250 tet10)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from fcvm_hip import dist_bench
+        dist_bench.run(args, CTL, MATERIAL, TRACTION, RTOL, HBM_PEAK_GBS, cpu_baseline)
+    else:
+        run_single(args)
+
+
+if __name__ == "__main__":
+    main()

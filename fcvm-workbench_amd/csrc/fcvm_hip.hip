@@ -1,0 +1,581 @@
+// libfcvm_hip.so : C-ABI (include/fcvm_hip.h) over the gfx950 kernels in fcvm_kernels.hip.h.
+#include "../../include/fcvm_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "fcvm_kernels.hip.h"
+#include "fcvm_pattern.h"
+
+using namespace fcvm;
+
+static thread_local std::string g_err;
+static int fail(const std::string &m) {
+    g_err = m;
+    return 1;
+}
+#define HCHK(x)                                                                                     \
+    do {                                                                                            \
+        hipError_t e__ = (x);                                                                       \
+        if (e__ != hipSuccess)                                                                      \
+            return fail(std::string(#x) + ": " + hipGetErrorString(e__) + " (" + __FILE__ + ":" + \
+                        std::to_string(__LINE__) + ")");                                            \
+    } while (0)
+#define NEED(cond, msg) \
+    do {                \
+        if (!(cond)) return fail(msg); \
+    } while (0)
+
+struct fcvm_ctx {
+    int device = 0;
+    hipStream_t own = nullptr, stream = nullptr;
+    Pattern pat;
+    int64_t ne = 0, nn = 0;
+    bool have_mesh = false, have_mat = false, assembled = false;
+    double E = 0, nu = 0, rho = 0;
+    // device mesh
+    int32_t *d_el = nullptr, *d_cols = nullptr, *d_rownode = nullptr, *d_noce = nullptr;
+    int64_t *d_sptr = nullptr;
+    uint32_t *d_emap = nullptr, *d_diagoff = nullptr;
+    uint8_t *d_fixmask = nullptr;
+    double *d_coord = nullptr, *d_fixval = nullptr, *d_vals = nullptr, *d_dblk = nullptr, *d_dinv = nullptr;
+    // pcg work
+    double *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_q = nullptr, *d_S = nullptr;
+    double *d_part_vec = nullptr, *d_part_spmv = nullptr, *d_part_misc = nullptr, *d_out8 = nullptr;
+    long long *d_pidx = nullptr;
+    int64_t nb_vec = 0, nb_spmv = 0, nb_gp = 0;
+    double last_spmv_ms = 0, last_total_ms = 0;
+    std::vector<hipEvent_t> evpool;
+};
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+template <class T>
+static int dalloc(T **p, int64_t n) {
+    HCHK(hipMalloc((void **)p, (size_t)std::max<int64_t>(n, 1) * sizeof(T)));
+    return 0;
+}
+template <class T>
+static void dfree(T *&p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+static MatConst matconst(const fcvm_ctx *c, double Et_E) {
+    MatConst m;
+    // fcVM.py:570-582 hooke and fcVM.py:2229-2234
+    const double dm = c->E * (1.0 - c->nu) / (1.0 + c->nu) / (1.0 - 2.0 * c->nu);
+    m.D11 = dm;
+    m.D12 = c->nu / (1.0 - c->nu) * dm;
+    m.D44 = 0.5 * (1.0 - 2.0 * c->nu) / (1.0 - c->nu) * dm;
+    m.G = c->E / 2.0 / (1 + c->nu);
+    if (Et_E > 0.95) Et_E = 0.95;
+    m.Et = Et_E * c->E;
+    m.H = m.Et / (1.0 - Et_E);
+    m.rho = c->rho;
+    return m;
+}
+
+extern "C" {
+
+const char *fcvm_last_error(void) { return g_err.c_str(); }
+int fcvm_version(void) { return 100; }
+
+int fcvm_device_count(int *count) {
+    *count = 0;
+    HCHK(hipGetDeviceCount(count));
+    return 0;
+}
+
+int fcvm_create(int device, fcvm_ctx **out) {
+    *out = nullptr;
+    int n = 0;
+    HCHK(hipGetDeviceCount(&n));
+    NEED(n > 0 && device >= 0 && device < n, "fcvm_create: no such HIP device");
+    HCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HCHK(hipGetDeviceProperties(&prop, device));
+    NEED(prop.warpSize == 64, "fcvm_create: this library is built for 64-wide wavefronts (gfx950)");
+    fcvm_ctx *c = new fcvm_ctx();
+    c->device = device;
+    HCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
+    c->stream = c->own;
+    if (dalloc(&c->d_S, S_COUNT) || dalloc(&c->d_out8, 16)) return 1;
+    *out = c;
+    return 0;
+}
+
+static void free_mesh(fcvm_ctx *c) {
+    dfree(c->d_el); dfree(c->d_cols); dfree(c->d_rownode); dfree(c->d_noce); dfree(c->d_sptr);
+    dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
+    dfree(c->d_vals); dfree(c->d_dblk); dfree(c->d_dinv); dfree(c->d_r); dfree(c->d_z); dfree(c->d_p);
+    dfree(c->d_q); dfree(c->d_part_vec); dfree(c->d_part_spmv); dfree(c->d_part_misc); dfree(c->d_pidx);
+    c->have_mesh = c->assembled = false;
+}
+
+int fcvm_destroy(fcvm_ctx *c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_mesh(c);
+    dfree(c->d_S); dfree(c->d_out8);
+    for (auto e : c->evpool) (void)hipEventDestroy(e);
+    if (c->own) (void)hipStreamDestroy(c->own);
+    delete c;
+    return 0;
+}
+
+int fcvm_synchronize(fcvm_ctx *c) {
+    HCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int fcvm_set_stream(fcvm_ctx *c, void *s) {
+    HCHK(hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own;
+    return 0;
+}
+int fcvm_malloc(fcvm_ctx *c, uint64_t bytes, void **dev) {
+    HCHK(hipSetDevice(c->device));
+    HCHK(hipMalloc(dev, bytes ? bytes : 8));
+    return 0;
+}
+int fcvm_free(fcvm_ctx *c, void *dev) {
+    HCHK(hipStreamSynchronize(c->stream));
+    HCHK(hipFree(dev));
+    return 0;
+}
+int fcvm_h2d(fcvm_ctx *c, void *dev, const void *host, uint64_t bytes) {
+    HCHK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int fcvm_d2h(fcvm_ctx *c, void *host, const void *dev, uint64_t bytes) {
+    HCHK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int fcvm_d2d(fcvm_ctx *c, void *dst, const void *src, uint64_t bytes) {
+    HCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+int fcvm_memset0(fcvm_ctx *c, void *dev, uint64_t bytes) {
+    HCHK(hipMemsetAsync(dev, 0, bytes, c->stream));
+    return 0;
+}
+
+int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, const double *nocoord) {
+    NEED(c && ne > 0 && nn > 0 && elNodes && nocoord, "fcvm_set_mesh: empty mesh");
+    NEED(nn < (1ll << 31) / 3, "fcvm_set_mesh: too many nodes for 32-bit node indices");
+    HCHK(hipSetDevice(c->device));
+    HCHK(hipStreamSynchronize(c->stream));
+    free_mesh(c);
+    std::vector<int32_t> el(ne * 10);
+    for (int64_t i = 0; i < ne * 10; i++) {
+        int64_t v = elNodes[i] - 1;
+        NEED(v >= 0 && v < nn, "fcvm_set_mesh: element node number out of range (expected 1..nn)");
+        el[i] = (int32_t)v;
+    }
+    try {
+        int nt = (int)std::thread::hardware_concurrency();
+        if (nt < 1) nt = 1;
+        if (nt > 32) nt = 32;
+        build_pattern(ne, nn, el.data(), c->pat, nt);
+    } catch (const std::exception &ex) {
+        return fail(std::string("fcvm_set_mesh: ") + ex.what());
+    }
+    c->ne = ne;
+    c->nn = nn;
+    const Pattern &p = c->pat;
+    std::vector<int32_t> noce(nn, 0);  // fcVM.py:183-185
+    for (int64_t i = 0; i < ne * 10; i++) noce[el[i]]++;
+    if (dalloc(&c->d_el, ne * 10) || dalloc(&c->d_cols, p.nslots) || dalloc(&c->d_rownode, p.nslices * SLICE) ||
+        dalloc(&c->d_noce, nn) || dalloc(&c->d_sptr, p.nslices + 1) || dalloc(&c->d_emap, ne * 100) ||
+        dalloc(&c->d_diagoff, nn) || dalloc(&c->d_fixmask, nn) || dalloc(&c->d_coord, nn * 3) ||
+        dalloc(&c->d_fixval, nn * 3) || dalloc(&c->d_vals, p.value_count()) || dalloc(&c->d_dblk, nn * 9) ||
+        dalloc(&c->d_dinv, nn * 9) || dalloc(&c->d_r, nn * 3) || dalloc(&c->d_z, nn * 3) || dalloc(&c->d_p, nn * 3) ||
+        dalloc(&c->d_q, nn * 3))
+        return 1;
+    c->nb_vec = cdiv(nn, 256);
+    c->nb_spmv = cdiv(p.nslices, 4);
+    c->nb_gp = cdiv(4 * ne, 256);
+    if (dalloc(&c->d_part_vec, 2 * c->nb_vec) || dalloc(&c->d_part_spmv, c->nb_spmv) ||
+        dalloc(&c->d_part_misc, 2 * std::max<int64_t>(c->nb_gp, 4096)) || dalloc(&c->d_pidx, c->nb_gp))
+        return 1;
+    hipStream_t s = c->stream;
+    HCHK(hipMemcpyAsync(c->d_el, el.data(), sizeof(int32_t) * ne * 10, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_cols, p.cols.data(), sizeof(int32_t) * p.nslots, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_rownode, p.rownode.data(), sizeof(int32_t) * p.nslices * SLICE, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_noce, noce.data(), sizeof(int32_t) * nn, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_sptr, p.sptr.data(), sizeof(int64_t) * (p.nslices + 1), hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_emap, p.emap.data(), sizeof(uint32_t) * ne * 100, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_diagoff, p.diagoff.data(), sizeof(uint32_t) * nn, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_coord, nocoord, sizeof(double) * nn * 3, hipMemcpyHostToDevice, s));
+    HCHK(hipMemsetAsync(c->d_fixmask, 0, nn, s));
+    HCHK(hipMemsetAsync(c->d_fixval, 0, sizeof(double) * nn * 3, s));
+    HCHK(hipMemsetAsync(c->d_vals, 0, sizeof(double) * p.value_count(), s));
+    HCHK(hipStreamSynchronize(s));
+    // the element->slot map is only needed on the device from here on
+    c->pat.emap.clear();
+    c->pat.emap.shrink_to_fit();
+    c->have_mesh = true;
+    return 0;
+}
+
+int fcvm_set_coords(fcvm_ctx *c, const double *nocoord) {
+    NEED(c && c->have_mesh, "fcvm_set_coords: no mesh");
+    HCHK(hipMemcpyAsync(c->d_coord, nocoord, sizeof(double) * c->nn * 3, hipMemcpyHostToDevice, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int fcvm_set_material(fcvm_ctx *c, double E, double nu, double density) {
+    NEED(c && E > 0 && nu > -1.0 && nu < 0.5, "fcvm_set_material: need E > 0 and -1 < nu < 0.5");
+    c->E = E; c->nu = nu; c->rho = density;
+    c->have_mat = true;
+    return 0;
+}
+
+int fcvm_set_fix(fcvm_ctx *c, int64_t nfix, const int64_t *dofs, const double *vals) {
+    NEED(c && c->have_mesh, "fcvm_set_fix: set the mesh first");
+    std::vector<uint8_t> mask(c->nn, 0);
+    std::vector<double> val(c->nn * 3, 0.0);
+    for (int64_t i = 0; i < nfix; i++) {
+        NEED(dofs[i] >= 0 && dofs[i] < 3 * c->nn, "fcvm_set_fix: dof out of range");
+        mask[dofs[i] / 3] |= (uint8_t)(1u << (dofs[i] % 3));
+        val[dofs[i]] = vals[i];
+    }
+    HCHK(hipMemcpyAsync(c->d_fixmask, mask.data(), c->nn, hipMemcpyHostToDevice, c->stream));
+    HCHK(hipMemcpyAsync(c->d_fixval, val.data(), sizeof(double) * c->nn * 3, hipMemcpyHostToDevice, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int fcvm_pattern_info(fcvm_ctx *c, int64_t out[6]) {
+    NEED(c && c->have_mesh, "fcvm_pattern_info: no mesh");
+    const Pattern &p = c->pat;
+    out[0] = p.nnzb; out[1] = p.nslots; out[2] = p.nslices;
+    out[3] = p.value_count() * 8 + p.nslots * 4;
+    out[4] = p.maxlen; out[5] = 3 * p.nn;
+    return 0;
+}
+
+int fcvm_matrix_to_coo(fcvm_ctx *c, int64_t *row, int64_t *col, double *val) {
+    NEED(c && c->have_mesh, "fcvm_matrix_to_coo: no mesh");
+    const Pattern &p = c->pat;
+    std::vector<double> v(p.value_count());
+    HCHK(hipMemcpyAsync(v.data(), c->d_vals, sizeof(double) * v.size(), hipMemcpyDeviceToHost, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+    int64_t k = 0;
+    for (int64_t i = 0; i < p.nn; i++)
+        for (int64_t q = p.rowptr[i]; q < p.rowptr[i + 1]; q++) {
+            uint64_t off = p.block_offset(p.slotof[i], q - p.rowptr[i]);
+            for (int r = 0; r < 3; r++)
+                for (int cc = 0; cc < 3; cc++) {
+                    row[k] = 3 * i + r;
+                    col[k] = 3 * (int64_t)p.colidx[q] + cc;
+                    val[k] = v[off + (r * 3 + cc) * VSTRIDE];
+                    k++;
+                }
+        }
+    return 0;
+}
+
+static int refresh_precond(fcvm_ctx *c) {
+    hipLaunchKernelGGL(k_diag_get, dim3(cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_diagoff, c->d_vals, c->d_dblk);
+    hipLaunchKernelGGL(k_diag_invert, dim3(cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_dblk, c->d_dinv);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint8_t *pgp, double Et_E,
+                  const double grav[3], double *glv_grav, double *modf, double *xgp, double *volume) {
+    NEED(c && c->have_mesh && c->have_mat, "fcvm_assemble: mesh and material must be set");
+    NEED(glv_grav && modf, "fcvm_assemble: glv_grav and modf are required");
+    NEED((sig == nullptr) == (pgp == nullptr), "fcvm_assemble: sig and pgp go together");
+    hipStream_t s = c->stream;
+    HCHK(hipMemsetAsync(c->d_vals, 0, sizeof(double) * c->pat.value_count(), s));
+    HCHK(hipMemsetAsync(glv_grav, 0, sizeof(double) * 3 * c->nn, s));
+    HCHK(hipMemsetAsync(modf, 0, sizeof(double) * 3 * c->nn, s));
+    HCHK(hipMemsetAsync(c->d_out8, 0, sizeof(double), s));
+    MatConst mc = matconst(c, Et_E);
+    dim3 grid((unsigned)cdiv(c->ne * 10, 256)), block(256);
+    if (sig)
+        hipLaunchKernelGGL(k_assemble<true>, grid, block, 0, s, c->ne, c->d_el, c->d_coord, disp, c->d_fixmask,
+                           c->d_fixval, c->d_emap, sig, pgp, mc, grav[0], grav[1], grav[2], c->d_vals, glv_grav, modf,
+                           xgp, c->d_out8);
+    else
+        hipLaunchKernelGGL(k_assemble<false>, grid, block, 0, s, c->ne, c->d_el, c->d_coord, disp, c->d_fixmask,
+                           c->d_fixval, c->d_emap, (const double *)nullptr, (const uint8_t *)nullptr, mc, grav[0],
+                           grav[1], grav[2], c->d_vals, glv_grav, modf, xgp, c->d_out8);
+    HCHK(hipGetLastError());
+    if (refresh_precond(c)) return 1;
+    if (volume) {
+        HCHK(hipMemcpyAsync(volume, c->d_out8, sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    HCHK(hipStreamSynchronize(s));
+    c->assembled = true;
+    return 0;
+}
+
+int fcvm_update_stress_load(fcvm_ctx *c, const double *sig_yield, const double *disp_new, const double *du,
+                            const double *sig_old, double *sig_new, double *sig_test, double *qin, double Et_E,
+                            int LD, uint8_t *pgp) {
+    NEED(c && c->have_mesh && c->have_mat, "fcvm_update_stress_load: mesh and material must be set");
+    NEED(sig_yield && du && sig_old && sig_new && sig_test && qin && pgp, "fcvm_update_stress_load: null array");
+    NEED(!LD || disp_new, "fcvm_update_stress_load: disp_new required when LD");
+    hipStream_t s = c->stream;
+    HCHK(hipMemsetAsync(qin, 0, sizeof(double) * 3 * c->nn, s));
+    MatConst mc = matconst(c, Et_E);
+    dim3 grid((unsigned)cdiv(c->ne * 4, 256)), block(256);
+    if (LD)
+        hipLaunchKernelGGL(k_update_stress<true>, grid, block, 0, s, c->ne, c->d_el, c->d_coord, disp_new, du, sig_old,
+                           sig_new, sig_test, sig_yield, pgp, qin, mc);
+    else
+        hipLaunchKernelGGL(k_update_stress<false>, grid, block, 0, s, c->ne, c->d_el, c->d_coord, disp_new, du,
+                           sig_old, sig_new, sig_test, sig_yield, pgp, qin, mc);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_update_peeq_csr(fcvm_ctx *c, const double *sig_test, const double *sig_new, double *sig_yield,
+                         double ultimate_strain, double *peeq, double *csr, double *triax, double *pressure,
+                         double *sigmises, double *ecr, double Et_E, double out[8]) {
+    NEED(c && c->have_mesh && c->have_mat, "fcvm_update_peeq_csr: mesh and material must be set");
+    MatConst mc = matconst(c, Et_E);
+    if (ultimate_strain == 0.0) ultimate_strain = 1.0e12;
+    const double alpha = std::sqrt(std::exp(1.0)) * ultimate_strain;
+    const int64_t ngp = 4 * c->ne, nb = c->nb_gp;
+    double *pmaxc = c->d_part_misc, *pmaxp = c->d_part_misc + nb;
+    hipLaunchKernelGGL(k_peeq_csr, dim3((unsigned)nb), dim3(256), 0, c->stream, ngp, sig_test, sig_new, sig_yield, peeq,
+                       csr, triax, pressure, sigmises, ecr, mc.G, mc.H, mc.Et, alpha, pmaxc, c->d_pidx, pmaxp);
+    hipLaunchKernelGGL(k_peeq_csr_final, dim3(1), dim3(256), 0, c->stream, nb, pmaxc, c->d_pidx, pmaxp, pressure,
+                       sigmises, triax, ecr, peeq, c->d_out8);
+    HCHK(hipGetLastError());
+    HCHK(hipMemcpyAsync(out, c->d_out8, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int fcvm_map_stresses(fcvm_ctx *c, int averaged, const double *sig, const double *peeq, const double *sigvm,
+                      const double *csr, double sig_yield, double *t10s, double *t10peeq, double *t10csr,
+                      double *t10svm, double *t10triax) {
+    NEED(c && c->have_mesh, "fcvm_map_stresses: no mesh");
+    hipStream_t s = c->stream;
+    HCHK(hipMemsetAsync(t10s, 0, sizeof(double) * 6 * c->nn, s));
+    HCHK(hipMemsetAsync(t10peeq, 0, sizeof(double) * c->nn, s));
+    HCHK(hipMemsetAsync(t10csr, 0, sizeof(double) * c->nn, s));
+    HCHK(hipMemsetAsync(t10svm, 0, sizeof(double) * c->nn, s));
+    HCHK(hipMemsetAsync(t10triax, 0, sizeof(double) * c->nn, s));
+    hipLaunchKernelGGL(k_map_corners, dim3((unsigned)cdiv(4 * c->ne, 256)), dim3(256), 0, s, c->ne, c->d_el, c->d_noce,
+                       averaged, sig, peeq, sigvm, csr, sig_yield, t10s, t10peeq, t10csr, t10svm, t10triax);
+    hipLaunchKernelGGL(k_map_midside, dim3((unsigned)cdiv(6 * c->ne, 256)), dim3(256), 0, s, c->ne, c->d_el, t10s,
+                       t10peeq, t10csr, t10svm, t10triax);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_principal_stress(fcvm_ctx *c, int64_t n, const double *t10s, double *ps, double *pv) {
+    NEED(c && n >= 0, "fcvm_principal_stress: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_principal, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, c->stream, n, t10s, ps, pv);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done) {
+    dim3 grid((unsigned)c->nb_spmv), block(256);
+    if (dot)
+        hipLaunchKernelGGL(k_spmv<true>, grid, block, 0, c->stream, c->pat.nslices, c->nb_spmv, c->d_sptr, c->d_cols,
+                           (const double2 *)c->d_vals, c->d_rownode, x, y, c->d_part_spmv, done);
+    else
+        hipLaunchKernelGGL(k_spmv<false>, grid, block, 0, c->stream, c->pat.nslices, c->nb_spmv, c->d_sptr, c->d_cols,
+                           (const double2 *)c->d_vals, c->d_rownode, x, y, (double *)nullptr, done);
+}
+
+int fcvm_spmv(fcvm_ctx *c, const double *x, double *y) {
+    NEED(c && c->have_mesh, "fcvm_spmv: no mesh");
+    NEED(x != y, "fcvm_spmv: x and y must not alias");
+    launch_spmv(c, false, x, y, nullptr);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_precond(fcvm_ctx *c, const double *r, double *z) {
+    NEED(c && c->have_mesh, "fcvm_precond: no mesh");
+    hipLaunchKernelGGL(k_precond, dim3((unsigned)c->nb_vec), dim3(256), 0, c->stream, c->nn, c->d_dinv, r, z);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_get_diag_blocks(fcvm_ctx *c, double *dblk) {
+    NEED(c && c->have_mesh, "fcvm_get_diag_blocks: no mesh");
+    hipLaunchKernelGGL(k_diag_get, dim3((unsigned)c->nb_vec), dim3(256), 0, c->stream, c->nn, c->d_diagoff, c->d_vals, dblk);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_set_diag_blocks(fcvm_ctx *c, const double *dblk) {
+    NEED(c && c->have_mesh, "fcvm_set_diag_blocks: no mesh");
+    hipLaunchKernelGGL(k_diag_invert, dim3((unsigned)c->nb_vec), dim3(256), 0, c->stream, c->nn, dblk, c->d_dinv);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_solve(fcvm_ctx *c, const double *f, double *u, double rtol, int64_t maxit, double info[3]) {
+    NEED(c && c->have_mesh && c->assembled, "fcvm_solve: assemble the matrix first");
+    NEED(f && u && f != u, "fcvm_solve: f and u must be distinct device arrays");
+    hipStream_t s = c->stream;
+    const int64_t nn = c->nn, n = 3 * nn, nbv = c->nb_vec;
+    const int CHUNK = 25;
+    if (c->evpool.size() < (size_t)(2 * CHUNK + 2)) {
+        while (c->evpool.size() < (size_t)(2 * CHUNK + 2)) {
+            hipEvent_t e;
+            HCHK(hipEventCreate(&e));
+            c->evpool.push_back(e);
+        }
+    }
+    hipEvent_t ev0 = c->evpool[2 * CHUNK], ev1 = c->evpool[2 * CHUNK + 1];
+    HCHK(hipEventRecord(ev0, s));
+    hipLaunchKernelGGL(k_pcg_init, dim3((unsigned)nbv), dim3(256), 0, s, nn, c->d_dinv, f, u, c->d_r, c->d_z, c->d_p,
+                       c->d_part_vec, nbv);
+    hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(256), 0, s, 0, c->d_part_vec, nbv, c->nb_spmv, c->d_S, rtol);
+    double S[S_COUNT];
+    int64_t it = 0, nspmv = 0;
+    double spmv_ms = 0.0;
+    bool done = false;
+    while (!done && it < maxit) {
+        int k = (int)std::min<int64_t>(CHUNK, maxit - it);
+        for (int j = 0; j < k; j++) {
+            HCHK(hipEventRecord(c->evpool[2 * j], s));
+            launch_spmv(c, true, c->d_p, c->d_q, c->d_S + S_DONE);
+            HCHK(hipEventRecord(c->evpool[2 * j + 1], s));
+            hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(256), 0, s, 1, c->d_part_spmv, nbv, c->nb_spmv, c->d_S, rtol);
+            hipLaunchKernelGGL(k_pcg_update_xr, dim3((unsigned)nbv), dim3(256), 0, s, nn, c->d_dinv, c->d_p, c->d_q, u,
+                               c->d_r, c->d_z, c->d_part_vec, nbv, c->d_S);
+            hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(256), 0, s, 2, c->d_part_vec, nbv, c->nb_spmv, c->d_S, rtol);
+            hipLaunchKernelGGL(k_pcg_update_p, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, n, c->d_z, c->d_p, c->d_S);
+        }
+        HCHK(hipGetLastError());
+        HCHK(hipMemcpyAsync(S, c->d_S, sizeof(S), hipMemcpyDeviceToHost, s));
+        HCHK(hipStreamSynchronize(s));
+        int64_t it_new = (int64_t)S[S_ITERS];
+        int64_t ran = it_new - it;  // SpMV launches that did real work in this chunk
+        for (int j = 0; j < ran && j < k; j++) {
+            float ms = 0.f;
+            HCHK(hipEventElapsedTime(&ms, c->evpool[2 * j], c->evpool[2 * j + 1]));
+            spmv_ms += ms;
+        }
+        nspmv += ran;
+        it = it_new;
+        done = S[S_DONE] != 0.0;
+        if (ran < k && !done) break;  // defensive: no progress
+        if (!std::isfinite(S[S_RR])) return fail("fcvm_solve: PCG broke down (non-finite residual; matrix not SPD?)");
+    }
+    HCHK(hipEventRecord(ev1, s));
+    HCHK(hipEventSynchronize(ev1));
+    float tot = 0.f;
+    HCHK(hipEventElapsedTime(&tot, ev0, ev1));
+    c->last_spmv_ms = spmv_ms;
+    c->last_total_ms = tot;
+    if (info) {
+        info[0] = (double)it;
+        info[1] = (S[S_BB] > 0.0) ? std::sqrt(S[S_RR] / S[S_BB]) : 0.0;
+        info[2] = (double)nspmv;
+    }
+    if (!done) return fail("fcvm_solve: PCG did not converge in " + std::to_string(maxit) + " iterations (rel. residual " +
+                           std::to_string(info ? info[1] : -1.0) + ")");
+    return 0;
+}
+
+int fcvm_solve_timing(fcvm_ctx *c, double out_ms[2]) {
+    out_ms[0] = c->last_spmv_ms;
+    out_ms[1] = c->last_total_ms;
+    return 0;
+}
+
+int fcvm_vec_axpby(fcvm_ctx *c, int64_t n, double a, const double *x, double b, const double *y, double *out) {
+    NEED(c && n >= 0 && x && out && (b == 0.0 || y), "fcvm_vec_axpby: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_axpby, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, c->stream, n, a, x, b, y ? y : x, out);
+    HCHK(hipGetLastError());
+    return 0;
+}
+int fcvm_vec_mul(fcvm_ctx *c, int64_t n, const double *x, const double *y, double *out) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_mul, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, c->stream, n, x, y, out);
+    HCHK(hipGetLastError());
+    return 0;
+}
+static int dot_common(fcvm_ctx *c, int64_t n, const double *w, const double *x, const double *y, double *result_dev) {
+    NEED(c && c->d_part_misc, "vector reductions need a mesh (work buffers)");
+    int64_t nb = std::min<int64_t>(std::max<int64_t>(cdiv(n, 256), 1), 2048);
+    hipLaunchKernelGGL(k_dot_partial, dim3((unsigned)nb), dim3(256), 0, c->stream, n, w, x, y, c->d_part_misc);
+    hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, c->stream, c->d_part_misc, nb, result_dev);
+    HCHK(hipGetLastError());
+    return 0;
+}
+int fcvm_vec_dot(fcvm_ctx *c, int64_t n, const double *x, const double *y, double *result_host) {
+    if (dot_common(c, n, nullptr, x, y, c->d_out8 + 8)) return 1;
+    HCHK(hipMemcpyAsync(result_host, c->d_out8 + 8, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int fcvm_vec_wdot_dev(fcvm_ctx *c, int64_t n, const double *w, const double *x, const double *y, double *result_dev) {
+    return dot_common(c, n, w, x, y, result_dev);
+}
+int fcvm_vec_max_node_norm(fcvm_ctx *c, int64_t nnodes, const double *u, double *result_host) {
+    NEED(c && c->d_part_misc, "vector reductions need a mesh (work buffers)");
+    int64_t nb = std::min<int64_t>(std::max<int64_t>(cdiv(nnodes, 256), 1), 2048);
+    hipLaunchKernelGGL(k_max_node_norm_partial, dim3((unsigned)nb), dim3(256), 0, c->stream, nnodes, u, c->d_part_misc);
+    hipLaunchKernelGGL(k_max_final, dim3(1), dim3(256), 0, c->stream, c->d_part_misc, nb, c->d_out8 + 8);
+    HCHK(hipGetLastError());
+    HCHK(hipMemcpyAsync(result_host, c->d_out8 + 8, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int fcvm_host_pattern_check(int64_t ne, int64_t nn, const int64_t *elNodes, int64_t out[8]) {
+    // host-only (no GPU needed): builds the sliced-ELL pattern and verifies its invariants
+    NEED(ne > 0 && nn > 0 && elNodes, "fcvm_host_pattern_check: empty mesh");
+    std::vector<int32_t> el(ne * 10);
+    for (int64_t i = 0; i < ne * 10; i++) {
+        int64_t v = elNodes[i] - 1;
+        NEED(v >= 0 && v < nn, "fcvm_host_pattern_check: element node number out of range");
+        el[i] = (int32_t)v;
+    }
+    Pattern p;
+    try {
+        build_pattern(ne, nn, el.data(), p, 4);
+    } catch (const std::exception &ex) {
+        return fail(std::string("fcvm_host_pattern_check: ") + ex.what());
+    }
+    int64_t bad = 0;
+    // every element block must land on a slot whose column is the block's column node and whose
+    // row slot belongs to the block's row node
+    for (int64_t e = 0; e < ne; e++)
+        for (int a = 0; a < 10; a++)
+            for (int b = 0; b < 10; b++) {
+                uint64_t off = p.emap[e * 100 + a * 10 + b];
+                int64_t j0 = (int64_t)(off & 1), rest = (int64_t)(off >> 1);
+                int64_t l = rest % SLICE, jp = rest / SLICE;  // jp = (sptr/2 + j/2) * 9
+                if (jp % 9 != 0) { bad++; continue; }
+                int64_t jglob = (jp / 9) * 2 + j0;  // = sptr[s] + j
+                int64_t slot = p.slotof[el[e * 10 + a]];
+                int64_t s = slot / SLICE;
+                if (slot % SLICE != l || jglob < p.sptr[s] || jglob >= p.sptr[s + 1]) { bad++; continue; }
+                if (p.cols[jglob * SLICE + l] != el[e * 10 + b]) bad++;
+            }
+    for (int64_t i = 0; i < nn; i++) {
+        int64_t slot = p.slotof[i];
+        if (slot < 0 || p.rownode[slot] != i) bad++;
+    }
+    out[0] = p.nnzb; out[1] = p.nslots; out[2] = p.nslices; out[3] = p.maxlen; out[4] = bad;
+    out[5] = p.value_count(); out[6] = p.sptr[p.nslices]; out[7] = 0;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+// Sparsity pattern builder (host, multi-threaded).  No reference counterpart: the reference
+// hands COO triplets to scipy (fcVM.py:1111); here the element -> matrix-slot map is fixed once
+// per mesh so that assembly is a pure scatter and SpMV streams a wavefront-shaped layout.
+#include "fcvm_pattern.h"
+
+#include <algorithm>
+#include <functional>
+#include <stdexcept>
+#include <thread>
+
+namespace fcvm {
+
+static void parallel_for(int64_t n, int nthreads, const std::function<void(int64_t, int64_t, int)> &fn) {
+    if (nthreads < 1) nthreads = 1;
+    if (n < 4096 || nthreads == 1) {
+        fn(0, n, 0);
+        return;
+    }
+    std::vector<std::thread> th;
+    int64_t chunk = (n + nthreads - 1) / nthreads;
+    for (int t = 0; t < nthreads; t++) {
+        int64_t b = t * chunk, e = std::min(n, b + chunk);
+        if (b >= e) break;
+        th.emplace_back(fn, b, e, t);
+    }
+    for (auto &x : th) x.join();
+}
+
+void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nthreads) {
+    if (ne <= 0 || nn <= 0) throw std::runtime_error("empty mesh");
+    for (int64_t i = 0; i < ne * 10; i++)
+        if (el[i] < 0 || el[i] >= nn) throw std::runtime_error("element node index out of range");
+    p.ne = ne;
+    p.nn = nn;
+    // node -> element incidence
+    std::vector<int64_t> nptr(nn + 1, 0);
+    for (int64_t i = 0; i < ne * 10; i++) nptr[el[i] + 1]++;
+    for (int64_t i = 0; i < nn; i++) nptr[i + 1] += nptr[i];
+    std::vector<int32_t> nel(ne * 10);
+    {
+        std::vector<int64_t> fill(nptr.begin(), nptr.end() - 1);
+        for (int64_t e = 0; e < ne; e++)
+            for (int k = 0; k < 10; k++) nel[fill[el[e * 10 + k]]++] = (int32_t)e;
+    }
+    // node -> sorted unique neighbour nodes (diagonal included)
+    int nt = std::max(1, nthreads);
+    std::vector<std::vector<int32_t>> chunks(nt);
+    std::vector<int64_t> len(nn, 0);
+    std::vector<int64_t> cbeg(nt, 0), cend(nt, 0);
+    parallel_for(nn, nt, [&](int64_t b, int64_t e, int t) {
+        cbeg[t] = b;
+        cend[t] = e;
+        std::vector<int32_t> tmp;
+        auto &out = chunks[t];
+        for (int64_t i = b; i < e; i++) {
+            tmp.clear();
+            for (int64_t q = nptr[i]; q < nptr[i + 1]; q++) {
+                const int32_t *nd = el + (int64_t)nel[q] * 10;
+                tmp.insert(tmp.end(), nd, nd + 10);
+            }
+            if (tmp.empty()) tmp.push_back((int32_t)i);  // isolated node: keep a diagonal block
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            len[i] = (int64_t)tmp.size();
+            out.insert(out.end(), tmp.begin(), tmp.end());
+        }
+    });
+    p.rowptr.assign(nn + 1, 0);
+    for (int64_t i = 0; i < nn; i++) p.rowptr[i + 1] = p.rowptr[i] + len[i];
+    p.nnzb = p.rowptr[nn];
+    p.colidx.resize(p.nnzb);
+    for (int t = 0; t < nt; t++)
+        if (cend[t] > cbeg[t])
+            std::copy(chunks[t].begin(), chunks[t].end(), p.colidx.begin() + p.rowptr[cbeg[t]]);
+    chunks.clear();
+    chunks.shrink_to_fit();
+    // slices: rows sorted by descending length inside windows of SORT_WINDOW slices
+    p.nslices = (nn + SLICE - 1) / SLICE;
+    p.rownode.assign(p.nslices * SLICE, -1);
+    p.slotof.assign(nn, -1);
+    const int64_t win = (int64_t)SLICE * SORT_WINDOW;
+    for (int64_t w0 = 0; w0 < nn; w0 += win) {
+        int64_t w1 = std::min(nn, w0 + win);
+        std::vector<int32_t> ids(w1 - w0);
+        for (int64_t i = w0; i < w1; i++) ids[i - w0] = (int32_t)i;
+        std::stable_sort(ids.begin(), ids.end(), [&](int32_t a, int32_t b) { return len[a] > len[b]; });
+        for (int64_t k = 0; k < (int64_t)ids.size(); k++) {
+            p.rownode[w0 + k] = ids[k];
+            p.slotof[ids[k]] = (int32_t)(w0 + k);
+        }
+    }
+    p.sptr.assign(p.nslices + 1, 0);
+    p.maxlen = 0;
+    for (int64_t s = 0; s < p.nslices; s++) {
+        int64_t m = 0;
+        for (int l = 0; l < SLICE; l++) {
+            int32_t nd = p.rownode[s * SLICE + l];
+            if (nd >= 0) m = std::max(m, len[nd]);
+        }
+        p.maxlen = std::max(p.maxlen, m);
+        m = (m + 1) & ~(int64_t)1;  // even: blocks are stored in pairs (one 16-byte load per lane)
+        p.sptr[s + 1] = p.sptr[s] + m;
+    }
+    p.nslots = p.sptr[p.nslices] * SLICE;
+    if ((uint64_t)p.value_count() >= (1ull << 32))
+        throw std::runtime_error("matrix too large for 32-bit slot offsets on one GPU");
+    p.cols.assign(p.nslots, 0);
+    parallel_for(p.nslices, nt, [&](int64_t b, int64_t e, int) {
+        for (int64_t s = b; s < e; s++) {
+            int64_t L = p.sptr[s + 1] - p.sptr[s];
+            for (int l = 0; l < SLICE; l++) {
+                int32_t nd = p.rownode[s * SLICE + l];
+                for (int64_t j = 0; j < L; j++) {
+                    int32_t c = 0;
+                    if (nd >= 0) c = (j < len[nd]) ? p.colidx[p.rowptr[nd] + j] : nd;
+                    p.cols[(p.sptr[s] + j) * SLICE + l] = c;
+                }
+            }
+        }
+    });
+    // element block (a,b) -> offset of its component 0
+    p.emap.resize(ne * 100);
+    parallel_for(ne, nt, [&](int64_t b, int64_t e, int) {
+        for (int64_t k = b; k < e; k++) {
+            const int32_t *nd = el + k * 10;
+            for (int a = 0; a < 10; a++) {
+                const int32_t *rb = p.colidx.data() + p.rowptr[nd[a]];
+                const int32_t *re = p.colidx.data() + p.rowptr[nd[a] + 1];
+                int64_t slot = p.slotof[nd[a]];
+                for (int c = 0; c < 10; c++) {
+                    int64_t j = std::lower_bound(rb, re, nd[c]) - rb;
+                    p.emap[k * 100 + a * 10 + c] = (uint32_t)p.block_offset(slot, j);
+                }
+            }
+        }
+    });
+    p.diagoff.resize(nn);
+    for (int64_t i = 0; i < nn; i++) {
+        const int32_t *rb = p.colidx.data() + p.rowptr[i];
+        const int32_t *re = p.colidx.data() + p.rowptr[i + 1];
+        int64_t j = std::lower_bound(rb, re, (int32_t)i) - rb;
+        p.diagoff[i] = (uint32_t)p.block_offset(p.slotof[i], j);
+    }
+}
+
+}  // namespace fcvm

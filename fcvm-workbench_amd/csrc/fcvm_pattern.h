@@ -1,0 +1,39 @@
+// Host-side sparsity pattern of the tet10 stiffness matrix in the sliced-ELL 3x3-block layout
+// the SpMV / assembly kernels use (see DESIGN.md "Matrix layout in HBM").
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace fcvm {
+
+constexpr int SLICE = 64;           // rows (nodes) per slice = one wavefront, one row per lane
+constexpr int SORT_WINDOW = 8;      // slices per length-sorting window (512 rows)
+constexpr int64_t VSTRIDE = 2 * SLICE;  // doubles between two components of one 3x3 block
+
+struct Pattern {
+    int64_t ne = 0, nn = 0;
+    int64_t nslices = 0;
+    int64_t nnzb = 0;       // true 3x3 blocks
+    int64_t nslots = 0;     // padded block slots (sum over slices of 64 * slice length)
+    int64_t maxlen = 0;
+    std::vector<int64_t> rowptr;    // [nn+1] CSR over nodes (sorted columns, diagonal included)
+    std::vector<int32_t> colidx;    // [nnzb]
+    std::vector<int64_t> sptr;      // [nslices+1] cumulative slice lengths (blocks per lane, even)
+    std::vector<int32_t> rownode;   // [nslices*64] node of slot, -1 = padding
+    std::vector<int32_t> slotof;    // [nn] slot (slice*64+lane) of node
+    std::vector<int32_t> cols;      // [sptr[nslices]*64] column node per (slice, j, lane)
+    std::vector<uint32_t> emap;     // [ne*100] offset (in doubles) of component 0 of block (a,b)
+    std::vector<uint32_t> diagoff;  // [nn] offset of component 0 of the diagonal block
+
+    // offset in doubles of component 0 of block j of the row living in `slot`
+    inline uint64_t block_offset(int64_t slot, int64_t j) const {
+        int64_t s = slot / SLICE, l = slot % SLICE;
+        return (uint64_t)(((sptr[s] / 2 + (j >> 1)) * 9 * SLICE + l) * 2 + (j & 1));
+    }
+    int64_t value_count() const { return sptr[nslices] * SLICE * 9; }
+};
+
+// elnodes0: 0-based int32 [ne*10].  Throws std::runtime_error on bad input.
+void build_pattern(int64_t ne, int64_t nn, const int32_t *elnodes0, Pattern &p, int nthreads);
+
+}  // namespace fcvm

@@ -1,0 +1,93 @@
+"""ctypes binding of libfcvm_hip.so (C-ABI declared in include/fcvm_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, FcvmError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfcvm_hip.so")
+
+
+class FcvmError(RuntimeError):
+    pass
+
+
+_vp, _i64, _f64, _int = C.c_void_p, C.c_int64, C.c_double, C.c_int
+_pf64, _pi64 = C.POINTER(C.c_double), C.POINTER(C.c_int64)
+
+# name -> argtypes (every function returns int status unless listed in _SPECIAL)
+SIGNATURES = {
+    "fcvm_device_count": [C.POINTER(C.c_int)],
+    "fcvm_create": [_int, C.POINTER(_vp)],
+    "fcvm_destroy": [_vp],
+    "fcvm_synchronize": [_vp],
+    "fcvm_set_stream": [_vp, _vp],
+    "fcvm_malloc": [_vp, C.c_uint64, C.POINTER(_vp)],
+    "fcvm_free": [_vp, _vp],
+    "fcvm_h2d": [_vp, _vp, _vp, C.c_uint64],
+    "fcvm_d2h": [_vp, _vp, _vp, C.c_uint64],
+    "fcvm_d2d": [_vp, _vp, _vp, C.c_uint64],
+    "fcvm_memset0": [_vp, _vp, C.c_uint64],
+    "fcvm_set_mesh": [_vp, _i64, _i64, _vp, _vp],
+    "fcvm_set_material": [_vp, _f64, _f64, _f64],
+    "fcvm_set_fix": [_vp, _i64, _vp, _vp],
+    "fcvm_set_coords": [_vp, _vp],
+    "fcvm_pattern_info": [_vp, _pi64],
+    "fcvm_matrix_to_coo": [_vp, _vp, _vp, _vp],
+    "fcvm_assemble": [_vp, _vp, _vp, _vp, _f64, _pf64, _vp, _vp, _vp, _pf64],
+    "fcvm_update_stress_load": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _int, _vp],
+    "fcvm_update_peeq_csr": [_vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _pf64],
+    "fcvm_map_stresses": [_vp, _int, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp, _vp],
+    "fcvm_principal_stress": [_vp, _i64, _vp, _vp, _vp],
+    "fcvm_solve": [_vp, _vp, _vp, _f64, _i64, _pf64],
+    "fcvm_spmv": [_vp, _vp, _vp],
+    "fcvm_precond": [_vp, _vp, _vp],
+    "fcvm_get_diag_blocks": [_vp, _vp],
+    "fcvm_set_diag_blocks": [_vp, _vp],
+    "fcvm_vec_axpby": [_vp, _i64, _f64, _vp, _f64, _vp, _vp],
+    "fcvm_vec_mul": [_vp, _i64, _vp, _vp, _vp],
+    "fcvm_vec_dot": [_vp, _i64, _vp, _vp, _pf64],
+    "fcvm_vec_wdot_dev": [_vp, _i64, _vp, _vp, _vp, _vp],
+    "fcvm_vec_max_node_norm": [_vp, _i64, _vp, _pf64],
+    "fcvm_solve_timing": [_vp, _pf64],
+    "fcvm_host_pattern_check": [_i64, _i64, _vp, _pi64],
+}
+_SPECIAL = {"fcvm_last_error": ([], C.c_char_p), "fcvm_version": ([], C.c_int)}
+
+_lib = None
+
+
+def load():
+    """Loads libfcvm_hip.so; raises FcvmError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FcvmError("libfcvm_hip.so not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "or `make -C fcvm-workbench_amd/csrc`); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, args in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        for name, (args, res) in _SPECIAL.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = res
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise FcvmError("%s failed: %s" % (name, lib.fcvm_last_error().decode("utf8", "replace")))
+
+
+def device_count():
+    n = C.c_int(0)
+    lib = load()
+    if lib.fcvm_device_count(C.byref(n)) != 0:
+        return 0
+    return n.value

@@ -1,0 +1,215 @@
+"""Device context and device-resident arrays over the C-ABI (no torch needed on one GPU)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import call
+
+
+class DArr:
+    """A device array owned by a Context (f64 unless dtype given)."""
+
+    __slots__ = ("ctx", "ptr", "n", "dtype", "_own")
+
+    def __init__(self, ctx, n, dtype=np.float64, ptr=None):
+        self.ctx, self.n, self.dtype = ctx, int(n), np.dtype(dtype)
+        if ptr is None:
+            p = C.c_void_p()
+            call("fcvm_malloc", ctx.h, self.n * self.dtype.itemsize, C.byref(p))
+            self.ptr, self._own = p.value, True
+        else:
+            self.ptr, self._own = int(ptr), False
+
+    @property
+    def nbytes(self):
+        return self.n * self.dtype.itemsize
+
+    def zero(self):
+        call("fcvm_memset0", self.ctx.h, self.ptr, self.nbytes)
+        return self
+
+    def set(self, host):
+        a = np.ascontiguousarray(host, dtype=self.dtype).reshape(-1)
+        assert a.size == self.n, (a.size, self.n)
+        call("fcvm_h2d", self.ctx.h, self.ptr, a.ctypes.data, self.nbytes)
+        return self
+
+    def get(self):
+        out = np.empty(self.n, dtype=self.dtype)
+        call("fcvm_d2h", self.ctx.h, out.ctypes.data, self.ptr, self.nbytes)
+        return out
+
+    def copy_from(self, other):
+        assert other.nbytes == self.nbytes
+        call("fcvm_d2d", self.ctx.h, self.ptr, other.ptr, self.nbytes)
+        return self
+
+    def clone(self):
+        return DArr(self.ctx, self.n, self.dtype).copy_from(self)
+
+    def free(self):
+        if self._own and self.ptr and self.ctx.h:
+            call("fcvm_free", self.ctx.h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU + one HIP stream + one mesh partition (fcvm_ctx)."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        call("fcvm_create", int(device), C.byref(h))
+        self.h = h
+        self.device = device
+        self.ne = self.nn = 0
+
+    def close(self):
+        if self.h:
+            _lib.load().fcvm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- allocation -------------------------------------------------------------------------
+    def zeros(self, n, dtype=np.float64):
+        return DArr(self, n, dtype).zero()
+
+    def empty(self, n, dtype=np.float64):
+        return DArr(self, n, dtype)
+
+    def array(self, host, dtype=np.float64):
+        a = np.asarray(host)
+        return DArr(self, a.size, dtype).set(a)
+
+    def sync(self):
+        call("fcvm_synchronize", self.h)
+
+    def set_stream(self, stream_handle):
+        call("fcvm_set_stream", self.h, C.c_void_p(stream_handle))
+
+    # -- model ------------------------------------------------------------------------------
+    def set_mesh(self, elNodes, nocoord):
+        el = np.ascontiguousarray(elNodes, dtype=np.int64)
+        xyz = np.ascontiguousarray(nocoord, dtype=np.float64)
+        assert el.ndim == 2 and el.shape[1] == 10 and xyz.ndim == 2 and xyz.shape[1] == 3
+        call("fcvm_set_mesh", self.h, len(el), len(xyz), el.ctypes.data, xyz.ctypes.data)
+        self.ne, self.nn = len(el), len(xyz)
+
+    def set_coords(self, nocoord):
+        xyz = np.ascontiguousarray(nocoord, dtype=np.float64)
+        assert xyz.shape == (self.nn, 3)
+        call("fcvm_set_coords", self.h, xyz.ctypes.data)
+
+    def set_material(self, E, nu, density):
+        call("fcvm_set_material", self.h, float(E), float(nu), float(density))
+
+    def set_fix(self, fix):
+        """fix: mapping dof -> prescribed value (the reference's `fix` Dict, fcVM.py:222-254)."""
+        dofs = np.fromiter(fix.keys(), dtype=np.int64, count=len(fix))
+        vals = np.fromiter(fix.values(), dtype=np.float64, count=len(fix))
+        call("fcvm_set_fix", self.h, len(dofs), dofs.ctypes.data, vals.ctypes.data)
+
+    def pattern_info(self):
+        out = (C.c_int64 * 6)()
+        call("fcvm_pattern_info", self.h, out)
+        return dict(nnz_blocks=out[0], padded_slots=out[1], slices=out[2], matrix_bytes=out[3],
+                    max_row_blocks=out[4], ndof=out[5])
+
+    def matrix_coo(self):
+        nnz = 9 * self.pattern_info()["nnz_blocks"]
+        r, c, v = np.empty(nnz, np.int64), np.empty(nnz, np.int64), np.empty(nnz, np.float64)
+        call("fcvm_matrix_to_coo", self.h, r.ctypes.data, c.ctypes.data, v.ctypes.data)
+        return r, c, v
+
+    # -- hot path ---------------------------------------------------------------------------
+    def assemble(self, grav=(0.0, 0.0, 0.0), disp=None, sig=None, pgp=None, Et_E=0.0, xgp=None):
+        """calcGSM / calcTSM stiffness part.  Returns (glv_grav, modf, volume) (device, device, float)."""
+        glv = self.empty(3 * self.nn)
+        modf = self.empty(3 * self.nn)
+        g = (C.c_double * 3)(*[float(v) for v in grav])
+        vol = C.c_double(0.0)
+        call("fcvm_assemble", self.h, disp.ptr if disp is not None else None,
+             sig.ptr if sig is not None else None, pgp.ptr if pgp is not None else None, float(Et_E), g,
+             glv.ptr, modf.ptr, xgp.ptr if xgp is not None else None, C.byref(vol))
+        return glv, modf, vol.value
+
+    def update_stress_load(self, sig_yield, disp_new, du, sig_old, sig_new, sig_test, qin, Et_E, LD, pgp):
+        call("fcvm_update_stress_load", self.h, sig_yield.ptr, disp_new.ptr if disp_new is not None else None,
+             du.ptr, sig_old.ptr, sig_new.ptr, sig_test.ptr, qin.ptr, float(Et_E), 1 if LD else 0, pgp.ptr)
+
+    def update_peeq_csr(self, sig_test, sig_new, sig_yield, ultimate_strain, peeq, csr, triax, pressure,
+                        sigmises, ecr, Et_E):
+        out = (C.c_double * 8)()
+        call("fcvm_update_peeq_csr", self.h, sig_test.ptr, sig_new.ptr, sig_yield.ptr, float(ultimate_strain),
+             peeq.ptr, csr.ptr, triax.ptr, pressure.ptr, sigmises.ptr, ecr.ptr, float(Et_E), out)
+        return dict(maxloc=int(out[0]), csr_max=out[1], peeq_max=out[2], pressure=out[3], sigmises=out[4],
+                    triax=out[5], ecr=out[6], peeq=out[7])
+
+    def map_stresses(self, averaged, sig, peeq, sigvm, csr, sig_yield):
+        nn = self.nn
+        o = [self.empty(6 * nn)] + [self.empty(nn) for _ in range(4)]
+        call("fcvm_map_stresses", self.h, 1 if averaged else 0, sig.ptr, peeq.ptr, sigvm.ptr, csr.ptr,
+             float(sig_yield), *[a.ptr for a in o])
+        return o
+
+    def principal_stress(self, t10s):
+        n = t10s.n // 6
+        ps, pv = self.empty(3 * n), self.empty(9 * n)
+        call("fcvm_principal_stress", self.h, n, t10s.ptr, ps.ptr, pv.ptr)
+        return ps, pv
+
+    def solve(self, f, u=None, rtol=1e-10, maxit=20000):
+        """K u = f (replaces CHOLMOD factor(f), fcVM.py:1130).  Returns (u, info dict)."""
+        if u is None:
+            u = self.empty(f.n)
+        info = (C.c_double * 3)()
+        call("fcvm_solve", self.h, f.ptr, u.ptr, float(rtol), int(maxit), info)
+        return u, dict(iterations=int(info[0]), rel_residual=info[1], spmv=int(info[2]))
+
+    def solve_timing(self):
+        t = (C.c_double * 2)()
+        call("fcvm_solve_timing", self.h, t)
+        return dict(spmv_ms=t[0], total_ms=t[1])
+
+    def spmv(self, x, y):
+        call("fcvm_spmv", self.h, x.ptr, y.ptr)
+        return y
+
+    def precond(self, r, z):
+        call("fcvm_precond", self.h, r.ptr, z.ptr)
+        return z
+
+    # -- vector helpers ----------------------------------------------------------------------
+    def axpby(self, a, x, b, y, out=None):
+        out = out if out is not None else self.empty(x.n)
+        call("fcvm_vec_axpby", self.h, x.n, float(a), x.ptr, float(b), y.ptr if y is not None else None, out.ptr)
+        return out
+
+    def mul(self, x, y, out=None):
+        out = out if out is not None else self.empty(x.n)
+        call("fcvm_vec_mul", self.h, x.n, x.ptr, y.ptr, out.ptr)
+        return out
+
+    def dot(self, x, y):
+        r = C.c_double(0.0)
+        call("fcvm_vec_dot", self.h, x.n, x.ptr, y.ptr, C.byref(r))
+        return r.value
+
+    def norm(self, x):
+        return float(np.sqrt(self.dot(x, x)))
+
+    def max_node_norm(self, u, nnodes):
+        r = C.c_double(0.0)
+        call("fcvm_vec_max_node_norm", self.h, int(nnodes), u.ptr, C.byref(r))
+        return r.value

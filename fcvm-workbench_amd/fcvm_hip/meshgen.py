@@ -1,0 +1,79 @@
+"""Synthetic tet10 meshes in fcVM's internal node order (BASELINE configs: "synthetic cube").
+
+Node order inside an element follows the reference's shape functions (fcVM.py:365-380): corners
+0-3, then mid-side nodes 4:(0,1) 5:(1,2) 6:(0,2) 7:(0,3) 8:(1,3) 9:(2,3).
+"""
+import itertools
+
+import numpy as np
+
+# local (corner, corner) pair of each mid-side node
+MID_PAIRS = ((0, 1), (1, 2), (0, 2), (0, 3), (1, 3), (2, 3))
+# the four 6-node faces of a tet10 in the 6-node triangle order of shape6tri (fcVM.py:485-496):
+# corners 0,1,2 then mids (0,1), (1,2), (0,2)
+TET_FACES = ((0, 1, 2, 4, 5, 6), (0, 1, 3, 4, 8, 7), (1, 2, 3, 5, 9, 8), (0, 2, 3, 6, 9, 7))
+
+
+def cube_tet10(nx, ny, nz, lx=1.0, ly=1.0, lz=1.0):
+    """Box [0,lx]x[0,ly]x[0,lz] cut into nx*ny*nz cells of 6 Kuhn tetrahedra each (conforming).
+
+    Returns (elNodes int64 [6*nx*ny*nz, 10] 1-based, nocoord f64 [(2nx+1)(2ny+1)(2nz+1), 3]).
+    Nodes live on the half-cell lattice, numbered x-fastest."""
+    mx, my, mz = 2 * nx + 1, 2 * ny + 1, 2 * nz + 1
+    gi, gj, gk = np.meshgrid(np.arange(mx), np.arange(my), np.arange(mz), indexing="ij")
+    nocoord = np.empty((mx * my * mz, 3))
+    idx = (gk * my + gj) * mx + gi
+    nocoord[idx.ravel(), 0] = gi.ravel() * (lx / (2 * nx))
+    nocoord[idx.ravel(), 1] = gj.ravel() * (ly / (2 * ny))
+    nocoord[idx.ravel(), 2] = gk.ravel() * (lz / (2 * nz))
+    ci, cj, ck = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    base = np.stack([2 * ci.ravel(), 2 * cj.ravel(), 2 * ck.ravel()], axis=1)  # [ncell,3] lattice origin
+    els = []
+    for perm in itertools.permutations(range(3)):
+        v = [np.zeros(3, dtype=np.int64)]
+        for ax in perm:
+            s = v[-1].copy()
+            s[ax] += 2
+            v.append(s)
+        v = np.array(v)  # 4 corner offsets on the lattice
+        d = np.linalg.det((v[1:] - v[0]).astype(float))
+        if d < 0:
+            v[[1, 2]] = v[[2, 1]]
+        loc = [v[0], v[1], v[2], v[3]] + [(v[a] + v[b]) // 2 for a, b in MID_PAIRS]
+        cols = []
+        for off in loc:
+            p = base + off
+            cols.append((p[:, 2] * my + p[:, 1]) * mx + p[:, 0] + 1)
+        els.append(np.stack(cols, axis=1))
+    elNodes = np.stack(els, axis=1).reshape(-1, 10).astype(np.int64)
+    return elNodes, nocoord
+
+
+def boundary_faces_on_plane(elNodes, nocoord, axis, value, tol=1e-9):
+    """6-node faces (1-based node numbers, shape6tri order) of elements lying in the plane
+    x[axis] == value."""
+    on = np.abs(nocoord[:, axis] - value) < tol
+    out = []
+    for f in TET_FACES:
+        nd = elNodes[:, list(f)]
+        m = on[nd[:, 0] - 1] & on[nd[:, 1] - 1] & on[nd[:, 2] - 1]
+        out.append(nd[m])
+    return np.concatenate(out, axis=0)
+
+
+def nodes_on_plane(nocoord, axis, value, tol=1e-9):
+    return np.where(np.abs(nocoord[:, axis] - value) < tol)[0]
+
+
+def cube_case(n, l=100.0, traction=(10.0, 0.0, 100.0)):
+    """The benchmark / test problem: n^3 cells, bottom face clamped, uniform traction on the top.
+
+    Returns dict(elNodes, nocoord, fix, loads kwargs)."""
+    elNodes, nocoord = cube_tet10(n, n, n, l, l, l)
+    fix = {}
+    for nd in nodes_on_plane(nocoord, 2, 0.0):
+        for k in range(3):
+            fix[3 * int(nd) + k] = 0.0
+    faces = boundary_faces_on_plane(elNodes, nocoord, 2, l)
+    uloads = np.tile(np.asarray(traction, dtype=np.float64), (len(faces), 1))
+    return dict(elNodes=elNodes, nocoord=nocoord, fix=fix, ufaces=faces, uloads=uloads)

@@ -1,0 +1,315 @@
+"""Device-resident Newton-Raphson / Riks driver: the GPU counterpart of the reference's calcGSM +
+calcDisp (fcVM.py:621-816, 1083-1635).
+
+All vectors (displacements, residual, Gauss-point stresses, hardening state) stay in HBM for the
+whole analysis; the host only sees scalars (norms, load factor, the per-step result row).  The
+CHOLMOD factorisation / back-substitution of the reference is replaced by the block-Jacobi PCG of
+libfcvm_hip (`Context.solve`); the control flow -- arc-length correction, restarts, step scaling,
+"target load" interpolation and its quirks -- follows the reference line by line so that the
+load-displacement curve matches.
+"""
+import time
+
+import numpy as np
+
+from .device import Context
+from .loads import Loads, external_loads
+
+
+class GpuModel:
+    """Mesh + material + boundary conditions + loads on one GPU."""
+
+    def __init__(self, elNodes, nocoord, material, fix, loads=None, device=0, ctx=None):
+        self.elNodes = np.ascontiguousarray(elNodes, dtype=np.int64)
+        self.nocoord = np.ascontiguousarray(nocoord, dtype=np.float64)
+        self.material = tuple(float(v) for v in np.asarray(material).reshape(-1)[:3])
+        self.fix = dict(fix)
+        self.loads = loads if loads is not None else Loads()
+        self.ctx = ctx if ctx is not None else Context(device)
+        t0 = time.perf_counter()
+        self.ctx.set_mesh(self.elNodes, self.nocoord)
+        self.t_pattern = time.perf_counter() - t0
+        self.ctx.set_material(*self.material)
+        self.ctx.set_fix(self.fix)
+        self.ne, self.nn = len(self.elNodes), len(self.nocoord)
+        self.ndof = 3 * self.nn
+        fixdof = np.ones(self.ndof)
+        movdof = np.zeros(self.ndof)
+        for d, v in self.fix.items():  # fcVM.py:222-258
+            fixdof[d] = 0.0
+            if v != 0.0:
+                movdof[d] = 1.0
+        self.fixdof_h, self.movdof_h = fixdof, movdof
+        self.fixdof = self.ctx.array(fixdof)
+        self.movdof = self.ctx.array(movdof)
+        self.moving = bool(movdof.max() == 1.0) if len(movdof) else False
+
+    def calc_gsm(self, grav, disp=None, sig=None, pgp=None, Et_E=0.0, want_x=True):
+        """calcGSM (fcVM.py:621-816) / calcTSM material part: assembles K on the GPU, returns
+        (glv, modf, V, xgp): glv = external + gravity loads (device)."""
+        c = self.ctx
+        xgp = c.empty(12 * self.ne) if want_x else None
+        glv_g, modf, V = c.assemble(grav, disp=disp, sig=sig, pgp=pgp, Et_E=Et_E, xgp=xgp)
+        ext = external_loads(self.nocoord, self.loads, None if disp is None else disp.get())
+        if np.any(ext != 0.0):
+            c.axpby(1.0, glv_g, 1.0, c.array(ext), out=glv_g)
+        return glv_g, modf, V, xgp
+
+
+class RiksDriver:
+    """State + the three moves of the reference's incremental-iterative loop (fcVM.py:1304-1559):
+    start_step() (predictor), iteration() (corrector: solve, arc-length correction, stress update,
+    residual) and restart().  calc_disp() strings them together exactly like calcDisp does;
+    bench.py drives iteration() directly to time Newton iterations."""
+
+    def __init__(self, model, ctl, log=None, rtol=1e-10, maxit=50000, stats=None):
+        self.say = log if log is not None else (lambda *a: None)
+        self.model, self.c = model, model.ctx
+        c = self.c
+        st = self.st = stats if stats is not None else {}
+        for k in ("pcg_iterations", "solves", "stress_updates", "newton_iterations", "spmv_launches"):
+            st.setdefault(k, 0)
+        st.setdefault("solve_s", 0.0)
+        st.setdefault("spmv_ms", 0.0)
+        self.rtol, self.maxit = rtol, maxit
+        self.nstep, self.iterat_max, self.error_max = int(ctl["nstep"]), int(ctl["iterat_max"]), float(ctl["error_max"])
+        self.relax, self.scale_re, self.scale_up, self.scale_dn = (
+            float(ctl[k]) for k in ("relax", "scale_re", "scale_up", "scale_dn"))
+        self.disp_output, self.ultimate_strain = ctl["disp_output"], float(ctl["ultimate_strain"])
+        self.Et_E, self.target_LF, self.sy_inp = float(ctl["Et_E"]), float(ctl["target_LF"]), float(ctl["sig_yield"])
+        self.grav = (float(ctl["grav_x"]), float(ctl["grav_y"]), float(ctl["grav_z"]))
+        self.LD = ctl.get("gnl", "GNLN") == "GNLY"
+        if self.LD:  # fcVM.py:1087-1094
+            self.relax, self.disp_output, self.scale_up = 1.0, "total", 1.1
+        ndof, nelem = model.ndof, model.ne
+        self.ndof, self.nelem = ndof, nelem
+        self.glv, self.modf, self.V, self.xgp = model.calc_gsm(self.grav)
+        self.glv_h = self.glv.get()
+        g3 = self.glv_h.reshape(-1, 3)
+        self.loadsum = (g3[:, 0].sum(), g3[:, 1].sum(), g3[:, 2].sum())
+        self.qnorm = float(np.linalg.norm(self.glv_h))
+        if self.qnorm < 1.0:
+            self.qnorm = 1.0
+        self.f = c.mul(model.fixdof, self.glv)
+        c.axpby(1.0, self.f, 1.0, self.modf, out=self.f)
+        self.ue = self.solve(self.f)
+        self.disp_el = self.ue.clone()
+        self.dl0 = 1.0 / self.nstep
+        self.dl = self.dl0
+        self.du = c.axpby(self.dl, self.ue, 0.0, None)
+        self.sig_new, self.sig_old, self.sig_test = c.zeros(24 * nelem), c.zeros(24 * nelem), c.zeros(24 * nelem)
+        self.sig_yield = c.array(np.full(4 * nelem, self.sy_inp))
+        self.peeq, self.triax, self.pressure = c.zeros(4 * nelem), c.zeros(4 * nelem), c.zeros(4 * nelem)
+        self.sigmises, self.ecr, self.csr = c.zeros(4 * nelem), c.zeros(4 * nelem), c.zeros(4 * nelem)
+        self.pgp = c.zeros(4 * nelem, np.uint8)
+        self.disp_new, self.disp_old = c.zeros(ndof), c.zeros(ndof)
+        self.qin, self.r, self.tmp = c.zeros(ndof), c.zeros(ndof), c.zeros(ndof)
+        self.a = None
+        self.lbd, self.rfl = [0.0], [0.0]
+        if model.moving:  # fcVM.py:1169-1177
+            self.usl(self.ue)
+            c.mul(model.movdof, self.qin, out=self.tmp)
+            self.qnorm = c.norm(self.tmp)
+            self.sig_new.zero()
+        self.step, self.fail, self.mrr = -1, False, False
+        self.iterat, self.iterat_tot, self.restart_count, self.aa = 0, 0, 0, 0.0
+        self.un, self.csrplot, self.crip, self.pplot, self.svmplot = [0.0], [0.0], [0], [0.0], [0.0]
+        self.triaxplot, self.peeqplot, self.peeqmax, self.ecrplot = [0.0], [0.0], [0.0], [0.0]
+        self.elastic_only = float(self.nstep) == 1.0
+        if self.elastic_only:  # fcVM.py:1216-1223
+            self.step = 0
+            self.disp_new = self.ue.clone()
+            self.lbd.append(1.0)
+            self.rfl.append(1.0)
+            self.un.append(float(np.max(np.abs(self.ue.get()))))
+        self.sig_new.zero()  # fcVM.py:1301-1302 (unconditional in the reference)
+        self.pgp.zero()
+
+    # -- building blocks ----------------------------------------------------------------------
+    def solve(self, rhs):
+        t0 = time.perf_counter()
+        u, info = self.c.solve(rhs, rtol=self.rtol, maxit=self.maxit)
+        st = self.st
+        st["solve_s"] += time.perf_counter() - t0
+        st["pcg_iterations"] += info["iterations"]
+        st["solves"] += 1
+        st["spmv_ms"] += self.c.solve_timing()["spmv_ms"]
+        st["spmv_launches"] += info["spmv"]
+        return u
+
+    def usl(self, d_u):
+        """update_stress_load with the current state (fcVM.py:1325, 1442, 1478)"""
+        self.c.update_stress_load(self.sig_yield, self.disp_new, d_u, self.sig_old, self.sig_new, self.sig_test,
+                                  self.qin, self.Et_E, self.LD, self.pgp)
+        self.st["stress_updates"] += 1
+
+    def residual(self, lam, with_modf=False):
+        """r = fixdof * (lam * glv - qin); returns ||r|| / qnorm (fcVM.py:1329-1341, 1446-1448, 1480-1482)"""
+        c = self.c
+        c.axpby(lam, self.glv, -1.0, self.qin, out=self.tmp)
+        if with_modf:
+            c.axpby(1.0, self.tmp, lam, self.modf, out=self.tmp)
+        c.mul(self.model.fixdof, self.tmp, out=self.r)
+        return c.norm(self.r) / self.qnorm
+
+    def record(self):
+        c = self.c
+        self.un.append(c.max_node_norm(self.disp_new, (self.ndof - 1) // 3))  # fcVM.py:1539-1542: last node skipped
+        o = c.update_peeq_csr(self.sig_test, self.sig_new, self.sig_yield, self.ultimate_strain, self.peeq, self.csr,
+                              self.triax, self.pressure, self.sigmises, self.ecr, self.Et_E)
+        self.csrplot.append(o["csr_max"]); self.crip.append(o["maxloc"]); self.pplot.append(o["pressure"])
+        self.svmplot.append(o["sigmises"]); self.triaxplot.append(o["triax"]); self.ecrplot.append(o["ecr"])
+        self.peeqplot.append(o["peeq"]); self.peeqmax.append(o["peeq_max"])
+
+    # -- the loop's moves ---------------------------------------------------------------------
+    def start_step(self):
+        """fcVM.py:1310-1344: predictor with the current (dl, du); returns the out-of-balance error."""
+        self.step += 1
+        self.restart_count = 0
+        self.say("Step: {}".format(self.step))
+        self.a = self.du.clone()
+        self.sig_old.copy_from(self.sig_new)
+        self.lbd.append(self.lbd[self.step] + self.dl)
+        self.usl(self.du)
+        self.error = self.residual(self.lbd[self.step + 1])
+        self.iterat = 0
+        self.say("Iteration: {}, Error: {:.2e}".format(self.iterat, self.error))
+        return self.error
+
+    def iteration(self):
+        """One Newton iteration, fcVM.py:1346-1455 (without the restart logic)."""
+        c, step, lbd = self.c, self.step, self.lbd
+        self.iterat += 1
+        self.iterat_tot += 1
+        self.st["newton_iterations"] += 1
+        if self.LD and (self.iterat == 1 or bool(self.pgp.get().any())):  # fcVM.py:1351-1396
+            self.glv, self.modf, _, _ = self.model.calc_gsm(self.grav, disp=self.disp_new, sig=self.sig_old,
+                                                            pgp=self.pgp, Et_E=self.Et_E, want_x=False)
+            c.mul(self.model.fixdof, self.glv, out=self.f)
+            c.axpby(1.0, self.f, 1.0, self.modf, out=self.f)
+            self.ue = self.solve(self.f)
+            self.a = self.ue.clone()
+            c.axpby(c.norm(self.du) / c.norm(self.a), self.a, 0.0, None, out=self.a)
+        c.axpby(self.relax, self.r, 0.0, None, out=self.f)
+        due = self.solve(self.f)
+        self.dl = -c.dot(self.a, due) / c.dot(self.a, self.ue)  # fcVM.py:1414-1417 Riks correction
+        lbd[step + 1] += self.dl
+        self.aa = c.norm(self.a)
+        c.axpby(1.0, self.du, 1.0, due, out=self.du)
+        c.axpby(1.0, self.du, self.dl, self.ue, out=self.du)
+        uu = c.norm(self.du)
+        sf = min(self.aa / uu, 1.0)
+        lbd[step + 1] = lbd[step] + sf * (lbd[step + 1] - lbd[step])
+        c.axpby(sf, self.du, 0.0, None, out=self.du)
+        self.usl(self.du)
+        self.error = self.residual(lbd[step + 1])
+        self.say("Iteration: {}, Error: {:.2e}".format(self.iterat, self.error))
+        return self.error
+
+    def restart(self):
+        """fcVM.py:1457-1484 (called when iterat > iterat_max)."""
+        c = self.c
+        self.say("RESTART # {}".format(self.restart_count + 1))
+        if self.restart_count > 3:
+            self.say("MAXIMUM RESTARTS REACHED")
+            self.fail = False
+            self.step -= 1
+            self.lbd = self.lbd[:-1]
+            self.mrr = True
+        self.restart_count += 1
+        step, lbd = self.step, self.lbd
+        if step > 0 and not self.mrr:
+            self.dl = (lbd[step] - lbd[step - 1]) / self.scale_re / self.restart_count
+            k = 1.0 / self.scale_re / self.restart_count
+            c.axpby(k, self.disp_new, -k, self.disp_old, out=self.du)
+        elif not self.mrr:
+            self.dl = self.dl0 / self.scale_re / self.restart_count
+            c.axpby(self.dl / self.scale_re / self.restart_count, self.ue, 0.0, None, out=self.du)
+        lbd[step + 1] = lbd[step] + self.dl
+        if not self.mrr:
+            self.usl(self.du)
+            self.error = self.residual(lbd[step + 1], with_modf=True)
+            self.iterat = 0
+
+    def end_step(self):
+        """fcVM.py:1486-1559; returns True when the pass must stop (target load reached)."""
+        c, step, lbd = self.c, self.step, self.lbd
+        if abs(self.target_LF - lbd[step]) < abs(lbd[step + 1] - lbd[step]):  # fcVM.py:1486-1510
+            self.say("REACHED TARGET LOAD")
+            fac = (self.target_LF - lbd[step]) / (lbd[step + 1] - lbd[step])
+            c.axpby(fac, self.du, 0.0, None, out=self.du)
+            c.axpby(fac, self.sig_new, 1.0 - fac, self.sig_old, out=self.sig_new)
+            c.axpby(fac, self.sig_test, 1.0 - fac, self.sig_old, out=self.sig_test)
+            lbd[step + 1] = self.target_LF
+            c.axpby(1.0, self.disp_new, 1.0, self.du, out=self.disp_new)
+            self.record()
+            return True
+        if not self.mrr:  # fcVM.py:1515-1559
+            self.disp_old.copy_from(self.disp_new)
+            c.axpby(1.0, self.disp_new, 1.0, self.du, out=self.disp_new)
+            self.dl = lbd[step + 1] - lbd[step]
+            if self.model.moving:
+                self.rfl.append(c.dot(self.model.movdof, self.qin))
+            if self.iterat > 10:
+                self.dl /= self.scale_dn
+                c.axpby(1.0 / self.scale_dn, self.du, 0.0, None, out=self.du)
+            if self.iterat < 5:
+                self.dl *= self.scale_up
+                c.axpby(self.scale_up, self.du, 0.0, None, out=self.du)
+            self.record()
+        return False
+
+    def result(self):
+        lout = self.rfl if self.model.moving else self.lbd
+        if self.disp_output == "total":
+            res = self.disp_new.get()
+        else:
+            res = self.disp_new.get() - self.disp_old.get()
+        return dict(displacements=res, disp_el=self.disp_el.get(), stresses=self.sig_new, peeq=self.peeq,
+                    sigmises=self.sigmises, csr=self.csr, lout=np.asarray(lout), un=np.asarray(self.un),
+                    crip=np.asarray(self.crip), peeqplot=np.asarray(self.peeqplot), pplot=np.asarray(self.pplot),
+                    svmplot=np.asarray(self.svmplot), triaxplot=np.asarray(self.triaxplot),
+                    ecrplot=np.asarray(self.ecrplot), csrplot=np.asarray(self.csrplot), fail=self.fail,
+                    iterat_tot=self.iterat_tot, lbd=np.asarray(self.lbd), x=self.xgp.get().reshape(-1, 3), V=self.V,
+                    loadsum=self.loadsum, glv=self.glv_h, sig_yield=self.sig_yield, stats=self.st)
+
+
+def calc_disp(model, ctl, log=None, rtol=1e-10, maxit=50000, max_passes=1, stats=None):
+    """GPU calcDisp (fcVM.py:1083-1635).  ctl: dict as read from the .inp control file
+    (inpout.read_inp).  The interactive plot() between passes (fcVM.py:1615) is replaced by
+    "stop after max_passes passes of nstep steps"."""
+    d = RiksDriver(model, ctl, log=log, rtol=rtol, maxit=maxit, stats=stats)
+    cnt = not d.elastic_only
+    passes = 0
+    while cnt:
+        pstep = 0
+        while pstep < d.nstep and not d.mrr:
+            pstep += 1
+            error = d.start_step()
+            while error > d.error_max and not d.mrr:
+                error = d.iteration()
+                if d.iterat > d.iterat_max:
+                    d.restart()
+                    error = d.error
+            if d.end_step():
+                break
+        passes += 1
+        cnt = passes < max_passes and not d.mrr
+    return d.result()
+
+
+def run_analysis(elNodes, nocoord, material, fix, loads, ctl, device=0, log=None, rtol=1e-10, model=None):
+    """fcVM.FCMacro:118-175 without FreeCAD: calcGSM -> calcDisp -> mapStresses (all on the GPU).
+    Returns the calc_disp dict extended with the nodal (tet10) result fields on the host."""
+    if model is None:
+        model = GpuModel(elNodes, nocoord, material, fix, loads, device=device)
+    res = calc_disp(model, ctl, log=log, rtol=rtol)
+    c = model.ctx
+    t10 = c.map_stresses(False, res["stresses"], res["peeq"], res["sigmises"], res["csr"], float(ctl["sig_yield"]))
+    ps, pv = c.principal_stress(t10[0])
+    res.update(tet10stress=t10[0].get().reshape(-1, 6), tet10peeq=t10[1].get(), tet10csr=t10[2].get(),
+               tet10svm=t10[3].get(), tet10triax=t10[4].get(), principal=ps.get().reshape(-1, 3),
+               principal_vec=pv.get().reshape(-1, 3, 3), model=model)
+    for k in ("stresses", "peeq", "sigmises", "csr", "sig_yield"):
+        res[k] = res[k].get()
+    return res

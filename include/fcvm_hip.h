@@ -1,0 +1,150 @@
+/*
+ * fcvm_hip.h -- C-ABI of libfcvm_hip.so: the MI355X (gfx950) hot path of the fcVM
+ * elastoplastic tet10 solver.
+ *
+ * The reference (HarryvL/fcVM-workbench, "source code/fcVM.py") is Python + numba + CHOLMOD; the
+ * entry points below are what a binding for its per-element / linear-solve path has to call.
+ * Each one cites the reference routine it replaces.  All pointers are plain host or device
+ * pointers (documented per argument as [host] / [dev]); no torch / numpy types cross this line.
+ *
+ * Conventions (same as the reference): elNodes 1-based [ne][10] in fcVM's internal node order;
+ * dof = 3*(node-1)+k; stress vectors (xx,yy,zz,xy,zx,yz); 4 Gauss points / element, Gauss-point
+ * arrays are [4*ne] or [24*ne]; everything is FP64.
+ *
+ * Every function returns 0 on success, non-zero on failure; fcvm_last_error() describes the
+ * failure of the calling thread's last call.
+ */
+#ifndef FCVM_HIP_H
+#define FCVM_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fcvm_ctx fcvm_ctx;
+
+const char *fcvm_last_error(void);
+int fcvm_version(void);
+int fcvm_device_count(int *count);
+
+/* one context = one GPU + one HIP stream + one mesh partition */
+int fcvm_create(int device, fcvm_ctx **out);
+int fcvm_destroy(fcvm_ctx *c);
+int fcvm_synchronize(fcvm_ctx *c);
+/* run the context's kernels on an externally owned hipStream_t (e.g. torch's current stream,
+ * needed so RCCL collectives issued by the host order correctly with them); 0 = own stream */
+int fcvm_set_stream(fcvm_ctx *c, void *hip_stream);
+
+/* raw device memory helpers for the host binding */
+int fcvm_malloc(fcvm_ctx *c, uint64_t bytes, void **dev);
+int fcvm_free(fcvm_ctx *c, void *dev);
+int fcvm_h2d(fcvm_ctx *c, void *dev, const void *host, uint64_t bytes);
+int fcvm_d2h(fcvm_ctx *c, void *host, const void *dev, uint64_t bytes);
+int fcvm_d2d(fcvm_ctx *c, void *dst, const void *src, uint64_t bytes);
+int fcvm_memset0(fcvm_ctx *c, void *dev, uint64_t bytes);
+
+/*
+ * Mesh, material and displacement boundary conditions.
+ * Replaces the (elNodes, nocoord, materialbyElement, fix) arguments of calcGSM / calcTSM /
+ * update_stress_load (fcVM.py:621, 820, 2197).  Builds the node-node sparsity pattern and the
+ * sliced-ELL 3x3-block matrix layout (host threads), uploads everything.
+ * elNodes [host] int64 [ne*10] 1-based, nocoord [host] f64 [nn*3].
+ * fix: nfix pairs (dof, value) -- the reference's numba Dict `fix` (fcVM.py:222-254).
+ */
+int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, const double *nocoord);
+int fcvm_set_material(fcvm_ctx *c, double E, double nu, double density);
+int fcvm_set_fix(fcvm_ctx *c, int64_t nfix, const int64_t *dofs, const double *vals);
+/* nodal coordinate update (imperfections, fcVM.py:1240) */
+int fcvm_set_coords(fcvm_ctx *c, const double *nocoord);
+
+/* pattern statistics: out[0]=nnz blocks, out[1]=padded block slots, out[2]=slices,
+ * out[3]=matrix bytes (values+cols), out[4]=max row length, out[5]=ndof */
+int fcvm_pattern_info(fcvm_ctx *c, int64_t out[6]);
+/* host copy of the assembled matrix as scalar COO (row, col, val) of the FULL symmetric matrix,
+ * nnz = 9 * nnz blocks; for tests.  Arrays must hold 9*out[0] entries. */
+int fcvm_matrix_to_coo(fcvm_ctx *c, int64_t *row, int64_t *col, double *val);
+
+/*
+ * calcGSM (fcVM.py:729-800) / material part of calcTSM (fcVM.py:940-1050).
+ * Integrates K^e = sum_gp B^T D B |J| w for every element on the GPU and scatters it into the
+ * global matrix with the displacement boundary conditions folded in exactly as the reference
+ * does (unit diagonal per element occurrence on fixed dofs, modf corrections).
+ *   disp   [dev|NULL] f64[3nn]  coordinates are nocoord+disp when given (calcTSM, fcVM.py:962-967)
+ *   sig    [dev|NULL] f64[24ne], pgp [dev|NULL] u8[4ne]: plastic tangent D - pmat at plastic
+ *          Gauss points (fcVM.py:983-998); Et_E hardening ratio
+ *   grav   gravity vector; glv_grav [dev] f64[3nn] receives (=, not +=) the gravity load vector
+ *   modf   [dev] f64[3nn] receives the boundary-condition load modification
+ *   xgp    [dev|NULL] f64[4ne*3] Gauss point coordinates; volume [host|NULL]
+ * Afterwards the block-Jacobi preconditioner is refreshed.
+ */
+int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint8_t *pgp,
+                  double Et_E, const double grav[3], double *glv_grav, double *modf, double *xgp,
+                  double *volume);
+
+/*
+ * update_stress_load (fcVM.py:2197-2464): strain increment, trial stress, von Mises radial
+ * return (vmises_original_optimised, fcVM.py:2469-2492), internal force vector.
+ * All arrays [dev].  qin is overwritten (the reference passes a zeroed vector).  LD != 0 selects
+ * the updated-Lagrange branch (fcVM.py:2256-2260, 2383-2429).
+ */
+int fcvm_update_stress_load(fcvm_ctx *c, const double *sig_yield, const double *disp_new,
+                            const double *du, const double *sig_old, double *sig_new,
+                            double *sig_test, double *qin, double Et_E, int LD, uint8_t *pgp);
+
+/*
+ * update_PEEQ_CSR (fcVM.py:2085-2137) plus the reductions calcDisp takes right after it
+ * (fcVM.py:1546-1554): out[0]=argmax(csr) (first occurrence), out[1]=max(csr), out[2]=max(peeq),
+ * out[3..7]= pressure, sigmises, triax, ecr, peeq at that Gauss point.  Arrays [dev], out [host].
+ */
+int fcvm_update_peeq_csr(fcvm_ctx *c, const double *sig_test, const double *sig_new,
+                         double *sig_yield, double ultimate_strain, double *peeq, double *csr,
+                         double *triax, double *pressure, double *sigmises, double *ecr,
+                         double Et_E, double out[8]);
+
+/* mapStresses (fcVM.py:2497-2554). sig etc. [dev]; outputs [dev]: t10s f64[nn*6], others f64[nn] */
+int fcvm_map_stresses(fcvm_ctx *c, int averaged, const double *sig, const double *peeq,
+                      const double *sigvm, const double *csr, double sig_yield, double *t10s,
+                      double *t10peeq, double *t10csr, double *t10svm, double *t10triax);
+
+/* calculate_principal_stress (fcVM.py:2954-2994): t10s [dev] f64[nn*6] ->
+ * ps [dev] f64[nn*3] (descending), pv [dev] f64[nn*9] (three eigenvectors scaled by their
+ * eigenvalue, row k = k-th principal direction) */
+int fcvm_principal_stress(fcvm_ctx *c, int64_t n, const double *t10s, double *ps, double *pv);
+
+/*
+ * Linear solve K u = f, replacing sksparse.cholmod `factor(f)` (fcVM.py:1121-1135, 1401):
+ * block-Jacobi preconditioned conjugate gradients on the assembled matrix, FP64, device resident.
+ * f, u [dev] f64[3nn].  Stops at ||r|| <= rtol*||f|| or maxit.  info[0]=iterations,
+ * info[1]=final relative residual, info[2]=SpMV launches.  [host]
+ */
+int fcvm_solve(fcvm_ctx *c, const double *f, double *u, double rtol, int64_t maxit, double info[3]);
+
+/* y = K x on the assembled matrix ([dev] f64[3nn]); building block of the multi-GPU solver */
+int fcvm_spmv(fcvm_ctx *c, const double *x, double *y);
+/* z = M^-1 r with the 3x3 block-Jacobi preconditioner */
+int fcvm_precond(fcvm_ctx *c, const double *r, double *z);
+/* diagonal 3x3 blocks [dev] f64[nn*9]: get (for the interface sum across ranks) / set+invert */
+int fcvm_get_diag_blocks(fcvm_ctx *c, double *dblk);
+int fcvm_set_diag_blocks(fcvm_ctx *c, const double *dblk);
+
+/* small FP64 vector kernels used by the Newton / Riks driver (all [dev], n entries) */
+int fcvm_vec_axpby(fcvm_ctx *c, int64_t n, double a, const double *x, double b, const double *y, double *out);
+int fcvm_vec_mul(fcvm_ctx *c, int64_t n, const double *x, const double *y, double *out);
+int fcvm_vec_dot(fcvm_ctx *c, int64_t n, const double *x, const double *y, double *result_host);
+/* w-weighted dot: sum w_i x_i y_i (owner weights of the multi-GPU partition); result [dev] */
+int fcvm_vec_wdot_dev(fcvm_ctx *c, int64_t n, const double *w, const double *x, const double *y, double *result_dev);
+/* sqrt(max over the first nnodes nodes of |u_node|^2) (fcVM.py:1539-1542) */
+int fcvm_vec_max_node_norm(fcvm_ctx *c, int64_t nnodes, const double *u, double *result_host);
+
+/* timing of the last fcvm_solve: HIP-event milliseconds spent in SpMV launches and in total */
+int fcvm_solve_timing(fcvm_ctx *c, double out_ms[2]);
+
+/* host-only self check of the sparsity pattern builder (no GPU needed): out[0]=nnz blocks,
+ * out[1]=padded slots, out[2]=slices, out[3]=max row length, out[4]=number of violated invariants
+ * (must be 0), out[5]=value count, out[6]=sum of slice lengths */
+int fcvm_host_pattern_check(int64_t ne, int64_t nn, const int64_t *elNodes, int64_t out[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,293 @@
+"""HIP path (through the C-ABI of libfcvm_hip.so) against the CPU oracle and the reference's
+golden result files.  FP64 throughout; tolerances are relative to the field's max magnitude:
+1e-11 for single kernels (only summation order differs), 1e-6 (north_star) for whole analyses."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from conftest import load_golden, small_case
+
+pytestmark = pytest.mark.gpu
+
+KTOL = 1e-11
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    s = np.abs(b).max()
+    return np.abs(a - b).max() / (s if s > 0 else 1.0)
+
+
+def make_model(case, loads=True):
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import GpuModel
+    ld = Loads(ufaces=case["ufaces"], uloads=case["uloads"]) if loads else Loads()
+    return GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"], ld)
+
+
+def oracle_full_matrix(orc, case, grav, **kw):
+    stm, row, col, glv, modf, V, *_ls, ne, nn, x = orc.calcGSM(
+        case["elNodes"], case["nocoord"], case["material"], case["fix"], grav,
+        orc.Loads(ufaces=case["ufaces"], uloads=case["uloads"]), **kw)
+    n = 3 * len(case["nocoord"])
+    low = sp.coo_matrix((stm, (row, col)), shape=(n, n)).tocsr()
+    full = low + sp.tril(low, -1).T
+    return full.tocsr(), glv, modf, V, x
+
+
+def gpu_matrix(model):
+    r, c, v = model.ctx.matrix_coo()
+    n = model.ndof
+    return sp.coo_matrix((v, (r, c)), shape=(n, n)).tocsr()
+
+
+@pytest.mark.parametrize("n", [1, 3])
+def test_assemble_matches_calcGSM(orc, n):
+    case = small_case(n)
+    grav = (0.3, -0.2, -9.81)
+    Ko, glv_o, modf_o, V_o, x_o = oracle_full_matrix(orc, case, grav)
+    m = make_model(case)
+    glv, modf, V, xgp = m.calc_gsm(grav)
+    Kg = gpu_matrix(m)
+    assert abs(Kg - Ko).max() <= KTOL * abs(Ko).max()
+    assert rel(glv.get(), glv_o) < KTOL
+    assert rel(modf.get(), modf_o) < KTOL
+    assert rel(xgp.get(), x_o.reshape(-1)) < KTOL
+    assert abs(V - V_o) < 1e-11 * abs(V_o)
+    # fixed dofs: unit diagonal per connected element, nothing else in row / column
+    d = Kg.diagonal()
+    noce = orc.node_element_count(case["elNodes"], len(case["nocoord"]))
+    for dof in case["fix"]:
+        assert d[dof] == noce[dof // 3]
+        assert Kg[dof].nnz == 1 or abs(Kg[dof]).sum() == d[dof]
+
+
+def _random_state(case, rng, scale):
+    nn, ne = len(case["nocoord"]), len(case["elNodes"])
+    du = rng.standard_normal(3 * nn) * scale
+    disp = rng.standard_normal(3 * nn) * scale
+    sig = rng.standard_normal(24 * ne) * 50.0
+    sy = np.full(4 * ne, 200.0) + rng.random(4 * ne) * 50.0
+    return du, disp, sig, sy
+
+
+@pytest.mark.parametrize("LD", [False, True])
+def test_update_stress_load_matches(orc, gpu_ctx, LD):
+    case = small_case(3)
+    rng = np.random.default_rng(5)
+    du, disp, sig, sy = _random_state(case, rng, 2e-3)
+    ne, nn = len(case["elNodes"]), len(case["nocoord"])
+    s_new, s_test, q = np.zeros(24 * ne), np.zeros(24 * ne), np.zeros(3 * nn)
+    pg = np.zeros(4 * ne, np.uint8)
+    orc.update_stress_load(case["elNodes"], case["nocoord"], case["material"], sy, disp, du, sig, s_new, s_test, q,
+                           0.05, LD, pg)
+    assert 0 < pg.sum() < len(pg), "test state must mix elastic and plastic Gauss points"
+    m = make_model(case)
+    c = m.ctx
+    d_new, d_test, d_q, d_pg = c.empty(24 * ne), c.empty(24 * ne), c.empty(3 * nn), c.empty(4 * ne, np.uint8)
+    c.update_stress_load(c.array(sy), c.array(disp), c.array(du), c.array(sig), d_new, d_test, d_q, 0.05, LD, d_pg)
+    assert np.array_equal(d_pg.get(), pg)
+    assert rel(d_test.get(), s_test) < KTOL
+    assert rel(d_new.get(), s_new) < KTOL
+    assert rel(d_q.get(), q) < KTOL
+
+
+def test_tangent_assemble_matches_calcTSM(orc):
+    case = small_case(3)
+    rng = np.random.default_rng(7)
+    du, disp, sig, sy = _random_state(case, rng, 1e-3)
+    ne = len(case["elNodes"])
+    pgp = (rng.random(4 * ne) < 0.4).astype(np.uint8)
+    grav = (0.0, 0.0, -9.81)
+    Ko, glv_o, modf_o, _, _ = oracle_full_matrix(orc, case, grav, disp=disp, sig=sig, pgp=pgp, Et_E=0.1)
+    m = make_model(case)
+    c = m.ctx
+    glv, modf, _, _ = m.calc_gsm(grav, disp=c.array(disp), sig=c.array(sig), pgp=c.array(pgp, np.uint8), Et_E=0.1)
+    Kg = gpu_matrix(m)
+    assert abs(Kg - Ko).max() <= KTOL * abs(Ko).max()
+    assert rel(modf.get(), modf_o) < KTOL
+    # pressure-free model: glv = uniform face load + gravity on the displaced geometry
+    assert rel(glv.get(), glv_o) < KTOL
+
+
+def test_update_peeq_csr_matches(orc, gpu_ctx):
+    case = small_case(2)
+    rng = np.random.default_rng(11)
+    ne = len(case["elNodes"])
+    mat = case["material"]
+    st, sn = rng.standard_normal(24 * ne) * 150, rng.standard_normal(24 * ne) * 100
+    arrs = dict(sy=np.full(4 * ne, 235.0), peeq=rng.random(4 * ne) * 1e-3, csr=rng.random(4 * ne) * 1e-2)
+    host = {k: v.copy() for k, v in arrs.items()}
+    tri, pre, svm, ecr = (np.zeros(4 * ne) for _ in range(4))
+    orc.update_PEEQ_CSR(ne, mat, st, sn, host["sy"], 0.25, host["peeq"], host["csr"], tri, pre, svm, ecr, 0.02)
+    m = make_model(case)
+    c = m.ctx
+    d = {k: c.array(v) for k, v in arrs.items()}
+    dt, dp, ds, de = (c.zeros(4 * ne) for _ in range(4))
+    o = c.update_peeq_csr(c.array(st), c.array(sn), d["sy"], 0.25, d["peeq"], d["csr"], dt, dp, ds, de, 0.02)
+    for k in arrs:
+        assert rel(d[k].get(), host[k]) < 1e-13, k
+    assert rel(dt.get(), tri) < 1e-13 and rel(dp.get(), pre) < 1e-13 and rel(ds.get(), svm) < 1e-13
+    assert rel(de.get(), ecr) < 1e-12
+    ml = int(np.argmax(host["csr"]))
+    assert o["maxloc"] == ml
+    assert o["csr_max"] == pytest.approx(host["csr"][ml], rel=1e-13)
+    assert o["peeq_max"] == pytest.approx(host["peeq"].max(), rel=1e-13)
+    assert o["pressure"] == pytest.approx(pre[ml], rel=1e-13)
+    assert o["sigmises"] == pytest.approx(svm[ml], rel=1e-13)
+
+
+@pytest.mark.parametrize("averaged", [False, True])
+def test_map_stresses_and_principal(orc, gpu_ctx, averaged):
+    case = small_case(3)
+    rng = np.random.default_rng(3)
+    ne, nn = len(case["elNodes"]), len(case["nocoord"])
+    sig, peeq = rng.standard_normal(24 * ne) * 100, rng.random(4 * ne)
+    svm, csr = rng.random(4 * ne) * 200, rng.random(4 * ne)
+    noce = orc.node_element_count(case["elNodes"], nn)
+    ref = orc.mapStresses(averaged, case["elNodes"], case["nocoord"], sig, peeq, svm, csr, noce, 235.0)
+    m = make_model(case)
+    c = m.ctx
+    out = c.map_stresses(averaged, c.array(sig), c.array(peeq), c.array(svm), c.array(csr), 235.0)
+    assert rel(out[0].get(), ref[0].reshape(-1)) < 1e-12
+    for k in range(1, 5):
+        assert rel(out[k].get(), ref[k]) < 1e-12, k
+    ps, pv = c.principal_stress(out[0])
+    s1, s2, s3, v1, v2, v3 = orc.calculate_principal_stress(ref[0])
+    ps = ps.get().reshape(-1, 3)
+    pv = pv.get().reshape(-1, 3, 3)
+    scale = np.abs(ref[0]).max()
+    assert np.abs(ps - np.stack([s1, s2, s3], 1)).max() < 1e-12 * scale
+    for k, v in enumerate((v1, v2, v3)):
+        d = np.minimum(np.abs(pv[:, k] - v).max(1), np.abs(pv[:, k] + v).max(1))
+        assert d.max() < 1e-9 * scale
+
+
+def test_pcg_solve_matches_direct(orc):
+    case = small_case(4)
+    Ko, glv_o, modf_o, _, _ = oracle_full_matrix(orc, case, (0, 0, -9.81))
+    m = make_model(case)
+    c = m.ctx
+    glv, modf, _, _ = m.calc_gsm((0, 0, -9.81))
+    f = c.mul(m.fixdof, glv)
+    c.axpby(1.0, f, 1.0, modf, out=f)
+    u, info = c.solve(f, rtol=1e-12)
+    fixdof = m.fixdof_h
+    u_ref = spla.spsolve(Ko.tocsc(), fixdof * glv_o + modf_o)
+    assert info["rel_residual"] <= 1e-12
+    assert rel(u.get(), u_ref) < 1e-9
+    for dof, val in case["fix"].items():
+        assert u.get()[dof] == pytest.approx(val, abs=1e-12)
+    # SpMV and preconditioner on their own
+    x = np.random.default_rng(1).standard_normal(m.ndof)
+    y = c.spmv(c.array(x), c.empty(m.ndof)).get()
+    assert rel(y, Ko @ x) < 1e-13
+    z = c.precond(c.array(x), c.empty(m.ndof)).get()
+    blocks = [np.linalg.inv(Ko[3 * i:3 * i + 3, 3 * i:3 * i + 3].toarray()) @ x[3 * i:3 * i + 3] for i in range(m.nn)]
+    assert rel(z, np.concatenate(blocks)) < 1e-10
+
+
+def test_vector_kernels(gpu_ctx):
+    c = make_model(small_case(1)).ctx
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(1000), rng.standard_normal(1000)
+    dx, dy = c.array(x), c.array(y)
+    assert np.allclose(c.axpby(2.0, dx, -0.5, dy).get(), 2 * x - 0.5 * y, rtol=0, atol=1e-15)
+    assert np.allclose(c.mul(dx, dy).get(), x * y, rtol=0, atol=1e-15)
+    assert c.dot(dx, dy) == pytest.approx(float(x @ y), rel=1e-13)
+    assert c.max_node_norm(dx, 300) == pytest.approx(np.sqrt((x[:900].reshape(-1, 3) ** 2).sum(1).max()), rel=1e-14)
+
+
+def test_embankment_analysis_matches_reference_files(orc, embankment):
+    """The whole GPU analysis (assembly, PCG, Riks loop, radial return, PEEQ/CSR, nodal mapping,
+    principal stresses) against the reference's own Embankment_with_Ditch_Example results."""
+    from fcvm_hip import inpout
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import run_analysis
+    from test_oracle_golden import sig3
+    g, meta = embankment
+    ctl = inpout.parse_inp_lines(meta["inp"])
+    fix = {int(d): float(v) for d, v in zip(g["fixed_dofs"], g["fixed_vals"])}
+    res = run_analysis(g["elNodes"], g["nocoord"], g["material"], fix, Loads(), ctl, rtol=1e-11)
+    tab = g["out_table"]
+    assert len(res["lout"]) == len(tab)
+    assert np.array_equal(res["crip"], tab[:, 0].astype(int))
+    for col, val in ((4, res["lout"]), (5, res["un"]), (6, res["peeqplot"]), (7, res["pplot"]), (8, res["svmplot"]),
+                     (9, res["triaxplot"]), (10, res["ecrplot"]), (11, res["csrplot"])):
+        assert sig3(val, tab[:, col]), "column %d" % col
+    tol = 1e-6  # north_star: 1e-6 relative on load-displacement curve and stresses
+    assert rel(res["displacements"], g["vtk_Displacement"].reshape(-1)) < tol
+    assert rel(res["tet10stress"], g["vtk_Stress_Tensor"]) < tol
+    assert rel(res["tet10peeq"], g["vtk_Equivalent_Plastic_Strain"]) < tol
+    assert rel(res["tet10csr"], g["vtk_Critical_Strain_Ratio"]) < tol
+    assert rel(res["tet10svm"], g["vtk_von_Mises_Stress"]) < tol
+    assert rel(res["principal"][:, 0], g["vtk_Major_Principal_Stress"]) < tol
+    assert rel(res["principal"][:, 2], g["vtk_Minor_Principal_Stress"]) < tol
+    # and against the oracle run of the same analysis: curve to 1e-6
+    o = orc.run_analysis(g["elNodes"], g["nocoord"], g["material"], fix, orc.Loads(), orc.read_inp_lines(meta["inp"]))
+    assert rel(res["lout"], o["lout"]) < tol and rel(res["un"], o["un"]) < tol
+
+
+def test_cube_analysis_matches_oracle(orc):
+    """Traction-loaded cube with prescribed displacements (moving boundary => reaction-force
+    output, fcVM.py:1169-1177, 1522-1523), hardening, 6 load steps."""
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import run_analysis
+    case = small_case(3)
+    ctl = dict(sig_yield=30.0, grav_x=0.0, grav_y=0.0, grav_z=-9.81, nstep=6, iterat_max=20, error_max=1e-4,
+               relax=1.2, scale_re=2.0, scale_up=1.2, scale_dn=1.2, disp_output="total", ultimate_strain=0.25,
+               Et_E=0.05, target_LF=10.0, csr_option="PEEQ", averaged_option="unaveraged", gnl="GNLN", maxImp="0.0",
+               ev1="1.0", ev2="0.0")
+    o = orc.run_analysis(case["elNodes"], case["nocoord"], case["material"], case["fix"],
+                         orc.Loads(ufaces=case["ufaces"], uloads=case["uloads"]), ctl)
+    assert o["peeq"].max() > 0, "case must yield"
+    res = run_analysis(case["elNodes"], case["nocoord"], case["material"], case["fix"],
+                       Loads(ufaces=case["ufaces"], uloads=case["uloads"]), ctl, rtol=1e-12)
+    assert len(res["lout"]) == len(o["lout"])
+    assert rel(res["lout"], o["lout"]) < 1e-6 and rel(res["un"], o["un"]) < 1e-6
+    assert rel(res["displacements"], o["displacements"]) < 1e-6
+    assert rel(res["stresses"], o["stresses"]) < 1e-6
+    assert rel(res["peeq"], o["peeq"]) < 1e-6
+    assert np.array_equal(res["crip"], o["crip"])
+
+
+def test_size_independent_properties_100k_elements(gpu_ctx):
+    """Properties that need no oracle, at a size the CPU restatement would take minutes for:
+    K symmetric (<x,Ky> = <y,Kx>), rigid translations in the null space of the unconstrained K,
+    elastic internal force == K du, PCG solution satisfies K u = f."""
+    from fcvm_hip import meshgen
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import GpuModel
+    el, xyz = meshgen.cube_tet10(26, 26, 26, 50.0, 50.0, 50.0)
+    mat = (210000.0, 0.3, 7.8e-6)
+    m = GpuModel(el, xyz, mat, {}, Loads())
+    c = m.ctx
+    glv, modf, V, _ = m.calc_gsm((0.0, 0.0, -9.81))
+    assert V == pytest.approx(50.0 ** 3, rel=1e-12)
+    assert glv.get().reshape(-1, 3)[:, 2].sum() == pytest.approx(-9.81 * 7.8e-6 * 50.0 ** 3, rel=1e-11)
+    rng = np.random.default_rng(2)
+    x, y = rng.standard_normal(m.ndof), rng.standard_normal(m.ndof)
+    dx, dy = c.array(x), c.array(y)
+    kx, ky = c.spmv(dx, c.empty(m.ndof)), c.spmv(dy, c.empty(m.ndof))
+    assert c.dot(dy, kx) == pytest.approx(c.dot(dx, ky), rel=1e-11)
+    t = np.tile([1.0, -2.0, 0.5], m.nn)
+    kt = c.spmv(c.array(t), c.empty(m.ndof)).get()
+    assert np.abs(kt).max() < 1e-9 * np.abs(kx.get()).max()
+    ne = m.ne
+    du = rng.standard_normal(m.ndof) * 1e-6
+    d_du = c.array(du)
+    q = c.empty(m.ndof)
+    c.update_stress_load(c.array(np.full(4 * ne, 1e30)), None, d_du, c.zeros(24 * ne), c.empty(24 * ne), c.empty(24 * ne),
+                         q, 0.0, False, c.empty(4 * ne, np.uint8))
+    kdu = c.spmv(d_du, c.empty(m.ndof)).get()
+    assert rel(q.get(), kdu) < 1e-10
+    # clamp the bottom, solve, check the residual of the returned solution with an independent SpMV
+    fix = {3 * int(n) + k: 0.0 for n in meshgen.nodes_on_plane(xyz, 2, 0.0) for k in range(3)}
+    m2 = GpuModel(el, xyz, mat, fix, Loads(), ctx=c)
+    glv, modf, _, _ = m2.calc_gsm((0.0, 0.0, -9.81))
+    f = c.mul(m2.fixdof, glv)
+    u, info = c.solve(f, rtol=1e-10)
+    r = c.axpby(1.0, f, -1.0, c.spmv(u, c.empty(m.ndof)))
+    assert c.norm(r) <= 2e-10 * c.norm(f)
+    assert info["iterations"] > 10
