@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -51,6 +52,7 @@ struct fcvm_ctx {
     long long *d_pidx = nullptr;
     int64_t nb_vec = 0, nb_spmv = 0, nb_gp = 0;
     double last_spmv_ms = 0, last_total_ms = 0;
+    int spmv_variant = 3;  // 0 plain, 1 nontemporal matrix loads, 2 unroll x2, 3 both (fastest measured)
     std::vector<hipEvent_t> evpool;
 };
 
@@ -80,6 +82,24 @@ static MatConst matconst(const fcvm_ctx *c, double Et_E) {
     return m;
 }
 
+template <bool DOT>
+static void launch_spmv_t(fcvm_ctx *c, const double *x, double *y, const double *done) {
+    dim3 grid((unsigned)c->nb_spmv), block(256);
+    double *part = DOT ? c->d_part_spmv : nullptr;
+#define FCVM_SPMV_ARGS c->pat.nslices, c->nb_spmv, c->d_sptr, c->d_cols, (const double2 *)c->d_vals, c->d_rownode, x, y, part, done
+    switch (c->spmv_variant) {
+        case 1: hipLaunchKernelGGL((k_spmv<DOT, true, 1>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
+        case 2: hipLaunchKernelGGL((k_spmv<DOT, false, 2>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
+        case 3: hipLaunchKernelGGL((k_spmv<DOT, true, 2>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
+        default: hipLaunchKernelGGL((k_spmv<DOT, false, 1>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
+    }
+#undef FCVM_SPMV_ARGS
+}
+static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done) {
+    if (dot) launch_spmv_t<true>(c, x, y, done);
+    else launch_spmv_t<false>(c, x, y, done);
+}
+
 extern "C" {
 
 const char *fcvm_last_error(void) { return g_err.c_str(); }
@@ -102,6 +122,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     NEED(prop.warpSize == 64, "fcvm_create: this library is built for 64-wide wavefronts (gfx950)");
     fcvm_ctx *c = new fcvm_ctx();
     c->device = device;
+    if (const char *v = getenv("FCVM_SPMV_VARIANT")) c->spmv_variant = atoi(v);
     HCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
     c->stream = c->own;
     if (dalloc(&c->d_S, S_COUNT) || dalloc(&c->d_out8, 16)) return 1;
@@ -183,7 +204,9 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
         int nt = (int)std::thread::hardware_concurrency();
         if (nt < 1) nt = 1;
         if (nt > 32) nt = 32;
-        build_pattern(ne, nn, el.data(), c->pat, nt);
+        int win = SORT_WINDOW;
+        if (const char *v = getenv("FCVM_SORT_WINDOW")) win = std::max(1, atoi(v));
+        build_pattern(ne, nn, el.data(), c->pat, nt, win);
     } catch (const std::exception &ex) {
         return fail(std::string("fcvm_set_mesh: ") + ex.what());
     }
@@ -386,16 +409,6 @@ int fcvm_principal_stress(fcvm_ctx *c, int64_t n, const double *t10s, double *ps
     return 0;
 }
 
-static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done) {
-    dim3 grid((unsigned)c->nb_spmv), block(256);
-    if (dot)
-        hipLaunchKernelGGL(k_spmv<true>, grid, block, 0, c->stream, c->pat.nslices, c->nb_spmv, c->d_sptr, c->d_cols,
-                           (const double2 *)c->d_vals, c->d_rownode, x, y, c->d_part_spmv, done);
-    else
-        hipLaunchKernelGGL(k_spmv<false>, grid, block, 0, c->stream, c->pat.nslices, c->nb_spmv, c->d_sptr, c->d_cols,
-                           (const double2 *)c->d_vals, c->d_rownode, x, y, (double *)nullptr, done);
-}
-
 int fcvm_spmv(fcvm_ctx *c, const double *x, double *y) {
     NEED(c && c->have_mesh, "fcvm_spmv: no mesh");
     NEED(x != y, "fcvm_spmv: x and y must not alias");
@@ -549,7 +562,7 @@ int fcvm_host_pattern_check(int64_t ne, int64_t nn, const int64_t *elNodes, int6
     }
     Pattern p;
     try {
-        build_pattern(ne, nn, el.data(), p, 4);
+        build_pattern(ne, nn, el.data(), p, 4, SORT_WINDOW);
     } catch (const std::exception &ex) {
         return fail(std::string("fcvm_host_pattern_check: ") + ex.what());
     }

@@ -431,7 +431,37 @@ __global__ __launch_bounds__(256) void k_diag_invert(int64_t nn, const double *_
 // instruction), two 4-byte column loads (coalesced) and two 24-byte gathers of x.
 // DOT: also emits the per-workgroup partial of sum_i x_i y_i (p.Ap of conjugate gradients).
 // ---------------------------------------------------------------------------------------------
-template <bool DOT>
+template <bool NT>
+__device__ __forceinline__ double2 ld_val(const double2 *p) {
+    if (NT) {
+        double2 r;
+        r.x = __builtin_nontemporal_load(&p->x);
+        r.y = __builtin_nontemporal_load(&p->y);
+        return r;
+    }
+    return *p;
+}
+template <bool NT>
+__device__ __forceinline__ int32_t ld_col(const int32_t *p) {
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+
+template <bool NT>
+__device__ __forceinline__ void spmv_pair(const int32_t *cp, const double2 *vp, const double *__restrict__ x,
+                                          double &y0, double &y1, double &y2) {
+    const int32_t c0 = ld_col<NT>(cp), c1 = ld_col<NT>(cp + 64);
+    double2 v[9];
+#pragma unroll
+    for (int c = 0; c < 9; c++) v[c] = ld_val<NT>(vp + c * 64);
+    const double *xa = x + 3 * (int64_t)c0, *xb = x + 3 * (int64_t)c1;
+    const double a0 = xa[0], a1 = xa[1], a2 = xa[2];
+    const double b0 = xb[0], b1 = xb[1], b2 = xb[2];
+    y0 += v[0].x * a0 + v[1].x * a1 + v[2].x * a2 + v[0].y * b0 + v[1].y * b1 + v[2].y * b2;
+    y1 += v[3].x * a0 + v[4].x * a1 + v[5].x * a2 + v[3].y * b0 + v[4].y * b1 + v[5].y * b2;
+    y2 += v[6].x * a0 + v[7].x * a1 + v[8].x * a2 + v[6].y * b0 + v[7].y * b1 + v[8].y * b2;
+}
+
+template <bool DOT, bool NT, int UNROLL>
 __global__ __launch_bounds__(256) void k_spmv(int64_t nslices, int64_t nblocks, const int64_t *__restrict__ sptr,
                                               const int32_t *__restrict__ cols,
                                               const double2 *__restrict__ vals,
@@ -453,18 +483,19 @@ __global__ __launch_bounds__(256) void k_spmv(int64_t nslices, int64_t nblocks, 
         const int64_t jb = sptr[s], je = sptr[s + 1];
         const int32_t *cp = cols + jb * 64 + lane;
         const double2 *vp = vals + (jb >> 1) * (9 * 64) + lane;
-        const int64_t np = (je - jb) >> 1;
-        for (int64_t jp = 0; jp < np; jp++) {
-            const int32_t c0 = cp[0], c1 = cp[64];
-            const double *xa = x + 3 * (int64_t)c0, *xb = x + 3 * (int64_t)c1;
-            double2 v[9];
-#pragma unroll
-            for (int c = 0; c < 9; c++) v[c] = vp[c * 64];
-            const double a0 = xa[0], a1 = xa[1], a2 = xa[2];
-            const double b0 = xb[0], b1 = xb[1], b2 = xb[2];
-            y0 += v[0].x * a0 + v[1].x * a1 + v[2].x * a2 + v[0].y * b0 + v[1].y * b1 + v[2].y * b2;
-            y1 += v[3].x * a0 + v[4].x * a1 + v[5].x * a2 + v[3].y * b0 + v[4].y * b1 + v[5].y * b2;
-            y2 += v[6].x * a0 + v[7].x * a1 + v[8].x * a2 + v[6].y * b0 + v[7].y * b1 + v[8].y * b2;
+        int64_t np = (je - jb) >> 1;
+        if (UNROLL == 2) {
+            double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+            for (; np >= 2; np -= 2) {
+                spmv_pair<NT>(cp, vp, x, y0, y1, y2);
+                spmv_pair<NT>(cp + 128, vp + 9 * 64, x, z0, z1, z2);
+                cp += 256;
+                vp += 18 * 64;
+            }
+            y0 += z0; y1 += z1; y2 += z2;
+        }
+        for (; np > 0; np--) {
+            spmv_pair<NT>(cp, vp, x, y0, y1, y2);
             cp += 128;
             vp += 9 * 64;
         }

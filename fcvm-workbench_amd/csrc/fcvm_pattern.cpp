@@ -26,7 +26,7 @@ static void parallel_for(int64_t n, int nthreads, const std::function<void(int64
     for (auto &x : th) x.join();
 }
 
-void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nthreads) {
+void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nthreads, int sort_window) {
     if (ne <= 0 || nn <= 0) throw std::runtime_error("empty mesh");
     for (int64_t i = 0; i < ne * 10; i++)
         if (el[i] < 0 || el[i] >= nn) throw std::runtime_error("element node index out of range");
@@ -78,7 +78,7 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
     p.nslices = (nn + SLICE - 1) / SLICE;
     p.rownode.assign(p.nslices * SLICE, -1);
     p.slotof.assign(nn, -1);
-    const int64_t win = (int64_t)SLICE * SORT_WINDOW;
+    const int64_t win = (int64_t)SLICE * sort_window;
     for (int64_t w0 = 0; w0 < nn; w0 += win) {
         int64_t w1 = std::min(nn, w0 + win);
         std::vector<int32_t> ids(w1 - w0);

@@ -7,7 +7,7 @@
 namespace fcvm {
 
 constexpr int SLICE = 64;           // rows (nodes) per slice = one wavefront, one row per lane
-constexpr int SORT_WINDOW = 8;      // slices per length-sorting window (512 rows)
+constexpr int SORT_WINDOW = 64;     // slices per length-sorting window (4096 rows); measured: 8 -> 64 = -4% bytes
 constexpr int64_t VSTRIDE = 2 * SLICE;  // doubles between two components of one 3x3 block
 
 struct Pattern {
@@ -34,6 +34,7 @@ struct Pattern {
 };
 
 // elnodes0: 0-based int32 [ne*10].  Throws std::runtime_error on bad input.
-void build_pattern(int64_t ne, int64_t nn, const int32_t *elnodes0, Pattern &p, int nthreads);
+void build_pattern(int64_t ne, int64_t nn, const int32_t *elnodes0, Pattern &p, int nthreads,
+                   int sort_window = SORT_WINDOW);
 
 }  // namespace fcvm
