@@ -1,0 +1,110 @@
+"""N > 1 leg of bench.py: one process per GPU (torch.distributed.run), weak scaling -- every rank
+owns one slab of cells^3 cells (6*cells^3 tet10) of a column of N stacked cubes; base clamped,
+traction on the top face of the last slab."""
+import json
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import meshgen
+from .dist import DistBackend, DistModel, HipLocalOps, Partition, TVec
+from .loads import Loads, external_loads
+from .solver import RiksDriver
+
+
+def build_rank_model(rank, world, cells, material, traction, device_index, backend_device, length=100.0, group=None):
+    c = cells
+    el, xyz = meshgen.cube_tet10(c, c, c, length, length, length)
+    mx = my = 2 * c + 1
+    el_g = el + rank * (2 * c) * mx * my  # z-slowest lattice numbering: slab r is a pure offset
+    xyz = xyz.copy()
+    xyz[:, 2] += rank * length
+    part = Partition(el_g, group=group)
+    assert part.nn == len(xyz) and np.array_equal(part.elNodes, el)
+    fix = {}
+    if rank == 0:
+        for nd in meshgen.nodes_on_plane(xyz, 2, 0.0):
+            for k in range(3):
+                fix[3 * int(nd) + k] = 0.0
+    if rank == world - 1:
+        faces = meshgen.boundary_faces_on_plane(el, xyz, 2, world * length)
+        loads = Loads(ufaces=faces, uloads=np.tile(np.asarray(traction, float), (len(faces), 1)))
+    else:
+        loads = Loads()
+    ops = HipLocalOps(part, xyz, material, fix, device_index, element_offset=rank * len(el))
+    be = DistBackend(part, ops, backend_device)
+    model = DistModel(part, be, xyz, material, fix, loads, external_loads)
+    return model, be, ops
+
+
+def run(args, ctl, material, traction, rtol, hbm_peak, cpu_baseline):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    share_gpu = os.environ.get("FCVM_DIST_SHARE_GPU") == "1"  # rehearsal: all ranks on GPU 0 over gloo
+    dev_index = 0 if share_gpu else local
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    backend = os.environ.get("FCVM_DIST_BACKEND", "gloo" if share_gpu else "nccl")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        model, be, ops = build_rank_model(rank, world, args.cells, material, traction, dev_index, device)
+        stats = {}
+        drv = RiksDriver(model, ctl, rtol=rtol, stats=stats)
+        drv.start_step()
+        for _ in range(args.warmup):
+            drv.iteration()
+        dist.barrier()
+        torch.cuda.synchronize()
+        s0 = dict(stats)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            drv.iteration()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        # local SpMV timing for the roofline object (HIP events on the stream the kernel runs on)
+        x, y = be.array(np.random.default_rng(rank).standard_normal(3 * model.nn)), be.empty(3 * model.nn)
+        for _ in range(3):
+            ops.spmv(x, y)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 30
+        e0.record()
+        for _ in range(reps):
+            ops.spmv(x, y)
+        e1.record()
+        torch.cuda.synchronize()
+        avg_ms = e0.elapsed_time(e1) / reps
+        info = ops.c.pattern_info()
+        alg = info["nnz_blocks"] * 76 + 2 * info["ndof"] * 8
+        ne_total = model.ne * world
+        pcg = stats["pcg_iterations"] - s0["pcg_iterations"]
+        if rank == 0:
+            achieved = alg / (avg_ms * 1e-3) / 1e9
+            out = {
+                "metric": "elements*GP/s over Newton iterations (Newton iterations/s x elements x 4 GP), 1M tet10 per GPU",
+                "value": ne_total * 4 * args.steps / dt, "unit": "elements*GP/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "column of %d cubes of %d^3 cells = %d tet10 (%d per GPU), element range partition "
+                                       "in z-slabs, clamped base, top traction, von Mises plasticity, one Newton/Riks "
+                                       "iteration per step" % (world, args.cells, ne_total, model.ne),
+                           "pcg_rtol": rtol, "preconditioner": "block-Jacobi 3x3", "parallelism": "element-partition x%d" % world,
+                           "exchange": "point-to-point shared-node sums per SpMV + 2 scalar all-reduces per PCG iteration (%s)" % backend},
+                "newton_iterations_per_s": args.steps / dt, "pcg_iterations_per_step": pcg / args.steps,
+                "roofline": {"bound": "hbm", "kernel": "k_spmv (rank 0, local matrix)", "achieved": achieved, "peak": hbm_peak,
+                             "unit": "GB/s", "frac": achieved / hbm_peak, "traffic": None,
+                             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms},
+            }
+            print(json.dumps(out))
+    finally:
+        dist.destroy_process_group()

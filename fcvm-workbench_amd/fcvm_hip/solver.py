@@ -85,9 +85,12 @@ class RiksDriver:
         self.ndof, self.nelem = ndof, nelem
         self.glv, self.modf, self.V, self.xgp = model.calc_gsm(self.grav)
         self.glv_h = self.glv.get()
-        g3 = self.glv_h.reshape(-1, 3)
-        self.loadsum = (g3[:, 0].sum(), g3[:, 1].sum(), g3[:, 2].sum())
-        self.qnorm = float(np.linalg.norm(self.glv_h))
+        if hasattr(c, "loadsum"):  # distributed backend: owner-weighted, all-reduced
+            self.loadsum = c.loadsum(self.glv)
+        else:
+            g3 = self.glv_h.reshape(-1, 3)
+            self.loadsum = (g3[:, 0].sum(), g3[:, 1].sum(), g3[:, 2].sum())
+        self.qnorm = c.norm(self.glv)  # fcVM.py:1115
         if self.qnorm < 1.0:
             self.qnorm = 1.0
         self.f = c.mul(model.fixdof, self.glv)

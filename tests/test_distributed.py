@@ -1,0 +1,99 @@
+"""world_size-2 (gloo, CPU) tests of the multi-GPU layer: partition, shared-node exchange,
+distributed PCG and the whole Riks analysis on two ranks against the single-process oracle.
+The local element kernels are the oracle's (injected from tests/dist_helpers.py); on the GPU box
+the same driver runs with HipLocalOps."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import small_case
+
+CTL = dict(sig_yield=30.0, grav_x=0.0, grav_y=0.0, grav_z=-9.81, nstep=4, iterat_max=20, error_max=1e-4, relax=1.2,
+           scale_re=2.0, scale_up=1.2, scale_dn=1.2, disp_output="total", ultimate_strain=0.25, Et_E=0.05, target_LF=10.0,
+           csr_option="PEEQ", averaged_option="unaveraged", gnl="GNLN", maxImp="0.0", ev1="1.0", ev2="0.0")
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dist_helpers import OracleLocalOps
+        from fcvm_hip import meshgen
+        from fcvm_hip.dist import DistBackend, DistModel, Partition
+        from fcvm_hip.loads import Loads, external_loads
+        from fcvm_hip.solver import RiksDriver, calc_disp
+        case = small_case(3)
+        el, xyz = case["elNodes"], case["nocoord"]
+        ne = len(el)
+        lo, hi = rank * ne // world, (rank + 1) * ne // world
+        part = Partition(el[lo:hi])
+        xyz_loc = xyz[part.gnodes - 1]
+        gd = np.array(sorted(case["fix"]), dtype=np.int64)
+        here, ld = part.local_dofs_of(gd)
+        fix_loc = {int(d): case["fix"][int(g)] for d, g in zip(ld, gd[here])}
+        faces = meshgen.boundary_faces_on_plane(el[lo:hi], xyz, 2, 10.0)
+        faces_loc = np.searchsorted(part.gnodes, faces) + 1
+        loads = Loads(ufaces=faces_loc, uloads=np.tile(case["uloads"][0], (len(faces_loc), 1)))
+        ops = OracleLocalOps(part, xyz_loc, case["material"], fix_loc, element_offset=lo)
+        be = DistBackend(part, ops, torch.device("cpu"), pcg_check_every=10)
+        model = DistModel(part, be, xyz_loc, case["material"], fix_loc, loads, external_loads)
+        # 1) exchange: the interface sum of "1 per rank" counts the ranks sharing each node
+        ones = be.array(np.ones(3 * part.nn))
+        be.ex.interface_sum(ones.t, 3)
+        res = calc_disp(model, CTL, rtol=1e-12)
+        payload = dict(rank=rank, gnodes=part.gnodes, owned=part.owned, mult=ones.get()[::3], lout=res["lout"],
+                       un=res["un"], crip=res["crip"], disp=res["displacements"], peeq=res["peeq"].get(), lo=lo, hi=hi,
+                       loadsum=res["loadsum"], nn_global=part.nn_global, pcg=res["stats"]["pcg_iterations"])
+        gathered = [None] * world
+        dist.all_gather_object(gathered, payload)
+        if rank == 0:
+            torch.save(gathered, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_analysis_matches_single_process_oracle(orc, tmp_path):
+    out = str(tmp_path / "res.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=False)
+    case = small_case(3)
+    ref = orc.run_analysis(case["elNodes"], case["nocoord"], case["material"], case["fix"],
+                           orc.Loads(ufaces=case["ufaces"], uloads=case["uloads"]), CTL)
+    nn = len(case["nocoord"])
+    assert got[0]["nn_global"] == nn
+    # partition bookkeeping: every node owned exactly once; multiplicity = number of ranks holding it
+    owners = np.zeros(nn, int)
+    holders = np.zeros(nn, int)
+    for g in got:
+        owners[g["gnodes"][g["owned"]] - 1] += 1
+        holders[g["gnodes"] - 1] += 1
+    assert np.all(owners == 1)
+    for g in got:
+        assert np.array_equal(g["mult"], holders[g["gnodes"] - 1])
+    assert (holders == 2).sum() > 0
+    rel = lambda a, b: np.abs(np.asarray(a) - b).max() / np.abs(b).max()  # noqa: E731
+    for g in got:
+        assert len(g["lout"]) == len(ref["lout"])
+        assert rel(g["lout"], ref["lout"]) < 1e-7 and rel(g["un"], ref["un"]) < 1e-7
+        assert np.array_equal(g["crip"], ref["crip"])
+        d = ref["displacements"].reshape(-1, 3)[g["gnodes"] - 1].reshape(-1)
+        assert rel(g["disp"], d) < 1e-7
+        assert np.abs(g["peeq"] - ref["peeq"][4 * g["lo"]:4 * g["hi"]]).max() < 1e-6 * ref["peeq"].max()
+        assert np.allclose(g["loadsum"], ref["loadsum"], rtol=1e-10, atol=1e-9)
+    assert ref["peeq"].max() > 0
