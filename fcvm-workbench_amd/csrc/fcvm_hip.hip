@@ -154,9 +154,9 @@ int fcvm_synchronize(fcvm_ctx *c) {
     HCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
-int fcvm_set_stream(fcvm_ctx *c, void *s) {
+int fcvm_set_stream(fcvm_ctx *c, void *s, int external) {
     HCHK(hipStreamSynchronize(c->stream));
-    c->stream = s ? (hipStream_t)s : c->own;
+    c->stream = external ? (hipStream_t)s : c->own;  // external NULL = HIP's default (null) stream
     return 0;
 }
 int fcvm_malloc(fcvm_ctx *c, uint64_t bytes, void **dev) {

@@ -22,7 +22,7 @@ SIGNATURES = {
     "fcvm_create": [_int, C.POINTER(_vp)],
     "fcvm_destroy": [_vp],
     "fcvm_synchronize": [_vp],
-    "fcvm_set_stream": [_vp, _vp],
+    "fcvm_set_stream": [_vp, _vp, _int],
     "fcvm_malloc": [_vp, C.c_uint64, C.POINTER(_vp)],
     "fcvm_free": [_vp, _vp],
     "fcvm_h2d": [_vp, _vp, _vp, C.c_uint64],

@@ -95,8 +95,9 @@ class Context:
     def sync(self):
         call("fcvm_synchronize", self.h)
 
-    def set_stream(self, stream_handle):
-        call("fcvm_set_stream", self.h, C.c_void_p(stream_handle))
+    def set_stream(self, stream_handle, external=True):
+        """Run this context's kernels on an external hipStream_t (0 = HIP's default stream)."""
+        call("fcvm_set_stream", self.h, C.c_void_p(stream_handle), 1 if external else 0)
 
     # -- model ------------------------------------------------------------------------------
     def set_mesh(self, elNodes, nocoord):

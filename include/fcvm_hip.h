@@ -31,9 +31,10 @@ int fcvm_device_count(int *count);
 int fcvm_create(int device, fcvm_ctx **out);
 int fcvm_destroy(fcvm_ctx *c);
 int fcvm_synchronize(fcvm_ctx *c);
-/* run the context's kernels on an externally owned hipStream_t (e.g. torch's current stream,
- * needed so RCCL collectives issued by the host order correctly with them); 0 = own stream */
-int fcvm_set_stream(fcvm_ctx *c, void *hip_stream);
+/* external != 0: run the context's kernels on the caller's hipStream_t (e.g. torch's current
+ * stream, so that torch ops and RCCL collectives issued by the host order correctly with them;
+ * a NULL handle then means HIP's default stream).  external == 0: back to the context's own stream */
+int fcvm_set_stream(fcvm_ctx *c, void *hip_stream, int external);
 
 /* raw device memory helpers for the host binding */
 int fcvm_malloc(fcvm_ctx *c, uint64_t bytes, void **dev);

@@ -27,7 +27,7 @@ def _worker(rank, world, port, out):
         from fcvm_hip.solver import calc_disp
         torch.cuda.set_device(0)
         model, be, ops = build_rank_model(rank, world, CELLS, MAT, TRACTION, 0, torch.device("cuda", 0), length=10.0)
-        res = calc_disp(model, CTL, rtol=1e-12)
+        res = calc_disp(model, CTL, rtol=1e-12, maxit=4000)
         payload = dict(gnodes=model.part.gnodes, disp=res["displacements"], lout=res["lout"], un=res["un"],
                        crip=res["crip"], peeq=res["peeq"].get())
         got = [None] * world
