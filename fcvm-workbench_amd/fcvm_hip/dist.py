@@ -322,10 +322,11 @@ class DistModel:
         xgp = c.empty(12 * self.ne) if want_x else None
         ext = self._ext(self.nocoord, self.loads, None if disp is None else disp.get())
         glv, modf, V = c.assemble(grav, disp=disp, sig=sig, pgp=pgp, Et_E=Et_E, xgp=xgp)
-        if np.any(ext != 0.0):
-            e = c.array(ext)
-            c.ex.interface_sum(e.t, 3)
-            glv.t.add_(e.t)
+        # every rank takes part in the exchange, loaded or not (a rank-local "any load?" test would
+        # leave the neighbours waiting)
+        e = c.array(ext)
+        c.ex.interface_sum(e.t, 3)
+        glv.t.add_(e.t)
         return glv, modf, V, xgp
 
 
