@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "fcvm_kernels.hip.h"
+#include "fcvm_mg_kernels.hip.h"
 #include "fcvm_pattern.h"
 
 using namespace fcvm;
@@ -53,6 +54,26 @@ struct fcvm_ctx {
     int64_t nb_vec = 0, nb_spmv = 0, nb_gp = 0;
     double last_spmv_ms = 0, last_total_ms = 0;
     int spmv_variant = 3;  // 0 plain, 1 nontemporal matrix loads, 2 unroll x2, 3 both (fastest measured)
+    double last_spmv_timed = 0;
+    // host copies needed to build the coarse level
+    std::vector<int32_t> h_el;
+    std::vector<double> h_coord;
+    std::vector<uint8_t> h_fixmask;
+    // p-multigrid preconditioner (mode 1): level 1 = linear tets on the corner nodes
+    int precond_mode = 0, mg_k0 = 2, mg_k1 = 30;
+    double mg_alpha0 = 8.0, mg_alpha1 = 300.0, mg_lmax0 = 0, mg_lmax1 = 0;
+    bool mg_topo = false;
+    int64_t nc = 0, nb_spmv1 = 0;
+    Pattern pat1;
+    int32_t *d_el4 = nullptr, *d_cols1 = nullptr, *d_rownode1 = nullptr, *d_c2f = nullptr, *d_mids = nullptr, *d_pa = nullptr,
+            *d_pb = nullptr;
+    int64_t *d_sptr1 = nullptr, *d_mptr = nullptr;
+    uint32_t *d_emap4 = nullptr, *d_diagoff1 = nullptr;
+    uint8_t *d_fixmask1 = nullptr;
+    double *d_coord1 = nullptr, *d_vals1 = nullptr, *d_dblk1 = nullptr, *d_dinv1 = nullptr;
+    double *d_mr = nullptr, *d_md = nullptr, *d_mt = nullptr, *d_r1 = nullptr, *d_x1 = nullptr, *d_d1 = nullptr, *d_t1 = nullptr,
+           *d_rr1 = nullptr;
+    int64_t mg_spmv0 = 0, mg_spmv1 = 0;
     std::vector<hipEvent_t> evpool;
 };
 
@@ -82,11 +103,20 @@ static MatConst matconst(const fcvm_ctx *c, double Et_E) {
     return m;
 }
 
+struct MatView {
+    int64_t nslices, nb;
+    const int64_t *sptr;
+    const int32_t *cols;
+    const double *vals;
+    const int32_t *rownode;
+};
+static MatView fine_view(const fcvm_ctx *c) { return {c->pat.nslices, c->nb_spmv, c->d_sptr, c->d_cols, c->d_vals, c->d_rownode}; }
+static MatView coarse_view(const fcvm_ctx *c) { return {c->pat1.nslices, c->nb_spmv1, c->d_sptr1, c->d_cols1, c->d_vals1, c->d_rownode1}; }
+
 template <bool DOT>
-static void launch_spmv_t(fcvm_ctx *c, const double *x, double *y, const double *done) {
-    dim3 grid((unsigned)c->nb_spmv), block(256);
-    double *part = DOT ? c->d_part_spmv : nullptr;
-#define FCVM_SPMV_ARGS c->pat.nslices, c->nb_spmv, c->d_sptr, c->d_cols, (const double2 *)c->d_vals, c->d_rownode, x, y, part, done
+static void launch_spmv_t(fcvm_ctx *c, const MatView &m, const double *x, double *y, double *part, const double *done) {
+    dim3 grid((unsigned)m.nb), block(256);
+#define FCVM_SPMV_ARGS m.nslices, m.nb, m.sptr, m.cols, (const double2 *)m.vals, m.rownode, x, y, part, done
     switch (c->spmv_variant) {
         case 1: hipLaunchKernelGGL((k_spmv<DOT, true, 1>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
         case 2: hipLaunchKernelGGL((k_spmv<DOT, false, 2>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
@@ -96,9 +126,19 @@ static void launch_spmv_t(fcvm_ctx *c, const double *x, double *y, const double 
 #undef FCVM_SPMV_ARGS
 }
 static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done) {
-    if (dot) launch_spmv_t<true>(c, x, y, done);
-    else launch_spmv_t<false>(c, x, y, done);
+    if (dot) launch_spmv_t<true>(c, fine_view(c), x, y, c->d_part_spmv, done);
+    else launch_spmv_t<false>(c, fine_view(c), x, y, nullptr, done);
 }
+
+static int dot_common(fcvm_ctx *c, int64_t n, const double *w, const double *x, const double *y, double *result_dev) {
+    NEED(c && c->d_part_misc, "vector reductions need a mesh (work buffers)");
+    int64_t nb = std::min<int64_t>(std::max<int64_t>(cdiv(n, 256), 1), 2048);
+    hipLaunchKernelGGL(k_dot_partial, dim3((unsigned)nb), dim3(256), 0, c->stream, n, w, x, y, c->d_part_misc);
+    hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, c->stream, c->d_part_misc, nb, result_dev);
+    HCHK(hipGetLastError());
+    return 0;
+}
+#include "fcvm_mg.inc"
 
 extern "C" {
 
@@ -135,6 +175,7 @@ static void free_mesh(fcvm_ctx *c) {
     dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
     dfree(c->d_vals); dfree(c->d_dblk); dfree(c->d_dinv); dfree(c->d_r); dfree(c->d_z); dfree(c->d_p);
     dfree(c->d_q); dfree(c->d_part_vec); dfree(c->d_part_spmv); dfree(c->d_part_misc); dfree(c->d_pidx);
+    mg_free(c);
     c->have_mesh = c->assembled = false;
 }
 
@@ -212,6 +253,9 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     }
     c->ne = ne;
     c->nn = nn;
+    c->h_el = el;
+    c->h_coord.assign(nocoord, nocoord + 3 * nn);
+    c->h_fixmask.assign(nn, 0);
     const Pattern &p = c->pat;
     std::vector<int32_t> noce(nn, 0);  // fcVM.py:183-185
     for (int64_t i = 0; i < ne * 10; i++) noce[el[i]]++;
@@ -252,6 +296,8 @@ int fcvm_set_coords(fcvm_ctx *c, const double *nocoord) {
     NEED(c && c->have_mesh, "fcvm_set_coords: no mesh");
     HCHK(hipMemcpyAsync(c->d_coord, nocoord, sizeof(double) * c->nn * 3, hipMemcpyHostToDevice, c->stream));
     HCHK(hipStreamSynchronize(c->stream));
+    c->h_coord.assign(nocoord, nocoord + 3 * c->nn);
+    c->mg_topo = false;
     return 0;
 }
 
@@ -271,6 +317,7 @@ int fcvm_set_fix(fcvm_ctx *c, int64_t nfix, const int64_t *dofs, const double *v
         mask[dofs[i] / 3] |= (uint8_t)(1u << (dofs[i] % 3));
         val[dofs[i]] = vals[i];
     }
+    c->h_fixmask = mask;
     HCHK(hipMemcpyAsync(c->d_fixmask, mask.data(), c->nn, hipMemcpyHostToDevice, c->stream));
     HCHK(hipMemcpyAsync(c->d_fixval, val.data(), sizeof(double) * c->nn * 3, hipMemcpyHostToDevice, c->stream));
     HCHK(hipStreamSynchronize(c->stream));
@@ -336,6 +383,10 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
                            grav[1], grav[2], c->d_vals, glv_grav, modf, xgp, c->d_out8);
     HCHK(hipGetLastError());
     if (refresh_precond(c)) return 1;
+    if (c->precond_mode == 1) {
+        HCHK(hipStreamSynchronize(s));
+        if (mg_setup(c)) return 1;
+    }
     if (volume) {
         HCHK(hipMemcpyAsync(volume, c->d_out8, sizeof(double), hipMemcpyDeviceToHost, s));
     }
@@ -441,6 +492,7 @@ int fcvm_set_diag_blocks(fcvm_ctx *c, const double *dblk) {
 int fcvm_solve(fcvm_ctx *c, const double *f, double *u, double rtol, int64_t maxit, double info[3]) {
     NEED(c && c->have_mesh && c->assembled, "fcvm_solve: assemble the matrix first");
     NEED(f && u && f != u, "fcvm_solve: f and u must be distinct device arrays");
+    if (c->precond_mode == 1) return mg_pcg(c, f, u, rtol, maxit, info);
     hipStream_t s = c->stream;
     const int64_t nn = c->nn, n = 3 * nn, nbv = c->nb_vec;
     const int CHUNK = 25;
@@ -493,6 +545,7 @@ int fcvm_solve(fcvm_ctx *c, const double *f, double *u, double rtol, int64_t max
     float tot = 0.f;
     HCHK(hipEventElapsedTime(&tot, ev0, ev1));
     c->last_spmv_ms = spmv_ms;
+    c->last_spmv_timed = (double)nspmv;
     c->last_total_ms = tot;
     if (info) {
         info[0] = (double)it;
@@ -504,9 +557,26 @@ int fcvm_solve(fcvm_ctx *c, const double *f, double *u, double rtol, int64_t max
     return 0;
 }
 
-int fcvm_solve_timing(fcvm_ctx *c, double out_ms[2]) {
+int fcvm_solve_timing(fcvm_ctx *c, double out_ms[4]) {
     out_ms[0] = c->last_spmv_ms;
     out_ms[1] = c->last_total_ms;
+    out_ms[2] = c->last_spmv_timed;
+    out_ms[3] = (double)c->mg_spmv1;
+    return 0;
+}
+
+int fcvm_set_precond(fcvm_ctx *c, int mode, int k0, int k1, double alpha0, double alpha1) {
+    NEED(c && (mode == 0 || mode == 1), "fcvm_set_precond: mode 0 (block-Jacobi) or 1 (p-multigrid)");
+    NEED(mode == 0 || (k0 >= 1 && k1 >= 1 && alpha0 > 1.0 && alpha1 > 1.0), "fcvm_set_precond: bad smoother parameters");
+    c->precond_mode = mode;
+    if (mode == 1) { c->mg_k0 = k0; c->mg_k1 = k1; c->mg_alpha0 = alpha0; c->mg_alpha1 = alpha1; }
+    c->assembled = false;  // the next fcvm_assemble builds what the mode needs
+    return 0;
+}
+
+int fcvm_precond_info(fcvm_ctx *c, double out[6]) {
+    out[0] = c->precond_mode; out[1] = (double)c->nc; out[2] = c->mg_lmax0; out[3] = c->mg_lmax1;
+    out[4] = c->mg_topo ? (double)c->pat1.nnzb : 0.0; out[5] = (double)c->mg_spmv0;
     return 0;
 }
 
@@ -520,14 +590,6 @@ int fcvm_vec_axpby(fcvm_ctx *c, int64_t n, double a, const double *x, double b, 
 int fcvm_vec_mul(fcvm_ctx *c, int64_t n, const double *x, const double *y, double *out) {
     if (n == 0) return 0;
     hipLaunchKernelGGL(k_mul, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, c->stream, n, x, y, out);
-    HCHK(hipGetLastError());
-    return 0;
-}
-static int dot_common(fcvm_ctx *c, int64_t n, const double *w, const double *x, const double *y, double *result_dev) {
-    NEED(c && c->d_part_misc, "vector reductions need a mesh (work buffers)");
-    int64_t nb = std::min<int64_t>(std::max<int64_t>(cdiv(n, 256), 1), 2048);
-    hipLaunchKernelGGL(k_dot_partial, dim3((unsigned)nb), dim3(256), 0, c->stream, n, w, x, y, c->d_part_misc);
-    hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, c->stream, c->d_part_misc, nb, result_dev);
     HCHK(hipGetLastError());
     return 0;
 }

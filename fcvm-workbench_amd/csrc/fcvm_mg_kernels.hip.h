@@ -1,0 +1,186 @@
+// p-multigrid preconditioner kernels: tet4 coarse operator, tet10 <-> tet4 transfer, Chebyshev
+// smoother steps.  No reference counterpart (the reference solves with CHOLMOD, fcVM.py:1121).
+#pragma once
+#include "fcvm_kernels.hip.h"
+
+namespace fcvm {
+
+// Linear-tetrahedron stiffness on the corner nodes of the tet10 elements, elastic D, same
+// boundary-condition folding as the fine matrix (unit diagonal per element on fixed dofs).
+// One work-item per (element, row corner a).
+__global__ __launch_bounds__(256) void k_assemble_tet4(int64_t ne, const int32_t *__restrict__ el4,
+                                                       const double *__restrict__ coord1,
+                                                       const uint8_t *__restrict__ fixmask1,
+                                                       const uint32_t *__restrict__ emap4, MatConst mc,
+                                                       double *__restrict__ vals) {
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= 4 * ne) return;
+    const int64_t e = t >> 2;
+    const int a = (int)(t & 3);
+    int nd[4];
+    double x[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        nd[k] = el4[e * 4 + k];
+#pragma unroll
+        for (int c = 0; c < 3; c++) x[k][c] = coord1[3 * (int64_t)nd[k] + c];
+    }
+    double e1[3], e2[3], e3[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        e1[c] = x[1][c] - x[0][c];
+        e2[c] = x[2][c] - x[0][c];
+        e3[c] = x[3][c] - x[0][c];
+    }
+    double g[4][3];
+    g[1][0] = e2[1] * e3[2] - e2[2] * e3[1]; g[1][1] = e2[2] * e3[0] - e2[0] * e3[2]; g[1][2] = e2[0] * e3[1] - e2[1] * e3[0];
+    g[2][0] = e3[1] * e1[2] - e3[2] * e1[1]; g[2][1] = e3[2] * e1[0] - e3[0] * e1[2]; g[2][2] = e3[0] * e1[1] - e3[1] * e1[0];
+    g[3][0] = e1[1] * e2[2] - e1[2] * e2[1]; g[3][1] = e1[2] * e2[0] - e1[0] * e2[2]; g[3][2] = e1[0] * e2[1] - e1[1] * e2[0];
+    const double det = e1[0] * g[1][0] + e1[1] * g[1][1] + e1[2] * g[1][2];
+    const double inv = 1.0 / det;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        g[1][c] *= inv; g[2][c] *= inv; g[3][c] *= inv;
+        g[0][c] = -(g[1][c] + g[2][c] + g[3][c]);
+    }
+    const double vol = fabs(det) / 6.0;
+    double ga[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (k == a) { ga[0] = g[k][0]; ga[1] = g[k][1]; ga[2] = g[k][2]; }
+    const int fa = fixmask1[nd[a]];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const double *gb = g[b];
+        const double dot = ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2];
+        const int fb = fixmask1[nd[b]];
+        double *dst = vals + emap4[(e * 4 + a) * 4 + b];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const bool rfix = (fa >> r) & 1;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const bool cfix = (fb >> c) & 1;
+                double v;
+                if (r == c) v = mc.D11 * ga[r] * gb[r] + mc.D44 * (dot - ga[r] * gb[r]);
+                else v = mc.D12 * ga[r] * gb[c] + mc.D44 * ga[c] * gb[r];
+                if (!rfix && !cfix) atomic_add_f64(dst + (r * 3 + c) * 128, vol * v);
+                else if (rfix && a == b && r == c) atomic_add_f64(dst + (r * 3 + c) * 128, 1.0);
+            }
+        }
+    }
+}
+
+// r1 = M1 P^T M0 r0 : coarse node c collects its own fine node and half of every mid-side node
+// on an edge ending in c (CSR lists, fixed order -> deterministic); M = free-dof masks.
+__global__ __launch_bounds__(256) void k_restrict(int64_t nc, const int32_t *__restrict__ c2f,
+                                                  const int64_t *__restrict__ mptr, const int32_t *__restrict__ mids,
+                                                  const uint8_t *__restrict__ fixmask0, const double *__restrict__ r0,
+                                                  double *__restrict__ r1) {
+    int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= nc) return;
+    const int64_t f = c2f[c];
+    const int fm = fixmask0[f];
+    double a0 = r0[3 * f], a1 = r0[3 * f + 1], a2 = r0[3 * f + 2];
+    for (int64_t q = mptr[c]; q < mptr[c + 1]; q++) {
+        const int64_t m = mids[q];
+        const int mm = fixmask0[m];
+        if (!(mm & 1)) a0 += 0.5 * r0[3 * m];
+        if (!(mm & 2)) a1 += 0.5 * r0[3 * m + 1];
+        if (!(mm & 4)) a2 += 0.5 * r0[3 * m + 2];
+    }
+    r1[3 * c] = (fm & 1) ? 0.0 : a0;
+    r1[3 * c + 1] = (fm & 2) ? 0.0 : a1;
+    r1[3 * c + 2] = (fm & 4) ? 0.0 : a2;
+}
+
+// d0 = M0 P M1 e1 : fine corner nodes copy, mid-side nodes average their two edge ends
+__global__ __launch_bounds__(256) void k_prolong(int64_t nn, const int32_t *__restrict__ pa, const int32_t *__restrict__ pb,
+                                                 const uint8_t *__restrict__ fixmask0, const double *__restrict__ e1,
+                                                 double *__restrict__ d0) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nn) return;
+    const int64_t a = pa[i], b = pb[i];
+    const int fm = fixmask0[i];
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+    if (a >= 0) {
+        v0 = 0.5 * (e1[3 * a] + e1[3 * b]);
+        v1 = 0.5 * (e1[3 * a + 1] + e1[3 * b + 1]);
+        v2 = 0.5 * (e1[3 * a + 2] + e1[3 * b + 2]);
+    }
+    d0[3 * i] = (fm & 1) ? 0.0 : v0;
+    d0[3 * i + 1] = (fm & 2) ? 0.0 : v1;
+    d0[3 * i + 2] = (fm & 4) ? 0.0 : v2;
+}
+
+// start of a Chebyshev sweep from the zero vector: x = 0, r = b, d = c0 * Dinv b
+__global__ __launch_bounds__(256) void k_cheb_init(int64_t nn, const double *__restrict__ dinv, const double *__restrict__ b,
+                                                   double *__restrict__ x, double *__restrict__ r, double *__restrict__ d,
+                                                   double c0) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nn) return;
+    const double r0 = b[3 * i], r1 = b[3 * i + 1], r2 = b[3 * i + 2];
+    double z0, z1, z2;
+    apply_dinv(dinv + i * 9, r0, r1, r2, z0, z1, z2);
+    x[3 * i] = 0.0; x[3 * i + 1] = 0.0; x[3 * i + 2] = 0.0;
+    if (r != b) { r[3 * i] = r0; r[3 * i + 1] = r1; r[3 * i + 2] = r2; }
+    d[3 * i] = c0 * z0; d[3 * i + 1] = c0 * z1; d[3 * i + 2] = c0 * z2;
+}
+
+// x += d ; r -= t (t = A d, may be NULL: then r is left alone) ; d = cdd * d + cdr * Dinv r
+__global__ __launch_bounds__(256) void k_cheb_step(int64_t nn, const double *__restrict__ dinv, const double *__restrict__ t,
+                                                   double *__restrict__ x, double *__restrict__ r, double *__restrict__ d,
+                                                   double cdd, double cdr, int update_d) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nn) return;
+    const double d0 = d[3 * i], d1 = d[3 * i + 1], d2 = d[3 * i + 2];
+    x[3 * i] += d0; x[3 * i + 1] += d1; x[3 * i + 2] += d2;
+    if (t) {
+        const double r0 = r[3 * i] - t[3 * i], r1 = r[3 * i + 1] - t[3 * i + 1], r2 = r[3 * i + 2] - t[3 * i + 2];
+        r[3 * i] = r0; r[3 * i + 1] = r1; r[3 * i + 2] = r2;
+        if (update_d) {
+            double z0, z1, z2;
+            apply_dinv(dinv + i * 9, r0, r1, r2, z0, z1, z2);
+            d[3 * i] = cdd * d0 + cdr * z0; d[3 * i + 1] = cdd * d1 + cdr * z1; d[3 * i + 2] = cdd * d2 + cdr * z2;
+        }
+    }
+}
+
+// PCG with an external preconditioner: x += alpha p ; r -= alpha q ; partial of r.r (slot 1)
+__global__ __launch_bounds__(256) void k_pcg_update_xr_plain(int64_t nn, const double *__restrict__ p, const double *__restrict__ q,
+                                                             double *__restrict__ x, double *__restrict__ r,
+                                                             const double *__restrict__ S) {
+    if (S[S_DONE] != 0.0) return;
+    const double alpha = S[S_ALPHA];
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nn) return;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        x[3 * i + c] += alpha * p[3 * i + c];
+        r[3 * i + c] -= alpha * q[3 * i + c];
+    }
+}
+
+// partials of r.z (slot 0) and r.r (slot 1), layout of k_pcg_scalars
+__global__ __launch_bounds__(256) void k_dot2_partial(int64_t nn, const double *__restrict__ r, const double *__restrict__ z,
+                                                      double *__restrict__ part, int64_t nb) {
+    __shared__ double sh[4];
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double rz = 0.0, rr = 0.0;
+    if (i < nn) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const double a = r[3 * i + c];
+            rz += a * z[3 * i + c];
+            rr += a * a;
+        }
+    }
+    rz = block_sum(rz, sh);
+    rr = block_sum(rr, sh);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = rz;
+        part[nb + blockIdx.x] = rr;
+    }
+}
+
+}  // namespace fcvm

@@ -26,21 +26,22 @@ static void parallel_for(int64_t n, int nthreads, const std::function<void(int64
     for (auto &x : th) x.join();
 }
 
-void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nthreads, int sort_window) {
+void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nthreads, int sort_window, int npe) {
     if (ne <= 0 || nn <= 0) throw std::runtime_error("empty mesh");
-    for (int64_t i = 0; i < ne * 10; i++)
+    for (int64_t i = 0; i < ne * npe; i++)
         if (el[i] < 0 || el[i] >= nn) throw std::runtime_error("element node index out of range");
     p.ne = ne;
     p.nn = nn;
+    p.npe = npe;
     // node -> element incidence
     std::vector<int64_t> nptr(nn + 1, 0);
-    for (int64_t i = 0; i < ne * 10; i++) nptr[el[i] + 1]++;
+    for (int64_t i = 0; i < ne * npe; i++) nptr[el[i] + 1]++;
     for (int64_t i = 0; i < nn; i++) nptr[i + 1] += nptr[i];
-    std::vector<int32_t> nel(ne * 10);
+    std::vector<int32_t> nel(ne * npe);
     {
         std::vector<int64_t> fill(nptr.begin(), nptr.end() - 1);
         for (int64_t e = 0; e < ne; e++)
-            for (int k = 0; k < 10; k++) nel[fill[el[e * 10 + k]]++] = (int32_t)e;
+            for (int k = 0; k < npe; k++) nel[fill[el[e * npe + k]]++] = (int32_t)e;
     }
     // node -> sorted unique neighbour nodes (diagonal included)
     int nt = std::max(1, nthreads);
@@ -55,8 +56,8 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
         for (int64_t i = b; i < e; i++) {
             tmp.clear();
             for (int64_t q = nptr[i]; q < nptr[i + 1]; q++) {
-                const int32_t *nd = el + (int64_t)nel[q] * 10;
-                tmp.insert(tmp.end(), nd, nd + 10);
+                const int32_t *nd = el + (int64_t)nel[q] * npe;
+                tmp.insert(tmp.end(), nd, nd + npe);
             }
             if (tmp.empty()) tmp.push_back((int32_t)i);  // isolated node: keep a diagonal block
             std::sort(tmp.begin(), tmp.end());
@@ -119,17 +120,17 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
         }
     });
     // element block (a,b) -> offset of its component 0
-    p.emap.resize(ne * 100);
+    p.emap.resize(ne * npe * npe);
     parallel_for(ne, nt, [&](int64_t b, int64_t e, int) {
         for (int64_t k = b; k < e; k++) {
-            const int32_t *nd = el + k * 10;
-            for (int a = 0; a < 10; a++) {
+            const int32_t *nd = el + k * npe;
+            for (int a = 0; a < npe; a++) {
                 const int32_t *rb = p.colidx.data() + p.rowptr[nd[a]];
                 const int32_t *re = p.colidx.data() + p.rowptr[nd[a] + 1];
                 int64_t slot = p.slotof[nd[a]];
-                for (int c = 0; c < 10; c++) {
+                for (int c = 0; c < npe; c++) {
                     int64_t j = std::lower_bound(rb, re, nd[c]) - rb;
-                    p.emap[k * 100 + a * 10 + c] = (uint32_t)p.block_offset(slot, j);
+                    p.emap[(k * npe + a) * npe + c] = (uint32_t)p.block_offset(slot, j);
                 }
             }
         }

@@ -12,6 +12,7 @@ constexpr int64_t VSTRIDE = 2 * SLICE;  // doubles between two components of one
 
 struct Pattern {
     int64_t ne = 0, nn = 0;
+    int npe = 10;           // nodes per element (10: tet10 fine level, 4: tet4 coarse level)
     int64_t nslices = 0;
     int64_t nnzb = 0;       // true 3x3 blocks
     int64_t nslots = 0;     // padded block slots (sum over slices of 64 * slice length)
@@ -22,7 +23,7 @@ struct Pattern {
     std::vector<int32_t> rownode;   // [nslices*64] node of slot, -1 = padding
     std::vector<int32_t> slotof;    // [nn] slot (slice*64+lane) of node
     std::vector<int32_t> cols;      // [sptr[nslices]*64] column node per (slice, j, lane)
-    std::vector<uint32_t> emap;     // [ne*100] offset (in doubles) of component 0 of block (a,b)
+    std::vector<uint32_t> emap;     // [ne*npe*npe] offset (in doubles) of component 0 of block (a,b)
     std::vector<uint32_t> diagoff;  // [nn] offset of component 0 of the diagonal block
 
     // offset in doubles of component 0 of block j of the row living in `slot`
@@ -35,6 +36,6 @@ struct Pattern {
 
 // elnodes0: 0-based int32 [ne*10].  Throws std::runtime_error on bad input.
 void build_pattern(int64_t ne, int64_t nn, const int32_t *elnodes0, Pattern &p, int nthreads,
-                   int sort_window = SORT_WINDOW);
+                   int sort_window = SORT_WINDOW, int npe = 10);
 
 }  // namespace fcvm

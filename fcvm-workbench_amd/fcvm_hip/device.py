@@ -179,9 +179,19 @@ class Context:
         return u, dict(iterations=int(info[0]), rel_residual=info[1], spmv=int(info[2]))
 
     def solve_timing(self):
-        t = (C.c_double * 2)()
+        t = (C.c_double * 4)()
         call("fcvm_solve_timing", self.h, t)
-        return dict(spmv_ms=t[0], total_ms=t[1])
+        return dict(spmv_ms=t[0], total_ms=t[1], spmv_timed=int(t[2]), coarse_spmv=int(t[3]))
+
+    def set_precond(self, mode="mg", k0=2, k1=30, alpha0=8.0, alpha1=300.0):
+        """mode "bj": 3x3 block-Jacobi; "mg": p-multigrid V-cycle (takes effect at the next assemble)."""
+        call("fcvm_set_precond", self.h, 1 if mode == "mg" else 0, int(k0), int(k1), float(alpha0), float(alpha1))
+
+    def precond_info(self):
+        o = (C.c_double * 6)()
+        call("fcvm_precond_info", self.h, o)
+        return dict(mode="mg" if o[0] == 1 else "bj", coarse_nodes=int(o[1]), lmax0=o[2], lmax1=o[3],
+                    coarse_nnz_blocks=int(o[4]), vcycle_fine_spmv=int(o[5]))
 
     def spmv(self, x, y):
         call("fcvm_spmv", self.h, x.ptr, y.ptr)

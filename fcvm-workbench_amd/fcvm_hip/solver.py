@@ -136,8 +136,10 @@ class RiksDriver:
         st["solve_s"] += time.perf_counter() - t0
         st["pcg_iterations"] += info["iterations"]
         st["solves"] += 1
-        st["spmv_ms"] += self.c.solve_timing()["spmv_ms"]
-        st["spmv_launches"] += info["spmv"]
+        tm = self.c.solve_timing()
+        st["spmv_ms"] += tm["spmv_ms"]
+        st["spmv_launches"] += tm.get("spmv_timed", info["spmv"])  # launches the HIP-event time covers
+        st["spmv_total"] = st.get("spmv_total", 0) + info["spmv"]    # incl. the SpMVs inside V-cycles
         return u
 
     def usl(self, d_u):

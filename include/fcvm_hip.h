@@ -137,8 +137,22 @@ int fcvm_vec_wdot_dev(fcvm_ctx *c, int64_t n, const double *w, const double *x, 
 /* sqrt(max over the first nnodes nodes of |u_node|^2) (fcVM.py:1539-1542) */
 int fcvm_vec_max_node_norm(fcvm_ctx *c, int64_t nnodes, const double *u, double *result_host);
 
-/* timing of the last fcvm_solve: HIP-event milliseconds spent in SpMV launches and in total */
-int fcvm_solve_timing(fcvm_ctx *c, double out_ms[2]);
+/* timing of the last fcvm_solve (HIP events on the solver's stream): out[0] = milliseconds spent in
+ * the timed fine-level SpMV launches, out[1] = total milliseconds, out[2] = number of timed SpMV
+ * launches, out[3] = coarse-level SpMV launches (multigrid) */
+int fcvm_solve_timing(fcvm_ctx *c, double out[4]);
+
+/*
+ * Preconditioner of fcvm_solve.  mode 0: 3x3 block-Jacobi.  mode 1: p-multigrid V-cycle
+ * (level 0 = assembled tet10 matrix, level 1 = linear tets on the corner nodes, Chebyshev
+ * smoothing in Dinv*A: k0 steps before and after the coarse correction on [lmax/alpha0, lmax],
+ * k1 steps as approximate coarse solve on [lmax1/alpha1, lmax1]).  Takes effect at the next
+ * fcvm_assemble.
+ */
+int fcvm_set_precond(fcvm_ctx *c, int mode, int k0, int k1, double alpha0, double alpha1);
+/* out[0]=mode, out[1]=coarse nodes, out[2]=lmax level 0, out[3]=lmax level 1, out[4]=coarse nnz
+ * blocks, out[5]=fine SpMV launches inside V-cycles of the last solve */
+int fcvm_precond_info(fcvm_ctx *c, double out[6]);
 
 /* host-only self check of the sparsity pattern builder (no GPU needed): out[0]=nnz blocks,
  * out[1]=padded slots, out[2]=slices, out[3]=max row length, out[4]=number of violated invariants

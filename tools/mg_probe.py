@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Preconditioner probe: solves K u = f on the synthetic cube with block-Jacobi and with the
+p-multigrid V-cycle for several smoother settings; prints iterations, time and SpMV counts."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "fcvm-workbench_amd"))
+from fcvm_hip import meshgen  # noqa: E402
+from fcvm_hip.loads import Loads  # noqa: E402
+from fcvm_hip.solver import GpuModel  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cells", type=int, default=24)
+ap.add_argument("--rtol", type=float, default=1e-10)
+ap.add_argument("--configs", type=str, default="bj;2,30,8,300;3,30,10,300;2,60,8,1000;3,60,10,1000")
+ap.add_argument("--nu", type=float, default=0.3)
+a = ap.parse_args()
+case = meshgen.cube_case(a.cells, l=100.0, traction=(20.0, 0.0, 200.0))
+m = GpuModel(case["elNodes"], case["nocoord"], (210000.0, a.nu, 7.8e-6), case["fix"],
+             Loads(ufaces=case["ufaces"], uloads=case["uloads"]))
+c = m.ctx
+print("elements", m.ne, "dof", m.ndof, flush=True)
+ref = None
+for cfg in a.configs.split(";"):
+    if cfg == "bj":
+        c.set_precond("bj")
+    else:
+        k0, k1, a0, a1 = cfg.split(",")
+        c.set_precond("mg", int(k0), int(k1), float(a0), float(a1))
+    t0 = time.perf_counter()
+    glv, modf, V, _ = m.calc_gsm((0.0, 0.0, 0.0), want_x=False)
+    c.sync()
+    t_setup = time.perf_counter() - t0
+    f = c.mul(m.fixdof, glv)
+    c.axpby(1.0, f, 1.0, modf, out=f)
+    c.sync()
+    t0 = time.perf_counter()
+    try:
+        u, info = c.solve(f, rtol=a.rtol, maxit=20000)
+    except Exception as e:
+        print(cfg, "FAILED", str(e)[:120], flush=True)
+        continue
+    c.sync()
+    dt = time.perf_counter() - t0
+    tm = c.solve_timing()
+    uh = u.get()
+    if ref is None:
+        ref = uh
+    # true residual with an independent SpMV
+    r = c.axpby(1.0, f, -1.0, c.spmv(u, c.empty(m.ndof)))
+    print("%-16s setup %.2fs  iters %5d  solve %.3fs  fine spmv %6d  coarse spmv %6d  spmv avg %.3f ms  true relres %.2e  |u-u_bj|/|u| %.2e  %s" % (
+        cfg, t_setup, info["iterations"], dt, info["spmv"], tm["coarse_spmv"], tm["spmv_ms"] / max(tm["spmv_timed"], 1),
+        c.norm(r) / c.norm(f), np.abs(uh - ref).max() / np.abs(ref).max(), c.precond_info() if cfg != "bj" else ""), flush=True)
