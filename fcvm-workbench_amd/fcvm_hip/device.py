@@ -1,5 +1,6 @@
 """Device context and device-resident arrays over the C-ABI (no torch needed on one GPU)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -69,6 +70,8 @@ class Context:
         self.h = h
         self.device = device
         self.ne = self.nn = 0
+        # preconditioner of the linear solve: p-multigrid by default, FCVM_PRECOND=bj for block-Jacobi
+        self.set_precond(os.environ.get("FCVM_PRECOND", "mg"))
 
     def close(self):
         if self.h:
@@ -183,7 +186,7 @@ class Context:
         call("fcvm_solve_timing", self.h, t)
         return dict(spmv_ms=t[0], total_ms=t[1], spmv_timed=int(t[2]), coarse_spmv=int(t[3]))
 
-    def set_precond(self, mode="mg", k0=2, k1=30, alpha0=8.0, alpha1=300.0):
+    def set_precond(self, mode="mg", k0=2, k1=60, alpha0=8.0, alpha1=1000.0):
         """mode "bj": 3x3 block-Jacobi; "mg": p-multigrid V-cycle (takes effect at the next assemble)."""
         call("fcvm_set_precond", self.h, 1 if mode == "mg" else 0, int(k0), int(k1), float(alpha0), float(alpha1))
 

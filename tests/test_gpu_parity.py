@@ -188,6 +188,28 @@ def test_pcg_solve_matches_direct(orc):
     assert rel(z, np.concatenate(blocks)) < 1e-10
 
 
+@pytest.mark.parametrize("mode", ["bj", "mg"])
+def test_both_preconditioners_solve_the_embankment_system(embankment, mode):
+    """unstructured Gmsh mesh, nu = 0.45: block-Jacobi and p-multigrid PCG reach the same solution"""
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import GpuModel
+    g, _ = embankment
+    fix = {int(d): float(v) for d, v in zip(g["fixed_dofs"], g["fixed_vals"])}
+    m = GpuModel(g["elNodes"], g["nocoord"], g["material"], fix, Loads())
+    c = m.ctx
+    c.set_precond(mode)
+    glv, modf, _, _ = m.calc_gsm((0.0, 0.0, -10.0))
+    f = c.mul(m.fixdof, glv)
+    u, info = c.solve(f, rtol=1e-12)
+    r = c.axpby(1.0, f, -1.0, c.spmv(u, c.empty(m.ndof)))
+    assert c.norm(r) <= 5e-12 * c.norm(f)
+    K = gpu_matrix(m)
+    u_ref = spla.spsolve(K.tocsc(), f.get())
+    assert rel(u.get(), u_ref) < 1e-8
+    if mode == "mg":
+        assert info["iterations"] < 200 and c.precond_info()["coarse_nodes"] > 0
+
+
 def test_vector_kernels(gpu_ctx):
     c = make_model(small_case(1)).ctx
     rng = np.random.default_rng(0)
