@@ -81,6 +81,14 @@ def cpu_baseline(cells=14, iters=3):
                       (cells, ne, 3 * nn, iters, t_asm, t_fac)}
 
 
+def precond_label(c):
+    pi = c.precond_info()
+    if pi["mode"] != "mg":
+        return "block-Jacobi 3x3"
+    return ("p-multigrid V-cycle: tet10 (Chebyshev/block-Jacobi smoothing) -> tet4 on %d corner nodes%s" %
+            (pi["coarse_nodes"], pi.get("level2", "")))
+
+
 def run_single(args):
     from fcvm_hip import _lib, meshgen
     from fcvm_hip.loads import Loads
@@ -131,9 +139,10 @@ def run_single(args):
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "synthetic cube %d^3 cells = %d tet10, %d dof, clamped base, top traction, von Mises "
                                "plasticity (%d of %d Gauss points plastic), one Newton/Riks iteration per step" %
-                               (n, ne, ndof, plastic, 4 * ne), "pcg_rtol": RTOL, "preconditioner": "block-Jacobi 3x3"},
+                               (n, ne, ndof, plastic, 4 * ne), "pcg_rtol": RTOL, "preconditioner": precond_label(c)},
         "newton_iterations_per_s": args.steps / dt,
         "pcg_iterations_per_step": pcg_its / args.steps,
+        "fine_spmv_per_step": (stats.get("spmv_total", 0) - s0.get("spmv_total", 0)) / args.steps,
         "assembly": {"ms": t_asm * 1e3, "elements_gp_per_s": ne * 4 / t_asm},
         "setup_s": {"mesh": t_mesh, "pattern_host": model.t_pattern},
         "roofline": {"bound": "hbm", "kernel": "k_spmv<true> (sliced-ELL 3x3-block SpMV + p.Ap partials)",
