@@ -74,6 +74,14 @@ struct fcvm_ctx {
     double *d_mr = nullptr, *d_md = nullptr, *d_mt = nullptr, *d_r1 = nullptr, *d_x1 = nullptr, *d_d1 = nullptr, *d_t1 = nullptr,
            *d_rr1 = nullptr;
     int64_t mg_spmv0 = 0, mg_spmv1 = 0;
+    // level 2: aggregates + dense inverse (set from the host binding)
+    bool l2 = false;
+    int64_t nagg = 0, n2 = 0;
+    int mg_k1s = 3;
+    double mg_alpha1s = 8.0;
+    int32_t *d_agg = nullptr, *d_anodes = nullptr;
+    int64_t *d_aoff = nullptr, *d_aptr = nullptr;
+    double *d_Z = nullptr, *d_A2inv = nullptr, *d_r2 = nullptr, *d_e2 = nullptr;
     std::vector<hipEvent_t> evpool;
 };
 
@@ -574,9 +582,10 @@ int fcvm_set_precond(fcvm_ctx *c, int mode, int k0, int k1, double alpha0, doubl
     return 0;
 }
 
-int fcvm_precond_info(fcvm_ctx *c, double out[6]) {
+int fcvm_precond_info(fcvm_ctx *c, double out[8]) {
     out[0] = c->precond_mode; out[1] = (double)c->nc; out[2] = c->mg_lmax0; out[3] = c->mg_lmax1;
     out[4] = c->mg_topo ? (double)c->pat1.nnzb : 0.0; out[5] = (double)c->mg_spmv0;
+    out[6] = c->l2 ? (double)c->nagg : 0.0; out[7] = c->l2 ? (double)c->n2 : 0.0;
     return 0;
 }
 
@@ -650,6 +659,74 @@ int fcvm_host_pattern_check(int64_t ne, int64_t nn, const int64_t *elNodes, int6
     }
     out[0] = p.nnzb; out[1] = p.nslots; out[2] = p.nslices; out[3] = p.maxlen; out[4] = bad;
     out[5] = p.value_count(); out[6] = p.sptr[p.nslices]; out[7] = 0;
+    return 0;
+}
+
+int fcvm_mg_coarse_nodes(fcvm_ctx *c, double *coord1, uint8_t *fixmask1) {
+    NEED(c && c->mg_topo, "fcvm_mg_coarse_nodes: assemble with the multigrid preconditioner first");
+    HCHK(hipMemcpyAsync(coord1, c->d_coord1, sizeof(double) * 3 * c->nc, hipMemcpyDeviceToHost, c->stream));
+    HCHK(hipMemcpyAsync(fixmask1, c->d_fixmask1, c->nc, hipMemcpyDeviceToHost, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int fcvm_mg_coarse_to_coo(fcvm_ctx *c, int64_t *row, int64_t *col, double *val) {
+    NEED(c && c->mg_topo, "fcvm_mg_coarse_to_coo: assemble with the multigrid preconditioner first");
+    const Pattern &p = c->pat1;
+    std::vector<double> v(p.value_count());
+    HCHK(hipMemcpyAsync(v.data(), c->d_vals1, sizeof(double) * v.size(), hipMemcpyDeviceToHost, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+    int64_t k = 0;
+    for (int64_t i = 0; i < p.nn; i++)
+        for (int64_t q = p.rowptr[i]; q < p.rowptr[i + 1]; q++) {
+            uint64_t off = p.block_offset(p.slotof[i], q - p.rowptr[i]);
+            for (int r = 0; r < 3; r++)
+                for (int cc = 0; cc < 3; cc++) {
+                    row[k] = 3 * i + r;
+                    col[k] = 3 * (int64_t)p.colidx[q] + cc;
+                    val[k] = v[off + (r * 3 + cc) * VSTRIDE];
+                    k++;
+                }
+        }
+    return 0;
+}
+
+int fcvm_mg_set_level2(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg, const int64_t *aoff, const double *Z,
+                       const double *A2inv, int k1s, double alpha1s) {
+    NEED(c && c->mg_topo, "fcvm_mg_set_level2: assemble with the multigrid preconditioner first");
+    NEED(nagg > 0 && n2 > 0 && n2 <= 6 * nagg && k1s >= 1 && alpha1s > 1.0, "fcvm_mg_set_level2: bad sizes");
+    const int64_t nc = c->nc;
+    std::vector<int64_t> aptr(nagg + 1, 0);
+    for (int64_t i = 0; i < nc; i++) {
+        NEED(agg[i] >= 0 && agg[i] < nagg, "fcvm_mg_set_level2: aggregate id out of range");
+        aptr[agg[i] + 1]++;
+    }
+    for (int64_t g = 0; g < nagg; g++) {
+        aptr[g + 1] += aptr[g];
+        NEED(aoff[g + 1] >= aoff[g] && aoff[g + 1] - aoff[g] <= 6, "fcvm_mg_set_level2: at most 6 modes per aggregate");
+    }
+    NEED(aoff[0] == 0 && aoff[nagg] == n2, "fcvm_mg_set_level2: aoff does not add up to n2");
+    std::vector<int32_t> anodes(nc);
+    {
+        std::vector<int64_t> fill(aptr.begin(), aptr.end() - 1);
+        for (int64_t i = 0; i < nc; i++) anodes[fill[agg[i]]++] = (int32_t)i;
+    }
+    HCHK(hipStreamSynchronize(c->stream));
+    dfree(c->d_agg); dfree(c->d_anodes); dfree(c->d_aoff); dfree(c->d_aptr); dfree(c->d_Z); dfree(c->d_A2inv);
+    dfree(c->d_r2); dfree(c->d_e2);
+    if (dalloc(&c->d_agg, nc) || dalloc(&c->d_anodes, nc) || dalloc(&c->d_aoff, nagg + 1) || dalloc(&c->d_aptr, nagg + 1) ||
+        dalloc(&c->d_Z, nc * 18) || dalloc(&c->d_A2inv, n2 * n2) || dalloc(&c->d_r2, n2) || dalloc(&c->d_e2, n2))
+        return 1;
+    hipStream_t s = c->stream;
+    HCHK(hipMemcpyAsync(c->d_agg, agg, sizeof(int32_t) * nc, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_anodes, anodes.data(), sizeof(int32_t) * nc, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_aoff, aoff, sizeof(int64_t) * (nagg + 1), hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_aptr, aptr.data(), sizeof(int64_t) * (nagg + 1), hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_Z, Z, sizeof(double) * nc * 18, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_A2inv, A2inv, sizeof(double) * n2 * n2, hipMemcpyHostToDevice, s));
+    HCHK(hipStreamSynchronize(s));
+    c->nagg = nagg; c->n2 = n2; c->mg_k1s = k1s; c->mg_alpha1s = alpha1s;
+    c->l2 = true;
     return 0;
 }
 

@@ -183,4 +183,55 @@ __global__ __launch_bounds__(256) void k_dot2_partial(int64_t nn, const double *
     }
 }
 
+// ---- level 2: aggregates of coarse nodes with (orthonormalised) rigid-body modes -------------
+// r2[aoff[g]+k] = sum_{i in aggregate g} sum_c Z[i][c][k] * r1[3i+c]; one wavefront per aggregate
+__global__ __launch_bounds__(256) void k_l2_restrict(int64_t nagg, const int64_t *__restrict__ aptr, const int32_t *__restrict__ anodes,
+                                                     const int64_t *__restrict__ aoff, const double *__restrict__ Z,
+                                                     const double *__restrict__ r1, double *__restrict__ r2) {
+    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= nagg) return;
+    const int lane = threadIdx.x & 63;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t q = aptr[g] + lane; q < aptr[g + 1]; q += 64) {
+        const int64_t i = anodes[q];
+        const double *z = Z + i * 18;
+        const double a0 = r1[3 * i], a1 = r1[3 * i + 1], a2 = r1[3 * i + 2];
+#pragma unroll
+        for (int k = 0; k < 6; k++) acc[k] += z[k] * a0 + z[6 + k] * a1 + z[12 + k] * a2;
+    }
+    const int64_t o = aoff[g], ncol = aoff[g + 1] - o;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const double v = wave_sum(acc[k]);
+        if (lane == 0 && k < ncol) r2[o + k] = v;
+    }
+}
+
+// y = A x, A dense row-major n x n; one wavefront per row
+__global__ __launch_bounds__(256) void k_gemv(int64_t n, const double *__restrict__ A, const double *__restrict__ x, double *__restrict__ y) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const int lane = threadIdx.x & 63;
+    const double *a = A + row * n;
+    double acc = 0.0;
+    for (int64_t j = lane; j < n; j += 64) acc += a[j] * x[j];
+    acc = wave_sum(acc);
+    if (lane == 0) y[row] = acc;
+}
+
+// d1[3i+c] = sum_k Z[i][c][k] * e2[aoff[agg[i]]+k]
+__global__ __launch_bounds__(256) void k_l2_prolong(int64_t nc, const int32_t *__restrict__ agg, const int64_t *__restrict__ aoff,
+                                                    const double *__restrict__ Z, const double *__restrict__ e2, double *__restrict__ d1) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nc) return;
+    const int64_t g = agg[i], o = aoff[g], ncol = aoff[g + 1] - o;
+    const double *z = Z + i * 18;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+    for (int k = 0; k < ncol; k++) {
+        const double e = e2[o + k];
+        v0 += z[k] * e; v1 += z[6 + k] * e; v2 += z[12 + k] * e;
+    }
+    d1[3 * i] = v0; d1[3 * i + 1] = v1; d1[3 * i + 2] = v2;
+}
+
 }  // namespace fcvm

@@ -72,6 +72,7 @@ class Context:
         self.ne = self.nn = 0
         # preconditioner of the linear solve: p-multigrid by default, FCVM_PRECOND=bj for block-Jacobi
         self.set_precond(os.environ.get("FCVM_PRECOND", "mg"))
+        self.l2_min_coarse_nodes = int(os.environ.get("FCVM_L2_MIN_COARSE", "20000"))
 
     def close(self):
         if self.h:
@@ -146,6 +147,8 @@ class Context:
         call("fcvm_assemble", self.h, disp.ptr if disp is not None else None,
              sig.ptr if sig is not None else None, pgp.ptr if pgp is not None else None, float(Et_E), g,
              glv.ptr, modf.ptr, xgp.ptr if xgp is not None else None, C.byref(vol))
+        if os.environ.get("FCVM_MG_LEVEL2", "1") != "0":
+            self.l2_info = self.build_level2()
         return glv, modf, vol.value
 
     def update_stress_load(self, sig_yield, disp_new, du, sig_old, sig_new, sig_test, qin, Et_E, LD, pgp):
@@ -191,10 +194,24 @@ class Context:
         call("fcvm_set_precond", self.h, 1 if mode == "mg" else 0, int(k0), int(k1), float(alpha0), float(alpha1))
 
     def precond_info(self):
-        o = (C.c_double * 6)()
+        o = (C.c_double * 8)()
         call("fcvm_precond_info", self.h, o)
-        return dict(mode="mg" if o[0] == 1 else "bj", coarse_nodes=int(o[1]), lmax0=o[2], lmax1=o[3],
-                    coarse_nnz_blocks=int(o[4]), vcycle_fine_spmv=int(o[5]))
+        d = dict(mode="mg" if o[0] == 1 else "bj", coarse_nodes=int(o[1]), lmax0=o[2], lmax1=o[3],
+                 coarse_nnz_blocks=int(o[4]), vcycle_fine_spmv=int(o[5]), l2_aggregates=int(o[6]), l2_unknowns=int(o[7]))
+        d["level2"] = (" -> %d aggregates x rigid-body modes (%d unknowns, dense inverse)" % (d["l2_aggregates"], d["l2_unknowns"])
+                       if d["l2_aggregates"] else "")
+        return d
+
+    def build_level2(self, target=None, k1s=3, alpha1s=8.0):
+        """Third multigrid level (aggregates of tet4 nodes); call after assemble().  Skipped for
+        small coarse levels where the long Chebyshev sweep is cheap anyway."""
+        from . import mg2
+        pi = self.precond_info()
+        if pi["mode"] != "mg" or pi["coarse_nodes"] < self.l2_min_coarse_nodes:
+            return None
+        if target is None:
+            target = max(60, int(round(pi["coarse_nodes"] / 1000.0)))  # ~1000 aggregates, >= 60 nodes each
+        return mg2.build_level2(self, target=target, k1s=k1s, alpha1s=alpha1s)
 
     def spmv(self, x, y):
         call("fcvm_spmv", self.h, x.ptr, y.ptr)

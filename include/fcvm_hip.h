@@ -151,8 +151,25 @@ int fcvm_solve_timing(fcvm_ctx *c, double out[4]);
  */
 int fcvm_set_precond(fcvm_ctx *c, int mode, int k0, int k1, double alpha0, double alpha1);
 /* out[0]=mode, out[1]=coarse nodes, out[2]=lmax level 0, out[3]=lmax level 1, out[4]=coarse nnz
- * blocks, out[5]=fine SpMV launches inside V-cycles of the last solve */
-int fcvm_precond_info(fcvm_ctx *c, double out[6]);
+ * blocks, out[5]=fine SpMV launches inside V-cycles of the last solve, out[6]=level-2 aggregates,
+ * out[7]=level-2 unknowns (0 = no level 2) */
+int fcvm_precond_info(fcvm_ctx *c, double out[8]);
+
+/*
+ * Optional third multigrid level.  The host binding groups the tet4 (level-1) nodes into
+ * aggregates, gives every aggregate up to 6 orthonormalised rigid-body modes Z (rows of fixed dofs
+ * zeroed), forms A2 = Z^T A1 Z from the level-1 matrix and hands over its dense inverse:
+ *   fcvm_mg_coarse_nodes   [host] coord1 f64[nc*3], fixmask1 u8[nc]   (inputs for the aggregation)
+ *   fcvm_mg_coarse_to_coo  [host] scalar COO of the level-1 matrix, 9 * (coarse nnz blocks) entries
+ *   fcvm_mg_set_level2     agg int32[nc] aggregate of each level-1 node, aoff int64[nagg+1] first
+ *                          level-2 unknown of each aggregate, Z f64[nc][3][6], A2inv f64[n2*n2]
+ *                          row-major, k1s/alpha1s: Chebyshev smoothing steps / range on level 1.
+ * Level 2 is dropped again by the next fcvm_assemble (the coarse operator changed).
+ */
+int fcvm_mg_coarse_nodes(fcvm_ctx *c, double *coord1, uint8_t *fixmask1);
+int fcvm_mg_coarse_to_coo(fcvm_ctx *c, int64_t *row, int64_t *col, double *val);
+int fcvm_mg_set_level2(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg, const int64_t *aoff,
+                       const double *Z, const double *A2inv, int k1s, double alpha1s);
 
 /* host-only self check of the sparsity pattern builder (no GPU needed): out[0]=nnz blocks,
  * out[1]=padded slots, out[2]=slices, out[3]=max row length, out[4]=number of violated invariants

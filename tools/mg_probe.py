@@ -19,6 +19,7 @@ ap.add_argument("--cells", type=int, default=24)
 ap.add_argument("--rtol", type=float, default=1e-10)
 ap.add_argument("--configs", type=str, default="bj;2,30,8,300;3,30,10,300;2,60,8,1000;3,60,10,1000")
 ap.add_argument("--nu", type=float, default=0.3)
+ap.add_argument("--l2", type=str, default="", help="level-2 settings target,k1s,alpha1s;... appended to each mg config")
 a = ap.parse_args()
 case = meshgen.cube_case(a.cells, l=100.0, traction=(20.0, 0.0, 200.0))
 m = GpuModel(case["elNodes"], case["nocoord"], (210000.0, a.nu, 7.8e-6), case["fix"],
@@ -26,7 +27,15 @@ m = GpuModel(case["elNodes"], case["nocoord"], (210000.0, a.nu, 7.8e-6), case["f
 c = m.ctx
 print("elements", m.ne, "dof", m.ndof, flush=True)
 ref = None
+os.environ["FCVM_MG_LEVEL2"] = "0"
+runs = []
 for cfg in a.configs.split(";"):
+    if cfg == "bj" or not a.l2:
+        runs.append((cfg, None))
+    for l2 in [x for x in a.l2.split(";") if x]:
+        if cfg != "bj":
+            runs.append((cfg, l2))
+for cfg, l2 in runs:
     if cfg == "bj":
         c.set_precond("bj")
     else:
@@ -36,6 +45,11 @@ for cfg in a.configs.split(";"):
     glv, modf, V, _ = m.calc_gsm((0.0, 0.0, 0.0), want_x=False)
     c.sync()
     t_setup = time.perf_counter() - t0
+    if l2:
+        tg, k1s, a1s = l2.split(",")
+        t0 = time.perf_counter()
+        li = c.build_level2(target=int(tg), k1s=int(k1s), alpha1s=float(a1s))
+        cfg = cfg + "|L2 " + l2 + " " + str(li) + " %.1fs" % (time.perf_counter() - t0)
     f = c.mul(m.fixdof, glv)
     c.axpby(1.0, f, 1.0, modf, out=f)
     c.sync()
