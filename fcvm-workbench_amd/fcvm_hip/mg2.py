@@ -2,6 +2,7 @@
 rigid-body modes, A2 = Z^T A1 Z and its dense inverse.  O(coarse) work, done once per assembled
 coarse operator; the V-cycle itself runs entirely in libfcvm_hip kernels."""
 import ctypes as C
+import os
 
 import numpy as np
 import scipy.linalg as sla
@@ -71,16 +72,19 @@ def build_level2(ctx, target=250, k1s=3, alpha1s=8.0, rank_tol=1e-8):
     A2 = 0.5 * (A2 + A2.T)
     A2[np.diag_indices(n2)] += 1e-13 * np.trace(A2) / n2
     A2inv = None
-    try:  # dense inverse on the GPU when torch is around (plumbing), LAPACK on the host otherwise
-        import torch
-        if torch.cuda.is_available() and n2 >= 2000:
-            t = torch.as_tensor(A2, device="cuda")
-            A2inv = torch.linalg.inv(t).cpu().numpy()
-    except Exception:
-        A2inv = None
-    if A2inv is None:
-        cf = sla.cho_factor(A2, lower=True, check_finite=False)
-        A2inv = sla.cho_solve(cf, np.eye(n2), check_finite=False)
+    if os.environ.get("FCVM_L2_TORCH", "0") == "1":  # optional: dense inverse on the GPU through torch
+        try:
+            import torch
+            if torch.cuda.is_available():
+                A2inv = torch.linalg.inv(torch.as_tensor(A2, device="cuda")).cpu().numpy()
+        except Exception:
+            A2inv = None
+    if A2inv is None:  # LAPACK on the host: Cholesky factor + inverse from the factor
+        L, info = sla.lapack.dpotrf(A2, lower=1, overwrite_a=0)
+        if info != 0:
+            raise RuntimeError("build_level2: coarse matrix not positive definite (dpotrf info %d)" % info)
+        Li, info = sla.lapack.dpotri(L, lower=1, overwrite_c=1)
+        A2inv = np.tril(Li) + np.tril(Li, -1).T
     A2inv = np.ascontiguousarray(0.5 * (A2inv + A2inv.T))
     Zc = np.ascontiguousarray(Z.reshape(nc, 18))
     agg = np.ascontiguousarray(agg, np.int32)
