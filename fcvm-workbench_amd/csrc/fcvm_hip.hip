@@ -60,8 +60,8 @@ struct fcvm_ctx {
     std::vector<double> h_coord;
     std::vector<uint8_t> h_fixmask;
     // p-multigrid preconditioner (mode 1): level 1 = linear tets on the corner nodes
-    int precond_mode = 0, mg_k0 = 2, mg_k1 = 30;
-    double mg_alpha0 = 8.0, mg_alpha1 = 300.0, mg_lmax0 = 0, mg_lmax1 = 0;
+    int precond_mode = 0, mg_k0 = 1, mg_k1 = 60;
+    double mg_alpha0 = 4.0, mg_alpha1 = 1000.0, mg_lmax0 = 0, mg_lmax1 = 0;
     bool mg_topo = false;
     int64_t nc = 0, nb_spmv1 = 0;
     Pattern pat1;
