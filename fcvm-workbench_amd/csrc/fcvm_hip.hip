@@ -74,6 +74,7 @@ struct fcvm_ctx {
     double *d_mr = nullptr, *d_md = nullptr, *d_mt = nullptr, *d_r1 = nullptr, *d_x1 = nullptr, *d_d1 = nullptr, *d_t1 = nullptr,
            *d_rr1 = nullptr;
     int64_t mg_spmv0 = 0, mg_spmv1 = 0;
+    const double *mg_done = nullptr;  // device flag that turns the V-cycle kernels into no-ops once PCG has converged
     // level 2: aggregates + dense inverse (set from the host binding)
     bool l2 = false;
     int64_t nagg = 0, n2 = 0;

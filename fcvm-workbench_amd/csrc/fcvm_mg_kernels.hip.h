@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void k_assemble_tet4(int64_t ne, const int32_t
 __global__ __launch_bounds__(256) void k_restrict(int64_t nc, const int32_t *__restrict__ c2f,
                                                   const int64_t *__restrict__ mptr, const int32_t *__restrict__ mids,
                                                   const uint8_t *__restrict__ fixmask0, const double *__restrict__ r0,
-                                                  double *__restrict__ r1) {
+                                                  double *__restrict__ r1, const double *__restrict__ done) {
+    if (done && *done != 0.0) return;
     int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= nc) return;
     const int64_t f = c2f[c];
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(256) void k_restrict(int64_t nc, const int32_t *__r
 // d0 = M0 P M1 e1 : fine corner nodes copy, mid-side nodes average their two edge ends
 __global__ __launch_bounds__(256) void k_prolong(int64_t nn, const int32_t *__restrict__ pa, const int32_t *__restrict__ pb,
                                                  const uint8_t *__restrict__ fixmask0, const double *__restrict__ e1,
-                                                 double *__restrict__ d0) {
+                                                 double *__restrict__ d0, const double *__restrict__ done) {
+    if (done && *done != 0.0) return;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nn) return;
     const int64_t a = pa[i], b = pb[i];
@@ -116,7 +118,8 @@ __global__ __launch_bounds__(256) void k_prolong(int64_t nn, const int32_t *__re
 // start of a Chebyshev sweep from the zero vector: x = 0, r = b, d = c0 * Dinv b
 __global__ __launch_bounds__(256) void k_cheb_init(int64_t nn, const double *__restrict__ dinv, const double *__restrict__ b,
                                                    double *__restrict__ x, double *__restrict__ r, double *__restrict__ d,
-                                                   double c0) {
+                                                   double c0, const double *__restrict__ done) {
+    if (done && *done != 0.0) return;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nn) return;
     const double r0 = b[3 * i], r1 = b[3 * i + 1], r2 = b[3 * i + 2];
@@ -130,7 +133,8 @@ __global__ __launch_bounds__(256) void k_cheb_init(int64_t nn, const double *__r
 // x += d ; r -= t (t = A d, may be NULL: then r is left alone) ; d = cdd * d + cdr * Dinv r
 __global__ __launch_bounds__(256) void k_cheb_step(int64_t nn, const double *__restrict__ dinv, const double *__restrict__ t,
                                                    double *__restrict__ x, double *__restrict__ r, double *__restrict__ d,
-                                                   double cdd, double cdr, int update_d) {
+                                                   double cdd, double cdr, int update_d, const double *__restrict__ done) {
+    if (done && *done != 0.0) return;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nn) return;
     const double d0 = d[3 * i], d1 = d[3 * i + 1], d2 = d[3 * i + 2];
@@ -163,7 +167,8 @@ __global__ __launch_bounds__(256) void k_pcg_update_xr_plain(int64_t nn, const d
 
 // partials of r.z (slot 0) and r.r (slot 1), layout of k_pcg_scalars
 __global__ __launch_bounds__(256) void k_dot2_partial(int64_t nn, const double *__restrict__ r, const double *__restrict__ z,
-                                                      double *__restrict__ part, int64_t nb) {
+                                                      double *__restrict__ part, int64_t nb, const double *__restrict__ done) {
+    if (done && *done != 0.0) return;
     __shared__ double sh[4];
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double rz = 0.0, rr = 0.0;
@@ -187,7 +192,8 @@ __global__ __launch_bounds__(256) void k_dot2_partial(int64_t nn, const double *
 // r2[aoff[g]+k] = sum_{i in aggregate g} sum_c Z[i][c][k] * r1[3i+c]; one wavefront per aggregate
 __global__ __launch_bounds__(256) void k_l2_restrict(int64_t nagg, const int64_t *__restrict__ aptr, const int32_t *__restrict__ anodes,
                                                      const int64_t *__restrict__ aoff, const double *__restrict__ Z,
-                                                     const double *__restrict__ r1, double *__restrict__ r2) {
+                                                     const double *__restrict__ r1, double *__restrict__ r2, const double *__restrict__ done) {
+    if (done && *done != 0.0) return;
     const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= nagg) return;
     const int lane = threadIdx.x & 63;
@@ -208,7 +214,8 @@ __global__ __launch_bounds__(256) void k_l2_restrict(int64_t nagg, const int64_t
 }
 
 // y = A x, A dense row-major n x n; one wavefront per row
-__global__ __launch_bounds__(256) void k_gemv(int64_t n, const double *__restrict__ A, const double *__restrict__ x, double *__restrict__ y) {
+__global__ __launch_bounds__(256) void k_gemv(int64_t n, const double *__restrict__ A, const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ done) {
+    if (done && *done != 0.0) return;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
     const int lane = threadIdx.x & 63;
@@ -221,7 +228,8 @@ __global__ __launch_bounds__(256) void k_gemv(int64_t n, const double *__restric
 
 // d1[3i+c] = sum_k Z[i][c][k] * e2[aoff[agg[i]]+k]
 __global__ __launch_bounds__(256) void k_l2_prolong(int64_t nc, const int32_t *__restrict__ agg, const int64_t *__restrict__ aoff,
-                                                    const double *__restrict__ Z, const double *__restrict__ e2, double *__restrict__ d1) {
+                                                    const double *__restrict__ Z, const double *__restrict__ e2, double *__restrict__ d1, const double *__restrict__ done) {
+    if (done && *done != 0.0) return;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nc) return;
     const int64_t g = agg[i], o = aoff[g], ncol = aoff[g + 1] - o;
