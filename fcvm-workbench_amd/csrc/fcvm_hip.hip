@@ -392,7 +392,7 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
                            grav[1], grav[2], c->d_vals, glv_grav, modf, xgp, c->d_out8);
     HCHK(hipGetLastError());
     if (refresh_precond(c)) return 1;
-    if (c->precond_mode == 1) {
+    if (c->precond_mode >= 1) {
         HCHK(hipStreamSynchronize(s));
         if (mg_setup(c)) return 1;
     }
@@ -502,6 +502,7 @@ int fcvm_solve(fcvm_ctx *c, const double *f, double *u, double rtol, int64_t max
     NEED(c && c->have_mesh && c->assembled, "fcvm_solve: assemble the matrix first");
     NEED(f && u && f != u, "fcvm_solve: f and u must be distinct device arrays");
     if (c->precond_mode == 1) return mg_pcg(c, f, u, rtol, maxit, info);
+    NEED(c->precond_mode == 0, "fcvm_solve: in hierarchy-only mode the solve is driven by the host (multi-GPU)");
     hipStream_t s = c->stream;
     const int64_t nn = c->nn, n = 3 * nn, nbv = c->nb_vec;
     const int CHUNK = 25;
@@ -575,10 +576,10 @@ int fcvm_solve_timing(fcvm_ctx *c, double out_ms[4]) {
 }
 
 int fcvm_set_precond(fcvm_ctx *c, int mode, int k0, int k1, double alpha0, double alpha1) {
-    NEED(c && (mode == 0 || mode == 1), "fcvm_set_precond: mode 0 (block-Jacobi) or 1 (p-multigrid)");
+    NEED(c && mode >= 0 && mode <= 2, "fcvm_set_precond: mode 0 (block-Jacobi), 1 (p-multigrid) or 2 (hierarchy only, host-driven V-cycle)");
     NEED(mode == 0 || (k0 >= 1 && k1 >= 1 && alpha0 > 1.0 && alpha1 > 1.0), "fcvm_set_precond: bad smoother parameters");
     c->precond_mode = mode;
-    if (mode == 1) { c->mg_k0 = k0; c->mg_k1 = k1; c->mg_alpha0 = alpha0; c->mg_alpha1 = alpha1; }
+    if (mode >= 1) { c->mg_k0 = k0; c->mg_k1 = k1; c->mg_alpha0 = alpha0; c->mg_alpha1 = alpha1; }
     c->assembled = false;  // the next fcvm_assemble builds what the mode needs
     return 0;
 }
@@ -728,6 +729,78 @@ int fcvm_mg_set_level2(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg
     HCHK(hipStreamSynchronize(s));
     c->nagg = nagg; c->n2 = n2; c->mg_k1s = k1s; c->mg_alpha1s = alpha1s;
     c->l2 = true;
+    return 0;
+}
+
+/* ---- fine-grained multigrid building blocks for the host-driven multi-GPU V-cycle ---- */
+static int mg_level(fcvm_ctx *c, int level, MatView *A, const double **dinv, int64_t *nnodes) {
+    NEED(c && c->have_mesh && (level == 0 || (level == 1 && c->mg_topo)), "multigrid level not available");
+    if (level == 0) { *A = fine_view(c); *dinv = c->d_dinv; *nnodes = c->nn; }
+    else { *A = coarse_view(c); *dinv = c->d_dinv1; *nnodes = c->nc; }
+    return 0;
+}
+
+int fcvm_mg_coarse_map(fcvm_ctx *c, int32_t *c2f) {
+    NEED(c && c->mg_topo, "fcvm_mg_coarse_map: no multigrid hierarchy");
+    HCHK(hipMemcpyAsync(c2f, c->d_c2f, sizeof(int32_t) * c->nc, hipMemcpyDeviceToHost, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int fcvm_spmv_level(fcvm_ctx *c, int level, const double *x, double *y) {
+    MatView A; const double *dinv; int64_t n;
+    if (mg_level(c, level, &A, &dinv, &n)) return 1;
+    launch_spmv_t<false>(c, A, x, y, nullptr, nullptr);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_mg_get_diag_blocks(fcvm_ctx *c, int level, double *dblk) {
+    if (level == 0) return fcvm_get_diag_blocks(c, dblk);
+    NEED(c && c->mg_topo, "fcvm_mg_get_diag_blocks: no multigrid hierarchy");
+    hipLaunchKernelGGL(k_diag_get, dim3((unsigned)cdiv(c->nc, 256)), dim3(256), 0, c->stream, c->nc, c->d_diagoff1, c->d_vals1, dblk);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_mg_set_diag_blocks(fcvm_ctx *c, int level, const double *dblk) {
+    if (level == 0) return fcvm_set_diag_blocks(c, dblk);
+    NEED(c && c->mg_topo, "fcvm_mg_set_diag_blocks: no multigrid hierarchy");
+    hipLaunchKernelGGL(k_diag_invert, dim3((unsigned)cdiv(c->nc, 256)), dim3(256), 0, c->stream, c->nc, dblk, c->d_dinv1);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_mg_cheb_init(fcvm_ctx *c, int level, const double *b, double *x, double *r, double *d, double c0) {
+    MatView A; const double *dinv; int64_t n;
+    if (mg_level(c, level, &A, &dinv, &n)) return 1;
+    hipLaunchKernelGGL(k_cheb_init, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, c->stream, n, dinv, b, x, r, d, c0, (const double *)nullptr);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_mg_cheb_step(fcvm_ctx *c, int level, const double *t, double *x, double *r, double *d, double cdd, double cdr, int update_d) {
+    MatView A; const double *dinv; int64_t n;
+    if (mg_level(c, level, &A, &dinv, &n)) return 1;
+    hipLaunchKernelGGL(k_cheb_step, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, c->stream, n, dinv, t, x, r, d, cdd, cdr, update_d,
+                       (const double *)nullptr);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_mg_restrict(fcvm_ctx *c, const double *r0, double *r1) {
+    NEED(c && c->mg_topo, "fcvm_mg_restrict: no multigrid hierarchy");
+    hipLaunchKernelGGL(k_restrict, dim3((unsigned)cdiv(c->nc, 256)), dim3(256), 0, c->stream, c->nc, c->d_c2f, c->d_mptr, c->d_mids,
+                       c->d_fixmask, r0, r1, (const double *)nullptr);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_mg_prolong(fcvm_ctx *c, const double *e1, double *d0) {
+    NEED(c && c->mg_topo, "fcvm_mg_prolong: no multigrid hierarchy");
+    hipLaunchKernelGGL(k_prolong, dim3((unsigned)cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_pa, c->d_pb, c->d_fixmask, e1,
+                       d0, (const double *)nullptr);
+    HCHK(hipGetLastError());
     return 0;
 }
 

@@ -57,6 +57,14 @@ SIGNATURES = {
     "fcvm_mg_coarse_nodes": [_vp, _vp, _vp],
     "fcvm_mg_coarse_to_coo": [_vp, _vp, _vp, _vp],
     "fcvm_mg_set_level2": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _int, _f64],
+    "fcvm_mg_coarse_map": [_vp, _vp],
+    "fcvm_spmv_level": [_vp, _int, _vp, _vp],
+    "fcvm_mg_get_diag_blocks": [_vp, _int, _vp],
+    "fcvm_mg_set_diag_blocks": [_vp, _int, _vp],
+    "fcvm_mg_cheb_init": [_vp, _int, _vp, _vp, _vp, _vp, _f64],
+    "fcvm_mg_cheb_step": [_vp, _int, _vp, _vp, _vp, _vp, _f64, _f64, _int],
+    "fcvm_mg_restrict": [_vp, _vp, _vp],
+    "fcvm_mg_prolong": [_vp, _vp, _vp],
 }
 _SPECIAL = {"fcvm_last_error": ([], C.c_char_p), "fcvm_version": ([], C.c_int)}
 

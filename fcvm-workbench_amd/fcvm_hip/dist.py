@@ -106,17 +106,18 @@ class Partition:
 class Exchanger:
     """Adds the partial sums at shared nodes across ranks (ncomp values per node)."""
 
-    def __init__(self, part, device):
+    def __init__(self, part, device, shared=None, nn=None):
         self.part, self.device = part, device
-        self.idx = {s: torch.as_tensor(ix, dtype=torch.int64, device=device) for s, ix in part.shared.items()}
-        self.bytes_per_call = {}
+        shared = part.shared if shared is None else shared
+        self.nn = part.nn if nn is None else nn
+        self.idx = {s: torch.as_tensor(ix, dtype=torch.int64, device=device) for s, ix in shared.items() if len(ix)}
 
     def interface_sum(self, t, ncomp):
         """t: flat tensor [nn*ncomp]; in place."""
         p = self.part
         if p.world == 1 or not self.idx:
             return t
-        v = t.view(p.nn, ncomp)
+        v = t.view(self.nn, ncomp)
         # gloo has no GPU point-to-point: stage through the host there (CPU tests / shared-GPU rehearsal);
         # with nccl (= RCCL) the buffers go GPU to GPU over xGMI
         stage = t.is_cuda and dist.get_backend(p.group) == "gloo"
@@ -147,7 +148,7 @@ class DistBackend:
         self.group = part.group
         self.check_every = pcg_check_every
         self._timing = dict(spmv_ms=0.0, total_ms=0.0)
-        self.dinv_ready = False
+        self.mg = None  # DistMG once enabled (enable_multigrid)
 
     # -- allocation ---------------------------------------------------------------------------
     def _dt(self, dtype):
@@ -222,7 +223,16 @@ class DistBackend:
         self.ex.interface_sum(dblk.t, 9)
         self.ops.set_diag_blocks(dblk)
         v = torch.tensor([vol], dtype=torch.float64, device=self.device)
+        if self.mg is not None:
+            self.mg.setup()
         return glv, modf, float(self._allreduce(v).item())
+
+    def enable_multigrid(self, nocoord_local, **kw):
+        """p-multigrid V-cycle as PCG preconditioner on all ranks (needs LocalOps with the mg_* methods)."""
+        self.ops.mg_enable()
+        self.mg = DistMG(self, nocoord_local, **kw)
+        if self.mg.check_every:
+            self.check_every = self.mg.check_every
 
     def update_stress_load(self, sig_yield, disp_new, du, sig_old, sig_new, sig_test, qin, Et_E, LD, pgp):
         self.ops.update_stress_load(sig_yield, disp_new, du, sig_old, sig_new, sig_test, qin, Et_E, LD, pgp)
@@ -248,7 +258,10 @@ class DistBackend:
         return y
 
     def precond(self, r, z):
-        self.ops.precond(r, z)
+        if self.mg is not None and self.mg.ready:
+            self.mg.vcycle(r, z)
+        else:
+            self.ops.precond(r, z)
         return z
 
     # -- distributed block-Jacobi PCG ---------------------------------------------------------
@@ -291,6 +304,209 @@ class DistBackend:
 
     def solve_timing(self):
         return self._timing
+
+
+class _Cheb:
+    """Chebyshev coefficients for eigenvalues of Dinv*A in [lmax/alpha, lmax] (same recurrences as
+    the single-GPU V-cycle in csrc/fcvm_mg.inc)."""
+
+    def __init__(self, lmax, alpha, k):
+        lmin = lmax / alpha
+        theta, delta = 0.5 * (lmax + lmin), 0.5 * (lmax - lmin)
+        sigma = theta / delta
+        self.c0 = 1.0 / theta
+        self.cdd, self.cdr = [0.0] * (k + 1), [0.0] * (k + 1)
+        rho = 1.0 / sigma
+        for j in range(1, k + 1):
+            rn = 1.0 / (2.0 * sigma - rho)
+            self.cdd[j], self.cdr[j] = rn * rho, 2.0 * rn / delta
+            rho = rn
+
+
+class DistMG:
+    """The three-level V-cycle of the single-GPU solver (tet10 -> tet4 -> aggregates with rigid-body
+    modes) on a partitioned mesh.  Vectors are consistent; every local SpMV is followed by the
+    shared-node exchange of its level; restriction weights every node by 1/multiplicity so that the
+    partial sums add up; the aggregate level is replicated (one small all-reduce per cycle)."""
+
+    def __init__(self, be, nocoord_local, k0=1, alpha0=4.0, k1s=3, alpha1s=8.0, target=None, check_every=4):
+        self.be, self.ops, self.part = be, be.ops, be.part
+        self.xyz = np.ascontiguousarray(nocoord_local, dtype=np.float64)
+        self.k0, self.alpha0, self.k1s, self.alpha1s, self.target = k0, alpha0, k1s, alpha1s, target
+        self.check_every = check_every
+        self.ready = False
+        self.topo = False
+
+    # -- set-up -------------------------------------------------------------------------------
+    def _topology(self):
+        be, part, dev = self.be, self.part, self.be.device
+        c2f = np.asarray(self.ops.mg_coarse_map(), dtype=np.int64)
+        self.nc = len(c2f)
+        f2c = np.full(part.nn, -1, dtype=np.int64)
+        f2c[c2f] = np.arange(self.nc)
+        shared1 = {}
+        for s, ix in part.shared.items():
+            cix = f2c[ix]
+            shared1[s] = cix[cix >= 0]  # shared corner nodes, same (global id) order on both sides
+        self.ex1 = Exchanger(part, dev, shared=shared1, nn=self.nc)
+        ones = torch.ones(part.nn, dtype=torch.float64, device=dev)
+        be.ex.interface_sum(ones, 1)
+        self.w0 = (1.0 / ones).repeat_interleave(3)           # 1 / (ranks holding the node), per dof
+        c2f_t = torch.as_tensor(c2f, device=dev)
+        self.own1 = be.w.view(-1, 3)[c2f_t].reshape(-1).contiguous()  # owner weights of level-1 dofs
+        self.c2f = c2f
+        n0, n1 = 3 * part.nn, 3 * self.nc
+        mk = lambda n: TVec(torch.zeros(n, dtype=torch.float64, device=dev))  # noqa: E731
+        self.r0, self.d0, self.t0, self.rw = mk(n0), mk(n0), mk(n0), mk(n0)
+        self.r1, self.x1, self.rr1, self.d1, self.t1 = mk(n1), mk(n1), mk(n1), mk(n1), mk(n1)
+        self.topo = True
+
+    def _lmax(self, level, n, wdot):
+        """power iteration on Dinv*A of a level with distributed SpMV; start vector is a fixed function
+        of the global node numbers so that it is consistent across ranks"""
+        dev = self.be.device
+        g = torch.as_tensor(self.part.gnodes if level == 0 else self.part.gnodes[self.c2f], dtype=torch.float64, device=dev)
+        v = TVec(torch.stack([torch.sin(0.7 * g + 0.1), torch.cos(1.3 * g), torch.sin(2.9 * g + 1.0)], 1).reshape(-1).contiguous())
+        w, z, tmp1, tmp2 = (TVec(torch.zeros(n, dtype=torch.float64, device=dev)) for _ in range(4))
+        ex = self.be.ex if level == 0 else self.ex1
+        nv = float(wdot(v.t, v.t).item())
+        lam = 0.0
+        for _ in range(15):
+            self.ops.mg_spmv(level, v, w)
+            ex.interface_sum(w.t, 3)
+            self.ops.mg_cheb_init(level, w, tmp1, tmp2, z, 1.0)  # z = Dinv w
+            nz = float(wdot(z.t, z.t).item())
+            lam = float(np.sqrt(nz / nv))
+            v.t.copy_(z.t / np.sqrt(nz))
+            nv = 1.0
+        return lam
+
+    def setup(self):
+        be, dev = self.be, self.be.device
+        if not self.topo:
+            self._topology()
+        # level-1 diagonal blocks: local partial sums -> consistent -> inverted for the smoother
+        dblk = TVec(torch.zeros(9 * self.nc, dtype=torch.float64, device=dev))
+        self.ops.mg_get_diag(1, dblk)
+        self.ex1.interface_sum(dblk.t, 9)
+        self.ops.mg_set_diag(1, dblk)
+        wdot0 = lambda a, b: be._allreduce(torch.sum(be.w * a * b).reshape(1))  # noqa: E731
+        wdot1 = lambda a, b: be._allreduce(torch.sum(self.own1 * a * b).reshape(1))  # noqa: E731
+        self.lmax0 = self._lmax(0, 3 * self.part.nn, wdot0)
+        self.lmax1 = self._lmax(1, 3 * self.nc, wdot1)
+        self.ch0 = _Cheb(1.1 * self.lmax0, self.alpha0, self.k0)
+        self.ch1 = _Cheb(1.1 * self.lmax1, self.alpha1s, self.k1s)
+        self._level2()
+        self.ready = True
+
+    def _level2(self):
+        """global aggregates (bins over the global bounding box), raw rigid-body modes about the global
+        aggregate centroids, A2 = sum over ranks of Z^T A1_local Z, replicated regularised inverse"""
+        import scipy.linalg as sla
+        import scipy.sparse as sp
+        be, dev, part = self.be, self.be.device, self.part
+        coord, fm = self.ops.mg_coarse_nodes()
+        own = self.own1.view(-1, 3)[:, 0].cpu().numpy() > 0.5
+        lo = torch.as_tensor(coord.min(0), device=dev)
+        hi = torch.as_tensor(coord.max(0), device=dev)
+        be._allreduce(lo, dist.ReduceOp.MIN)
+        be._allreduce(hi, dist.ReduceOp.MAX)
+        lo, hi = lo.cpu().numpy(), hi.cpu().numpy()
+        ncg = torch.tensor([float(own.sum())], dtype=torch.float64, device=dev)
+        ncg = float(be._allreduce(ncg).item())
+        target = self.target if self.target else max(60, int(round(ncg / 1000.0)))
+        ext = np.maximum(hi - lo, 1e-300)
+        live = ext > 1e-9 * ext.max()
+        h = (np.prod(ext[live]) / max(1.0, ncg / target)) ** (1.0 / max(1, live.sum()))
+        nb = np.where(live, np.maximum(1, np.round(ext / h)), 1).astype(np.int64)
+        ij = np.minimum((np.where(live, (coord - lo) / ext, 0.0) * nb).astype(np.int64), nb - 1)
+        key = (ij[:, 0] * nb[1] + ij[:, 1]) * nb[2] + ij[:, 2]
+        keys = [None] * part.world
+        dist.all_gather_object(keys, np.unique(key), group=part.group)
+        allk = np.unique(np.concatenate(keys))
+        agg = np.searchsorted(allk, key)
+        nagg = len(allk)
+        # global centroid / extent of every aggregate (owner-weighted sums)
+        acc = np.zeros((nagg, 5))
+        np.add.at(acc, agg[own], np.concatenate([coord[own], np.ones((own.sum(), 1)), np.zeros((own.sum(), 1))], 1))
+        acc_t = torch.as_tensor(acc, device=dev)
+        be._allreduce(acc_t)
+        acc = acc_t.cpu().numpy()
+        cen = acc[:, :3] / np.maximum(acc[:, 3:4], 1.0)
+        x = coord - cen[agg]
+        sc = np.zeros(nagg)
+        np.maximum.at(sc, agg, np.abs(x).max(1))
+        sc_t = torch.as_tensor(sc, device=dev)
+        be._allreduce(sc_t, dist.ReduceOp.MAX)
+        x = x / np.maximum(sc_t.cpu().numpy(), 1e-300)[agg][:, None]
+        Z = np.zeros((self.nc, 3, 6))
+        Z[:, 0, 0] = Z[:, 1, 1] = Z[:, 2, 2] = 1.0
+        Z[:, 1, 3], Z[:, 2, 3] = -x[:, 2], x[:, 1]
+        Z[:, 0, 4], Z[:, 2, 4] = x[:, 2], -x[:, 0]
+        Z[:, 0, 5], Z[:, 1, 5] = -x[:, 1], x[:, 0]
+        free = np.stack([(fm & 1) == 0, (fm & 2) == 0, (fm & 4) == 0], 1).astype(np.float64)
+        Z *= free[:, :, None]
+        n2 = 6 * nagg
+        row, col, val = self.ops.mg_coarse_coo()
+        A1 = sp.csr_matrix((val, (row, col)), shape=(3 * self.nc, 3 * self.nc))
+        ii = np.repeat(np.arange(self.nc), 18)
+        cc = np.tile(np.repeat(np.arange(3), 6), self.nc)
+        kk = np.tile(np.arange(6), 3 * self.nc)
+        Zs = sp.csr_matrix((Z.reshape(-1), (3 * ii + cc, 6 * agg[ii] + kk)), shape=(3 * self.nc, n2))
+        A2 = torch.as_tensor((Zs.T @ (A1 @ Zs)).toarray(), device=dev)
+        be._allreduce(A2)
+        A2 = A2.cpu().numpy()
+        A2 = 0.5 * (A2 + A2.T)
+        A2[np.diag_indices(n2)] += 1e-10 * np.abs(np.diag(A2)).max()
+        L, info = sla.lapack.dpotrf(A2, lower=1)
+        if info != 0:
+            raise RuntimeError("DistMG: aggregate-level matrix not positive definite (dpotrf info %d)" % info)
+        Li, info = sla.lapack.dpotri(L, lower=1, overwrite_c=1)
+        A2inv = np.tril(Li) + np.tril(Li, -1).T
+        self.A2inv = torch.as_tensor(np.ascontiguousarray(A2inv), device=dev)
+        self.Z = torch.as_tensor(Z, device=dev)
+        self.agg = torch.as_tensor(agg, dtype=torch.int64, device=dev)
+        self.nagg = nagg
+        self.l2_info = dict(aggregates=nagg, unknowns=n2, target=target)
+
+    # -- V-cycle ------------------------------------------------------------------------------
+    def _spmv(self, level, x, y):
+        self.ops.mg_spmv(level, x, y)
+        (self.be.ex if level == 0 else self.ex1).interface_sum(y.t, 3)
+
+    def _from_zero(self, level, ch, k, b, x, r, d, t):
+        self.ops.mg_cheb_init(level, b, x, r, d, ch.c0)
+        for j in range(1, k + 1):
+            self._spmv(level, d, t)
+            self.ops.mg_cheb_step(level, t, x, r, d, ch.cdd[j], ch.cdr[j], j < k)
+
+    def _post(self, level, ch, k, x, r, d, t):
+        self._spmv(level, d, t)
+        self.ops.mg_cheb_step(level, t, x, r, d, 0.0, ch.c0, True)
+        for j in range(1, k + 1):
+            if j < k:
+                self._spmv(level, d, t)
+                self.ops.mg_cheb_step(level, t, x, r, d, ch.cdd[j], ch.cdr[j], True)
+            else:
+                self.ops.mg_cheb_step(level, None, x, r, d, 0.0, 0.0, False)
+
+    def vcycle(self, b, x):
+        """x = M^-1 b (consistent fine vectors)"""
+        be = self.be
+        self._from_zero(0, self.ch0, self.k0, b, x, self.r0, self.d0, self.t0)
+        torch.mul(self.r0.t, self.w0, out=self.rw.t)
+        self.ops.mg_restrict(self.rw, self.r1)
+        self.ex1.interface_sum(self.r1.t, 3)
+        self._from_zero(1, self.ch1, self.k1s, self.r1, self.x1, self.rr1, self.d1, self.t1)
+        v = (self.rr1.t * self.own1).view(self.nc, 3)
+        r2 = torch.zeros(self.nagg, 6, dtype=torch.float64, device=be.device)
+        r2.index_add_(0, self.agg, torch.einsum("nck,nc->nk", self.Z, v))
+        be._allreduce(r2)
+        e2 = (self.A2inv @ r2.reshape(-1)).view(self.nagg, 6)
+        self.d1.t.copy_(torch.einsum("nck,nk->nc", self.Z, e2[self.agg]).reshape(-1))
+        self._post(1, self.ch1, self.k1s, self.x1, self.rr1, self.d1, self.t1)
+        self.ops.mg_prolong(self.x1, self.d0)
+        self._post(0, self.ch0, self.k0, x, self.r0, self.d0, self.t0)
 
 
 class DistModel:
@@ -338,6 +554,7 @@ class HipLocalOps:
         from .device import Context
         self.c = Context(device_index)
         self.c.set_stream(torch.cuda.current_stream(device_index).cuda_stream)
+        self.c.set_precond("bj")  # mg_enable() switches to "hierarchy only": the V-cycle is driven by DistMG
         self.c.set_mesh(part.elNodes, nocoord_local)
         self.c.set_material(*material)
         self.c.set_fix(fix_local)
@@ -382,3 +599,58 @@ class HipLocalOps:
 
     def precond(self, r, z):
         self.c.precond(self._p(r), self._p(z))
+
+    # -- multigrid building blocks (fcvm_set_precond mode 2 builds the hierarchy at assemble) --
+    def mg_enable(self):
+        from ._lib import call
+        call("fcvm_set_precond", self.c.h, 2, 1, 1, 4.0, 8.0)
+
+    def mg_coarse_map(self):
+        from ._lib import call
+        nc = self.c.precond_info()["coarse_nodes"]
+        out = np.empty(nc, np.int32)
+        call("fcvm_mg_coarse_map", self.c.h, out.ctypes.data)
+        return out
+
+    def mg_coarse_nodes(self):
+        from ._lib import call
+        nc = self.c.precond_info()["coarse_nodes"]
+        coord, fm = np.empty((nc, 3)), np.empty(nc, np.uint8)
+        call("fcvm_mg_coarse_nodes", self.c.h, coord.ctypes.data, fm.ctypes.data)
+        return coord, fm
+
+    def mg_coarse_coo(self):
+        from ._lib import call
+        nnz = 9 * self.c.precond_info()["coarse_nnz_blocks"]
+        r, c, v = np.empty(nnz, np.int64), np.empty(nnz, np.int64), np.empty(nnz)
+        call("fcvm_mg_coarse_to_coo", self.c.h, r.ctypes.data, c.ctypes.data, v.ctypes.data)
+        return r, c, v
+
+    def mg_spmv(self, level, x, y):
+        from ._lib import call
+        call("fcvm_spmv_level", self.c.h, level, x.ptr, y.ptr)
+
+    def mg_get_diag(self, level, dblk):
+        from ._lib import call
+        call("fcvm_mg_get_diag_blocks", self.c.h, level, dblk.ptr)
+
+    def mg_set_diag(self, level, dblk):
+        from ._lib import call
+        call("fcvm_mg_set_diag_blocks", self.c.h, level, dblk.ptr)
+
+    def mg_cheb_init(self, level, b, x, r, d, c0):
+        from ._lib import call
+        call("fcvm_mg_cheb_init", self.c.h, level, b.ptr, x.ptr, r.ptr, d.ptr, float(c0))
+
+    def mg_cheb_step(self, level, t, x, r, d, cdd, cdr, update_d):
+        from ._lib import call
+        call("fcvm_mg_cheb_step", self.c.h, level, t.ptr if t is not None else None, x.ptr, r.ptr, d.ptr, float(cdd),
+             float(cdr), 1 if update_d else 0)
+
+    def mg_restrict(self, r0, r1):
+        from ._lib import call
+        call("fcvm_mg_restrict", self.c.h, r0.ptr, r1.ptr)
+
+    def mg_prolong(self, e1, d0):
+        from ._lib import call
+        call("fcvm_mg_prolong", self.c.h, e1.ptr, d0.ptr)

@@ -36,6 +36,8 @@ def build_rank_model(rank, world, cells, material, traction, device_index, backe
         loads = Loads()
     ops = HipLocalOps(part, xyz, material, fix, device_index, element_offset=rank * len(el))
     be = DistBackend(part, ops, backend_device)
+    if os.environ.get("FCVM_PRECOND", "mg") == "mg":
+        be.enable_multigrid(xyz)
     model = DistModel(part, be, xyz, material, fix, loads, external_loads)
     return model, be, ops
 
@@ -98,7 +100,9 @@ def run(args, ctl, material, traction, rtol, hbm_peak, cpu_baseline):
                 "config": {"workload": "column of %d cubes of %d^3 cells = %d tet10 (%d per GPU), element range partition "
                                        "in z-slabs, clamped base, top traction, von Mises plasticity, one Newton/Riks "
                                        "iteration per step" % (world, args.cells, ne_total, model.ne),
-                           "pcg_rtol": rtol, "preconditioner": "block-Jacobi 3x3", "parallelism": "element-partition x%d" % world,
+                           "pcg_rtol": rtol,
+                           "preconditioner": ("distributed p-multigrid V-cycle (tet10 -> tet4 -> %d replicated aggregates)" %
+                                              be.mg.nagg) if be.mg is not None else "block-Jacobi 3x3", "parallelism": "element-partition x%d" % world,
                            "exchange": "point-to-point shared-node sums per SpMV + 2 scalar all-reduces per PCG iteration (%s)" % backend},
                 "newton_iterations_per_s": args.steps / dt, "pcg_iterations_per_step": pcg / args.steps,
                 "roofline": {"bound": "hbm", "kernel": "k_spmv (rank 0, local matrix)", "achieved": achieved, "peak": hbm_peak,

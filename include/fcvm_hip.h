@@ -143,7 +143,8 @@ int fcvm_vec_max_node_norm(fcvm_ctx *c, int64_t nnodes, const double *u, double 
 int fcvm_solve_timing(fcvm_ctx *c, double out[4]);
 
 /*
- * Preconditioner of fcvm_solve.  mode 0: 3x3 block-Jacobi.  mode 1: p-multigrid V-cycle
+ * Preconditioner of fcvm_solve.  mode 0: 3x3 block-Jacobi.  mode 2: build the multigrid hierarchy
+ * only (host-driven V-cycle, multi-GPU).  mode 1: p-multigrid V-cycle
  * (level 0 = assembled tet10 matrix, level 1 = linear tets on the corner nodes, Chebyshev
  * smoothing in Dinv*A: k0 steps before and after the coarse correction on [lmax/alpha0, lmax],
  * k1 steps as approximate coarse solve on [lmax1/alpha1, lmax1]).  Takes effect at the next
@@ -175,6 +176,28 @@ int fcvm_mg_set_level2(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg
  * out[1]=padded slots, out[2]=slices, out[3]=max row length, out[4]=number of violated invariants
  * (must be 0), out[5]=value count, out[6]=sum of slice lengths */
 int fcvm_host_pattern_check(int64_t ne, int64_t nn, const int64_t *elNodes, int64_t out[8]);
+
+/*
+ * Fine-grained multigrid building blocks (levels 0 = tet10 matrix, 1 = tet4 matrix) for a V-cycle
+ * driven by the host, as the multi-GPU solver does (it has to exchange shared-node sums between the
+ * ranks after every local SpMV).  fcvm_set_precond mode 2 builds the hierarchy at fcvm_assemble but
+ * leaves the solve to the host.  All vectors [dev]; level-1 vectors have 3*nc entries.
+ *   fcvm_mg_coarse_map      c2f int32[nc] [host]: fine node of every level-1 node
+ *   fcvm_spmv_level         y = A_level x
+ *   fcvm_mg_get/set_diag_blocks   3x3 diagonal blocks of a level (set: inverts them for the smoother)
+ *   fcvm_mg_cheb_init       x = 0, r = b, d = c0 * Dinv b
+ *   fcvm_mg_cheb_step       x += d; r -= t (skipped when t is NULL); if update_d: d = cdd*d + cdr*Dinv r
+ *   fcvm_mg_restrict        r1 = M1 P^T M0 r0        fcvm_mg_prolong   d0 = M0 P M1 e1
+ */
+int fcvm_mg_coarse_map(fcvm_ctx *c, int32_t *c2f);
+int fcvm_spmv_level(fcvm_ctx *c, int level, const double *x, double *y);
+int fcvm_mg_get_diag_blocks(fcvm_ctx *c, int level, double *dblk);
+int fcvm_mg_set_diag_blocks(fcvm_ctx *c, int level, const double *dblk);
+int fcvm_mg_cheb_init(fcvm_ctx *c, int level, const double *b, double *x, double *r, double *d, double c0);
+int fcvm_mg_cheb_step(fcvm_ctx *c, int level, const double *t, double *x, double *r, double *d, double cdd,
+                      double cdr, int update_d);
+int fcvm_mg_restrict(fcvm_ctx *c, const double *r0, double *r1);
+int fcvm_mg_prolong(fcvm_ctx *c, const double *e1, double *d0);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,103 @@ class OracleLocalOps:
     def spmv(self, x, y):
         y.set(self.K @ x.get())
 
+    # -- multigrid building blocks, numpy / scipy restatement for the CPU tests -----------------
+    def mg_enable(self):
+        self.mg = True
+
+    def _hier(self):
+        if getattr(self, "_hier_K", None) is self.K:
+            return
+        el0 = self.el - 1
+        nn = len(self.xyz)
+        corners = np.unique(el0[:, :4])
+        f2c = np.full(nn, -1)
+        f2c[corners] = np.arange(len(corners))
+        pa, pb = f2c.copy(), f2c.copy()
+        pairs = ((0, 1), (1, 2), (0, 2), (0, 3), (1, 3), (2, 3))
+        for j, (a, b) in enumerate(pairs):
+            pa[el0[:, 4 + j]] = f2c[el0[:, a]]
+            pb[el0[:, 4 + j]] = f2c[el0[:, b]]
+        nc = len(corners)
+        rows, cols, vals = [], [], []
+        for i in range(nn):
+            if pa[i] < 0:
+                continue
+            for k in range(3):
+                rows += [3 * i + k, 3 * i + k]
+                cols += [3 * pa[i] + k, 3 * pb[i] + k]
+                vals += [0.5, 0.5]
+        P = sp.csr_matrix((vals, (rows, cols)), shape=(3 * nn, 3 * nc))
+        free0 = np.ones(3 * nn)
+        free0[list(self.fix.keys())] = 0.0
+        free1 = free0.reshape(-1, 3)[corners].reshape(-1)
+        self.Pm = sp.diags(free0) @ P @ sp.diags(free1)
+        self.A1 = (self.Pm.T @ self.K @ self.Pm + sp.diags(1.0 - free1)).tocsr()
+        self.c2f, self.free1 = corners, free1
+        self.dinv1 = None
+        self._hier_K = self.K
+
+    def mg_coarse_map(self):
+        self._hier()
+        return self.c2f.astype(np.int32)
+
+    def mg_coarse_nodes(self):
+        self._hier()
+        f = (1.0 - self.free1).reshape(-1, 3).astype(np.uint8)
+        return self.xyz[self.c2f], (f[:, 0] | (f[:, 1] << 1) | (f[:, 2] << 2)).astype(np.uint8)
+
+    def mg_coarse_coo(self):
+        self._hier()
+        m = self.A1.tocoo()
+        return m.row.astype(np.int64), m.col.astype(np.int64), m.data
+
+    def _A(self, level):
+        self._hier()
+        return self.K if level == 0 else self.A1
+
+    def mg_spmv(self, level, x, y):
+        y.set(self._A(level) @ x.get())
+
+    def mg_get_diag(self, level, dblk):
+        A = self._A(level)
+        n = A.shape[0] // 3
+        out = np.zeros((n, 3, 3))
+        for i in range(n):
+            out[i] = A[3 * i:3 * i + 3, 3 * i:3 * i + 3].toarray()
+        dblk.set(out.reshape(-1))
+
+    def mg_set_diag(self, level, dblk):
+        inv = np.linalg.inv(dblk.get().reshape(-1, 3, 3))
+        if level == 0:
+            self.dinv = inv
+        else:
+            self.dinv1 = inv
+
+    def _dinv(self, level, v):
+        d = self.dinv if level == 0 else self.dinv1
+        return np.einsum("nij,nj->ni", d, v.reshape(-1, 3)).reshape(-1)
+
+    def mg_cheb_init(self, level, b, x, r, d, c0):
+        bb = b.get()
+        x.set(np.zeros_like(bb)); r.set(bb); d.set(c0 * self._dinv(level, bb))
+
+    def mg_cheb_step(self, level, t, x, r, d, cdd, cdr, update_d):
+        dd = d.get()
+        x.set(x.get() + dd)
+        if t is not None:
+            rr = r.get() - t.get()
+            r.set(rr)
+            if update_d:
+                d.set(cdd * dd + cdr * self._dinv(level, rr))
+
+    def mg_restrict(self, r0, r1):
+        self._hier()
+        r1.set(self.Pm.T @ r0.get())
+
+    def mg_prolong(self, e1, d0):
+        self._hier()
+        d0.set(self.Pm @ e1.get())
+
     def precond(self, r, z):
         z.set(np.einsum("nij,nj->ni", self.dinv, r.get().reshape(-1, 3)).reshape(-1))
 

@@ -19,7 +19,8 @@ MAT = (210000.0, 0.3, 7.8e-6)
 TRACTION = (20.0, 0.0, 200.0)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, precond):
+    os.environ["FCVM_PRECOND"] = precond
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -29,7 +30,8 @@ def _worker(rank, world, port, out):
         model, be, ops = build_rank_model(rank, world, CELLS, MAT, TRACTION, 0, torch.device("cuda", 0), length=10.0)
         res = calc_disp(model, CTL, rtol=1e-12, maxit=4000)
         payload = dict(gnodes=model.part.gnodes, disp=res["displacements"], lout=res["lout"], un=res["un"],
-                       crip=res["crip"], peeq=res["peeq"].get())
+                       crip=res["crip"], peeq=res["peeq"].get(), pcg=res["stats"]["pcg_iterations"],
+                       solves=res["stats"]["solves"])
         got = [None] * world
         dist.all_gather_object(got, payload)
         if rank == 0:
@@ -38,11 +40,12 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path):
+@pytest.mark.parametrize("precond", ["mg", "bj"])
+def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, precond):
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "r.pt")
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, out, precond), nprocs=2, join=True)
     got = torch.load(out, weights_only=False)
     from fcvm_hip import meshgen
     from fcvm_hip.loads import Loads
@@ -61,5 +64,7 @@ def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path):
         assert rel(g["disp"], d) < 1e-8
     # the slab partition of the column == the first / second half of the global element list up to
     # a permutation of elements inside the slabs: compare sorted plastic strains
+    per_solve = got[0]["pcg"] / got[0]["solves"]
+    assert per_solve < 60 if precond == "mg" else per_solve > 100, per_solve
     allp = np.sort(np.concatenate([g["peeq"] for g in got]))
     assert np.abs(allp - np.sort(ref["peeq"])).max() < 1e-8 * ref["peeq"].max()
