@@ -804,4 +804,27 @@ int fcvm_mg_prolong(fcvm_ctx *c, const double *e1, double *d0) {
     return 0;
 }
 
+int fcvm_mg_l2_restrict(fcvm_ctx *c, const double *r1, double *r2) {
+    NEED(c && c->l2, "fcvm_mg_l2_restrict: no aggregate level (fcvm_mg_set_level2)");
+    hipLaunchKernelGGL(k_l2_restrict, dim3((unsigned)cdiv(c->nagg, 4)), dim3(256), 0, c->stream, c->nagg, c->d_aptr, c->d_anodes,
+                       c->d_aoff, c->d_Z, r1, r2, (const double *)nullptr);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_mg_l2_solve(fcvm_ctx *c, const double *r2, double *e2) {
+    NEED(c && c->l2, "fcvm_mg_l2_solve: no aggregate level (fcvm_mg_set_level2)");
+    hipLaunchKernelGGL(k_gemv, dim3((unsigned)cdiv(c->n2, 4)), dim3(256), 0, c->stream, c->n2, c->d_A2inv, r2, e2, (const double *)nullptr);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_mg_l2_prolong(fcvm_ctx *c, const double *e2, double *d1) {
+    NEED(c && c->l2, "fcvm_mg_l2_prolong: no aggregate level (fcvm_mg_set_level2)");
+    hipLaunchKernelGGL(k_l2_prolong, dim3((unsigned)cdiv(c->nc, 256)), dim3(256), 0, c->stream, c->nc, c->d_agg, c->d_aoff, c->d_Z, e2,
+                       d1, (const double *)nullptr);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
 }  // extern "C"

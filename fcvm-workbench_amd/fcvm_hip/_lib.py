@@ -65,6 +65,9 @@ SIGNATURES = {
     "fcvm_mg_cheb_step": [_vp, _int, _vp, _vp, _vp, _vp, _f64, _f64, _int],
     "fcvm_mg_restrict": [_vp, _vp, _vp],
     "fcvm_mg_prolong": [_vp, _vp, _vp],
+    "fcvm_mg_l2_restrict": [_vp, _vp, _vp],
+    "fcvm_mg_l2_solve": [_vp, _vp, _vp],
+    "fcvm_mg_l2_prolong": [_vp, _vp, _vp],
 }
 _SPECIAL = {"fcvm_last_error": ([], C.c_char_p), "fcvm_version": ([], C.c_int)}
 

@@ -285,11 +285,11 @@ class DistBackend:
             for _ in range(self.check_every):
                 self.spmv(p, q)
                 alpha = rz / self.dot_t(p.t, q.t)
-                x.add_(alpha * p.t)
-                r.sub_(alpha * q.t)
+                x.addcmul_(p.t, alpha)                      # x += alpha p   (alpha stays on the device)
+                r.addcmul_(q.t, -alpha)                     # r -= alpha q
                 self.precond(TVec(r), z)
                 rz_new = self.dot_t(r, z.t)
-                p.t.mul_(rz_new / rz).add_(z.t)
+                torch.addcmul(z.t, p.t, rz_new / rz, out=p.t)  # p = z + beta p
                 rz = rz_new
                 it += 1
             rr = float(self.dot_t(r, r).item())
@@ -463,10 +463,11 @@ class DistMG:
             raise RuntimeError("DistMG: aggregate-level matrix not positive definite (dpotrf info %d)" % info)
         Li, info = sla.lapack.dpotri(L, lower=1, overwrite_c=1)
         A2inv = np.tril(Li) + np.tril(Li, -1).T
-        self.A2inv = torch.as_tensor(np.ascontiguousarray(A2inv), device=dev)
-        self.Z = torch.as_tensor(Z, device=dev)
-        self.agg = torch.as_tensor(agg, dtype=torch.int64, device=dev)
+        self.ops.mg_set_level2(nagg, np.ascontiguousarray(agg, np.int32), np.ascontiguousarray(Z.reshape(self.nc, 18)),
+                               np.ascontiguousarray(A2inv))
         self.nagg = nagg
+        self.r2 = TVec(torch.zeros(n2, dtype=torch.float64, device=dev))
+        self.e2 = TVec(torch.zeros(n2, dtype=torch.float64, device=dev))
         self.l2_info = dict(aggregates=nagg, unknowns=n2, target=target)
 
     # -- V-cycle ------------------------------------------------------------------------------
@@ -498,12 +499,11 @@ class DistMG:
         self.ops.mg_restrict(self.rw, self.r1)
         self.ex1.interface_sum(self.r1.t, 3)
         self._from_zero(1, self.ch1, self.k1s, self.r1, self.x1, self.rr1, self.d1, self.t1)
-        v = (self.rr1.t * self.own1).view(self.nc, 3)
-        r2 = torch.zeros(self.nagg, 6, dtype=torch.float64, device=be.device)
-        r2.index_add_(0, self.agg, torch.einsum("nck,nc->nk", self.Z, v))
-        be._allreduce(r2)
-        e2 = (self.A2inv @ r2.reshape(-1)).view(self.nagg, 6)
-        self.d1.t.copy_(torch.einsum("nck,nk->nc", self.Z, e2[self.agg]).reshape(-1))
+        torch.mul(self.rr1.t, self.own1, out=self.t1.t)       # owner-weighted: shared nodes count once
+        self.ops.mg_l2_restrict(self.t1, self.r2)             # r2 = Z^T (.)  (local part)
+        be._allreduce(self.r2.t)                              # replicated aggregate level
+        self.ops.mg_l2_solve(self.r2, self.e2)
+        self.ops.mg_l2_prolong(self.e2, self.d1)
         self._post(1, self.ch1, self.k1s, self.x1, self.rr1, self.d1, self.t1)
         self.ops.mg_prolong(self.x1, self.d0)
         self._post(0, self.ch0, self.k0, x, self.r0, self.d0, self.t0)
@@ -650,6 +650,24 @@ class HipLocalOps:
     def mg_restrict(self, r0, r1):
         from ._lib import call
         call("fcvm_mg_restrict", self.c.h, r0.ptr, r1.ptr)
+
+    def mg_set_level2(self, nagg, agg, Z, A2inv):
+        from ._lib import call
+        aoff = 6 * np.arange(nagg + 1, dtype=np.int64)
+        call("fcvm_mg_set_level2", self.c.h, nagg, 6 * nagg, agg.ctypes.data, aoff.ctypes.data, Z.ctypes.data,
+             A2inv.ctypes.data, 3, 8.0)
+
+    def mg_l2_restrict(self, r1, r2):
+        from ._lib import call
+        call("fcvm_mg_l2_restrict", self.c.h, r1.ptr, r2.ptr)
+
+    def mg_l2_solve(self, r2, e2):
+        from ._lib import call
+        call("fcvm_mg_l2_solve", self.c.h, r2.ptr, e2.ptr)
+
+    def mg_l2_prolong(self, e2, d1):
+        from ._lib import call
+        call("fcvm_mg_l2_prolong", self.c.h, e2.ptr, d1.ptr)
 
     def mg_prolong(self, e1, d0):
         from ._lib import call

@@ -198,6 +198,10 @@ int fcvm_mg_cheb_step(fcvm_ctx *c, int level, const double *t, double *x, double
                       double cdr, int update_d);
 int fcvm_mg_restrict(fcvm_ctx *c, const double *r0, double *r1);
 int fcvm_mg_prolong(fcvm_ctx *c, const double *e1, double *d0);
+/* aggregate level after fcvm_mg_set_level2: r2 = Z^T r1 (f64[n2]), e2 = A2inv r2, d1 = Z e2 */
+int fcvm_mg_l2_restrict(fcvm_ctx *c, const double *r1, double *r2);
+int fcvm_mg_l2_solve(fcvm_ctx *c, const double *r2, double *e2);
+int fcvm_mg_l2_prolong(fcvm_ctx *c, const double *e2, double *d1);
 
 #ifdef __cplusplus
 }
