@@ -77,3 +77,29 @@ def cube_case(n, l=100.0, traction=(10.0, 0.0, 100.0)):
     faces = boundary_faces_on_plane(elNodes, nocoord, 2, l)
     uloads = np.tile(np.asarray(traction, dtype=np.float64), (len(faces), 1))
     return dict(elNodes=elNodes, nocoord=nocoord, fix=fix, ufaces=faces, uloads=uloads)
+
+
+def refine_tet10(elNodes, nocoord):
+    """Uniform (red) refinement of a straight-sided tet10 mesh: every element is cut into 8 children
+    whose corners are the parent's 10 nodes (4 corner tets + the inner octahedron split along the
+    diagonal m02-m13, Bey's rule); new nodes are the midpoints of the children's edges.  Existing
+    nodes keep their numbers, new nodes are appended.  Returns (elNodes2 [8*ne,10], nocoord2).
+    Used to scale the reference's example meshes (BASELINE config "Embankment refined to ~500k")."""
+    el = np.asarray(elNodes, dtype=np.int64) - 1
+    xyz = np.asarray(nocoord, dtype=np.float64)
+    v0, v1, v2, v3, m01, m12, m02, m03, m13, m23 = (el[:, k] for k in range(10))
+    kids = [(v0, m01, m02, m03), (m01, v1, m12, m13), (m02, m12, v2, m23), (m03, m13, m23, v3),
+            (m01, m02, m03, m13), (m01, m02, m12, m13), (m02, m03, m13, m23), (m02, m12, m13, m23)]
+    c = np.stack([np.stack(k, axis=1) for k in kids], axis=1).reshape(-1, 4)  # [8ne,4], children of a parent adjacent
+    e1, e2, e3 = xyz[c[:, 1]] - xyz[c[:, 0]], xyz[c[:, 2]] - xyz[c[:, 0]], xyz[c[:, 3]] - xyz[c[:, 0]]
+    neg = np.einsum("ij,ij->i", e1, np.cross(e2, e3)) < 0
+    c[neg, 1], c[neg, 2] = c[neg, 2].copy(), c[neg, 1].copy()
+    pairs = np.stack([c[:, [a, b]] for a, b in MID_PAIRS], axis=1).reshape(-1, 2)  # [8ne*6,2]
+    pairs.sort(axis=1)
+    key = pairs[:, 0] * (len(xyz) + 1) + pairs[:, 1]
+    uniq, inv = np.unique(key, return_inverse=True)
+    a, b = uniq // (len(xyz) + 1), uniq % (len(xyz) + 1)
+    new_xyz = 0.5 * (xyz[a] + xyz[b])
+    mids = (len(xyz) + inv).reshape(-1, 6)
+    el2 = np.concatenate([c, mids], axis=1) + 1
+    return el2.astype(np.int64), np.concatenate([xyz, new_xyz], axis=0)

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Whole elastoplastic collapse analysis of the (refined) Embankment example on one GPU; prints
+timing and solver statistics.   python tools/embankment_run.py --refine 3"""
+import argparse
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "fcvm-workbench_amd"))
+from fcvm_hip import examples  # noqa: E402
+from fcvm_hip.loads import Loads  # noqa: E402
+from fcvm_hip.solver import GpuModel, calc_disp  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--refine", type=int, default=2)
+ap.add_argument("--nstep", type=int, default=0)
+a = ap.parse_args()
+case = examples.embankment(a.refine)
+if a.nstep:
+    case["ctl"]["nstep"] = a.nstep
+t0 = time.perf_counter()
+m = GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"], Loads())
+t1 = time.perf_counter()
+st = {}
+last = [time.perf_counter()]
+
+
+def log(msg):
+    if msg.startswith("Step"):
+        print(msg, "  (%.1fs)" % (time.perf_counter() - last[0]), flush=True)
+
+
+res = calc_disp(m, case["ctl"], log=log, stats=st)
+t2 = time.perf_counter()
+print("%s: %d tet10, %d dof; set-up %.2fs; analysis %.2fs; steps %d; Newton iterations %d; solves %d; PCG iterations %d "
+      "(%.1f per solve); solve time %.2fs; load factor %.4f; max |u| %.3f; %s" % (
+          case["name"], m.ne, m.ndof, t1 - t0, t2 - t1, len(res["lout"]) - 1, st["newton_iterations"], st["solves"],
+          st["pcg_iterations"], st["pcg_iterations"] / max(st["solves"], 1), st["solve_s"], res["lout"][-1], res["un"][-1],
+          m.ctx.precond_info()))
