@@ -74,11 +74,15 @@ struct fcvm_ctx {
     double *d_mr = nullptr, *d_md = nullptr, *d_mt = nullptr, *d_r1 = nullptr, *d_x1 = nullptr, *d_d1 = nullptr, *d_t1 = nullptr,
            *d_rr1 = nullptr;
     int64_t mg_spmv0 = 0, mg_spmv1 = 0;
+    // level-0 correction: additive (x = w Dinv b + P M1^-1 P^T b: no fine SpMV inside the preconditioner; measured
+    // fastest on the benchmark cube) or multiplicative (Chebyshev pre/post smoothing, FCVM_MG_ADDITIVE=0)
+    int mg_additive = 1;
+    double mg_add_w = 1.0;
     const double *mg_done = nullptr;  // device flag that turns the V-cycle kernels into no-ops once PCG has converged
     // level 2: aggregates + dense inverse (set from the host binding)
     bool l2 = false;
     int64_t nagg = 0, n2 = 0;
-    int mg_k1s = 3;
+    int mg_k1s = 2;
     double mg_alpha1s = 8.0;
     int32_t *d_agg = nullptr, *d_anodes = nullptr;
     int64_t *d_aoff = nullptr, *d_aptr = nullptr;
@@ -172,6 +176,8 @@ int fcvm_create(int device, fcvm_ctx **out) {
     fcvm_ctx *c = new fcvm_ctx();
     c->device = device;
     if (const char *v = getenv("FCVM_SPMV_VARIANT")) c->spmv_variant = atoi(v);
+    if (const char *v = getenv("FCVM_MG_ADDITIVE")) c->mg_additive = atoi(v);
+    if (const char *v = getenv("FCVM_MG_ADD_W")) c->mg_add_w = atof(v);
     HCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
     c->stream = c->own;
     if (dalloc(&c->d_S, S_COUNT) || dalloc(&c->d_out8, 16)) return 1;
@@ -824,6 +830,13 @@ int fcvm_mg_l2_prolong(fcvm_ctx *c, const double *e2, double *d1) {
     hipLaunchKernelGGL(k_l2_prolong, dim3((unsigned)cdiv(c->nc, 256)), dim3(256), 0, c->stream, c->nc, c->d_agg, c->d_aoff, c->d_Z, e2,
                        d1, (const double *)nullptr);
     HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_set_mg_cycle(fcvm_ctx *c, int additive, double weight) {
+    NEED(c && weight > 0.0, "fcvm_set_mg_cycle: weight must be positive");
+    c->mg_additive = additive ? 1 : 0;
+    c->mg_add_w = weight;
     return 0;
 }
 

@@ -242,4 +242,11 @@ __global__ __launch_bounds__(256) void k_l2_prolong(int64_t nc, const int32_t *_
     d1[3 * i] = v0; d1[3 * i + 1] = v1; d1[3 * i + 2] = v2;
 }
 
+__global__ __launch_bounds__(256) void k_add_if(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ o,
+                                                const double *__restrict__ done) {
+    if (done && *done != 0.0) return;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) o[i] = a[i] + b[i];
+}
+
 }  // namespace fcvm

@@ -54,6 +54,7 @@ SIGNATURES = {
     "fcvm_host_pattern_check": [_i64, _i64, _vp, _pi64],
     "fcvm_set_precond": [_vp, _int, _int, _int, _f64, _f64],
     "fcvm_precond_info": [_vp, _pf64],
+    "fcvm_set_mg_cycle": [_vp, _int, _f64],
     "fcvm_mg_coarse_nodes": [_vp, _vp, _vp],
     "fcvm_mg_coarse_to_coo": [_vp, _vp, _vp, _vp],
     "fcvm_mg_set_level2": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _int, _f64],

@@ -202,7 +202,10 @@ class Context:
                        if d["l2_aggregates"] else "")
         return d
 
-    def build_level2(self, target=None, k1s=3, alpha1s=8.0):
+    def set_mg_cycle(self, additive=True, weight=1.0):
+        call("fcvm_set_mg_cycle", self.h, 1 if additive else 0, float(weight))
+
+    def build_level2(self, target=None, k1s=2, alpha1s=8.0):
         """Third multigrid level (aggregates of tet4 nodes); call after assemble().  Skipped for
         small coarse levels where the long Chebyshev sweep is cheap anyway."""
         from . import mg2

@@ -329,11 +329,13 @@ class DistMG:
     shared-node exchange of its level; restriction weights every node by 1/multiplicity so that the
     partial sums add up; the aggregate level is replicated (one small all-reduce per cycle)."""
 
-    def __init__(self, be, nocoord_local, k0=1, alpha0=4.0, k1s=3, alpha1s=8.0, target=None, check_every=4):
+    def __init__(self, be, nocoord_local, k0=1, alpha0=4.0, k1s=2, alpha1s=8.0, target=None, check_every=4, additive=True,
+                 weight=1.0):
         self.be, self.ops, self.part = be, be.ops, be.part
         self.xyz = np.ascontiguousarray(nocoord_local, dtype=np.float64)
         self.k0, self.alpha0, self.k1s, self.alpha1s, self.target = k0, alpha0, k1s, alpha1s, target
         self.check_every = check_every
+        self.additive, self.weight = additive, weight
         self.ready = False
         self.topo = False
 
@@ -494,7 +496,10 @@ class DistMG:
     def vcycle(self, b, x):
         """x = M^-1 b (consistent fine vectors)"""
         be = self.be
-        self._from_zero(0, self.ch0, self.k0, b, x, self.r0, self.d0, self.t0)
+        if self.additive:   # x = w c0 Dinv b + P M1^-1 P^T b : no fine-level SpMV / exchange in the preconditioner
+            self.ops.mg_cheb_init(0, b, x, self.r0, self.d0, self.weight * self.ch0.c0)
+        else:
+            self._from_zero(0, self.ch0, self.k0, b, x, self.r0, self.d0, self.t0)
         torch.mul(self.r0.t, self.w0, out=self.rw.t)
         self.ops.mg_restrict(self.rw, self.r1)
         self.ex1.interface_sum(self.r1.t, 3)
@@ -505,6 +510,10 @@ class DistMG:
         self.ops.mg_l2_solve(self.r2, self.e2)
         self.ops.mg_l2_prolong(self.e2, self.d1)
         self._post(1, self.ch1, self.k1s, self.x1, self.rr1, self.d1, self.t1)
+        if self.additive:
+            self.ops.mg_prolong(self.x1, self.t0)
+            torch.add(self.d0.t, self.t0.t, out=x.t)
+            return
         self.ops.mg_prolong(self.x1, self.d0)
         self._post(0, self.ch0, self.k0, x, self.r0, self.d0, self.t0)
 

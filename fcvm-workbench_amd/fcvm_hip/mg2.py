@@ -26,7 +26,7 @@ def _aggregate(coord, target):
     return agg.astype(np.int32), int(agg.max()) + 1
 
 
-def build_level2(ctx, target=250, k1s=3, alpha1s=8.0, rank_tol=1e-8):
+def build_level2(ctx, target=250, k1s=2, alpha1s=8.0, rank_tol=1e-8):
     pi = ctx.precond_info()
     if pi["mode"] != "mg" or pi["coarse_nodes"] == 0:
         raise RuntimeError("build_level2: assemble with the multigrid preconditioner first")

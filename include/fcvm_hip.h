@@ -151,6 +151,9 @@ int fcvm_solve_timing(fcvm_ctx *c, double out[4]);
  * fcvm_assemble.
  */
 int fcvm_set_precond(fcvm_ctx *c, int mode, int k0, int k1, double alpha0, double alpha1);
+/* level-0 part of the V-cycle: additive != 0 (default): x = weight*c0*Dinv b + P M1^-1 P^T b, i.e. no
+ * fine-level SpMV inside the preconditioner; additive == 0: multiplicative Chebyshev pre/post smoothing */
+int fcvm_set_mg_cycle(fcvm_ctx *c, int additive, double weight);
 /* out[0]=mode, out[1]=coarse nodes, out[2]=lmax level 0, out[3]=lmax level 1, out[4]=coarse nnz
  * blocks, out[5]=fine SpMV launches inside V-cycles of the last solve, out[6]=level-2 aggregates,
  * out[7]=level-2 unknowns (0 = no level 2) */

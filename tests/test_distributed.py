@@ -100,5 +100,5 @@ def test_two_rank_analysis_matches_single_process_oracle(orc, tmp_path, use_mg):
         assert np.abs(g["peeq"] - ref["peeq"][4 * g["lo"]:4 * g["hi"]]).max() < 1e-6 * ref["peeq"].max()
         assert np.allclose(g["loadsum"], ref["loadsum"], rtol=1e-10, atol=1e-9)
     assert ref["peeq"].max() > 0
-    # ~90 linear solves at rtol 1e-12: ~31 iterations each with the distributed V-cycle, ~190 with block-Jacobi
-    assert (got[0]["pcg"] < 4000) if use_mg else (got[0]["pcg"] > 10000), got[0]["pcg"]
+    # ~90 linear solves at rtol 1e-12: ~50 iterations each with the distributed (additive) multigrid cycle, ~190 with block-Jacobi
+    assert (got[0]["pcg"] < 8000) if use_mg else (got[0]["pcg"] > 10000), got[0]["pcg"]

@@ -65,6 +65,6 @@ def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, precond):
     # the slab partition of the column == the first / second half of the global element list up to
     # a permutation of elements inside the slabs: compare sorted plastic strains
     per_solve = got[0]["pcg"] / got[0]["solves"]
-    assert per_solve < 60 if precond == "mg" else per_solve > 100, per_solve
+    assert per_solve < 90 if precond == "mg" else per_solve > 100, per_solve
     allp = np.sort(np.concatenate([g["peeq"] for g in got]))
     assert np.abs(allp - np.sort(ref["peeq"])).max() < 1e-8 * ref["peeq"].max()
