@@ -5,8 +5,9 @@ tet10 solver on the synthetic 1M-tet10 cube, SpMV GB/s against the HBM roofline.
   python bench.py [--gpus N] [--steps K] [--warmup W] [--cells C]
 
 A "step" is one Newton (Riks-corrected, modified-Newton) iteration of the reference's calcDisp
-inner loop (fcVM.py:1346-1455): PCG solve of K due = relax*r (replacing the CHOLMOD back
-substitution), arc-length correction, update_stress_load over all elements, out-of-balance norm.
+inner loop (fcVM.py:1346-1455): multigrid-preconditioned CG solve of K due = relax*r to 1e-10
+(replacing the CHOLMOD back substitution), arc-length correction, update_stress_load over all
+elements, out-of-balance norm.
 The one-time work of an analysis (pattern, K assembly = calcGSM, elastic solve) is done before the
 timed region, exactly where the reference does it (it factorises once, fcVM.py:1121), and is
 reported separately in the same JSON line.
@@ -41,7 +42,7 @@ RTOL = 1.0e-10
 SPMV_TRAFFIC_BYTES = 3.170e9
 
 
-def cpu_baseline(cells=14, iters=3):
+def cpu_baseline(cells=12, iters=5):
     """The oracle (C restatement + SuperLU in place of CHOLMOD) on this host: one Newton iteration =
     back substitution + update_stress_load, factorisation outside (as in the reference)."""
     from fcvm_hip import meshgen
