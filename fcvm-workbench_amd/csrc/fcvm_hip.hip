@@ -53,7 +53,7 @@ struct fcvm_ctx {
     long long *d_pidx = nullptr;
     int64_t nb_vec = 0, nb_spmv = 0, nb_gp = 0;
     double last_spmv_ms = 0, last_total_ms = 0;
-    int spmv_variant = 3;  // 0 plain, 1 nontemporal matrix loads, 2 unroll x2, 3 both (fastest measured)
+    int spmv_variant = 4;  // 0 plain, 1 nontemporal matrix loads, 2 unroll x2, 3 nt + x2, 4 nt + x4 (fastest measured)
     double last_spmv_timed = 0;
     // host copies needed to build the coarse level
     std::vector<int32_t> h_el;
@@ -77,6 +77,8 @@ struct fcvm_ctx {
     // level-0 correction: additive (x = w Dinv b + P M1^-1 P^T b: no fine SpMV inside the preconditioner; measured
     // fastest on the benchmark cube) or multiplicative (Chebyshev pre/post smoothing, FCVM_MG_ADDITIVE=0)
     int mg_additive = 1;
+    int mg_fp32 = 1;           // coarse levels: level-1 matrix and aggregate inverse stored in FP32 (FP64 vectors / accumulation)
+    float *d_vals1f = nullptr, *d_A2invf = nullptr;
     double mg_add_w = 1.0;
     const double *mg_done = nullptr;  // device flag that turns the V-cycle kernels into no-ops once PCG has converged
     // level 2: aggregates + dense inverse (set from the host binding)
@@ -122,19 +124,28 @@ struct MatView {
     const int32_t *cols;
     const double *vals;
     const int32_t *rownode;
+    const float *vals32 = nullptr;  // optional FP32 copy of the values (coarse multigrid level)
 };
 static MatView fine_view(const fcvm_ctx *c) { return {c->pat.nslices, c->nb_spmv, c->d_sptr, c->d_cols, c->d_vals, c->d_rownode}; }
-static MatView coarse_view(const fcvm_ctx *c) { return {c->pat1.nslices, c->nb_spmv1, c->d_sptr1, c->d_cols1, c->d_vals1, c->d_rownode1}; }
+static MatView coarse_view(const fcvm_ctx *c) {
+    return {c->pat1.nslices, c->nb_spmv1, c->d_sptr1, c->d_cols1, c->d_vals1, c->d_rownode1, c->mg_fp32 ? c->d_vals1f : nullptr};
+}
 
 template <bool DOT>
 static void launch_spmv_t(fcvm_ctx *c, const MatView &m, const double *x, double *y, double *part, const double *done) {
     dim3 grid((unsigned)m.nb), block(256);
+    if (m.vals32) {  // FP32-stored matrix, FP64 vectors and accumulation
+        hipLaunchKernelGGL((k_spmv<DOT, false, 4, float2>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols,
+                           (const float2 *)m.vals32, m.rownode, x, y, part, done);
+        return;
+    }
 #define FCVM_SPMV_ARGS m.nslices, m.nb, m.sptr, m.cols, (const double2 *)m.vals, m.rownode, x, y, part, done
     switch (c->spmv_variant) {
+        case 0: hipLaunchKernelGGL((k_spmv<DOT, false, 1>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
         case 1: hipLaunchKernelGGL((k_spmv<DOT, true, 1>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
         case 2: hipLaunchKernelGGL((k_spmv<DOT, false, 2>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
         case 3: hipLaunchKernelGGL((k_spmv<DOT, true, 2>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
-        default: hipLaunchKernelGGL((k_spmv<DOT, false, 1>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
+        default: hipLaunchKernelGGL((k_spmv<DOT, true, 4>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
     }
 #undef FCVM_SPMV_ARGS
 }
@@ -177,6 +188,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     c->device = device;
     if (const char *v = getenv("FCVM_SPMV_VARIANT")) c->spmv_variant = atoi(v);
     if (const char *v = getenv("FCVM_MG_ADDITIVE")) c->mg_additive = atoi(v);
+    if (const char *v = getenv("FCVM_MG_FP32")) c->mg_fp32 = atoi(v);
     if (const char *v = getenv("FCVM_MG_ADD_W")) c->mg_add_w = atof(v);
     HCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
     c->stream = c->own;
@@ -732,6 +744,10 @@ int fcvm_mg_set_level2(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg
     HCHK(hipMemcpyAsync(c->d_aptr, aptr.data(), sizeof(int64_t) * (nagg + 1), hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_Z, Z, sizeof(double) * nc * 18, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_A2inv, A2inv, sizeof(double) * n2 * n2, hipMemcpyHostToDevice, s));
+    dfree(c->d_A2invf);
+    if (dalloc(&c->d_A2invf, n2 * n2)) return 1;
+    hipLaunchKernelGGL(k_to_f32, dim3((unsigned)cdiv(n2 * n2, 256)), dim3(256), 0, s, n2 * n2, c->d_A2inv, c->d_A2invf);
+    HCHK(hipGetLastError());
     HCHK(hipStreamSynchronize(s));
     c->nagg = nagg; c->n2 = n2; c->mg_k1s = k1s; c->mg_alpha1s = alpha1s;
     c->l2 = true;
@@ -820,7 +836,10 @@ int fcvm_mg_l2_restrict(fcvm_ctx *c, const double *r1, double *r2) {
 
 int fcvm_mg_l2_solve(fcvm_ctx *c, const double *r2, double *e2) {
     NEED(c && c->l2, "fcvm_mg_l2_solve: no aggregate level (fcvm_mg_set_level2)");
-    hipLaunchKernelGGL(k_gemv, dim3((unsigned)cdiv(c->n2, 4)), dim3(256), 0, c->stream, c->n2, c->d_A2inv, r2, e2, (const double *)nullptr);
+    if (c->mg_fp32)
+        hipLaunchKernelGGL(k_gemv<float>, dim3((unsigned)cdiv(c->n2, 4)), dim3(256), 0, c->stream, c->n2, c->d_A2invf, r2, e2, (const double *)nullptr);
+    else
+        hipLaunchKernelGGL(k_gemv<double>, dim3((unsigned)cdiv(c->n2, 4)), dim3(256), 0, c->stream, c->n2, c->d_A2inv, r2, e2, (const double *)nullptr);
     HCHK(hipGetLastError());
     return 0;
 }

@@ -441,13 +441,28 @@ __device__ __forceinline__ double2 ld_val(const double2 *p) {
     }
     return *p;
 }
+// matrix stored in FP32 (coarse multigrid level): widened to FP64 in registers
+template <bool NT>
+__device__ __forceinline__ double2 ld_val(const float2 *p) {
+    float2 f;
+    if (NT) {
+        f.x = __builtin_nontemporal_load(&p->x);
+        f.y = __builtin_nontemporal_load(&p->y);
+    } else {
+        f = *p;
+    }
+    double2 r;
+    r.x = (double)f.x;
+    r.y = (double)f.y;
+    return r;
+}
 template <bool NT>
 __device__ __forceinline__ int32_t ld_col(const int32_t *p) {
     return NT ? __builtin_nontemporal_load(p) : *p;
 }
 
-template <bool NT>
-__device__ __forceinline__ void spmv_pair(const int32_t *cp, const double2 *vp, const double *__restrict__ x,
+template <bool NT, class V2>
+__device__ __forceinline__ void spmv_pair(const int32_t *cp, const V2 *vp, const double *__restrict__ x,
                                           double &y0, double &y1, double &y2) {
     const int32_t c0 = ld_col<NT>(cp), c1 = ld_col<NT>(cp + 64);
     double2 v[9];
@@ -461,10 +476,10 @@ __device__ __forceinline__ void spmv_pair(const int32_t *cp, const double2 *vp, 
     y2 += v[6].x * a0 + v[7].x * a1 + v[8].x * a2 + v[6].y * b0 + v[7].y * b1 + v[8].y * b2;
 }
 
-template <bool DOT, bool NT, int UNROLL>
+template <bool DOT, bool NT, int UNROLL, class V2 = double2>
 __global__ __launch_bounds__(256) void k_spmv(int64_t nslices, int64_t nblocks, const int64_t *__restrict__ sptr,
                                               const int32_t *__restrict__ cols,
-                                              const double2 *__restrict__ vals,
+                                              const V2 *__restrict__ vals,
                                               const int32_t *__restrict__ rownode,
                                               const double *__restrict__ x, double *__restrict__ y,
                                               double *__restrict__ partial, const double *__restrict__ done) {
@@ -482,20 +497,32 @@ __global__ __launch_bounds__(256) void k_spmv(int64_t nslices, int64_t nblocks, 
     if (s < nslices) {
         const int64_t jb = sptr[s], je = sptr[s + 1];
         const int32_t *cp = cols + jb * 64 + lane;
-        const double2 *vp = vals + (jb >> 1) * (9 * 64) + lane;
+        const V2 *vp = vals + (jb >> 1) * (9 * 64) + lane;
         int64_t np = (je - jb) >> 1;
-        if (UNROLL == 2) {
+        if (UNROLL == 4) {
+            double z0 = 0.0, z1 = 0.0, z2 = 0.0, u0 = 0.0, u1 = 0.0, u2 = 0.0, w0 = 0.0, w1 = 0.0, w2 = 0.0;
+            for (; np >= 4; np -= 4) {
+                spmv_pair<NT, V2>(cp, vp, x, y0, y1, y2);
+                spmv_pair<NT, V2>(cp + 128, vp + 9 * 64, x, z0, z1, z2);
+                spmv_pair<NT, V2>(cp + 256, vp + 18 * 64, x, u0, u1, u2);
+                spmv_pair<NT, V2>(cp + 384, vp + 27 * 64, x, w0, w1, w2);
+                cp += 512;
+                vp += 36 * 64;
+            }
+            y0 += z0 + u0 + w0; y1 += z1 + u1 + w1; y2 += z2 + u2 + w2;
+        }
+        if (UNROLL >= 2) {
             double z0 = 0.0, z1 = 0.0, z2 = 0.0;
             for (; np >= 2; np -= 2) {
-                spmv_pair<NT>(cp, vp, x, y0, y1, y2);
-                spmv_pair<NT>(cp + 128, vp + 9 * 64, x, z0, z1, z2);
+                spmv_pair<NT, V2>(cp, vp, x, y0, y1, y2);
+                spmv_pair<NT, V2>(cp + 128, vp + 9 * 64, x, z0, z1, z2);
                 cp += 256;
                 vp += 18 * 64;
             }
             y0 += z0; y1 += z1; y2 += z2;
         }
         for (; np > 0; np--) {
-            spmv_pair<NT>(cp, vp, x, y0, y1, y2);
+            spmv_pair<NT, V2>(cp, vp, x, y0, y1, y2);
             cp += 128;
             vp += 9 * 64;
         }
@@ -878,6 +905,11 @@ __global__ __launch_bounds__(256) void k_principal(int64_t n, const double *__re
         ps[3 * i + k] = ev;
         for (int c = 0; c < 3; c++) pv[9 * i + 3 * k + c] = ev * V[c][ord[k]];
     }
+}
+
+__global__ __launch_bounds__(256) void k_to_f32(int64_t n, const double *__restrict__ a, float *__restrict__ o) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) o[i] = (float)a[i];
 }
 
 }  // namespace fcvm

@@ -213,15 +213,16 @@ __global__ __launch_bounds__(256) void k_l2_restrict(int64_t nagg, const int64_t
     }
 }
 
-// y = A x, A dense row-major n x n; one wavefront per row
-__global__ __launch_bounds__(256) void k_gemv(int64_t n, const double *__restrict__ A, const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ done) {
+// y = A x, A dense row-major n x n (FP64 or FP32 storage, FP64 accumulation); one wavefront per row
+template <class T>
+__global__ __launch_bounds__(256) void k_gemv(int64_t n, const T *__restrict__ A, const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ done) {
     if (done && *done != 0.0) return;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
     const int lane = threadIdx.x & 63;
-    const double *a = A + row * n;
+    const T *a = A + row * n;
     double acc = 0.0;
-    for (int64_t j = lane; j < n; j += 64) acc += a[j] * x[j];
+    for (int64_t j = lane; j < n; j += 64) acc += (double)a[j] * x[j];
     acc = wave_sum(acc);
     if (lane == 0) y[row] = acc;
 }
