@@ -147,8 +147,8 @@ class Context:
         call("fcvm_assemble", self.h, disp.ptr if disp is not None else None,
              sig.ptr if sig is not None else None, pgp.ptr if pgp is not None else None, float(Et_E), g,
              glv.ptr, modf.ptr, xgp.ptr if xgp is not None else None, C.byref(vol))
-        if os.environ.get("FCVM_MG_LEVEL2", "1") != "0":
-            self.l2_info = self.build_level2()
+        if os.environ.get("FCVM_MG_LEVEL2", "1") != "0" and self.precond_info()["l2_aggregates"] == 0:
+            self.l2_info = self.build_level2()   # once per mesh; tangent re-assemblies keep it
         return glv, modf, vol.value
 
     def update_stress_load(self, sig_yield, disp_new, du, sig_old, sig_new, sig_test, qin, Et_E, LD, pgp):

@@ -398,7 +398,8 @@ class DistMG:
         self.lmax1 = self._lmax(1, 3 * self.nc, wdot1)
         self.ch0 = _Cheb(1.1 * self.lmax0, self.alpha0, self.k0)
         self.ch1 = _Cheb(1.1 * self.lmax1, self.alpha1s, self.k1s)
-        self._level2()
+        if not getattr(self, "nagg", 0):
+            self._level2()   # once per mesh; tangent re-assemblies keep the aggregate level
         self.ready = True
 
     def _level2(self):

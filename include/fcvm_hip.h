@@ -168,7 +168,8 @@ int fcvm_precond_info(fcvm_ctx *c, double out[8]);
  *   fcvm_mg_set_level2     agg int32[nc] aggregate of each level-1 node, aoff int64[nagg+1] first
  *                          level-2 unknown of each aggregate, Z f64[nc][3][6], A2inv f64[n2*n2]
  *                          row-major, k1s/alpha1s: Chebyshev smoothing steps / range on level 1.
- * Level 2 is dropped again by the next fcvm_assemble (the coarse operator changed).
+ * Level 2 survives re-assemblies on the same mesh (tangent updates) and is dropped when the mesh or
+ * its coordinates change.
  */
 int fcvm_mg_coarse_nodes(fcvm_ctx *c, double *coord1, uint8_t *fixmask1);
 int fcvm_mg_coarse_to_coo(fcvm_ctx *c, int64_t *row, int64_t *col, double *val);
