@@ -334,3 +334,26 @@ def test_refined_embankment_analysis_matches_oracle(orc, monkeypatch):
     assert rel(res["displacements"], o["displacements"]) < 1e-6
     assert rel(res["stresses"], o["stresses"]) < 1e-6
     assert rel(res["peeq"], o["peeq"]) < 1e-6
+
+
+def test_gnly_updated_lagrange_analysis_matches_oracle(orc):
+    """gnl == "GNLY" without imperfection (no buckling pre-analysis): tangent re-assembly with the
+    plastic D - pmat and updated coordinates every Newton iteration (calcTSM), stress convection,
+    follower geometry -- GPU against the oracle's restatement of that branch."""
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import run_analysis
+    case = small_case(3, prescribed=False)
+    ctl = dict(sig_yield=30.0, grav_x=0.0, grav_y=0.0, grav_z=-9.81, nstep=4, iterat_max=20, error_max=1e-5, relax=1.2,
+               scale_re=2.0, scale_up=1.2, scale_dn=1.2, disp_output="total", ultimate_strain=0.25, Et_E=0.05, target_LF=10.0,
+               csr_option="PEEQ", averaged_option="unaveraged", gnl="GNLY", maxImp="0.0", ev1="1.0", ev2="0.0")
+    case["uloads"] = case["uloads"] * 4.0
+    o = orc.run_analysis(case["elNodes"], case["nocoord"], case["material"], case["fix"],
+                         orc.Loads(ufaces=case["ufaces"], uloads=case["uloads"]), ctl)
+    assert o["peeq"].max() > 0
+    res = run_analysis(case["elNodes"], case["nocoord"], case["material"], case["fix"],
+                       Loads(ufaces=case["ufaces"], uloads=case["uloads"]), ctl, rtol=1e-12)
+    assert len(res["lout"]) == len(o["lout"])
+    assert rel(res["lout"], o["lout"]) < 1e-6 and rel(res["un"], o["un"]) < 1e-6
+    assert rel(res["displacements"], o["displacements"]) < 1e-6
+    assert rel(res["stresses"], o["stresses"]) < 1e-6
+    assert rel(res["peeq"], o["peeq"]) < 1e-6
