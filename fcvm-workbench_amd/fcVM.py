@@ -235,3 +235,13 @@ def run(name, elNodes, nocoord, materialbyElement, fix, loads=None, control_dir=
               ctl["sig_yield"], os.path.join(output_dir, name + ".vtk"), ctl["maxImp"], ctl["nstep"],
               principal=(pr[0][:, 0], pr[0][:, 1], pr[0][:, 2], pr[1][:, 0], pr[1][:, 1], pr[1][:, 2]))
     return res
+
+
+def run_fcstd(fcstd_path, control_dir, output_dir, name=None):
+    """Box-shaped FreeCAD documents end to end without FreeCAD: <name>.FCStd (mesh + constraints, read by
+    fcvm_hip.fcstd) + <control_dir>/<name>.inp -> <output_dir>/<name>.out / .vtk.  Replaces, for such
+    models, setUpAnalysis + setUpInput (fcVM.py:87-347) in front of the solver path."""
+    from fcvm_hip import fcstd
+    m = fcstd.load_model(fcstd_path)
+    name = name or os.path.splitext(os.path.basename(fcstd_path))[0]
+    return run(name, m["elNodes"], m["nocoord"], [m["material"]], m["fix"], m["loads"], control_dir, output_dir)

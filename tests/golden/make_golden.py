@@ -127,7 +127,18 @@ def vtk_only(name, key):
     print(name, "ne", len(cells), "nn", len(pts), "E nu rho", E, nu, rho, "fields", list(data))
 
 
+def fcstd_fixture(name, key):
+    """Document.xml + FemMesh.unv of a reference FreeCAD document (data: model definition + mesh),
+    re-zipped without thumbnails / result arrays."""
+    src = zipfile.ZipFile(os.path.join(REF, "freeCAD files", name + ".FCStd"))
+    with zipfile.ZipFile(os.path.join(HERE, key + ".FCStd"), "w", zipfile.ZIP_DEFLATED) as out:
+        for member in ("Document.xml", "FemMesh.unv"):
+            out.writestr(member, src.read(member))
+    print(name, "->", key + ".FCStd")
+
+
 if __name__ == "__main__":
+    fcstd_fixture("tensile", "tensile")
     embankment()
     vtk_only("tensile", "tensile")
     vtk_only("Buckling", "buckling")

@@ -118,3 +118,41 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(root, f), errors="replace").read()
                 assert "import oracle" not in src and "from oracle" not in src and "fcvm_oracle" not in src, f
+
+
+def test_fcstd_reader_reproduces_reference_mesh_and_first_load_step(orc):
+    """tests/golden/tensile.FCStd = Document.xml + FemMesh.unv of the reference's tensile model.
+    The reader must give the very mesh the reference solved (cells / nodes of its tensile.vtk, which
+    pins the UNV -> fcVM node-order tables), the load sum of its .out header and -- solved with the
+    oracle -- the first row and the plastic plateau of its .out table (later rows of that file were
+    produced with other step-scaling settings than the shipped .inp and interactive continuation)."""
+    from fcvm_hip import fcstd
+    m = fcstd.load_model(os.path.join(REPO, "tests", "golden", "tensile.FCStd"))
+    g, meta = load_golden("tensile")
+    assert np.array_equal(m["elNodes"], g["elNodes"]) and np.array_equal(m["nocoord"], g["nocoord"])
+    assert np.allclose(m["material"], [100000.0, 0.0, 7.8e-6])
+    assert len(m["fix"]) == 39 and set(m["fix"].values()) == {0.0}
+    ctl = orc.read_inp_lines(meta["inp"])
+    ctl["target_LF"] = 10.0
+    L = m["loads"]
+    res = orc.run_analysis(m["elNodes"], m["nocoord"], m["material"], m["fix"], orc.Loads(ufaces=L.ufaces, uloads=L.uloads), ctl)
+    assert np.allclose(res["loadsum"], g["out_loadsum"], rtol=1e-9, atol=1e-6)
+    tab = g["out_table"]
+    mine = np.array([res["lout"], res["un"], res["peeqplot"], res["pplot"], res["svmplot"], res["triaxplot"], res["ecrplot"],
+                     res["csrplot"]]).T
+    fmt = lambda a: np.array([float("%.2e" % v) for v in a])  # noqa: E731
+    assert np.array_equal(fmt(mine[1]), tab[1, 4:12])
+    # plateau: load factor 0.5, pressure / von Mises / triaxiality / critical strain as in the reference rows
+    assert np.array_equal(fmt(mine[-1][[0, 3, 4, 5, 6]]), tab[-1, [4, 7, 8, 9, 10]])
+
+
+def test_fcstd_reader_rejects_non_box_geometry(tmp_path):
+    import zipfile
+    import pytest
+    from fcvm_hip import fcstd
+    p = tmp_path / "x.FCStd"
+    with zipfile.ZipFile(p, "w") as z:
+        z.writestr("Document.xml", '<Document><Objects><Object type="Part::Extrusion" name="Extrude" id="1" /></Objects><ObjectData></ObjectData></Document>')
+        z.writestr("FemMesh.unv", "")
+    with pytest.raises(NotImplementedError):
+        fcstd.load_model(str(p))
