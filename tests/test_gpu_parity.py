@@ -357,3 +357,52 @@ def test_gnly_updated_lagrange_analysis_matches_oracle(orc):
     assert rel(res["displacements"], o["displacements"]) < 1e-6
     assert rel(res["stresses"], o["stresses"]) < 1e-6
     assert rel(res["peeq"], o["peeq"]) < 1e-6
+
+
+def test_fcVM_mirror_api_and_files(orc, tmp_path):
+    """The reference-named entry points (fcVM.calcGSM / calcDisp / mapStresses / exportVTK with the
+    reference's argument lists incl. the dummy first load rows) and the headless macro equivalent
+    fcVM.run_fcstd: .FCStd + .inp in, .out + .vtk out; results against the oracle."""
+    import os
+    import fcVM as ft
+    from conftest import REPO
+    from fcvm_hip import fcstd, inpout, vtkio
+    g, meta = load_golden("tensile")
+    ctl = inpout.parse_inp_lines(meta["inp"])
+    ctl["target_LF"] = 10.0
+    inpout.write_inp(tmp_path / "tensile.inp", ctl)
+    src = os.path.join(REPO, "tests", "golden", "tensile.FCStd")
+    res = ft.run_fcstd(src, str(tmp_path), str(tmp_path), name="tensile")
+    m = fcstd.load_model(src)
+    L = m["loads"]
+    o = orc.run_analysis(m["elNodes"], m["nocoord"], m["material"], m["fix"], orc.Loads(ufaces=L.ufaces, uloads=L.uloads),
+                         orc.read_inp_lines([str(ctl[k]) for k in inpout.INP_KEYS]))
+    assert rel(res["lout"], o["lout"]) < 1e-6 and rel(res["un"], o["un"]) < 1e-6
+    rows = [ln.split() for ln in open(tmp_path / "tensile.out") if ln[:12].strip().isdigit()]
+    assert len(rows) == len(o["lout"])
+    assert np.allclose(np.array(rows, float)[:, 4], [float("%.2e" % v) for v in o["lout"]])
+    pts, cells, data = vtkio.read_vtk(tmp_path / "tensile.vtk")
+    assert np.array_equal(cells, m["elNodes"] - 1)
+    assert rel(data["Displacement"].reshape(-1), o["displacements"]) < 1e-6
+    assert rel(data["Stress_Tensor"], o["tet10stress"]) < 1e-6
+    assert list(data)[:6] == ["Critical_Strain_Ratio\n", "Equivalent_Plastic_Strain\n", "von_Mises_Stress\n", "Triaxiality\n",
+                              "Displacement", "Stress_Tensor"]
+    # reference-style calls (numba-signature dummy rows in front of every load array)
+    lf = np.vstack([[0] * 6, L.ufaces])
+    fl = np.vstack([[0.0] * 3, L.uloads])
+    dummy6, dummyp = np.array([[0] * 6]), np.array([0.0])
+    args = (dummy6, dummyp, np.array([[0]]), np.array([[0.0, 0.0, 0.0]]), np.array([[0, 0, 0]]), np.array([[0.0, 0.0, 0.0]]), lf, fl)
+    mat = np.array([m["material"]])
+    stm, row, col, glv, modf, V, lsx, lsy, lsz, ne, nn, x = ft.calcGSM(m["elNodes"], m["nocoord"], mat, m["fix"], 0.0, 0.0, 0.0, *args)
+    assert ne == 24 and nn == 63 and abs(V - 1000.0) < 1e-9 and abs(lsz - 1.0e5) < 1e-6
+    sv, sr, sc = stm.to_coo()
+    assert len(sv) > 0 and np.all(sr >= sc)
+    fixdof = np.ones(3 * nn); fixdof[list(m["fix"])] = 0
+    out = ft.calcDisp(m["elNodes"], m["nocoord"], fixdof, np.zeros(3 * nn), modf, mat, stm, row, col, glv, ctl["nstep"],
+                      ctl["iterat_max"], ctl["error_max"], ctl["relax"], ctl["scale_re"], ctl["scale_up"], ctl["scale_dn"],
+                      ctl["sig_yield"], ctl["disp_output"], ctl["ultimate_strain"], ft.HeadlessWindow(), ctl["Et_E"],
+                      ctl["target_LF"], x, None, m["fix"], 0.0, 0.0, 0.0, *args, ctl["gnl"], ctl["maxImp"], ctl["ev1"], ctl["ev2"])
+    assert len(out) == 19
+    assert rel(out[0], o["displacements"]) < 1e-6 and rel(out[8], o["lout"]) < 1e-6 and rel(out[4], o["stresses"]) < 1e-6
+    t10 = ft.mapStresses(False, m["elNodes"], m["nocoord"], out[4], out[5], out[6], out[7], None, ctl["sig_yield"])
+    assert rel(t10[0], o["tet10stress"]) < 1e-6
