@@ -7,9 +7,9 @@
  * fcvm-workbench_amd/ may include, link, import or call it.
  *
  * Parity status: PINNED -- tests/test_oracle_golden.py replays the reference's
- * Embankment_with_Ditch_Example analysis with these routines and matches the reference's own
- * result files (output files: .out table, .vtk nodal fields, stored in
- * tests/golden/).
+ * Embankment_with_Ditch_Example (GNLN) and Bar buckling (GNLY, incl. buckling factors) analyses with
+ * these routines and matches the reference's own result files (.out tables, .vtk nodal fields in
+ * f64, stored in tests/golden/).
  *
  * Every routine cites the reference lines it restates.  Conventions follow the reference:
  * elNodes is 1-based [ne][10] in fcVM's internal node order, dofs are 3*(node-1)+k, the
@@ -494,5 +494,66 @@ void orc_map_stresses(int averaged, int64_t ne, int64_t nn, const int64_t *elNod
             t10svm[nd] = 0.5 * t10svm[a] + 0.5 * t10svm[b];
             t10triax[nd] = 0.5 * t10triax[a] + 0.5 * t10triax[b];
         }
+    }
+}
+
+/*
+ * Linear-buckling branch of calcTSM (nstep == 1), fcVM.py:1002-1006, 1051-1062: per element the
+ * material stiffness esm (elastic D) and the geometric stiffness
+ *   nsm = sum_gp GM^T SM GM |J| w,  GM = kron(dshpg, I3),  SM = kron(sigma, I3)
+ * are written as FULL 30x30 COO blocks (no boundary-condition elimination); the material diagonal of
+ * fixed dofs is multiplied by 100 (fcVM.py:1060-1061).  row/col/stms/stmg hold 900*ne entries.
+ */
+void orc_buckling_matrices(int64_t ne, const int64_t *elNodes, const double *nocoord, double E, double nu,
+                           const uint8_t *isfix, const double *sig, int64_t *row, int64_t *col,
+                           double *stms, double *stmg) {
+    double dmat[6][6], b[6][30], dg[3][10], xl[10][3], db[6][30];
+    static double esm[30][30], nsm[30][30];
+    hooke(E, nu, dmat);
+    int64_t pos = 0;
+    for (int64_t el = 0; el < ne; el++) {
+        const int64_t *nodes = elNodes + 10 * el;
+        int64_t dof[30];
+        memset(esm, 0, sizeof esm);
+        memset(nsm, 0, sizeof nsm);
+        for (int j = 0; j < 10; j++)
+            for (int i = 0; i < 3; i++) xl[j][i] = nocoord[3 * (nodes[j] - 1) + i];
+        for (int g = 0; g < 4; g++) {
+            double xsj = dshp10(GP10[g][0], GP10[g][1], GP10[g][2], xl, dg);
+            bmat_from_dg(dg, b);
+            double w = GP10[g][3] * fabs(xsj);
+            for (int i = 0; i < 6; i++)
+                for (int j = 0; j < 30; j++) {
+                    double t = 0.0;
+                    for (int k = 0; k < 6; k++) t += dmat[i][k] * b[k][j];
+                    db[i][j] = t;
+                }
+            for (int i = 0; i < 30; i++)
+                for (int j = 0; j < 30; j++) {
+                    double t = 0.0;
+                    for (int k = 0; k < 6; k++) t += b[k][i] * db[k][j];
+                    esm[i][j] += t * w;
+                }
+            const double *s0 = sig + 24 * el + 6 * g;
+            double s[3][3] = {{s0[0], s0[3], s0[4]}, {s0[3], s0[1], s0[5]}, {s0[4], s0[5], s0[2]}};
+            for (int a = 0; a < 10; a++)
+                for (int c = 0; c < 10; c++) {
+                    double t = 0.0;
+                    for (int k = 0; k < 3; k++)
+                        for (int l = 0; l < 3; l++) t += dg[k][a] * s[k][l] * dg[l][c];
+                    for (int i = 0; i < 3; i++) nsm[3 * a + i][3 * c + i] += t * w;
+                }
+        }
+        for (int i = 0; i < 10; i++)
+            for (int k = 0; k < 3; k++) dof[3 * i + k] = 3 * (nodes[i] - 1) + k;
+        for (int i = 0; i < 30; i++)
+            for (int j = 0; j < 30; j++) {
+                row[pos] = dof[i];
+                col[pos] = dof[j];
+                stms[pos] = esm[i][j];
+                stmg[pos] = nsm[i][j];
+                if (i == j && isfix[dof[i]]) stms[pos] *= 100.0;
+                pos++;
+            }
     }
 }

@@ -12,11 +12,16 @@ Third-party pieces of the reference that are absent from /root/reference and fro
     same SPD system, equal up to round-off.
   * numba ``@jit`` (fcVM.py:351 ff.): only a compiler for the loops restated in C here.
 
-Parity status: PINNED by tests/test_oracle_golden.py against the reference's own result files
-(tests/golden/embankment.npz: 30-step elastoplastic collapse analysis, .out table and .vtk
-nodal fields).  The geometrically non-linear branch (gnl == "GNLY": calcTSM + eigsh buckling,
-fcVM.py:1199-1296, 1351-1396) is restated for the tangent update only; the eigen-buckling
-pre-analysis is not restated (parity unpinned for that branch).
+Parity status: PINNED by tests/test_oracle_golden.py against the reference's own result files:
+  * tests/golden/embankment.npz -- GNLN: 30-step gravity-driven elastoplastic collapse analysis, every
+    row of the .out table and the f64 nodal fields of the .vtk (7e-15 / 3e-14 relative);
+  * tests/golden/barbuckling.npz -- GNLY: the two elastic buckling factors (K / geometric stiffness of
+    calcTSM(nstep = 1) + ARPACK buckling mode, fcVM.py:1199-1214) and the geometrically non-linear
+    elastic-plastic post-buckling run (calcTSM tangent re-assembly, stress convection, Riks control,
+    face-force loads), .out table and f64 nodal fields (2e-9 relative);
+  * principal stresses of four .vtk files.
+Not pinned by a reference fixture: pressure / edge / vertex load integrals (fcVM.py:649-727), hardening
+(Et_E > 0) and prescribed non-zero displacements (no shipped result file with recoverable inputs uses them).
 """
 import ctypes as C
 import os
@@ -60,6 +65,8 @@ def lib():
         L.orc_update_peeq_csr.restype = None
         L.orc_update_peeq_csr.argtypes = [C.c_int64, C.c_double, C.c_double, _pd, _pd, _pd,
                                           C.c_double, _pd, _pd, _pd, _pd, _pd, _pd, C.c_double]
+        L.orc_buckling_matrices.restype = None
+        L.orc_buckling_matrices.argtypes = [C.c_int64, _pi, _pd, C.c_double, C.c_double, _pb, _pd, _pi, _pi, _pd, _pd]
         L.orc_map_stresses.restype = None
         L.orc_map_stresses.argtypes = [C.c_int, C.c_int64, C.c_int64, _pi, _pd, _pd, _pd, _pd, _ps,
                                        C.c_double, _pd, _pd, _pd, _pd, _pd]
@@ -173,6 +180,31 @@ def calculate_principal_stress(tet10stress):
     v = v[:, :, ::-1]
     return (w[:, 0].copy(), w[:, 1].copy(), w[:, 2].copy(), w[:, 0:1] * v[:, :, 0],
             w[:, 1:2] * v[:, :, 1], w[:, 2:3] * v[:, :, 2])
+
+
+def buckling_analysis(elNodes, nocoord, material, fix, grav, loads, k=2):
+    """Elastic (linear) buckling pre-analysis of the GNLY mode, fcVM.py:1110-1137 + 1195-1214: elastic
+    solution for the full load, its Gauss-point stresses, K / G of calcTSM(nstep = 1) and
+    eigsh(K, k=2, M=G, sigma=0.1, which='LM', mode='buckling').  Returns (eigenvalues, eigenvectors)."""
+    elNodes = np.ascontiguousarray(elNodes, np.int64)
+    nocoord = np.ascontiguousarray(nocoord, np.float64)
+    ne, nn = len(elNodes), len(nocoord)
+    ndof = 3 * nn
+    stm, row, col, glv, modf, *_ = calcGSM(elNodes, nocoord, material, fix, grav, loads)
+    fixdof = np.ones(ndof)
+    fixdof[list(fix.keys())] = 0.0
+    ue = _Direct(stm, row, col, ndof)(fixdof * glv + modf)
+    sig_new, sig_test = np.zeros(24 * ne), np.zeros(24 * ne)
+    pgp = np.zeros(4 * ne, np.uint8)
+    update_stress_load(elNodes, nocoord, material, np.full(4 * ne, 1.0e30), np.zeros(ndof), ue, np.zeros(24 * ne), sig_new,
+                       sig_test, np.zeros(ndof), 0.0, False, pgp)  # fcVM.py:1195-1197: elastic stresses of ue
+    isfix, _ = fix_arrays(fix, ndof)
+    r, c = np.zeros(900 * ne, np.int64), np.zeros(900 * ne, np.int64)
+    ks, kg = np.zeros(900 * ne), np.zeros(900 * ne)
+    lib().orc_buckling_matrices(ne, elNodes, nocoord, material[0], material[1], isfix, sig_new, r, c, ks, kg)
+    K = sp.csc_matrix((ks, (r, c)), shape=(ndof, ndof))
+    G = -sp.csc_matrix((kg, (r, c)), shape=(ndof, ndof))
+    return spla.eigsh(K, k=k, M=G, sigma=0.1, which="LM", mode="buckling")
 
 
 class _Direct:

@@ -127,6 +127,33 @@ def vtk_only(name, key):
     print(name, "ne", len(cells), "nn", len(pts), "E nu rho", E, nu, rho, "fields", list(data))
 
 
+def barbuckling():
+    """GNLY (geometrically non-linear) reference run: 1000 x 10 x 10 bar (Part::Box), clamped at x = 0,
+    axial force at x = L, imperfection of 10 mm along the first buckling shape.  Mesh, constraints and
+    loads come from the FreeCAD document through fcvm_hip.fcstd (box faces are planes); the reference
+    wrote the IMPERFECT coordinates into its .vtk (fcVM.py:1240, 2912), so the imperfection it drew
+    from its ARPACK eigenvectors is recovered exactly as vtk points - mesh coordinates."""
+    from fcvm_hip import fcstd
+    name = "Bar buckling"
+    pts, cells, data = read_vtk(os.path.join(REF, "output files", name + ".vtk"))
+    head, table = parse_out(os.path.join(REF, "output files", name + ".out"))
+    ev = [float(v) for v in re.search(r"elastic buckling factors:\s*\[([^\]]*)\]", open(os.path.join(REF, "output files", name + ".out")).read()).group(1).split()]
+    inp = [ln.strip() for ln in open(os.path.join(REF, "control files", name + ".inp"))]
+    inp = [s for s in inp if s != ""][:21]
+    m = fcstd.load_model(os.path.join(REF, "freeCAD files", name + ".FCStd"))
+    assert np.array_equal(m["elNodes"], cells + 1)
+    fd = np.array(sorted(m["fix"]), dtype=np.int64)
+    np.savez_compressed(
+        os.path.join(HERE, "barbuckling.npz"),
+        nocoord0=m["nocoord"], nocoord=pts, elNodes=m["elNodes"], fixed_dofs=fd,
+        fixed_vals=np.array([m["fix"][int(d)] for d in fd]), ufaces=m["loads"].ufaces, uloads=m["loads"].uloads,
+        material=m["material"], out_table=table, out_loadsum=np.array(head["loadsum"]), buckling_factors=np.array(ev),
+        **{"vtk_" + re.sub(r"\W", "", k): v for k, v in data.items()},
+    )
+    json.dump({"name": name, "inp": inp}, open(os.path.join(HERE, "barbuckling.json"), "w"), indent=1)
+    print(name, "ne", len(cells), "nn", len(pts), "buckling factors", ev, "max imperfection", np.abs(pts - m["nocoord"]).max())
+
+
 def fcstd_fixture(name, key):
     """Document.xml + FemMesh.unv of a reference FreeCAD document (data: model definition + mesh),
     re-zipped without thumbnails / result arrays."""
@@ -139,6 +166,7 @@ def fcstd_fixture(name, key):
 
 if __name__ == "__main__":
     fcstd_fixture("tensile", "tensile")
+    barbuckling()
     embankment()
     vtk_only("tensile", "tensile")
     vtk_only("Buckling", "buckling")

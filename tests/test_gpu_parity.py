@@ -406,3 +406,24 @@ def test_fcVM_mirror_api_and_files(orc, tmp_path):
     assert rel(out[0], o["displacements"]) < 1e-6 and rel(out[8], o["lout"]) < 1e-6 and rel(out[4], o["stresses"]) < 1e-6
     t10 = ft.mapStresses(False, m["elNodes"], m["nocoord"], out[4], out[5], out[6], out[7], None, ctl["sig_yield"])
     assert rel(t10[0], o["tet10stress"]) < 1e-6
+
+
+def test_bar_buckling_gnly_matches_reference_files(orc):
+    """GNLY on the GPU against the reference's own 'Bar buckling' results (imperfect geometry as
+    exported by the reference): .out table and f64 nodal fields."""
+    from fcvm_hip import inpout
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import run_analysis
+    from test_oracle_golden import sig3
+    g, meta = load_golden("barbuckling")
+    fix = {int(d): float(v) for d, v in zip(g["fixed_dofs"], g["fixed_vals"])}
+    ctl = inpout.parse_inp_lines(meta["inp"])
+    res = run_analysis(g["elNodes"], g["nocoord"], g["material"], fix, Loads(ufaces=g["ufaces"], uloads=g["uloads"]), ctl,
+                       rtol=1e-12)
+    tab = g["out_table"]
+    assert len(res["lout"]) == len(tab)
+    for col, val in ((4, res["lout"]), (5, res["un"]), (7, res["pplot"]), (8, res["svmplot"]), (9, res["triaxplot"])):
+        assert sig3(val, tab[:, col]), "column %d" % col
+    assert rel(res["displacements"], g["vtk_Displacement"].reshape(-1)) < 1e-6
+    assert rel(res["disp_el"], g["vtk_Elastic_Displacement"].reshape(-1)) < 1e-6
+    assert rel(res["tet10stress"], g["vtk_Stress_Tensor"]) < 1e-6

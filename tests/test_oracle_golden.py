@@ -67,3 +67,39 @@ def test_elastic_stress_recovery_lug(orc):
     g, meta = load_golden("lug")
     sy = float(meta["inp"][0])
     assert g["vtk_von_Mises_Stress"].max() <= sy * (1 + 1e-9)
+
+
+def _bar(orc):
+    g, meta = load_golden("barbuckling")
+    fix = {int(d): float(v) for d, v in zip(g["fixed_dofs"], g["fixed_vals"])}
+    return g, meta, fix, orc.Loads(ufaces=g["ufaces"], uloads=g["uloads"])
+
+
+def test_bar_buckling_factors(orc):
+    """Reference 'Bar buckling' model (GNLY): the two elastic buckling factors of its .out header
+    (fcVM.py:1199-1214: K and geometric stiffness of calcTSM(nstep = 1), ARPACK buckling mode)."""
+    g, meta, fix, loads = _bar(orc)
+    w, v = orc.buckling_analysis(g["elNodes"], g["nocoord0"], g["material"], fix, (0.0, 0.0, 0.0), loads)
+    assert np.allclose(np.sort(w), g["buckling_factors"], rtol=0, atol=6e-6)   # printed with 5 decimals
+    assert abs(np.sort(w)[0] - np.pi ** 2 * g["material"][0] * (10.0 ** 4 / 12) / (4 * 1000.0 ** 2) / 1000.0) < 0.01  # Euler
+
+
+def test_bar_buckling_gnly_analysis(orc):
+    """The geometrically non-linear elastic-plastic run of the same model: updated-Lagrange tangent
+    re-assembly (calcTSM), stress convection and Riks control, started from the imperfect geometry the
+    reference exported.  Every row of its .out table and its final f64 nodal fields."""
+    g, meta, fix, loads = _bar(orc)
+    ctl = orc.read_inp_lines(meta["inp"])
+    assert ctl["gnl"] == "GNLY" and float(ctl["maxImp"]) == 10.0
+    res = orc.run_analysis(g["elNodes"], g["nocoord"], g["material"], fix, loads, ctl)
+    tab = g["out_table"]
+    assert len(res["lout"]) == len(tab) == 11
+    for col, val in ((4, res["lout"]), (5, res["un"]), (6, res["peeqplot"]), (7, res["pplot"]), (8, res["svmplot"]),
+                     (9, res["triaxplot"]), (10, res["ecrplot"]), (11, res["csrplot"])):
+        assert sig3(val, tab[:, col]), "column %d" % col
+    rel = lambda a, b: np.abs(np.asarray(a) - b).max() / np.abs(b).max()  # noqa: E731
+    # 1e-7: the exported coordinates carry the reference's imperfection on the (nominally) clamped nodes too (1.6e-6 mm)
+    assert rel(res["disp_el"], g["vtk_Elastic_Displacement"].reshape(-1)) < 1e-7
+    assert rel(res["displacements"], g["vtk_Displacement"].reshape(-1)) < 1e-7
+    assert rel(res["tet10stress"], g["vtk_Stress_Tensor"]) < 1e-7
+    assert rel(res["tet10svm"], g["vtk_von_Mises_Stress"]) < 1e-7
