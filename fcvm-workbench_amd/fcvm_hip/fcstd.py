@@ -65,8 +65,7 @@ def read_unv(text):
 
 def _objects(xml):
     body = xml[xml.find("<ObjectData"):]
-    types = dict(re.findall(r'<Object type="([^"]+)" name="([^"]+)"', xml))
-    types = {name: t for t, name in types.items()} if False else {m[1]: m[0] for m in re.findall(r'<Object type="([^"]+)" name="([^"]+)"', xml)}
+    types = {name: typ for typ, name in re.findall(r'<Object type="([^"]+)" name="([^"]+)"', xml)}
     out = {}
     for name in types:
         m = re.search(r'<Object name="%s"[^>]*>(.*?)</Object>' % re.escape(name), body, re.S)
