@@ -47,6 +47,7 @@ struct fcvm_ctx {
     uint32_t *d_emap = nullptr, *d_diagoff = nullptr;
     uint8_t *d_fixmask = nullptr;
     double *d_coord = nullptr, *d_fixval = nullptr, *d_vals = nullptr, *d_dblk = nullptr, *d_dinv = nullptr;
+    double *d_vals_g = nullptr;  // geometric stiffness (linear buckling), same pattern as d_vals
     // pcg work
     double *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_q = nullptr, *d_S = nullptr;
     double *d_part_vec = nullptr, *d_part_spmv = nullptr, *d_part_misc = nullptr, *d_out8 = nullptr;
@@ -200,7 +201,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
 static void free_mesh(fcvm_ctx *c) {
     dfree(c->d_el); dfree(c->d_cols); dfree(c->d_rownode); dfree(c->d_noce); dfree(c->d_sptr);
     dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
-    dfree(c->d_vals); dfree(c->d_dblk); dfree(c->d_dinv); dfree(c->d_r); dfree(c->d_z); dfree(c->d_p);
+    dfree(c->d_vals); dfree(c->d_vals_g); dfree(c->d_dblk); dfree(c->d_dinv); dfree(c->d_r); dfree(c->d_z); dfree(c->d_p);
     dfree(c->d_q); dfree(c->d_part_vec); dfree(c->d_part_spmv); dfree(c->d_part_misc); dfree(c->d_pidx);
     mg_free(c);
     c->have_mesh = c->assembled = false;
@@ -403,11 +404,11 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
     if (sig)
         hipLaunchKernelGGL(k_assemble<true>, grid, block, 0, s, c->ne, c->d_el, c->d_coord, disp, c->d_fixmask,
                            c->d_fixval, c->d_emap, sig, pgp, mc, grav[0], grav[1], grav[2], c->d_vals, glv_grav, modf,
-                           xgp, c->d_out8);
+                           xgp, c->d_out8, 0);
     else
         hipLaunchKernelGGL(k_assemble<false>, grid, block, 0, s, c->ne, c->d_el, c->d_coord, disp, c->d_fixmask,
                            c->d_fixval, c->d_emap, (const double *)nullptr, (const uint8_t *)nullptr, mc, grav[0],
-                           grav[1], grav[2], c->d_vals, glv_grav, modf, xgp, c->d_out8);
+                           grav[1], grav[2], c->d_vals, glv_grav, modf, xgp, c->d_out8, 0);
     HCHK(hipGetLastError());
     if (refresh_precond(c)) return 1;
     if (c->precond_mode >= 1) {
@@ -856,6 +857,49 @@ int fcvm_set_mg_cycle(fcvm_ctx *c, int additive, double weight) {
     NEED(c && weight > 0.0, "fcvm_set_mg_cycle: weight must be positive");
     c->mg_additive = additive ? 1 : 0;
     c->mg_add_w = weight;
+    return 0;
+}
+
+/*
+ * Linear-buckling matrices of calcTSM(nstep = 1) (fcVM.py:1002-1006, 1051-1062): K_b = elastic stiffness
+ * without boundary-condition elimination, diagonal of fixed dofs x 100; K_g = geometric stiffness of the
+ * Gauss-point stresses sig.  The solver matrix becomes A = K_b + shift * K_g (= K_b - shift * G with the
+ * reference's G = -K_g), preconditioner and multigrid hierarchy are refreshed for it.
+ */
+int fcvm_assemble_buckling(fcvm_ctx *c, const double *sig, double shift) {
+    NEED(c && c->have_mesh && c->have_mat && sig, "fcvm_assemble_buckling: mesh, material and stresses are required");
+    hipStream_t s = c->stream;
+    const int64_t nv = c->pat.value_count();
+    if (!c->d_vals_g && dalloc(&c->d_vals_g, nv)) return 1;
+    HCHK(hipMemsetAsync(c->d_vals, 0, sizeof(double) * nv, s));
+    HCHK(hipMemsetAsync(c->d_vals_g, 0, sizeof(double) * nv, s));
+    MatConst mc = matconst(c, 0.0);
+    dim3 grid((unsigned)cdiv(c->ne * 10, 256)), block(256);
+    hipLaunchKernelGGL(k_assemble<false>, grid, block, 0, s, c->ne, c->d_el, c->d_coord, (const double *)nullptr, c->d_fixmask,
+                       c->d_fixval, c->d_emap, (const double *)nullptr, (const uint8_t *)nullptr, mc, 0.0, 0.0, 0.0, c->d_vals,
+                       c->d_r, c->d_z, (double *)nullptr, (double *)nullptr, 1);
+    hipLaunchKernelGGL(k_assemble_geometric, grid, block, 0, s, c->ne, c->d_el, c->d_coord, c->d_emap, sig, c->d_vals_g);
+    if (shift != 0.0)
+        hipLaunchKernelGGL(k_axpby, dim3((unsigned)cdiv(nv, 256)), dim3(256), 0, s, nv, 1.0, c->d_vals, shift, c->d_vals_g, c->d_vals);
+    HCHK(hipGetLastError());
+    if (refresh_precond(c)) return 1;
+    if (c->precond_mode >= 1) {
+        HCHK(hipStreamSynchronize(s));
+        if (mg_setup(c)) return 1;
+    }
+    HCHK(hipStreamSynchronize(s));
+    c->assembled = true;
+    return 0;
+}
+
+/* y = K_g x with the geometric stiffness of the last fcvm_assemble_buckling */
+int fcvm_spmv_geometric(fcvm_ctx *c, const double *x, double *y) {
+    NEED(c && c->have_mesh && c->d_vals_g, "fcvm_spmv_geometric: call fcvm_assemble_buckling first");
+    NEED(x != y, "fcvm_spmv_geometric: x and y must not alias");
+    MatView m = fine_view(c);
+    m.vals = c->d_vals_g;
+    launch_spmv_t<false>(c, m, x, y, nullptr, nullptr);
+    HCHK(hipGetLastError());
     return 0;
 }
 

@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void k_assemble(int64_t ne, const int32_t *__r
                                                   const uint8_t *__restrict__ pgp, MatConst mc, double gx,
                                                   double gy, double gz, double *__restrict__ vals,
                                                   double *__restrict__ glv, double *__restrict__ modf,
-                                                  double *__restrict__ xgp, double *__restrict__ volume) {
+                                                  double *__restrict__ xgp, double *__restrict__ volume, int penalty_bc) {
     int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t e = t / 10;
     const int a = (int)(t - e * 10);
@@ -384,7 +384,9 @@ __global__ __launch_bounds__(256) void k_assemble(int64_t ne, const int32_t *__r
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 const bool cfix = (fb >> c) & 1;
-                if (!rfix && !cfix) {
+                if (penalty_bc) {  // linear-buckling matrices (fcVM.py:1051-1062): no elimination, fixed diagonal x 100
+                    atomic_add_f64(dst + (r * 3 + c) * 128, (rfix && a == b && r == c) ? 100.0 * K[r * 3 + c] : K[r * 3 + c]);
+                } else if (!rfix && !cfix) {
                     atomic_add_f64(dst + (r * 3 + c) * 128, K[r * 3 + c]);
                 } else if (!rfix && cfix) {
                     macc[r] -= K[r * 3 + c] * fixval[3 * (int64_t)nd[b] + c];
@@ -910,6 +912,66 @@ __global__ __launch_bounds__(256) void k_principal(int64_t n, const double *__re
 __global__ __launch_bounds__(256) void k_to_f32(int64_t n, const double *__restrict__ a, float *__restrict__ o) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) o[i] = (float)a[i];
+}
+
+// geometric stiffness of calcTSM(nstep = 1), fcVM.py:1002-1006: Kg_ab = (sum_gp w ga . sigma . gb) I3, scattered into a
+// second value array that shares the pattern of the stiffness matrix.  One work-item per (element, row node a).
+__global__ __launch_bounds__(256) void k_assemble_geometric(int64_t ne, const int32_t *__restrict__ el,
+                                                            const double *__restrict__ coord, const uint32_t *__restrict__ emap,
+                                                            const double *__restrict__ sig, double *__restrict__ vals_g) {
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t e = t / 10;
+    const int a = (int)(t - e * 10);
+    if (e >= ne) return;
+    int nd[10];
+    double cx[10], cy[10], cz[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+        nd[k] = el[e * 10 + k];
+        const double *c = coord + 3 * (int64_t)nd[k];
+        cx[k] = c[0]; cy[k] = c[1]; cz[k] = c[2];
+    }
+    double xsi[4][9], w[4], sa[4][3];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        double xi, et, ze;
+        gp_point(g, xi, et, ze);
+        double xs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            double d0, d1, d2;
+            dshp_k(k, xi, et, ze, d0, d1, d2);
+            xs[0] += cx[k] * d0; xs[1] += cx[k] * d1; xs[2] += cx[k] * d2;
+            xs[3] += cy[k] * d0; xs[4] += cy[k] * d1; xs[5] += cy[k] * d2;
+            xs[6] += cz[k] * d0; xs[7] += cz[k] * d1; xs[8] += cz[k] * d2;
+        }
+        const double xsj = jac_inverse(xs, xsi[g]);
+        w[g] = FCVM_GPW * fabs(xsj);
+        double d0, d1, d2, g0, g1, g2;
+        dshp_k(a, xi, et, ze, d0, d1, d2);
+        to_global(xsi[g], d0, d1, d2, g0, g1, g2);
+        const double *s = sig + 24 * e + 6 * g;  // (xx, yy, zz, xy, zx, yz)
+        sa[g][0] = g0 * s[0] + g1 * s[3] + g2 * s[4];
+        sa[g][1] = g0 * s[3] + g1 * s[1] + g2 * s[5];
+        sa[g][2] = g0 * s[4] + g1 * s[5] + g2 * s[2];
+    }
+    const uint32_t *em = emap + e * 100 + a * 10;
+#pragma unroll
+    for (int b = 0; b < 10; b++) {
+        double v = 0.0;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            double xi, et, ze, d0, d1, d2, g0, g1, g2;
+            gp_point(g, xi, et, ze);
+            dshp_k(b, xi, et, ze, d0, d1, d2);
+            to_global(xsi[g], d0, d1, d2, g0, g1, g2);
+            v += w[g] * (sa[g][0] * g0 + sa[g][1] * g1 + sa[g][2] * g2);
+        }
+        double *dst = vals_g + em[b];
+        atomic_add_f64(dst, v);
+        atomic_add_f64(dst + 4 * 128, v);
+        atomic_add_f64(dst + 8 * 128, v);
+    }
 }
 
 }  // namespace fcvm

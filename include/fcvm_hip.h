@@ -120,6 +120,17 @@ int fcvm_principal_stress(fcvm_ctx *c, int64_t n, const double *t10s, double *ps
  */
 int fcvm_solve(fcvm_ctx *c, const double *f, double *u, double rtol, int64_t maxit, double info[3]);
 
+/*
+ * Linear buckling (gnl == "GNLY", fcVM.py:1199-1214).  fcvm_assemble_buckling builds the matrices of
+ * calcTSM(nstep = 1): K_b (elastic stiffness, no boundary-condition elimination, fixed diagonal x 100,
+ * fcVM.py:1051-1062) and K_g (geometric stiffness of the Gauss-point stresses sig [dev] f64[24ne],
+ * fcVM.py:1002-1006), and makes A = K_b + shift*K_g the matrix of fcvm_solve / fcvm_spmv (the
+ * reference's shifted operator K - sigma*G with G = -K_g).  fcvm_spmv_geometric: y = K_g x.
+ * The next fcvm_assemble restores the ordinary stiffness matrix.
+ */
+int fcvm_assemble_buckling(fcvm_ctx *c, const double *sig, double shift);
+int fcvm_spmv_geometric(fcvm_ctx *c, const double *x, double *y);
+
 /* y = K x on the assembled matrix ([dev] f64[3nn]); building block of the multi-GPU solver */
 int fcvm_spmv(fcvm_ctx *c, const double *x, double *y);
 /* z = M^-1 r with the 3x3 block-Jacobi preconditioner */

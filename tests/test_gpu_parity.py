@@ -427,3 +427,31 @@ def test_bar_buckling_gnly_matches_reference_files(orc):
     assert rel(res["displacements"], g["vtk_Displacement"].reshape(-1)) < 1e-6
     assert rel(res["disp_el"], g["vtk_Elastic_Displacement"].reshape(-1)) < 1e-6
     assert rel(res["tet10stress"], g["vtk_Stress_Tensor"]) < 1e-6
+
+
+def test_buckling_factors_on_gpu(orc):
+    """GPU buckling pre-analysis (subspace iteration on the shifted operator, multigrid-PCG solves)
+    against (a) the reference's printed factors of its 'Bar buckling' model and (b) the oracle's ARPACK
+    restatement on a column with a rectangular (non-degenerate) cross-section."""
+    from fcvm_hip import buckling, meshgen
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import GpuModel
+    g, meta = load_golden("barbuckling")
+    fix = {int(d): float(v) for d, v in zip(g["fixed_dofs"], g["fixed_vals"])}
+    m = GpuModel(g["elNodes"], g["nocoord0"], g["material"], fix, Loads(ufaces=g["ufaces"], uloads=g["uloads"]))
+    lam, vec, ue = buckling.buckling_factors(m, (0.0, 0.0, 0.0))
+    assert np.allclose(np.sort(lam), g["buckling_factors"], rtol=0, atol=6e-6)
+    # (b) 40 x 6 x 10 column, clamped at x = 0, compressed at x = L: two distinct bending modes
+    el, xyz = meshgen.cube_tet10(10, 2, 3, 40.0, 6.0, 10.0)
+    fixc = {3 * int(n) + k: 0.0 for n in meshgen.nodes_on_plane(xyz, 0, 0.0) for k in range(3)}
+    faces = meshgen.boundary_faces_on_plane(el, xyz, 0, 40.0)
+    ul = np.tile([-5000.0, 0.0, 0.0], (len(faces), 1))
+    mat = np.array([210000.0, 0.3, 7.8e-6])
+    w, v = orc.buckling_analysis(el, xyz, mat, fixc, (0.0, 0.0, 0.0), orc.Loads(ufaces=faces, uloads=ul))
+    m2 = GpuModel(el, xyz, mat, fixc, Loads(ufaces=faces, uloads=ul))
+    lam2, vec2, _ = buckling.buckling_factors(m2, (0.0, 0.0, 0.0))
+    assert np.allclose(np.sort(lam2), np.sort(w), rtol=1e-7)
+    for j in range(2):  # same shapes up to scale / sign
+        a, b = vec2[:, np.argsort(lam2)[j]], v[:, np.argsort(w)[j]]
+        cos = abs(a @ b) / np.linalg.norm(a) / np.linalg.norm(b)
+        assert cos > 1 - 1e-6
