@@ -72,7 +72,7 @@ class Context:
         self.ne = self.nn = 0
         # preconditioner of the linear solve: p-multigrid by default, FCVM_PRECOND=bj for block-Jacobi
         self.set_precond(os.environ.get("FCVM_PRECOND", "mg"))
-        self.l2_min_coarse_nodes = int(os.environ.get("FCVM_L2_MIN_COARSE", "20000"))
+        self.l2_min_coarse_nodes = int(os.environ.get("FCVM_L2_MIN_COARSE", "50"))
 
     def close(self):
         if self.h:
@@ -213,7 +213,7 @@ class Context:
         if pi["mode"] != "mg" or pi["coarse_nodes"] < self.l2_min_coarse_nodes:
             return None
         if target is None:
-            target = max(60, int(round(pi["coarse_nodes"] / 1000.0)))  # ~1000 aggregates, >= 60 nodes each
+            target = max(16, int(round(pi["coarse_nodes"] / 1000.0)))  # ~1000 aggregates, >= 16 nodes each
         return mg2.build_level2(self, target=target, k1s=k1s, alpha1s=alpha1s)
 
     def spmv(self, x, y):

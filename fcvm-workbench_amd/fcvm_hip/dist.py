@@ -417,7 +417,7 @@ class DistMG:
         lo, hi = lo.cpu().numpy(), hi.cpu().numpy()
         ncg = torch.tensor([float(own.sum())], dtype=torch.float64, device=dev)
         ncg = float(be._allreduce(ncg).item())
-        target = self.target if self.target else max(60, int(round(ncg / 1000.0)))
+        target = self.target if self.target else max(16, int(round(ncg / 1000.0)))
         ext = np.maximum(hi - lo, 1e-300)
         live = ext > 1e-9 * ext.max()
         h = (np.prod(ext[live]) / max(1.0, ncg / target)) ** (1.0 / max(1, live.sum()))
