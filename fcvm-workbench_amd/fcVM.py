@@ -8,7 +8,7 @@ GPU is missing -- there is no CPU fallback.
 
 Not mirrored here (out of scope): the FreeCAD document access (setUpAnalysis,
 setUpInput, pasteResults), the interactive matplotlib / pyvista windows (plot) and the
-eigen-buckling pre-analysis of the "GNLY" mode.
+multi-GPU form of the "GNLY" buckling pre-analysis.
 
 Usage like the reference macro:   sys.path.append(<repo>/fcvm-workbench_amd); import fcVM as ft
 """
@@ -105,8 +105,6 @@ def calcDisp(elNodes, nocoord, fixdof, movdof, modf, materialbyElement, stm, row
                scale_up=scale_up, scale_dn=scale_dn, sig_yield=sig_yield_inp, disp_output=disp_output,
                ultimate_strain=ultimate_strain, Et_E=Et_E, target_LF=target_LF, grav_x=grav_x, grav_y=grav_y,
                grav_z=grav_z, gnl=gnl, maxImp=maxImp, ev1=ev1, ev2=ev2)
-    if gnl == "GNLY" and not (float(nstep) > 1.0 and float(maxImp) == 0.0):
-        raise NotImplementedError("eigen-buckling pre-analysis (fcVM.py:1199-1296) is not part of the GPU path yet")
     w = fcVM_window
 
     def log(msg):
@@ -118,11 +116,13 @@ def calcDisp(elNodes, nocoord, fixdof, movdof, modf, materialbyElement, stm, row
     if w is not None:
         w.Load_Factor.setText(str(round(float(res["lbd"][-1]), 3)))
     g = lambda k: res[k].get()  # noqa: E731
-    eigenval, eigenvec = np.zeros(1), np.zeros((1, 1))
+    eigenval, eigenvec = res["eigenval"], res["eigenvec"]
+    if hasattr(nocoord, "__setitem__") and res["nocoord"].shape == np.shape(nocoord):
+        nocoord[:] = res["nocoord"]  # the reference adds the imperfection to nocoord in place (fcVM.py:1240)
     return (res["displacements"], res["disp_el"], eigenval, eigenvec, g("stresses"), g("peeq"), g("sigmises"),
             g("csr"), res["lout"], list(res["un"]), list(res["crip"]), list(res["peeqplot"]), list(res["pplot"]),
             list(res["svmplot"]), list(res["triaxplot"]), list(res["ecrplot"]), list(res["csrplot"]), res["fail"],
-            np.copy(nocoord))
+            res["nocoord_old"])
 
 
 _model_cache = {}
@@ -205,6 +205,12 @@ def exportVTK(gnl, elNodes, nocoord, nocoord_old, dis, disp_el, eigenval, eigenv
     data["von Mises Stress\n"] = np.asarray(tet10svm).reshape(-1)
     data["Triaxiality\n"] = np.asarray(tet10triax).reshape(-1)
     data["Displacement"] = np.asarray(dis).reshape(nn, 3)
+    if gnl == "GNLY" and not (float(nstep) > 1.0 and float(maxImp) == 0.0):  # fcVM.py:2924-2931
+        ev = np.asarray(eigenvec)
+        data["Elastic Displacement"] = np.asarray(disp_el).reshape(nn, 3)
+        for k in range(2):
+            shape = ev[:, k] / np.max(np.abs(ev[:, k]))
+            data["Buckling shape for lambda%d = %s" % (k + 1, str(round(float(eigenval[k]), 3)))] = shape.reshape(nn, 3)
     data["Stress Tensor"] = np.asarray(tet10stress).reshape(nn, 6)
     data["Major Principal Stress\n"] = s1
     data["Intermediate Principal Stress\n"] = s2
@@ -227,10 +233,11 @@ def run(name, elNodes, nocoord, materialbyElement, fix, loads=None, control_dir=
     _model_cache.clear()
     _model_cache["run"] = res["model"]
     inpout.write_out(os.path.join(output_dir, name + ".out"), name, len(elNodes), len(nocoord), ctl["gnl"],
-                     ctl["nstep"], np.zeros(1), res["loadsum"], res["crip"], res["x"], res["lout"], res["un"],
+                     ctl["nstep"], res["eigenval"], res["loadsum"], res["crip"], res["x"], res["lout"], res["un"],
                      res["peeqplot"], res["pplot"], res["svmplot"], res["triaxplot"], res["ecrplot"], res["csrplot"])
     pr = res["principal"], res["principal_vec"]
-    exportVTK(ctl["gnl"], elNodes, nocoord, nocoord, res["displacements"], res["disp_el"], np.zeros(1), np.zeros((1, 1)),
+    exportVTK(ctl["gnl"], elNodes, res["nocoord"], res["nocoord_old"], res["displacements"], res["disp_el"], res["eigenval"],
+              res["eigenvec"],
               res["tet10stress"], res["tet10peeq"], res["tet10csr"], res["tet10svm"], res["tet10triax"],
               ctl["sig_yield"], os.path.join(output_dir, name + ".vtk"), ctl["maxImp"], ctl["nstep"],
               principal=(pr[0][:, 0], pr[0][:, 1], pr[0][:, 2], pr[1][:, 0], pr[1][:, 1], pr[1][:, 2]))

@@ -119,6 +119,31 @@ class RiksDriver:
         self.un, self.csrplot, self.crip, self.pplot, self.svmplot = [0.0], [0.0], [0], [0.0], [0.0]
         self.triaxplot, self.peeqplot, self.peeqmax, self.ecrplot = [0.0], [0.0], [0.0], [0.0]
         self.elastic_only = float(self.nstep) == 1.0
+        # linear buckling pre-analysis and imperfection of the GNLY mode (fcVM.py:1199-1214, 1224-1296)
+        self.eigenval, self.eigenvec = np.zeros(1), np.zeros((1, 1))
+        self.nocoord_old = np.copy(model.nocoord)
+        maxImp = float(ctl.get("maxImp", 0.0)) if self.LD else 0.0
+        if self.LD and ctl.get("buckling", True) and not (float(self.nstep) > 1.0 and maxImp == 0.0):
+            from . import buckling
+            if not hasattr(c, "h"):
+                raise NotImplementedError("the buckling pre-analysis runs on one GPU only")
+            self.eigenval, self.eigenvec, _ = buckling.buckling_factors(model, self.grav, log=self.say)
+            self.say("buckling load factors: {}".format(self.eigenval))
+            if not self.elastic_only and maxImp != 0.0:
+                imper = buckling.imperfection(self.eigenvec, float(ctl["ev1"]), float(ctl["ev2"]), maxImp)
+                model.nocoord = model.nocoord + imper.reshape(-1, 3)
+                c.set_coords(model.nocoord)
+            # back to the ordinary stiffness matrix (on the imperfect geometry, if any) and its elastic solution
+            self.glv, self.modf, self.V, self.xgp = model.calc_gsm(self.grav)
+            self.glv_h = self.glv.get()
+            self.qnorm = c.norm(self.glv)
+            if self.qnorm < 1.0:
+                self.qnorm = 1.0
+            c.mul(model.fixdof, self.glv, out=self.f)
+            c.axpby(1.0, self.f, 1.0, self.modf, out=self.f)
+            self.ue = self.solve(self.f)
+            self.disp_el = self.ue.clone()
+            c.axpby(self.dl, self.ue, 0.0, None, out=self.du)
         if self.elastic_only:  # fcVM.py:1216-1223
             self.step = 0
             self.disp_new = self.ue.clone()
@@ -276,7 +301,8 @@ class RiksDriver:
                     svmplot=np.asarray(self.svmplot), triaxplot=np.asarray(self.triaxplot),
                     ecrplot=np.asarray(self.ecrplot), csrplot=np.asarray(self.csrplot), fail=self.fail,
                     iterat_tot=self.iterat_tot, lbd=np.asarray(self.lbd), x=self.xgp.get().reshape(-1, 3), V=self.V,
-                    loadsum=self.loadsum, glv=self.glv_h, sig_yield=self.sig_yield, stats=self.st)
+                    loadsum=self.loadsum, glv=self.glv_h, sig_yield=self.sig_yield, stats=self.st, eigenval=self.eigenval,
+                    eigenvec=self.eigenvec, nocoord=self.model.nocoord, nocoord_old=self.nocoord_old)
 
 
 def calc_disp(model, ctl, log=None, rtol=1e-10, maxit=50000, max_passes=1, stats=None):

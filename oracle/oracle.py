@@ -223,7 +223,7 @@ class _Direct:
 def calcDisp(elNodes, nocoord, fixdof, movdof, modf, material, stm, row, col, glv, nstep,
              iterat_max, error_max, relax, scale_re, scale_up, scale_dn, sig_yield_inp,
              disp_output, ultimate_strain, Et_E, target_LF, x, noce, fix, grav, loads, gnl="GNLN",
-             log=None, max_passes=1):
+             log=None, max_passes=1, maxImp=0.0, ev1=1.0, ev2=0.0):
     """Restatement of fcVM.py:1083-1635 (calcDisp) for gnl == "GNLN" plus the tangent-update
     part of "GNLY".  The GUI hooks (progress bar, matplotlib `plot`, fcVM.py:1104-1108, 1615)
     are replaced by "stop after `max_passes` passes of nstep steps" (the reference's result
@@ -270,8 +270,11 @@ def calcDisp(elNodes, nocoord, fixdof, movdof, modf, material, stm, row, col, gl
     un, csrplot, crip, pplot, svmplot = [0.0], [0.0], [0], [0.0], [0.0]
     triaxplot, peeqplot, peeqmax, ecrplot = [0.0], [0.0], [0.0], [0.0]
     usl(1.0e6 * sig_yield, np.zeros(ndof), ue, sig_old, sig_new, sig_test, np.zeros(ndof), False)  # :1195
-    if LD and not (float(nstep) > 1.0 and False):
-        pass  # eigen-buckling pre-analysis (fcVM.py:1200-1214) not restated
+    eigenval, eigenvec = np.zeros(1), np.zeros((1, 1))
+    maxImp_f = float(maxImp) if LD else 0.0
+    if LD and not (float(nstep) > 1.0 and maxImp_f == 0.0):  # fcVM.py:1199-1214
+        eigenval, eigenvec = buckling_analysis(elNodes, nocoord, material, fix, grav, loads)
+        say("buckling load factors: {}".format(eigenval))
     if float(nstep) == 1.0:  # fcVM.py:1216-1223
         step = 0
         disp_new = ue
@@ -279,6 +282,29 @@ def calcDisp(elNodes, nocoord, fixdof, movdof, modf, material, stm, row, col, gl
         rfl = np.append(rfl, 1.0)
         un.append(np.max(np.abs(disp_new)))
         cnt = False
+    elif LD and maxImp_f != 0.0:  # fcVM.py:1224-1296: imperfection from the two buckling shapes, restart
+        e1, e2 = float(ev1), float(ev2)
+        ua = e1 / (e1 + e2) * eigenvec[:, 0] + e2 / (e1 + e2) * eigenvec[:, 1]
+        ub = e1 / (e1 + e2) * eigenvec[:, 0] - e2 / (e1 + e2) * eigenvec[:, 1]
+        ma, mb = np.max(np.abs(ua)), np.max(np.abs(ub))
+        if ma > mb:
+            imper = maxImp_f / ma * np.sign(ua[np.argmax(np.abs(ua))]) * ua
+        else:
+            imper = maxImp_f / mb * np.sign(ub[np.argmax(np.abs(ub))]) * ub
+        nocoord = nocoord + imper.reshape(-1, 3)
+        stm, row, col, glv, modf, *_ = calcGSM(elNodes, nocoord, material, fix, grav, loads)
+        qnorm = np.linalg.norm(glv)
+        if qnorm < 1.0:
+            qnorm = 1.0
+        factor = _Direct(stm, row, col, ndof)
+        ue = factor(fixdof * glv + modf)
+        disp_el = ue.copy()
+        dl = dl0
+        du = dl * ue
+        sig_old = np.zeros(24 * nelem)
+        sig_test = np.zeros(24 * nelem)
+        disp_new, disp_old = np.zeros(ndof), np.zeros(ndof)
+        lbd = np.zeros(1)
     iterat_tot, mrr = 0, False
     sig_new = np.zeros(24 * nelem)
     pgp[:] = 0
@@ -402,7 +428,8 @@ def calcDisp(elNodes, nocoord, fixdof, movdof, modf, material, stm, row, col, gl
                 peeqplot=np.asarray(peeqplot), pplot=np.asarray(pplot), svmplot=np.asarray(svmplot),
                 triaxplot=np.asarray(triaxplot), ecrplot=np.asarray(ecrplot),
                 csrplot=np.asarray(csrplot), fail=fail, iterat_tot=iterat_tot, disp_new=disp_new,
-                disp_old=disp_old, sig_yield=sig_yield, pgp=pgp, lbd=lbd)
+                disp_old=disp_old, sig_yield=sig_yield, pgp=pgp, lbd=lbd, eigenval=eigenval, eigenvec=eigenvec,
+                nocoord=nocoord)
 
 
 def read_inp_lines(lines):
@@ -415,8 +442,10 @@ def read_inp_lines(lines):
                 csr_option=t[15], averaged_option=t[16], gnl=t[17], maxImp=t[18], ev1=t[19], ev2=t[20])
 
 
-def run_analysis(elNodes, nocoord, material, fix, loads, ctl, log=None):
-    """fcVM.FCMacro:118-175: calcGSM -> calcDisp -> mapStresses, no FreeCAD objects."""
+def run_analysis(elNodes, nocoord, material, fix, loads, ctl, log=None, use_imperfection=False):
+    """fcVM.FCMacro:118-175: calcGSM -> calcDisp -> mapStresses, no FreeCAD objects.
+    use_imperfection: run the GNLY buckling pre-analysis and apply ctl["maxImp"] (fcVM.py:1199-1296);
+    default False = the given coordinates are used as they are."""
     elNodes = np.ascontiguousarray(elNodes, np.int64)
     nocoord = np.ascontiguousarray(nocoord, np.float64)
     nn = len(nocoord)
@@ -432,7 +461,9 @@ def run_analysis(elNodes, nocoord, material, fix, loads, ctl, log=None):
     res = calcDisp(elNodes, nocoord, fixdof, movdof, modf, material, stm, row, col, glv, ctl["nstep"],
                    ctl["iterat_max"], ctl["error_max"], ctl["relax"], ctl["scale_re"], ctl["scale_up"],
                    ctl["scale_dn"], ctl["sig_yield"], ctl["disp_output"], ctl["ultimate_strain"],
-                   ctl["Et_E"], ctl["target_LF"], x, noce, fix, grav, loads, gnl=ctl["gnl"], log=log)
+                   ctl["Et_E"], ctl["target_LF"], x, noce, fix, grav, loads, gnl=ctl["gnl"], log=log,
+                   maxImp=ctl.get("maxImp", 0.0) if use_imperfection else 0.0, ev1=ctl.get("ev1", 1.0), ev2=ctl.get("ev2", 0.0))
+    nocoord = res["nocoord"]
     t10 = mapStresses(False, elNodes, nocoord, res["stresses"], res["peeq"], res["sigmises"],
                       res["csr"], noce, ctl["sig_yield"])
     res.update(tet10stress=t10[0], tet10peeq=t10[1], tet10csr=t10[2], tet10svm=t10[3],

@@ -418,6 +418,7 @@ def test_bar_buckling_gnly_matches_reference_files(orc):
     g, meta = load_golden("barbuckling")
     fix = {int(d): float(v) for d, v in zip(g["fixed_dofs"], g["fixed_vals"])}
     ctl = inpout.parse_inp_lines(meta["inp"])
+    ctl["buckling"] = False   # the exported coordinates already carry the reference's imperfection
     res = run_analysis(g["elNodes"], g["nocoord"], g["material"], fix, Loads(ufaces=g["ufaces"], uloads=g["uloads"]), ctl,
                        rtol=1e-12)
     tab = g["out_table"]
@@ -455,3 +456,49 @@ def test_buckling_factors_on_gpu(orc):
         a, b = vec2[:, np.argsort(lam2)[j]], v[:, np.argsort(w)[j]]
         cos = abs(a @ b) / np.linalg.norm(a) / np.linalg.norm(b)
         assert cos > 1 - 1e-6
+
+
+def test_gnly_with_buckling_imperfection_full_flow(orc, tmp_path):
+    """The complete GNLY flow on the GPU -- elastic solution, buckling factors, imperfection from the
+    buckling shapes, restart on the imperfect geometry, non-linear run, .out / .vtk with the buckling
+    fields -- (a) on a column with distinct buckling modes against the oracle's ARPACK-based
+    restatement, (b) on the reference's Bar buckling model from its PERFECT geometry: the direction
+    of the imperfection inside the double eigenvalue is arbitrary (ARPACK start vector in the
+    reference), so its load-displacement curve is met to ~1 % only."""
+    import fcVM as ft
+    from fcvm_hip import inpout, meshgen, vtkio
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import run_analysis
+    el, xyz = meshgen.cube_tet10(10, 2, 3, 40.0, 6.0, 10.0)
+    fix = {3 * int(n) + k: 0.0 for n in meshgen.nodes_on_plane(xyz, 0, 0.0) for k in range(3)}
+    faces = meshgen.boundary_faces_on_plane(el, xyz, 0, 40.0)
+    ul = np.tile([-5000.0, 0.0, 0.0], (len(faces), 1))
+    mat = np.array([210000.0, 0.3, 7.8e-6])
+    ctl = dict(sig_yield=240.0, grav_x=0.0, grav_y=0.0, grav_z=0.0, nstep=5, iterat_max=20, error_max=1e-4, relax=1.2,
+               scale_re=2.0, scale_up=1.2, scale_dn=1.2, disp_output="total", ultimate_strain=0.25, Et_E=0.0, target_LF=10.0,
+               csr_option="PEEQ", averaged_option="unaveraged", gnl="GNLY", maxImp="0.5", ev1="1.0", ev2="0.3")
+    o = orc.run_analysis(el, xyz, mat, fix, orc.Loads(ufaces=faces, uloads=ul), ctl, use_imperfection=True)
+    inpout.write_inp(tmp_path / "column.inp", ctl)
+    res = ft.run("column", el, xyz.copy(), [mat], fix, Loads(ufaces=faces, uloads=ul), str(tmp_path), str(tmp_path))
+    assert np.allclose(np.sort(res["eigenval"]), np.sort(o["eigenval"]), rtol=1e-7)
+    assert rel(res["nocoord"], o["nocoord"]) < 1e-7               # same imperfection
+    assert len(res["lout"]) == len(o["lout"])
+    assert rel(res["lout"], o["lout"]) < 1e-5 and rel(res["un"], o["un"]) < 1e-5
+    assert rel(res["displacements"], o["displacements"]) < 1e-5 and rel(res["stresses"], o["stresses"]) < 1e-5
+    head = open(tmp_path / "column.out").read()
+    assert "analysis type:" in head and "elastic-plastic, geometric non-linear" in head and "elastic buckling factors:" in head
+    pts, cells, data = vtkio.read_vtk(tmp_path / "column.vtk")
+    names = list(data)
+    assert names[4:8] == ["Displacement", "Elastic_Displacement", "Buckling_shape_for_lambda1_=_%s" % round(float(res["eigenval"][0]), 3),
+                          "Buckling_shape_for_lambda2_=_%s" % round(float(res["eigenval"][1]), 3)]
+    assert rel(pts, o["nocoord"]) < 1e-7
+    # (b) the reference's bar from its perfect geometry
+    g, meta = load_golden("barbuckling")
+    fixb = {int(d): float(v) for d, v in zip(g["fixed_dofs"], g["fixed_vals"])}
+    r = run_analysis(g["elNodes"], g["nocoord0"], g["material"], fixb, Loads(ufaces=g["ufaces"], uloads=g["uloads"]),
+                     inpout.parse_inp_lines(meta["inp"]))
+    assert np.allclose(np.sort(r["eigenval"]), g["buckling_factors"], atol=6e-6)
+    assert np.abs(r["nocoord"] - g["nocoord0"]).max() == pytest.approx(10.0, rel=1e-9)
+    tab = g["out_table"]
+    assert len(r["lout"]) == len(tab)
+    assert np.allclose(r["lout"], tab[:, 4], rtol=2e-2, atol=1e-3) and np.allclose(r["un"], tab[:, 5], rtol=2e-2, atol=1e-2)
