@@ -72,7 +72,10 @@ def buckling_factors(model, grav, k=2, sigma=0.1, block=6, tol=1e-10, maxit=80, 
         if theta_old is not None and np.all(np.abs(th[:k] - theta_old) <= tol * np.abs(th[:k])):
             break
         theta_old = th[:k].copy()
-    vec = np.stack([X[j].get() for j in range(k)], axis=1)
+    # ARPACK's buckling mode returns K-normalised vectors (x^T K x = 1; checked against scipy); the Ritz vectors
+    # are A-normalised (A = K - sigma G) with x^T G x = theta, so x^T K x = 1 + sigma * theta.  The relative scale of
+    # the two shapes matters for the imperfection mix of fcVM.py:1226-1227.
+    vec = np.stack([X[j].get() / np.sqrt(1.0 + sigma * th[j]) for j in range(k)], axis=1)
     return lam, vec, ue
 
 
