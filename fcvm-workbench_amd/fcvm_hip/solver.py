@@ -8,6 +8,7 @@ libfcvm_hip (`Context.solve`); the control flow -- arc-length correction, restar
 "target load" interpolation and its quirks -- follows the reference line by line so that the
 load-displacement curve matches.
 """
+import os
 import time
 
 import numpy as np
@@ -72,6 +73,8 @@ class RiksDriver:
         st.setdefault("solve_s", 0.0)
         st.setdefault("spmv_ms", 0.0)
         self.rtol, self.maxit = rtol, maxit
+        self.proj_depth = int(os.environ.get("FCVM_RHS_PROJECTION", "6"))  # previous solutions kept for the start vector
+        self._hist, self._gram = [], None
         self.nstep, self.iterat_max, self.error_max = int(ctl["nstep"]), int(ctl["iterat_max"]), float(ctl["error_max"])
         self.relax, self.scale_re, self.scale_up, self.scale_dn = (
             float(ctl[k]) for k in ("relax", "scale_re", "scale_up", "scale_dn"))
@@ -134,6 +137,7 @@ class RiksDriver:
                 model.nocoord = model.nocoord + imper.reshape(-1, 3)
                 c.set_coords(model.nocoord)
             # back to the ordinary stiffness matrix (on the imperfect geometry, if any) and its elastic solution
+            self._hist, self._gram = [], None
             self.glv, self.modf, self.V, self.xgp = model.calc_gsm(self.grav)
             self.glv_h = self.glv.get()
             self.qnorm = c.norm(self.glv)
@@ -155,12 +159,54 @@ class RiksDriver:
 
     # -- building blocks ----------------------------------------------------------------------
     def solve(self, rhs):
+        """K u = rhs to ||r|| <= rtol ||rhs||.  The Newton loop solves with the same matrix over and over
+        (the reference back-substitutes with one factorisation); successive right-hand sides are far from
+        independent, so the solve starts from the Galerkin projection of rhs onto the last few solutions
+        (u = U a with (U^T F) a = U^T rhs, F = K U already known) and only the remainder goes through PCG."""
         t0 = time.perf_counter()
-        u, info = self.c.solve(rhs, rtol=self.rtol, maxit=self.maxit)
-        st = self.st
+        c, st = self.c, self.st
+        hist = self._hist
+        if hist and self.proj_depth > 0:
+            U, F = [h[0] for h in hist], [h[1] for h in hist]
+            b = np.array([c.dot(ui, rhs) for ui in U])
+            try:
+                a = np.linalg.solve(self._gram, b)
+            except np.linalg.LinAlgError:
+                a = np.zeros(len(U))
+            x0 = c.axpby(a[0], U[0], 0.0, None)
+            r0 = c.axpby(1.0, rhs, -a[0], F[0])
+            for ai, ui, fi in zip(a[1:], U[1:], F[1:]):
+                c.axpby(1.0, x0, ai, ui, out=x0)
+                c.axpby(1.0, r0, -ai, fi, out=r0)
+            nf, n0 = c.norm(rhs), c.norm(r0)
+            if not np.isfinite(n0) or n0 >= nf:      # projection did not help: plain solve
+                x0, r0, n0 = None, rhs, nf
+        else:
+            x0, r0 = None, rhs
+            nf = n0 = 1.0
+        if x0 is not None and n0 <= self.rtol * nf:
+            u, info = x0, dict(iterations=0, rel_residual=n0 / nf, spmv=0)
+        else:
+            d, info = c.solve(r0, rtol=min(1.0, self.rtol * nf / n0) if x0 is not None else self.rtol, maxit=self.maxit)
+            u = d if x0 is None else c.axpby(1.0, x0, 1.0, d, out=d)
+        if self.proj_depth > 0:
+            hist.append((u, rhs.clone()))
+            if len(hist) > self.proj_depth:
+                hist.pop(0)
+            m = len(hist)
+            g = np.zeros((m, m))
+            old = self._gram
+            if old is not None and old.shape[0] >= m - 1 and m > 1:
+                keep = old[-(m - 1):, -(m - 1):]
+                g[:m - 1, :m - 1] = keep
+            for i in range(m):      # new row / column: U_i . F_new  (symmetric: U^T K U)
+                g[i, m - 1] = g[m - 1, i] = c.dot(hist[i][0], hist[m - 1][1])
+            self._gram = g
         st["solve_s"] += time.perf_counter() - t0
         st["pcg_iterations"] += info["iterations"]
         st["solves"] += 1
+        if info["iterations"] == 0 and info["spmv"] == 0:
+            return u
         tm = self.c.solve_timing()
         st["spmv_ms"] += tm["spmv_ms"]
         st["spmv_launches"] += tm.get("spmv_timed", info["spmv"])  # launches the HIP-event time covers
@@ -215,6 +261,7 @@ class RiksDriver:
         if self.LD and (self.iterat == 1 or bool(self.pgp.get().any())):  # fcVM.py:1351-1396
             self.glv, self.modf, _, _ = self.model.calc_gsm(self.grav, disp=self.disp_new, sig=self.sig_old,
                                                             pgp=self.pgp, Et_E=self.Et_E, want_x=False)
+            self._hist, self._gram = [], None   # new tangent matrix: the stored K U products are stale
             c.mul(self.model.fixdof, self.glv, out=self.f)
             c.axpby(1.0, self.f, 1.0, self.modf, out=self.f)
             self.ue = self.solve(self.f)
