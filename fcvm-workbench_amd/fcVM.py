@@ -252,3 +252,69 @@ def run_fcstd(fcstd_path, control_dir, output_dir, name=None):
     m = fcstd.load_model(fcstd_path)
     name = name or os.path.splitext(os.path.basename(fcstd_path))[0]
     return run(name, m["elNodes"], m["nocoord"], [m["material"]], m["fix"], m["loads"], control_dir, output_dir)
+
+
+def calcSum(Edge_Elements, Face_Elements, mesh, CSR, peeq, svm):
+    """fcVM.py:2830-2900: length / area weighted averages of the nodal results over selected CAD
+    edges (lists of 3-node line elements) and faces (lists of 6-node triangles).  `mesh` is either
+    the nodal coordinate array [nn,3] (node numbers 1-based as everywhere) or an object with a
+    `.Nodes` mapping node -> vector with x, y, z (FreeCAD's FemMesh).  Host-side post-processing
+    of O(selection) size."""
+    from fcvm_hip.loads import GP2, GP6, _tri6
+    if hasattr(mesh, "Nodes"):
+        nodes = mesh.Nodes
+        xyz = lambda n: np.array([nodes[n].x, nodes[n].y, nodes[n].z])  # noqa: E731
+    else:
+        arr = np.asarray(mesh, dtype=np.float64)
+        xyz = lambda n: arr[n - 1]  # noqa: E731
+    CSR, peeq, svm = np.asarray(CSR, float), np.asarray(peeq, float), np.asarray(svm, float)
+
+    def integrate(groups, nper, weights):
+        size, a_peeq, a_csr, a_svm = [], [], [], []
+        for group in groups:
+            tot = np.zeros(4)
+            for element in group:
+                x = np.array([xyz(n) for n in element])            # [nper, 3]
+                nd = np.asarray(element) - 1
+                for shp, jac, w in weights(x):
+                    d = shp * abs(jac) * w
+                    tot += np.array([d.sum(), (peeq[nd] * d).sum(), (CSR[nd] * d).sum(), (svm[nd] * d).sum()])
+            if tot[0] > 0.0:
+                tot[1:] /= tot[0]
+            size.append(tot[0]); a_peeq.append(tot[1]); a_csr.append(tot[2]); a_svm.append(tot[3])
+        return size, a_peeq, a_csr, a_svm
+
+    def line_weights(x):
+        for xi, w in GP2:  # shape2lin, fcVM.py:545-565
+            shp = np.array([-0.5 * (1.0 - xi) * xi, 0.5 * (1.0 + xi) * xi, (1.0 + xi) * (1.0 - xi)])
+            d = np.array([xi - 0.5, xi + 0.5, -2.0 * xi])
+            yield shp, np.linalg.norm(d @ x), w
+
+    def face_weights(x):
+        for xi, et, w in GP6:  # shape6tri, fcVM.py:485-541
+            shp, d = _tri6(xi, et)
+            yield shp, np.linalg.norm(np.cross(d[0] @ x, d[1] @ x)), w
+
+    el, ep, ec, es = integrate(Edge_Elements, 3, line_weights)
+    fa, fp, fc, fs = integrate(Face_Elements, 6, face_weights)
+    return el, ep, ec, es, fa, fp, fc, fs
+
+
+def write_avr(path, name, Edge_Names, Face_Names, edge_length, edge_peeq, edge_CSR, edge_svm, face_area, face_peeq,
+              face_CSR, face_svm):
+    """The .avr summary written by fcVM_sum.FCMacro:110-160."""
+    sep = "\n=========================================================================================================================\n\n"
+    with open(path, "w") as f:
+        f.write("model name:{0: >30}\n\n".format(name))
+        f.write("average values")
+        f.write(sep)
+        f.write("{0: >10}{1: >10}{2: >10}{3: >10}    {4}\n".format("Length", "peeq", "CSR", "svmises", "edge"))
+        for i, edge in enumerate(Edge_Names):
+            f.write("{0: >10.2e}{1: >10.2e}{2: >10.2e}{3: >10.2e}    {4}\n".format(edge_length[i], edge_peeq[i], edge_CSR[i],
+                                                                             edge_svm[i], edge))
+        f.write(sep)
+        f.write("{0: >10}{1: >10}{2: >10}{3: >10}    {4}\n".format("Area", "peeq", "CSR", "svmises", "face"))
+        for i, face in enumerate(Face_Names):
+            f.write("{0: >10.2e}{1: >10.2e}{2: >10.2e}{3: >10.2e}    {4}\n".format(face_area[i], face_peeq[i], face_CSR[i],
+                                                                             face_svm[i], face))
+        f.write(sep)

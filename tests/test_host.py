@@ -5,6 +5,7 @@ import os
 import re
 
 import numpy as np
+import pytest
 import scipy.sparse as sp
 
 from conftest import REPO, load_golden
@@ -156,3 +157,27 @@ def test_fcstd_reader_rejects_non_box_geometry(tmp_path):
         z.writestr("FemMesh.unv", "")
     with pytest.raises(NotImplementedError):
         fcstd.load_model(str(p))
+
+
+def test_calcSum_and_avr_format(tmp_path):
+    """fcVM.calcSum / .avr writer (host post-processing): exact length / area of a box edge / face,
+    averages of linear nodal fields, and the file layout of the reference's shipped .avr files."""
+    import fcVM as ft
+    from fcvm_hip import meshgen
+    el, xyz = meshgen.cube_tet10(2, 2, 2, 4.0, 6.0, 10.0)
+    faces = meshgen.boundary_faces_on_plane(el, xyz, 2, 10.0)                       # top face, area 24
+    edge = [[f[0], f[1], f[3]] for f in faces if abs(xyz[f[0] - 1][1]) < 1e-9 and abs(xyz[f[1] - 1][1]) < 1e-9]
+    assert len(edge) == 2                                                          # the edge y = 0, z = 10: length 4
+    field = 2.0 + 3.0 * xyz[:, 0]                                                  # linear in x
+    out = ft.calcSum([edge], [faces.tolist()], xyz, field, 2 * field, np.ones(len(xyz)))
+    el_, ep, ec, es, fa, fp, fc, fs = out
+    assert el_[0] == pytest.approx(4.0) and fa[0] == pytest.approx(24.0)
+    assert ec[0] == pytest.approx(2.0 + 3.0 * 2.0) and ep[0] == pytest.approx(2 * 8.0) and es[0] == pytest.approx(1.0)
+    assert fc[0] == pytest.approx(8.0) and fs[0] == pytest.approx(1.0)
+    p = tmp_path / "m.avr"
+    ft.write_avr(p, "m", ["Box(Cube).Edge1"], ["Box(Cube).Face6"], *out)
+    lines = open(p).read().splitlines()
+    assert lines[0] == "model name:" + "m".rjust(30) and lines[2] == "average values"
+    assert lines[5].split() == ["Length", "peeq", "CSR", "svmises", "edge"]
+    assert lines[6].split() == ["4.00e+00", "1.60e+01", "8.00e+00", "1.00e+00", "Box(Cube).Edge1"]
+    assert lines[10].split() == ["Area", "peeq", "CSR", "svmises", "face"]
