@@ -461,11 +461,24 @@ class DistMG:
         A2 = A2.cpu().numpy()
         A2 = 0.5 * (A2 + A2.T)
         A2[np.diag_indices(n2)] += 1e-10 * np.abs(np.diag(A2)).max()
-        L, info = sla.lapack.dpotrf(A2, lower=1)
-        if info != 0:
-            raise RuntimeError("DistMG: aggregate-level matrix not positive definite (dpotrf info %d)" % info)
-        Li, info = sla.lapack.dpotri(L, lower=1, overwrite_c=1)
-        A2inv = np.tril(Li) + np.tril(Li, -1).T
+        # inverted on rank 0 only and broadcast, so that every rank applies bit-identical coarse corrections
+        # (a threaded LAPACK may round differently from process to process)
+        inv_t = torch.empty(n2, n2, dtype=torch.float64, device=dev)
+        ok = torch.ones(1, dtype=torch.float64, device=dev)
+        if part.rank == 0:
+            L, info = sla.lapack.dpotrf(A2, lower=1)
+            if info == 0:
+                Li, info = sla.lapack.dpotri(L, lower=1, overwrite_c=1)
+            if info == 0:
+                inv_t.copy_(torch.as_tensor(np.tril(Li) + np.tril(Li, -1).T))
+            else:
+                ok.zero_()
+        if part.world > 1:
+            dist.broadcast(ok, 0, group=part.group)
+            dist.broadcast(inv_t, 0, group=part.group)
+        if float(ok.item()) == 0.0:
+            raise RuntimeError("DistMG: aggregate-level matrix not positive definite")
+        A2inv = inv_t.cpu().numpy()
         self.ops.mg_set_level2(nagg, np.ascontiguousarray(agg, np.int32), np.ascontiguousarray(Z.reshape(self.nc, 18)),
                                np.ascontiguousarray(A2inv))
         self.nagg = nagg
