@@ -31,7 +31,10 @@ def build_rank_model(rank, world, cells, material, traction, device_index, backe
                 fix[3 * int(nd) + k] = 0.0
     if rank == world - 1:
         faces = meshgen.boundary_faces_on_plane(el, xyz, 2, world * length)
-        loads = Loads(ufaces=faces, uloads=np.tile(np.asarray(traction, float), (len(faces), 1)))
+        # the shear part of the traction is scaled by 1/world: the column gets taller with the rank count and the
+        # bending stress at the clamped base (which drives the plastic zone) would grow with it otherwise
+        tr = np.asarray(traction, float) * np.array([1.0 / world, 1.0 / world, 1.0])
+        loads = Loads(ufaces=faces, uloads=np.tile(tr, (len(faces), 1)))
     else:
         loads = Loads()
     ops = HipLocalOps(part, xyz, material, fix, device_index, element_offset=rank * len(el))
