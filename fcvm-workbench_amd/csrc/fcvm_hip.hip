@@ -63,7 +63,7 @@ struct fcvm_ctx {
     // p-multigrid preconditioner (mode 1): level 1 = linear tets on the corner nodes
     int precond_mode = 0, mg_k0 = 1, mg_k1 = 60;
     double mg_alpha0 = 4.0, mg_alpha1 = 1000.0, mg_lmax0 = 0, mg_lmax1 = 0;
-    bool mg_topo = false;
+    bool mg_topo = false, mg_lmax_stale = true;
     int64_t nc = 0, nb_spmv1 = 0;
     Pattern pat1;
     int32_t *d_el4 = nullptr, *d_cols1 = nullptr, *d_rownode1 = nullptr, *d_c2f = nullptr, *d_mids = nullptr, *d_pa = nullptr,
@@ -333,6 +333,7 @@ int fcvm_set_material(fcvm_ctx *c, double E, double nu, double density) {
     NEED(c && E > 0 && nu > -1.0 && nu < 0.5, "fcvm_set_material: need E > 0 and -1 < nu < 0.5");
     c->E = E; c->nu = nu; c->rho = density;
     c->have_mat = true;
+    c->mg_lmax_stale = true;
     return 0;
 }
 
@@ -346,6 +347,7 @@ int fcvm_set_fix(fcvm_ctx *c, int64_t nfix, const int64_t *dofs, const double *v
         val[dofs[i]] = vals[i];
     }
     c->h_fixmask = mask;
+    c->mg_lmax_stale = true;
     HCHK(hipMemcpyAsync(c->d_fixmask, mask.data(), c->nn, hipMemcpyHostToDevice, c->stream));
     HCHK(hipMemcpyAsync(c->d_fixval, val.data(), sizeof(double) * c->nn * 3, hipMemcpyHostToDevice, c->stream));
     HCHK(hipStreamSynchronize(c->stream));
@@ -885,7 +887,9 @@ int fcvm_assemble_buckling(fcvm_ctx *c, const double *sig, double shift) {
     if (refresh_precond(c)) return 1;
     if (c->precond_mode >= 1) {
         HCHK(hipStreamSynchronize(s));
+        c->mg_lmax_stale = true;  // different operator (penalty rows, shift)
         if (mg_setup(c)) return 1;
+        c->mg_lmax_stale = true;  // and the next ordinary assembly is different again
     }
     HCHK(hipStreamSynchronize(s));
     c->assembled = true;
