@@ -54,6 +54,8 @@ struct fcvm_ctx {
     long long *d_pidx = nullptr;
     int64_t nb_vec = 0, nb_spmv = 0, nb_gp = 0;
     double last_spmv_ms = 0, last_total_ms = 0;
+    double row_spread = 0.0;
+    bool row_order_morton = false;
     int spmv_variant = 4;  // 0 plain, 1 nontemporal matrix loads, 2 unroll x2, 3 nt + x2, 4 nt + x4 (fastest measured)
     double last_spmv_timed = 0;
     // host copies needed to build the coarse level
@@ -275,7 +277,17 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
         if (nt > 32) nt = 32;
         int win = SORT_WINDOW;
         if (const char *v = getenv("FCVM_SORT_WINDOW")) win = std::max(1, atoi(v));
-        build_pattern(ne, nn, el.data(), c->pat, nt, win);
+        // row order of the matrix: the caller's numbering when it is band-like (structured meshes), otherwise a
+        // Morton curve through the node coordinates (vectors keep the caller's order; only the order in which the
+        // SpMV walks the rows -- and with it the locality of its x-gathers -- changes)
+        int mode = -1;  // auto
+        if (const char *v = getenv("FCVM_ROW_ORDER")) mode = atoi(v);
+        c->row_spread = numbering_spread(ne, nn, el.data(), 10);
+        const bool use_morton = mode == 1 || (mode < 0 && nn > 4096 && c->row_spread > 0.05);
+        std::vector<int32_t> order;
+        if (use_morton) order = morton_order(nn, nocoord);
+        c->row_order_morton = use_morton;
+        build_pattern(ne, nn, el.data(), c->pat, nt, win, 10, use_morton ? order.data() : nullptr);
     } catch (const std::exception &ex) {
         return fail(std::string("fcvm_set_mesh: ") + ex.what());
     }

@@ -26,7 +26,8 @@ static void parallel_for(int64_t n, int nthreads, const std::function<void(int64
     for (auto &x : th) x.join();
 }
 
-void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nthreads, int sort_window, int npe) {
+void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nthreads, int sort_window, int npe,
+                   const int32_t *row_order) {
     if (ne <= 0 || nn <= 0) throw std::runtime_error("empty mesh");
     for (int64_t i = 0; i < ne * npe; i++)
         if (el[i] < 0 || el[i] >= nn) throw std::runtime_error("element node index out of range");
@@ -83,7 +84,7 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
     for (int64_t w0 = 0; w0 < nn; w0 += win) {
         int64_t w1 = std::min(nn, w0 + win);
         std::vector<int32_t> ids(w1 - w0);
-        for (int64_t i = w0; i < w1; i++) ids[i - w0] = (int32_t)i;
+        for (int64_t i = w0; i < w1; i++) ids[i - w0] = row_order ? row_order[i] : (int32_t)i;
         std::stable_sort(ids.begin(), ids.end(), [&](int32_t a, int32_t b) { return len[a] > len[b]; });
         for (int64_t k = 0; k < (int64_t)ids.size(); k++) {
             p.rownode[w0 + k] = ids[k];
@@ -142,6 +143,50 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
         int64_t j = std::lower_bound(rb, re, (int32_t)i) - rb;
         p.diagoff[i] = (uint32_t)p.block_offset(p.slotof[i], j);
     }
+}
+
+std::vector<int32_t> morton_order(int64_t nn, const double *xyz) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int64_t i = 0; i < nn; i++)
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min(lo[k], xyz[3 * i + k]);
+            hi[k] = std::max(hi[k], xyz[3 * i + k]);
+        }
+    auto spread = [](uint64_t v) {  // 21 bits -> every third bit
+        v &= 0x1fffff;
+        v = (v | v << 32) & 0x1f00000000ffffull;
+        v = (v | v << 16) & 0x1f0000ff0000ffull;
+        v = (v | v << 8) & 0x100f00f00f00f00full;
+        v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+        v = (v | v << 2) & 0x1249249249249249ull;
+        return v;
+    };
+    std::vector<std::pair<uint64_t, int32_t>> key(nn);
+    for (int64_t i = 0; i < nn; i++) {
+        uint64_t q[3];
+        for (int k = 0; k < 3; k++) {
+            double ext = hi[k] - lo[k];
+            q[k] = ext > 0 ? (uint64_t)((xyz[3 * i + k] - lo[k]) / ext * 2097151.0) : 0;
+        }
+        key[i] = {spread(q[0]) | spread(q[1]) << 1 | spread(q[2]) << 2, (int32_t)i};
+    }
+    std::sort(key.begin(), key.end());
+    std::vector<int32_t> order(nn);
+    for (int64_t i = 0; i < nn; i++) order[i] = key[i].second;
+    return order;
+}
+
+double numbering_spread(int64_t ne, int64_t nn, const int32_t *el, int npe) {
+    double s = 0.0;
+    for (int64_t e = 0; e < ne; e++) {
+        int32_t mn = el[e * npe], mx = mn;
+        for (int k = 1; k < npe; k++) {
+            mn = std::min(mn, el[e * npe + k]);
+            mx = std::max(mx, el[e * npe + k]);
+        }
+        s += (double)(mx - mn);
+    }
+    return ne > 0 && nn > 0 ? s / (double)ne / (double)nn : 0.0;
 }
 
 }  // namespace fcvm

@@ -36,6 +36,12 @@ struct Pattern {
 
 // elnodes0: 0-based int32 [ne*10].  Throws std::runtime_error on bad input.
 void build_pattern(int64_t ne, int64_t nn, const int32_t *elnodes0, Pattern &p, int nthreads,
-                   int sort_window = SORT_WINDOW, int npe = 10);
+                   int sort_window = SORT_WINDOW, int npe = 10, const int32_t *row_order = nullptr);
+
+// nodes sorted along a Morton (Z-order) curve through their coordinates: a locality-preserving order in which
+// the SpMV walks the rows when the caller's node numbering has none (unstructured meshes)
+std::vector<int32_t> morton_order(int64_t nn, const double *xyz);
+// mean |max - min| of the node numbers of an element, relative to nn: ~0 for band-like numberings
+double numbering_spread(int64_t ne, int64_t nn, const int32_t *el, int npe);
 
 }  // namespace fcvm
