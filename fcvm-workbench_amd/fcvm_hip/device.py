@@ -16,9 +16,7 @@ class DArr:
     def __init__(self, ctx, n, dtype=np.float64, ptr=None):
         self.ctx, self.n, self.dtype = ctx, int(n), np.dtype(dtype)
         if ptr is None:
-            p = C.c_void_p()
-            call("fcvm_malloc", ctx.h, self.n * self.dtype.itemsize, C.byref(p))
-            self.ptr, self._own = p.value, True
+            self.ptr, self._own = ctx._alloc(self.n * self.dtype.itemsize), True
         else:
             self.ptr, self._own = int(ptr), False
 
@@ -51,7 +49,7 @@ class DArr:
 
     def free(self):
         if self._own and self.ptr and self.ctx.h:
-            call("fcvm_free", self.ctx.h, self.ptr)
+            self.ctx._release(self.ptr, self.nbytes)
         self.ptr = None
 
     def __del__(self):
@@ -70,12 +68,46 @@ class Context:
         self.h = h
         self.device = device
         self.ne = self.nn = 0
+        self._pool, self._pooled = {}, 0
         # preconditioner of the linear solve: p-multigrid by default, FCVM_PRECOND=bj for block-Jacobi
         self.set_precond(os.environ.get("FCVM_PRECOND", "mg"))
         self.l2_min_coarse_nodes = int(os.environ.get("FCVM_L2_MIN_COARSE", "50"))
 
+    # device buffers of the driver's temporaries are recycled: all work of a context runs on one stream, so a
+    # released buffer can be handed out again at once (stream order protects it); hipMalloc/hipFree (+ the
+    # synchronisation hipFree implies) would otherwise cost several milliseconds per Newton iteration
+    _POOL_LIMIT = 8 << 30
+
+    def _alloc(self, nbytes):
+        nbytes = max(int(nbytes), 8)
+        lst = self._pool.get(nbytes)
+        if lst:
+            self._pooled -= nbytes
+            return lst.pop()
+        p = C.c_void_p()
+        call("fcvm_malloc", self.h, nbytes, C.byref(p))
+        return p.value
+
+    def _release(self, ptr, nbytes):
+        nbytes = max(int(nbytes), 8)
+        if self._pooled + nbytes <= self._POOL_LIMIT:
+            self._pool.setdefault(nbytes, []).append(ptr)
+            self._pooled += nbytes
+        else:
+            call("fcvm_free", self.h, ptr)
+
+    def trim_pool(self):
+        for lst in self._pool.values():
+            for ptr in lst:
+                call("fcvm_free", self.h, ptr)
+        self._pool, self._pooled = {}, 0
+
     def close(self):
         if self.h:
+            try:
+                self.trim_pool()
+            except Exception:
+                pass
             _lib.load().fcvm_destroy(self.h)
             self.h = None
 
