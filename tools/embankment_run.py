@@ -15,10 +15,14 @@ from fcvm_hip.solver import GpuModel, calc_disp  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--refine", type=int, default=2)
 ap.add_argument("--nstep", type=int, default=0)
+ap.add_argument("--gnl", type=str, default="", help="GNLY: geometrically non-linear (tangent re-assembly every Newton iteration)")
 a = ap.parse_args()
 case = examples.embankment(a.refine)
 if a.nstep:
     case["ctl"]["nstep"] = a.nstep
+if a.gnl:
+    case["ctl"]["gnl"] = a.gnl
+    case["ctl"]["maxImp"] = "0.0"
 t0 = time.perf_counter()
 m = GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"], Loads())
 t1 = time.perf_counter()
