@@ -502,3 +502,62 @@ def test_gnly_with_buckling_imperfection_full_flow(orc, tmp_path):
     tab = g["out_table"]
     assert len(r["lout"]) == len(tab)
     assert np.allclose(r["lout"], tab[:, 4], rtol=2e-2, atol=1e-3) and np.allclose(r["un"], tab[:, 5], rtol=2e-2, atol=1e-2)
+
+
+def test_error_paths_and_mirror_kernels(orc, gpu_ctx):
+    """Loud failures (no silent fallback) and the array-level mirrors fcVM.update_stress_load /
+    update_PEEQ_CSR / calculate_principal_stress."""
+    import fcVM as ft
+    from fcvm_hip._lib import FcvmError
+    from fcvm_hip.device import Context
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import GpuModel
+    c = Context(0)
+    with pytest.raises(FcvmError, match="mesh"):
+        c.solve(c.zeros(3), rtol=1e-8)                      # no mesh / matrix yet
+    case = small_case(2)
+    el_bad = case["elNodes"].copy()
+    el_bad[0, 0] = len(case["nocoord"]) + 5
+    with pytest.raises(FcvmError, match="out of range"):
+        c.set_mesh(el_bad, case["nocoord"])
+    c.set_mesh(case["elNodes"], case["nocoord"])
+    with pytest.raises(FcvmError, match="nu"):
+        c.set_material(210000.0, 0.5, 1.0)
+    with pytest.raises(FcvmError, match="dof out of range"):
+        c.set_fix({3 * len(case["nocoord"]) + 1: 0.0})
+    c.set_material(210000.0, 0.3, 7.8e-6)
+    f = c.array(np.ones(3 * len(case["nocoord"])))
+    with pytest.raises(FcvmError, match="assemble"):
+        c.solve(f)
+    # unconstrained body: K is singular, the rhs is not self-equilibrated -> PCG must report, not return garbage
+    m = GpuModel(case["elNodes"], case["nocoord"], case["material"], {}, Loads())
+    m.ctx.set_precond("bj")
+    glv, modf, _, _ = m.calc_gsm((0.0, 0.0, -9.81))
+    with pytest.raises(FcvmError, match="PCG"):
+        m.ctx.solve(glv, rtol=1e-12, maxit=200)
+    # array-level mirrors
+    rng = np.random.default_rng(4)
+    ne, nn = len(case["elNodes"]), len(case["nocoord"])
+    du, disp = rng.standard_normal(3 * nn) * 2e-3, np.zeros(3 * nn)
+    sig, sy = rng.standard_normal(24 * ne) * 40, np.full(4 * ne, 220.0)
+    mat = np.array([case["material"]])
+    out = [np.zeros(24 * ne), np.zeros(24 * ne), np.ones(3 * nn), np.zeros(4 * ne, bool)]
+    ft.update_stress_load(ft.gaussPoints()[0], case["elNodes"], case["nocoord"], mat, sy, disp, du, sig, out[0], out[1], out[2],
+                          0.0, False, out[3])
+    ref = [np.zeros(24 * ne), np.zeros(24 * ne), np.ones(3 * nn), np.zeros(4 * ne, np.uint8)]
+    orc.update_stress_load(case["elNodes"], case["nocoord"], case["material"], sy, disp, du, sig, ref[0], ref[1], ref[2], 0.0,
+                           False, ref[3])
+    assert rel(out[0], ref[0]) < KTOL and rel(out[1], ref[1]) < KTOL and rel(out[2], ref[2]) < KTOL   # qin is ADDED to
+    assert np.array_equal(out[3].astype(np.uint8), ref[3])
+    peeq, csr, tri, pre, svm, ecr = (np.zeros(4 * ne) for _ in range(6))
+    sy2 = sy.copy()
+    ft.update_PEEQ_CSR(ne, mat, out[1], out[0], sy2, 0.25, peeq, csr, tri, pre, svm, ecr, 0.0)
+    p2, c2, t2, pr2, s2, e2 = (np.zeros(4 * ne) for _ in range(6))
+    sy3 = sy.copy()
+    orc.update_PEEQ_CSR(ne, case["material"], ref[1], ref[0], sy3, 0.25, p2, c2, t2, pr2, s2, e2, 0.0)
+    assert rel(peeq, p2) < 1e-12 and rel(csr, c2) < 1e-12 and rel(svm, s2) < 1e-12 and rel(ecr, e2) < 1e-12
+    t10 = rng.standard_normal((nn, 6))
+    got = ft.calculate_principal_stress(t10)
+    want = orc.calculate_principal_stress(t10)
+    for a, b in zip(got[:3], want[:3]):
+        assert rel(a, b) < 1e-12
