@@ -513,7 +513,7 @@ def test_error_paths_and_mirror_kernels(orc, gpu_ctx):
     from fcvm_hip.loads import Loads
     from fcvm_hip.solver import GpuModel
     c = Context(0)
-    with pytest.raises(FcvmError, match="mesh"):
+    with pytest.raises(FcvmError, match="assemble"):
         c.solve(c.zeros(3), rtol=1e-8)                      # no mesh / matrix yet
     case = small_case(2)
     el_bad = case["elNodes"].copy()
