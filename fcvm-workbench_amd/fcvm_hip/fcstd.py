@@ -5,8 +5,9 @@ This covers, for box-shaped models, what the reference's setUpInput does through
 (reference: source code/fcVM.py:122-347): element / node arrays in fcVM's internal node order,
 the `fix` dictionary, load faces with their tractions and the material triple.  Face references of a
 Part::Box are planes (OpenCASCADE numbering: Face1 x=0, Face2 x=L, Face3 y=0, Face4 y=W, Face5 z=0,
-Face6 z=H, then translated by the Placement); other shapes need FreeCAD's geometry kernel and raise
-NotImplementedError.
+Face6 z=H, then translated by the Placement) and its corners are Vertex1..8 = (0,0,H) (0,0,0) (0,W,H)
+(0,W,0) (L,0,H) (L,0,0) (L,W,H) (L,W,0) (the order of the vertex records in the document's
+PartShape.brp); other shapes need FreeCAD's geometry kernel and raise NotImplementedError.
 
 UNV -> fcVM node order (derived from the reference's own data: the FemMesh.unv stored in
 tensile.FCStd against the cells of tensile.vtk, identical for all elements):
@@ -122,13 +123,22 @@ def load_model(path_or_bytes, mesh_member="FemMesh.unv"):
     tol = 1e-6 * dims.max()
 
     def plane(face):
+        if not face.startswith("Face") or not face[4:].isdigit() or not 0 <= int(face[4:]) - 1 < 6:
+            raise NotImplementedError("reference %s: only Face1..Face6 / Vertex1..Vertex8 of the box are supported" % face)
         k = int(face[4:]) - 1
-        if not face.startswith("Face") or not 0 <= k < 6:
-            raise NotImplementedError("reference %s: only Face1..Face6 of the box are supported" % face)
         ax = k // 2
         return ax, org[ax] + (dims[ax] if k % 2 else 0.0)
 
     def nodes_of(face):
+        if face.startswith("Vertex"):
+            k = int(face[6:]) - 1
+            if not 0 <= k < 8:
+                raise NotImplementedError("reference %s: a box has Vertex1..Vertex8" % face)
+            p = org + dims * np.array([(k >> 2) & 1, (k >> 1) & 1, 1 - (k & 1)])
+            hit = np.where(np.abs(xyz - p).max(1) < tol)[0]
+            if len(hit) != 1:
+                raise ValueError("no mesh node at %s of the box" % face)
+            return hit
         ax, v = plane(face)
         return np.where(np.abs(xyz[:, ax] - v) < tol)[0]
 

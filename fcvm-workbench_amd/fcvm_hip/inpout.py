@@ -10,10 +10,18 @@ _INT = {"nstep", "iterat_max"}
 _STR = {"disp_output", "csr_option", "averaged_option", "gnl", "maxImp", "ev1", "ev2"}
 
 
+_MIN_LINES = 15  # up to target_LF every field is numeric or used unconditionally
+
+
 def parse_inp_lines(lines):
+    """Older control files stop after `averaged_option` (17 lines, e.g. VM_Uniaxial_Tension_Example.inp):
+    the macro's readline() then returns "" for gnl / maxImp / ev1 / ev2 (fcVM.FCMacro:91-94), which
+    selects the geometrically linear analysis.  A file that ends inside the numeric block makes the
+    macro's float("") raise, so that is an error here too."""
     t = [s.strip() for s in lines if s.strip() != ""]
-    if len(t) < len(INP_KEYS):
-        raise ValueError("control file needs %d lines, got %d" % (len(INP_KEYS), len(t)))
+    if len(t) < _MIN_LINES:
+        raise ValueError("control file needs at least %d lines, got %d" % (_MIN_LINES, len(t)))
+    t = t + [""] * (len(INP_KEYS) - len(t))
     ctl = {}
     for k, v in zip(INP_KEYS, t):
         ctl[k] = v if k in _STR else (int(v) if k in _INT else float(v))

@@ -338,6 +338,8 @@ class RiksDriver:
 
     def result(self):
         lout = self.rfl if self.model.moving else self.lbd
+        if self.elastic_only:
+            lout = [0.0]  # fcVM.py:1193: the load history is only filled inside the step loop
         if self.disp_output == "total":
             res = self.disp_new.get()
         else:

@@ -309,6 +309,7 @@ def calcDisp(elNodes, nocoord, fixdof, movdof, modf, material, stm, row, col, gl
     sig_new = np.zeros(24 * nelem)
     pgp[:] = 0
     passes = 0
+    lout = [0.0]  # fcVM.py:1193: what an nstep == 1 run returns (one all-zero row in the .out table)
 
     def record():
         dn = disp_new.reshape(-1, 3)

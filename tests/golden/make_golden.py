@@ -154,20 +154,67 @@ def barbuckling():
     print(name, "ne", len(cells), "nn", len(pts), "buckling factors", ev, "max imperfection", np.abs(pts - m["nocoord"]).max())
 
 
+def buckling():
+    """Linear buckling reference run (GNLY, nstep = 1) of a 1000 x 10 x 10 cantilever with an end block.
+    The mesh embedded in Buckling.FCStd is a later one (206 elements) than the one the shipped results
+    were computed on (214), so mesh and fields come from the .vtk, the constraints from the document
+    (ConstraintFixed on x = 0; ConstraintDisplacement yFree = false on the y = 0 faces of the four
+    BooleanFragments solids; ConstraintForce 100 N along -x on one end face), resolved geometrically and
+    cross-checked against the reference's own elastic displacement field: fixed dofs are exactly its
+    exact zeros, and the loaded face is where K u has its only non-zero residual (checked in
+    tests/test_oracle_golden.py to 1e-10: uniform traction -1 N/mm^2 on x = 1010, 0 <= z <= 10)."""
+    from fcvm_hip import meshgen
+    name = "Buckling"
+    pts, cells, data = read_vtk(os.path.join(REF, "output files", name + ".vtk"))
+    head, table = parse_out(os.path.join(REF, "output files", name + ".out"))
+    ev = [float(v) for v in re.search(r"elastic buckling factors:\s*\[([^\]]*)\]", open(os.path.join(REF, "output files", name + ".out")).read()).group(1).split()]
+    E, nu, rho, xml = material_from_fcstd(os.path.join(REF, "freeCAD files", name + ".FCStd"))
+    inp = [ln.strip() for ln in open(os.path.join(REF, "control files", name + ".inp"))]
+    inp = [s for s in inp if s != ""][:21]
+    assert xml.count('<Object type="Fem::ConstraintFixed"') == 1 and xml.count('<Object type="Fem::ConstraintDisplacement"') == 1
+    el = (cells + 1).astype(np.int64)
+    fix = {}
+    for n in np.where(np.abs(pts[:, 0]) < 1e-9)[0]:
+        for k in range(3):
+            fix[3 * int(n) + k] = 0.0
+    for n in np.where(np.abs(pts[:, 1]) < 1e-9)[0]:
+        fix[3 * int(n) + 1] = 0.0
+    u = data["Elastic_Displacement"].reshape(-1)
+    assert set(np.where(u == 0.0)[0].tolist()) == set(fix), "BC inference mismatch"
+    faces = meshgen.boundary_faces_on_plane(el, pts, 0, pts[:, 0].max())
+    zc = pts[faces[:, :3] - 1, 2].mean(1)
+    faces = faces[(zc > 0.0) & (zc < 10.0)]
+    area = 100.0
+    assert abs(head["loadsum"][0] + 100.0) < 1e-9
+    fd = np.array(sorted(fix), dtype=np.int64)
+    np.savez_compressed(
+        os.path.join(HERE, "buckling.npz"),
+        nocoord=pts, elNodes=el, fixed_dofs=fd, fixed_vals=np.zeros(len(fd)), ufaces=faces,
+        uloads=np.tile([head["loadsum"][0] / area, 0.0, 0.0], (len(faces), 1)), material=np.array([E, nu, rho]),
+        out_table=table, out_loadsum=np.array(head["loadsum"]), buckling_factors=np.array(ev),
+        **{"vtk_" + re.sub(r"\W", "", k): v for k, v in data.items()},
+    )
+    json.dump({"name": name, "inp": inp}, open(os.path.join(HERE, "buckling.json"), "w"), indent=1)
+    print(name, "ne", len(cells), "nn", len(pts), "fixed dofs", len(fd), "loaded faces", len(faces), "factors", ev)
+
+
 def fcstd_fixture(name, key):
     """Document.xml + FemMesh.unv of a reference FreeCAD document (data: model definition + mesh),
     re-zipped without thumbnails / result arrays."""
     src = zipfile.ZipFile(os.path.join(REF, "freeCAD files", name + ".FCStd"))
     with zipfile.ZipFile(os.path.join(HERE, key + ".FCStd"), "w", zipfile.ZIP_DEFLATED) as out:
         for member in ("Document.xml", "FemMesh.unv"):
-            out.writestr(member, src.read(member))
+            out.writestr(zipfile.ZipInfo(member, date_time=(2025, 1, 1, 0, 0, 0)), src.read(member), zipfile.ZIP_DEFLATED)
     print(name, "->", key + ".FCStd")
 
 
 if __name__ == "__main__":
     fcstd_fixture("tensile", "tensile")
+    fcstd_fixture("VM_Uniaxial_Tension_Example", "vm_uniaxial")  # BASELINE configs[0]
+    inp = [ln.strip() for ln in open(os.path.join(REF, "control files", "VM_Uniaxial_Tension_Example.inp"))]
+    json.dump({"name": "VM_Uniaxial_Tension_Example", "inp": [s for s in inp if s != ""]}, open(os.path.join(HERE, "vm_uniaxial.json"), "w"), indent=1)
     barbuckling()
     embankment()
     vtk_only("tensile", "tensile")
-    vtk_only("Buckling", "buckling")
+    buckling()
     vtk_only("Lug_Pressure_Example", "lug")

@@ -359,6 +359,39 @@ def test_gnly_updated_lagrange_analysis_matches_oracle(orc):
     assert rel(res["peeq"], o["peeq"]) < 1e-6
 
 
+@pytest.mark.parametrize("sig_yield", [100.0, 20.0])
+def test_vm_uniaxial_example_config0(orc, tmp_path, sig_yield):
+    """BASELINE configs[0] end to end on the GPU: the reference's VM_Uniaxial_Tension_Example document and its
+    (17-line) control file through fcVM.run_fcstd; against the oracle and the closed-form answers
+    (elastic: stress diag(30,0,30) at load factor 3; sig_yield = 20: limit load factor 2)."""
+    import json
+    import os
+    import fcVM as ft
+    from conftest import REPO
+    from fcvm_hip import fcstd, inpout
+    meta = json.load(open(os.path.join(REPO, "tests", "golden", "vm_uniaxial.json")))
+    lines = list(meta["inp"])
+    lines[0] = str(sig_yield)
+    with open(tmp_path / "vm.inp", "w") as f:
+        f.write("\n".join(lines) + "\n")
+    src = os.path.join(REPO, "tests", "golden", "vm_uniaxial.FCStd")
+    res = ft.run_fcstd(src, str(tmp_path), str(tmp_path), name="vm")
+    m = fcstd.load_model(src)
+    L = m["loads"]
+    o = orc.run_analysis(m["elNodes"], m["nocoord"], m["material"], m["fix"], orc.Loads(pfaces=L.pfaces, pvals=L.pvals),
+                         inpout.parse_inp_lines(lines))
+    assert len(res["lout"]) == len(o["lout"])
+    assert rel(res["lout"], o["lout"]) < 1e-6 and rel(res["un"], o["un"]) < 1e-6
+    assert rel(res["displacements"], o["displacements"]) < 1e-6
+    assert rel(res["tet10stress"], o["tet10stress"]) < 1e-6 and rel(res["sigmises"], o["sigmises"]) < 1e-6
+    if sig_yield == 100.0:
+        assert res["lout"][-1] == 3.0
+        assert np.abs(res["tet10stress"] - [30.0, 0.0, 30.0, 0.0, 0.0, 0.0]).max() < 1e-7
+    else:
+        assert abs(np.max(res["lout"]) - 2.0) < 3e-3 and rel(res["peeq"], o["peeq"]) < 1e-6
+    assert os.path.getsize(tmp_path / "vm.out") > 0 and os.path.getsize(tmp_path / "vm.vtk") > 0
+
+
 def test_fcVM_mirror_api_and_files(orc, tmp_path):
     """The reference-named entry points (fcVM.calcGSM / calcDisp / mapStresses / exportVTK with the
     reference's argument lists incl. the dummy first load rows) and the headless macro equivalent

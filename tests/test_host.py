@@ -1,6 +1,7 @@
 """CPU-only checks: the C-ABI library loads here and exports every symbol the header declares,
 the host-side pattern builder, the text/VTK formats, the mesh generator and the host load vector."""
 import ctypes as C
+import json
 import os
 import re
 
@@ -145,6 +146,35 @@ def test_fcstd_reader_reproduces_reference_mesh_and_first_load_step(orc):
     assert np.array_equal(fmt(mine[1]), tab[1, 4:12])
     # plateau: load factor 0.5, pressure / von Mises / triaxiality / critical strain as in the reference rows
     assert np.array_equal(fmt(mine[-1][[0, 3, 4, 5, 6]]), tab[-1, [4, 7, 8, 9, 10]])
+
+
+def test_vm_uniaxial_example_known_answers(orc):
+    """BASELINE configs[0]: VM_Uniaxial_Tension_Example (.FCStd + its 17-line .inp of an older macro
+    revision: gnl / maxImp / ev1 / ev2 are read as "" = geometrically linear, fcVM.FCMacro:91-94).
+    Vertex-referenced supports (statically determinate) and pressure loads on box faces: 10 N/mm^2 pulling on
+    the x and z faces, nothing on y.  Closed-form answers the oracle has to hit:
+      * elastic, target load factor 3: uniform stress diag(30, 0, 30) in every node, von Mises 30;
+      * yield stress lowered to 20: von Mises of the biaxial state is 10 * lambda, so the limit load factor
+        of the perfectly plastic cube is exactly 2 (the arc-length steps hover around it within error_max)."""
+    from fcvm_hip import fcstd, inpout
+    m = fcstd.load_model(os.path.join(REPO, "tests", "golden", "vm_uniaxial.FCStd"))
+    meta = json.load(open(os.path.join(REPO, "tests", "golden", "vm_uniaxial.json")))
+    ctl = inpout.parse_inp_lines(meta["inp"])
+    assert len(meta["inp"]) == 17 and ctl["gnl"] == "" and ctl["nstep"] == 25 and ctl["target_LF"] == 3.0
+    assert sorted(m["fix"]) == [3, 4, 5, 9, 11, 17]                      # Vertex2 fixed, Vertex4: x,z  Vertex6: z
+    assert np.allclose(m["nocoord"][[1, 3, 5]], [[0, 0, 0], [0, 10, 0], [10, 0, 0]])
+    L = m["loads"]
+    assert len(L.pfaces) == 24 and sorted(set(np.abs(L.pvals))) == [0.0, 10.0]
+    loads = orc.Loads(pfaces=L.pfaces, pvals=L.pvals)
+    res = orc.run_analysis(m["elNodes"], m["nocoord"], m["material"], m["fix"], loads, dict(ctl))
+    assert res["lout"][-1] == 3.0 and np.abs(res["loadsum"]).max() < 1e-9   # self-equilibrated
+    assert np.abs(res["tet10stress"] - [30.0, 0.0, 30.0, 0.0, 0.0, 0.0]).max() < 1e-10
+    assert np.abs(res["tet10svm"] - 30.0).max() < 1e-10 and res["peeq"].max() == 0.0
+    ctl["sig_yield"] = 20.0
+    res = orc.run_analysis(m["elNodes"], m["nocoord"], m["material"], m["fix"], loads, dict(ctl))
+    lo = np.asarray(res["lout"])
+    assert len(lo) == 26 and abs(lo.max() - 2.0) < 3e-3 and np.all(np.abs(lo[-10:] - 2.0) < 3e-3)
+    assert np.abs(res["sigmises"] - 20.0).max() < 1e-9 and res["peeq"].min() > 1e-3
 
 
 def test_fcstd_reader_rejects_non_box_geometry(tmp_path):

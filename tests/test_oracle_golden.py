@@ -103,3 +103,35 @@ def test_bar_buckling_gnly_analysis(orc):
     assert rel(res["displacements"], g["vtk_Displacement"].reshape(-1)) < 1e-7
     assert rel(res["tet10stress"], g["vtk_Stress_Tensor"]) < 1e-7
     assert rel(res["tet10svm"], g["vtk_von_Mises_Stress"]) < 1e-7
+
+
+def test_buckling_model_equilibrium_and_factors(orc):
+    """Reference 'Buckling' model (linear buckling run, nstep = 1, ConstraintDisplacement + end block).
+    (1) K u_ref = f: the reference's own f64 elastic displacement field is in equilibrium with the
+        oracle's stiffness and its consistent face load -- residual 1e-10 of the load at every free dof;
+    (2) the elastic solution itself; (3) the buckling factors / shapes of its .out / .vtk.  Those were
+        written by an earlier revision of the reference (shapes scaled to max 1, mesh older than the one in
+        the .FCStd): factors agree to 5e-6 relative, shapes to 2e-6 of their maximum."""
+    import scipy.sparse as sp
+    g, meta = load_golden("buckling")
+    fix = {int(d): float(v) for d, v in zip(g["fixed_dofs"], g["fixed_vals"])}
+    loads = orc.Loads(ufaces=g["ufaces"], uloads=g["uloads"])
+    el, xyz, mat = g["elNodes"], g["nocoord"], g["material"]
+    nn = len(xyz)
+    stm, row, col, glv, *_ = orc.calcGSM(el, xyz, mat, {}, (0.0, 0.0, 0.0), loads)
+    K = sp.coo_matrix((stm, (row, col)), shape=(3 * nn, 3 * nn)).tocsr()
+    K = K + sp.tril(K, -1).T
+    u_ref = g["vtk_Elastic_Displacement"].reshape(-1)
+    free = np.ones(3 * nn, bool)
+    free[g["fixed_dofs"]] = False
+    assert np.abs((K @ u_ref - glv)[free]).max() < 1e-10 * np.abs(glv).max()
+    assert abs(glv.reshape(-1, 3)[:, 0].sum() - g["out_loadsum"][0]) < 1e-9
+    res = orc.run_analysis(el, xyz, mat, fix, loads, orc.read_inp_lines(meta["inp"]))
+    assert np.abs(res["disp_el"] - u_ref).max() < 1e-7 * np.abs(u_ref).max()  # slender bar: cond(K) ~ 1e9
+    assert np.array_equal(res["lout"], [0.0]) and len(g["out_table"]) == 1  # fcVM.py:1193
+    w, v = res["eigenval"], res["eigenvec"]
+    assert np.allclose(w, g["buckling_factors"], rtol=5e-6, atol=0)
+    for i, key in enumerate(("vtk_Buckling_shape_for_lambda1__4263", "vtk_Buckling_shape_for_lambda2__38524")):
+        r, x = g[key].reshape(-1), v[:, i]
+        s = (x @ r) / (x @ x)
+        assert np.abs(s * x - r).max() < 2e-6
