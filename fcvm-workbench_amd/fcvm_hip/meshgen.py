@@ -103,3 +103,65 @@ def refine_tet10(elNodes, nocoord):
     mids = (len(xyz) + inv).reshape(-1, 6)
     el2 = np.concatenate([c, mids], axis=1) + 1
     return el2.astype(np.int64), np.concatenate([xyz, new_xyz], axis=0)
+
+
+def fix_orientation(elNodes, nocoord):
+    """Swaps corners 1 <-> 2 (and the mid-side nodes that go with them) of every element whose corner
+    Jacobian is negative.  In place on elNodes; returns the number of elements flipped."""
+    el = elNodes - 1
+    p = nocoord
+    e1, e2, e3 = p[el[:, 1]] - p[el[:, 0]], p[el[:, 2]] - p[el[:, 0]], p[el[:, 3]] - p[el[:, 0]]
+    neg = np.einsum("ij,ij->i", e1, np.cross(e2, e3)) < 0
+    for a, b in ((1, 2), (4, 6), (8, 9)):  # c1<->c2 : m01<->m02, m13<->m23; m12 and m03 stay
+        elNodes[neg, a], elNodes[neg, b] = elNodes[neg, b].copy(), elNodes[neg, a].copy()
+    return int(neg.sum())
+
+
+def merge_blocks(blocks, tol=1e-7):
+    """Glues structured blocks [(elNodes, nocoord), ...] with matching interface lattices into one mesh:
+    nodes closer than tol (per coordinate, after rounding) become one.  Straight-sided elements: every
+    mid-side node is put at the mean of its two corners before merging, so mapped blocks stay conforming."""
+    els, pts, off = [], [], 0
+    for el, xyz in blocks:
+        xyz = xyz.copy()
+        e0 = el - 1
+        for k, (a, b) in enumerate(MID_PAIRS):
+            xyz[e0[:, 4 + k]] = 0.5 * (xyz[e0[:, a]] + xyz[e0[:, b]])
+        els.append(el + off)
+        pts.append(xyz)
+        off += len(xyz)
+    el, xyz = np.concatenate(els), np.concatenate(pts)
+    key = np.round(xyz / tol).astype(np.int64)
+    _, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
+    inv = inv.reshape(-1)
+    order = np.argsort(first)  # keep first-appearance order (block by block, lattice order inside a block)
+    rank = np.empty(len(order), np.int64)
+    rank[order] = np.arange(len(order))
+    el = rank[inv[el - 1]] + 1
+    xyz = xyz[first[order]]
+    fix_orientation(el, xyz)
+    return el.astype(np.int64), xyz
+
+
+def plate_with_hole(h, length=200.0, width=100.0, thick=10.0, radius=50.0):
+    """The geometry of the reference's Plate_with_hole_Example (FreeCAD document: Part::Box 200 x 100 x 10
+    minus a Part::Cylinder of radius 50 about the z axis through the box corner at the origin), meshed with
+    mapped Kuhn tetrahedra of edge length about h.  Two blocks: a strip between the quarter arc and the
+    polyline (w,0) -> (w,w) -> (0,w) (w = width; transfinite interpolation, parameters radial x angular x z),
+    and the box [w, length] x [0, w] behind it.  Returns (elNodes, nocoord)."""
+    w = width
+    n_a = max(2, int(round(w / h)))
+    n_t = max(2, int(round((0.6 * (w - radius) + 0.4 * (np.sqrt(2.0) * w - radius)) / h)))
+    n_x = max(1, int(round((length - w) / h)))
+    n_z = max(2, int(round(thick / h)))
+    # strip: parameter box (t radial, s along the arc, z); s in [0,1] -> outer point on x = w, s in [1,2] -> on y = w
+    el1, q = cube_tet10(n_t, 2 * n_a, n_z, 1.0, 2.0, thick)
+    t, s = q[:, 0], q[:, 1]
+    th = 0.25 * np.pi * s
+    inner = radius * np.stack([np.cos(th), np.sin(th)], axis=1)
+    outer = np.where((s <= 1.0)[:, None], np.stack([np.full_like(s, w), w * s], axis=1),
+                     np.stack([w * (2.0 - s), np.full_like(s, w)], axis=1))
+    p1 = np.concatenate([(1.0 - t)[:, None] * inner + t[:, None] * outer, q[:, 2:3]], axis=1)
+    el2, p2 = cube_tet10(n_x, n_a, n_z, length - w, w, thick)
+    p2[:, 0] += w
+    return merge_blocks([(el1, p1), (el2, p2)])

@@ -198,6 +198,16 @@ def buckling():
     print(name, "ne", len(cells), "nn", len(pts), "fixed dofs", len(fd), "loaded faces", len(faces), "factors", ev)
 
 
+def out_only(name, key):
+    """Control file + .out table of a model whose document holds no mesh (BASELINE configs[1])."""
+    head, table = parse_out(os.path.join(REF, "output files", name + ".out"))
+    E, nu, rho, _ = material_from_fcstd(os.path.join(REF, "freeCAD files", name + ".FCStd"))
+    inp = [ln.strip() for ln in open(os.path.join(REF, "control files", name + ".inp"))]
+    json.dump({"name": name, "inp": [s for s in inp if s != ""][:21], "ne": head["ne"], "nn": head["nn"], "loadsum": head["loadsum"],
+               "material": [E, nu, rho], "out_table": table.tolist()}, open(os.path.join(HERE, key + ".json"), "w"), indent=1)
+    print(name, "ne", head["ne"], "rows", len(table))
+
+
 def fcstd_fixture(name, key):
     """Document.xml + FemMesh.unv of a reference FreeCAD document (data: model definition + mesh),
     re-zipped without thumbnails / result arrays."""
@@ -217,4 +227,5 @@ if __name__ == "__main__":
     embankment()
     vtk_only("tensile", "tensile")
     buckling()
+    out_only("Plate_with_hole_Example", "plate_with_hole")
     vtk_only("Lug_Pressure_Example", "lug")
