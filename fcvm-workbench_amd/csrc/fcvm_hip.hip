@@ -139,10 +139,10 @@ static void launch_spmv_t(fcvm_ctx *c, const MatView &m, const double *x, double
     dim3 grid((unsigned)m.nb), block(256);
     if (m.vals32) {  // FP32-stored matrix, FP64 vectors and accumulation
         hipLaunchKernelGGL((k_spmv<DOT, false, 4, float2>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols,
-                           (const float2 *)m.vals32, m.rownode, x, y, part, done);
+                           (const float2 *)m.vals32, m.rownode, x, y, part, done, ChebEpi{});
         return;
     }
-#define FCVM_SPMV_ARGS m.nslices, m.nb, m.sptr, m.cols, (const double2 *)m.vals, m.rownode, x, y, part, done
+#define FCVM_SPMV_ARGS m.nslices, m.nb, m.sptr, m.cols, (const double2 *)m.vals, m.rownode, x, y, part, done, ChebEpi{}
     switch (c->spmv_variant) {
         case 0: hipLaunchKernelGGL((k_spmv<DOT, false, 1>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
         case 1: hipLaunchKernelGGL((k_spmv<DOT, true, 1>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
@@ -151,6 +151,16 @@ static void launch_spmv_t(fcvm_ctx *c, const MatView &m, const double *x, double
         default: hipLaunchKernelGGL((k_spmv<DOT, true, 4>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
     }
 #undef FCVM_SPMV_ARGS
+}
+// SpMV t = A d fused with a Chebyshev smoother step on the same rows (see ChebEpi); nothing is written but epi's vectors
+static void launch_spmv_cheb(fcvm_ctx *c, const MatView &m, const double *d, const double *done, const ChebEpi &epi) {
+    dim3 grid((unsigned)m.nb), block(256);
+    if (m.vals32)
+        hipLaunchKernelGGL((k_spmv<false, false, 4, float2, 1>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols,
+                           (const float2 *)m.vals32, m.rownode, d, (double *)nullptr, (double *)nullptr, done, epi);
+    else
+        hipLaunchKernelGGL((k_spmv<false, true, 4, double2, 1>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols,
+                           (const double2 *)m.vals, m.rownode, d, (double *)nullptr, (double *)nullptr, done, epi);
 }
 static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done) {
     if (dot) launch_spmv_t<true>(c, fine_view(c), x, y, c->d_part_spmv, done);

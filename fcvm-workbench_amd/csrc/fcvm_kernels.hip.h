@@ -478,13 +478,26 @@ __device__ __forceinline__ void spmv_pair(const int32_t *cp, const V2 *vp, const
     y2 += v[6].x * a0 + v[7].x * a1 + v[8].x * a2 + v[6].y * b0 + v[7].y * b1 + v[8].y * b2;
 }
 
-template <bool DOT, bool NT, int UNROLL, class V2 = double2>
+// Optional epilogue of the SpMV (EPI = 1): one Chebyshev step of the multigrid smoother on the row's own node,
+// with t = (A d)_node still in registers (no t vector, no second kernel):
+//   x += d ; r -= t ; if (update_d) { dout = cdd * d + cdr * Dinv r ; if (add_dout) x += dout }
+// d (the SpMV input, gathered by other rows while this kernel runs) is not written: dout != d.
+struct ChebEpi {
+    const double *dinv;
+    double *x, *r, *dout;
+    double cdd, cdr;
+    int update_d, add_dout;
+};
+__device__ __forceinline__ void apply_dinv(const double *d, double r0, double r1, double r2, double &z0, double &z1, double &z2);
+
+template <bool DOT, bool NT, int UNROLL, class V2 = double2, int EPI = 0>
 __global__ __launch_bounds__(256) void k_spmv(int64_t nslices, int64_t nblocks, const int64_t *__restrict__ sptr,
                                               const int32_t *__restrict__ cols,
                                               const V2 *__restrict__ vals,
                                               const int32_t *__restrict__ rownode,
                                               const double *__restrict__ x, double *__restrict__ y,
-                                              double *__restrict__ partial, const double *__restrict__ done) {
+                                              double *__restrict__ partial, const double *__restrict__ done,
+                                              ChebEpi epi) {
     __shared__ double sh[4];
     if (done && *done != 0.0) return;
     // XCD-aware remap: workgroups b, b+8, b+16.. share an XCD (and its L2); give each XCD a
@@ -529,9 +542,25 @@ __global__ __launch_bounds__(256) void k_spmv(int64_t nslices, int64_t nblocks, 
             vp += 9 * 64;
         }
         node = rownode[s * 64 + lane];
-        if (node >= 0) {
-            double *yo = y + 3 * (int64_t)node;
-            yo[0] = y0; yo[1] = y1; yo[2] = y2;
+        if (EPI == 0) {
+            if (node >= 0) {
+                double *yo = y + 3 * (int64_t)node;
+                yo[0] = y0; yo[1] = y1; yo[2] = y2;
+            }
+        } else if (node >= 0) {
+            const int64_t o = 3 * (int64_t)node;
+            const double d0 = x[o], d1 = x[o + 1], d2 = x[o + 2];
+            const double r0 = epi.r[o] - y0, r1 = epi.r[o + 1] - y1, r2 = epi.r[o + 2] - y2;
+            epi.r[o] = r0; epi.r[o + 1] = r1; epi.r[o + 2] = r2;
+            double a0 = d0, a1 = d1, a2 = d2;
+            if (epi.update_d) {
+                double z0, z1, z2;
+                apply_dinv(epi.dinv + (int64_t)node * 9, r0, r1, r2, z0, z1, z2);
+                const double n0 = epi.cdd * d0 + epi.cdr * z0, n1 = epi.cdd * d1 + epi.cdr * z1, n2 = epi.cdd * d2 + epi.cdr * z2;
+                epi.dout[o] = n0; epi.dout[o + 1] = n1; epi.dout[o + 2] = n2;
+                if (epi.add_dout) { a0 += n0; a1 += n1; a2 += n2; }
+            }
+            epi.x[o] += a0; epi.x[o + 1] += a1; epi.x[o + 2] += a2;
         }
     }
     if (DOT) {

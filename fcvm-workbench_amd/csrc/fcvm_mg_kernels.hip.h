@@ -165,6 +165,62 @@ __global__ __launch_bounds__(256) void k_pcg_update_xr_plain(int64_t nn, const d
     }
 }
 
+// additive cycle, fused with the PCG update: x += alpha p ; r -= alpha q ; z0 = w * Dinv r (the smoother part of z)
+__global__ __launch_bounds__(256) void k_pcg_update_xr_z0(int64_t nn, const double *__restrict__ p, const double *__restrict__ q,
+                                                          double *__restrict__ x, double *__restrict__ r,
+                                                          const double *__restrict__ dinv, double *__restrict__ z0, double w,
+                                                          const double *__restrict__ S) {
+    if (S[S_DONE] != 0.0) return;
+    const double alpha = S[S_ALPHA];
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nn) return;
+    double rn[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        x[3 * i + c] += alpha * p[3 * i + c];
+        rn[c] = r[3 * i + c] - alpha * q[3 * i + c];
+        r[3 * i + c] = rn[c];
+    }
+    double a0, a1, a2;
+    apply_dinv(dinv + i * 9, rn[0], rn[1], rn[2], a0, a1, a2);
+    z0[3 * i] = w * a0; z0[3 * i + 1] = w * a1; z0[3 * i + 2] = w * a2;
+}
+
+// additive cycle, second half: z = z0 + M0 P M1 e1 and the partials of r.z (slot 0) and r.r (slot 1)
+__global__ __launch_bounds__(256) void k_prolong_add_dot(int64_t nn, const int32_t *__restrict__ pa, const int32_t *__restrict__ pb,
+                                                         const uint8_t *__restrict__ fixmask0, const double *__restrict__ e1,
+                                                         const double *__restrict__ z0, const double *__restrict__ r,
+                                                         double *__restrict__ z, double *__restrict__ part, int64_t nb,
+                                                         const double *__restrict__ done) {
+    if (done && *done != 0.0) return;
+    __shared__ double sh[4];
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double rz = 0.0, rr = 0.0;
+    if (i < nn) {
+        const int64_t a = pa[i], b = pb[i];
+        const int fm = fixmask0[i];
+        double v[3] = {0.0, 0.0, 0.0};
+        if (a >= 0) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) v[c] = 0.5 * (e1[3 * a + c] + e1[3 * b + c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const double zc = z0[3 * i + c] + (((fm >> c) & 1) ? 0.0 : v[c]);
+            const double rc = r[3 * i + c];
+            z[3 * i + c] = zc;
+            rz += rc * zc;
+            rr += rc * rc;
+        }
+    }
+    rz = block_sum(rz, sh);
+    rr = block_sum(rr, sh);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = rz;
+        part[nb + blockIdx.x] = rr;
+    }
+}
+
 // partials of r.z (slot 0) and r.r (slot 1), layout of k_pcg_scalars
 __global__ __launch_bounds__(256) void k_dot2_partial(int64_t nn, const double *__restrict__ r, const double *__restrict__ z,
                                                       double *__restrict__ part, int64_t nb, const double *__restrict__ done) {

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfcvm_hip.so")
+LIB_PATH = os.environ.get("FCVM_HIP_LIB") or os.path.join(_HERE, "libfcvm_hip.so")  # FCVM_HIP_LIB: A/B runs of two builds
 
 
 class FcvmError(RuntimeError):

@@ -146,22 +146,25 @@ def merge_blocks(blocks, tol=1e-7):
 def plate_with_hole(h, length=200.0, width=100.0, thick=10.0, radius=50.0):
     """The geometry of the reference's Plate_with_hole_Example (FreeCAD document: Part::Box 200 x 100 x 10
     minus a Part::Cylinder of radius 50 about the z axis through the box corner at the origin), meshed with
-    mapped Kuhn tetrahedra of edge length about h.  Two blocks: a strip between the quarter arc and the
-    polyline (w,0) -> (w,w) -> (0,w) (w = width; transfinite interpolation, parameters radial x angular x z),
-    and the box [w, length] x [0, w] behind it.  Returns (elNodes, nocoord)."""
+    mapped Kuhn tetrahedra; h = edge length away from the hole.  Two blocks: a strip between the quarter arc
+    and the polyline (w,0) -> (w,w) -> (0,w) (w = width), parameters radial x angular x z with rays from the
+    origin and radii in geometric progression (dr / r = d theta: near-isotropic cells that shrink towards the
+    hole, where the plastic zone starts), and the box [w, length] x [0, w] behind it.  The thickness is
+    divided to the geometric mean of the in-plane sizes.  Returns (elNodes, nocoord)."""
     w = width
     n_a = max(2, int(round(w / h)))
-    n_t = max(2, int(round((0.6 * (w - radius) + 0.4 * (np.sqrt(2.0) * w - radius)) / h)))
+    dth = 0.25 * np.pi / n_a
+    n_t = max(2, int(round(0.5 * (np.log(w / radius) + np.log(np.sqrt(2.0) * w / radius)) / dth)))
     n_x = max(1, int(round((length - w) / h)))
-    n_z = max(2, int(round(thick / h)))
+    n_z = max(2, int(round(thick / (np.sqrt(radius * dth * h)))))
     # strip: parameter box (t radial, s along the arc, z); s in [0,1] -> outer point on x = w, s in [1,2] -> on y = w
     el1, q = cube_tet10(n_t, 2 * n_a, n_z, 1.0, 2.0, thick)
     t, s = q[:, 0], q[:, 1]
-    th = 0.25 * np.pi * s
-    inner = radius * np.stack([np.cos(th), np.sin(th)], axis=1)
-    outer = np.where((s <= 1.0)[:, None], np.stack([np.full_like(s, w), w * s], axis=1),
-                     np.stack([w * (2.0 - s), np.full_like(s, w)], axis=1))
-    p1 = np.concatenate([(1.0 - t)[:, None] * inner + t[:, None] * outer, q[:, 2:3]], axis=1)
+    out = np.where((s <= 1.0)[:, None], np.stack([np.full_like(s, w), w * s], axis=1),
+                   np.stack([w * (2.0 - s), np.full_like(s, w)], axis=1))   # uniform points on the polyline
+    rout = np.linalg.norm(out, axis=1)
+    r = radius * (rout / radius) ** t
+    p1 = np.concatenate([out * (r / rout)[:, None], q[:, 2:3]], axis=1)
     el2, p2 = cube_tet10(n_x, n_a, n_z, length - w, w, thick)
     p2[:, 0] += w
     return merge_blocks([(el1, p1), (el2, p2)])
