@@ -162,6 +162,10 @@ static void launch_spmv_cheb(fcvm_ctx *c, const MatView &m, const double *d, con
         hipLaunchKernelGGL((k_spmv<false, true, 4, double2, 1>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols,
                            (const double2 *)m.vals, m.rownode, d, (double *)nullptr, (double *)nullptr, done, epi);
 }
+static void launch_gemv_f32(fcvm_ctx *c, const double *r2, double *e2, const double *done) {
+    hipLaunchKernelGGL(k_gemv_f32x4, dim3((unsigned)cdiv(c->n2, 16)), dim3(256), 0, c->stream, c->n2, (c->n2 + 3) / 4 * 4, c->d_A2invf, r2,
+                       e2, done);
+}
 static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done) {
     if (dot) launch_spmv_t<true>(c, fine_view(c), x, y, c->d_part_spmv, done);
     else launch_spmv_t<false>(c, fine_view(c), x, y, nullptr, done);
@@ -770,8 +774,9 @@ int fcvm_mg_set_level2(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg
     HCHK(hipMemcpyAsync(c->d_Z, Z, sizeof(double) * nc * 18, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_A2inv, A2inv, sizeof(double) * n2 * n2, hipMemcpyHostToDevice, s));
     dfree(c->d_A2invf);
-    if (dalloc(&c->d_A2invf, n2 * n2)) return 1;
-    hipLaunchKernelGGL(k_to_f32, dim3((unsigned)cdiv(n2 * n2, 256)), dim3(256), 0, s, n2 * n2, c->d_A2inv, c->d_A2invf);
+    const int64_t lda = (n2 + 3) / 4 * 4;
+    if (dalloc(&c->d_A2invf, n2 * lda)) return 1;
+    hipLaunchKernelGGL(k_to_f32_padded, dim3((unsigned)cdiv(n2 * lda, 256)), dim3(256), 0, s, n2, lda, c->d_A2inv, c->d_A2invf);
     HCHK(hipGetLastError());
     HCHK(hipStreamSynchronize(s));
     c->nagg = nagg; c->n2 = n2; c->mg_k1s = k1s; c->mg_alpha1s = alpha1s;
@@ -862,7 +867,7 @@ int fcvm_mg_l2_restrict(fcvm_ctx *c, const double *r1, double *r2) {
 int fcvm_mg_l2_solve(fcvm_ctx *c, const double *r2, double *e2) {
     NEED(c && c->l2, "fcvm_mg_l2_solve: no aggregate level (fcvm_mg_set_level2)");
     if (c->mg_fp32)
-        hipLaunchKernelGGL(k_gemv<float>, dim3((unsigned)cdiv(c->n2, 4)), dim3(256), 0, c->stream, c->n2, c->d_A2invf, r2, e2, (const double *)nullptr);
+        launch_gemv_f32(c, r2, e2, nullptr);
     else
         hipLaunchKernelGGL(k_gemv<double>, dim3((unsigned)cdiv(c->n2, 4)), dim3(256), 0, c->stream, c->n2, c->d_A2inv, r2, e2, (const double *)nullptr);
     HCHK(hipGetLastError());

@@ -283,6 +283,42 @@ __global__ __launch_bounds__(256) void k_gemv(int64_t n, const T *__restrict__ A
     if (lane == 0) y[row] = acc;
 }
 
+// y = A x for the FP32-stored dense inverse, rows padded to lda (multiple of 4, zero filled): four rows per wavefront share
+// the x values in registers, 16-byte loads, FP64 accumulation
+__global__ __launch_bounds__(256) void k_gemv_f32x4(int64_t n, int64_t lda, const float *__restrict__ A, const double *__restrict__ x,
+                                                    double *__restrict__ y, const double *__restrict__ done) {
+    if (done && *done != 0.0) return;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (row0 >= n) return;
+    const int lane = threadIdx.x & 63;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f *a[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) a[r] = (const v4f *)(A + (row0 + r < n ? row0 + r : n - 1) * lda);
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t j = lane * 4; j < lda; j += 256) {
+        v4f v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = __builtin_nontemporal_load(a[r] + (j >> 2));
+        const double x0 = x[j], x1 = j + 1 < n ? x[j + 1] : 0.0, x2 = j + 2 < n ? x[j + 2] : 0.0, x3 = j + 3 < n ? x[j + 3] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] += (double)v[r].x * x0 + (double)v[r].y * x1 + (double)v[r].z * x2 + (double)v[r].w * x3;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const double t = wave_sum(acc[r]);
+        if (lane == 0 && row0 + r < n) y[row0 + r] = t;
+    }
+}
+
+// FP64 n x n -> FP32 n x lda (zero padded)
+__global__ __launch_bounds__(256) void k_to_f32_padded(int64_t n, int64_t lda, const double *__restrict__ a, float *__restrict__ o) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * lda) return;
+    const int64_t r = i / lda, c = i - r * lda;
+    o[i] = c < n ? (float)a[r * n + c] : 0.0f;
+}
+
 // d1[3i+c] = sum_k Z[i][c][k] * e2[aoff[agg[i]]+k]
 __global__ __launch_bounds__(256) void k_l2_prolong(int64_t nc, const int32_t *__restrict__ agg, const int64_t *__restrict__ aoff,
                                                     const double *__restrict__ Z, const double *__restrict__ e2, double *__restrict__ d1, const double *__restrict__ done) {
