@@ -93,6 +93,34 @@ def precond_label(c):
             (pi["coarse_nodes"], pi.get("level2", "")))
 
 
+def plate_with_hole_run(h):
+    """The north-star workload as a whole job: the reference's Plate_with_hole_Example (its shipped control file: 10
+    arc-length steps to collapse, error_max 5e-3) on the mapped mesh of ~1M tet10, mesh arrays in -> load history out.
+    Reported next to the headline line, not part of `value`."""
+    from fcvm_hip import examples
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import GpuModel, calc_disp
+    t0 = time.perf_counter()
+    case = examples.plate_with_hole(h)
+    t_mesh = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    m = GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"], Loads(ufaces=case["ufaces"], uloads=case["uloads"]))
+    t_model = time.perf_counter() - t0
+    st = {}
+    t0 = time.perf_counter()
+    res = calc_disp(m, case["ctl"], rtol=RTOL, stats=st)
+    m.ctx.sync()
+    dt = time.perf_counter() - t0
+    out = {"workload": "%s: %d tet10, %d dof, control file of the reference example (10 Riks steps to collapse)" % (case["name"], m.ne, m.ndof),
+           "analysis_s": dt, "mesh_s": t_mesh, "pattern_and_upload_s": t_model, "steps": len(res["lout"]) - 1,
+           "newton_iterations": st["newton_iterations"], "newton_iterations_per_s": st["newton_iterations"] / dt,
+           "elements_gp_per_s": st["newton_iterations"] * m.ne * 4 / dt,
+           "linear_solves": st["solves"], "pcg_iterations_per_solve": st["pcg_iterations"] / max(st["solves"], 1),
+           "collapse_load_factor": float(res["lout"][-1]), "reference_out_load_factor_395_elements": 0.232}
+    m.ctx.close()
+    return out
+
+
 def run_single(args):
     from fcvm_hip import _lib, meshgen
     from fcvm_hip.loads import Loads
@@ -168,6 +196,9 @@ def run_single(args):
     }
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline()
+    if not args.no_plate:
+        del drv, model
+        out["north_star_workload"] = plate_with_hole_run(args.plate_h)
     print(json.dumps(out))
 
 
@@ -178,6 +209,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cells", type=int, default=55, help="cells per cube edge (55 -> 998,250 tet10)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-plate", action="store_true", help="skip the Plate_with_hole whole-analysis leg (N = 1 only)")
+    ap.add_argument("--plate-h", type=float, default=1.45, help="mesh size of the Plate_with_hole leg (1.45 -> 1,006,434 tet10)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1:
