@@ -82,6 +82,7 @@ struct fcvm_ctx {
     int mg_additive = 1;
     int mg_fp32 = 1;           // coarse levels: level-1 matrix and aggregate inverse stored in FP32 (FP64 vectors / accumulation)
     float *d_vals1f = nullptr, *d_A2invf = nullptr;
+    bool l2_has_inverse = false;
     double mg_add_w = 1.0;
     const double *mg_done = nullptr;  // device flag that turns the V-cycle kernels into no-ops once PCG has converged
     // level 2: aggregates + dense inverse (set from the host binding)
@@ -163,8 +164,8 @@ static void launch_spmv_cheb(fcvm_ctx *c, const MatView &m, const double *d, con
                            (const double2 *)m.vals, m.rownode, d, (double *)nullptr, (double *)nullptr, done, epi);
 }
 static void launch_gemv_f32(fcvm_ctx *c, const double *r2, double *e2, const double *done) {
-    hipLaunchKernelGGL(k_gemv_f32x4, dim3((unsigned)cdiv(c->n2, 16)), dim3(256), 0, c->stream, c->n2, (c->n2 + 3) / 4 * 4, c->d_A2invf, r2,
-                       e2, done);
+    hipLaunchKernelGGL(k_gemv_f32x4, dim3((unsigned)cdiv(c->n2, 16)), dim3(256), 0, c->stream, c->n2, c->n2, (c->n2 + 3) / 4 * 4,
+                       c->d_A2invf, r2, e2, done);
 }
 static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done) {
     if (dot) launch_spmv_t<true>(c, fine_view(c), x, y, c->d_part_spmv, done);
@@ -764,7 +765,7 @@ int fcvm_mg_set_level2(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg
     dfree(c->d_agg); dfree(c->d_anodes); dfree(c->d_aoff); dfree(c->d_aptr); dfree(c->d_Z); dfree(c->d_A2inv);
     dfree(c->d_r2); dfree(c->d_e2);
     if (dalloc(&c->d_agg, nc) || dalloc(&c->d_anodes, nc) || dalloc(&c->d_aoff, nagg + 1) || dalloc(&c->d_aptr, nagg + 1) ||
-        dalloc(&c->d_Z, nc * 18) || dalloc(&c->d_A2inv, n2 * n2) || dalloc(&c->d_r2, n2) || dalloc(&c->d_e2, n2))
+        dalloc(&c->d_Z, nc * 18) || (A2inv && dalloc(&c->d_A2inv, n2 * n2)) || dalloc(&c->d_r2, n2) || dalloc(&c->d_e2, n2))
         return 1;
     hipStream_t s = c->stream;
     HCHK(hipMemcpyAsync(c->d_agg, agg, sizeof(int32_t) * nc, hipMemcpyHostToDevice, s));
@@ -772,15 +773,18 @@ int fcvm_mg_set_level2(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg
     HCHK(hipMemcpyAsync(c->d_aoff, aoff, sizeof(int64_t) * (nagg + 1), hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_aptr, aptr.data(), sizeof(int64_t) * (nagg + 1), hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_Z, Z, sizeof(double) * nc * 18, hipMemcpyHostToDevice, s));
-    HCHK(hipMemcpyAsync(c->d_A2inv, A2inv, sizeof(double) * n2 * n2, hipMemcpyHostToDevice, s));
     dfree(c->d_A2invf);
-    const int64_t lda = (n2 + 3) / 4 * 4;
-    if (dalloc(&c->d_A2invf, n2 * lda)) return 1;
-    hipLaunchKernelGGL(k_to_f32_padded, dim3((unsigned)cdiv(n2 * lda, 256)), dim3(256), 0, s, n2, lda, c->d_A2inv, c->d_A2invf);
+    if (A2inv) {
+        HCHK(hipMemcpyAsync(c->d_A2inv, A2inv, sizeof(double) * n2 * n2, hipMemcpyHostToDevice, s));
+        const int64_t lda = (n2 + 3) / 4 * 4;
+        if (dalloc(&c->d_A2invf, n2 * lda)) return 1;
+        hipLaunchKernelGGL(k_to_f32_padded, dim3((unsigned)cdiv(n2 * lda, 256)), dim3(256), 0, s, n2, lda, c->d_A2inv, c->d_A2invf);
+    }
     HCHK(hipGetLastError());
     HCHK(hipStreamSynchronize(s));
     c->nagg = nagg; c->n2 = n2; c->mg_k1s = k1s; c->mg_alpha1s = alpha1s;
     c->l2 = true;
+    c->l2_has_inverse = A2inv != nullptr;  // without it only the transfer operators exist (distributed aggregate level)
     return 0;
 }
 
@@ -865,11 +869,18 @@ int fcvm_mg_l2_restrict(fcvm_ctx *c, const double *r1, double *r2) {
 }
 
 int fcvm_mg_l2_solve(fcvm_ctx *c, const double *r2, double *e2) {
-    NEED(c && c->l2, "fcvm_mg_l2_solve: no aggregate level (fcvm_mg_set_level2)");
+    NEED(c && c->l2 && c->l2_has_inverse, "fcvm_mg_l2_solve: no aggregate level with a dense inverse (fcvm_mg_set_level2)");
     if (c->mg_fp32)
         launch_gemv_f32(c, r2, e2, nullptr);
     else
         hipLaunchKernelGGL(k_gemv<double>, dim3((unsigned)cdiv(c->n2, 4)), dim3(256), 0, c->stream, c->n2, c->d_A2inv, r2, e2, (const double *)nullptr);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_gemv_f32(fcvm_ctx *c, int64_t m, int64_t n, int64_t lda, const float *A, const double *x, double *y) {
+    NEED(c && m > 0 && n > 0 && lda >= n && lda % 4 == 0 && A && x && y, "fcvm_gemv_f32: bad arguments (lda must be a multiple of 4)");
+    hipLaunchKernelGGL(k_gemv_f32x4, dim3((unsigned)cdiv(m, 16)), dim3(256), 0, c->stream, m, n, lda, A, x, y, (const double *)nullptr);
     HCHK(hipGetLastError());
     return 0;
 }

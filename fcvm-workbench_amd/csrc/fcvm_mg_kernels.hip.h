@@ -283,18 +283,19 @@ __global__ __launch_bounds__(256) void k_gemv(int64_t n, const T *__restrict__ A
     if (lane == 0) y[row] = acc;
 }
 
-// y = A x for the FP32-stored dense inverse, rows padded to lda (multiple of 4, zero filled): four rows per wavefront share
-// the x values in registers, 16-byte loads, FP64 accumulation
-__global__ __launch_bounds__(256) void k_gemv_f32x4(int64_t n, int64_t lda, const float *__restrict__ A, const double *__restrict__ x,
-                                                    double *__restrict__ y, const double *__restrict__ done) {
+// y = A x for the FP32-stored dense inverse (m x n, rows padded to lda = multiple of 4, zero filled): four rows per
+// wavefront share the x values in registers, 16-byte loads, FP64 accumulation
+__global__ __launch_bounds__(256) void k_gemv_f32x4(int64_t m, int64_t n, int64_t lda, const float *__restrict__ A,
+                                                    const double *__restrict__ x, double *__restrict__ y,
+                                                    const double *__restrict__ done) {
     if (done && *done != 0.0) return;
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
-    if (row0 >= n) return;
+    if (row0 >= m) return;
     const int lane = threadIdx.x & 63;
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f *a[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) a[r] = (const v4f *)(A + (row0 + r < n ? row0 + r : n - 1) * lda);
+    for (int r = 0; r < 4; r++) a[r] = (const v4f *)(A + (row0 + r < m ? row0 + r : m - 1) * lda);
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     for (int64_t j = lane * 4; j < lda; j += 256) {
         v4f v[4];
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(256) void k_gemv_f32x4(int64_t n, int64_t lda, cons
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const double t = wave_sum(acc[r]);
-        if (lane == 0 && row0 + r < n) y[row0 + r] = t;
+        if (lane == 0 && row0 + r < m) y[row0 + r] = t;
     }
 }
 

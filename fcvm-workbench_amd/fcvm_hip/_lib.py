@@ -70,6 +70,7 @@ SIGNATURES = {
     "fcvm_mg_prolong": [_vp, _vp, _vp],
     "fcvm_mg_l2_restrict": [_vp, _vp, _vp],
     "fcvm_mg_l2_solve": [_vp, _vp, _vp],
+    "fcvm_gemv_f32": [_vp, _i64, _i64, _i64, _vp, _vp, _vp],
     "fcvm_mg_l2_prolong": [_vp, _vp, _vp],
 }
 _SPECIAL = {"fcvm_last_error": ([], C.c_char_p), "fcvm_version": ([], C.c_int)}

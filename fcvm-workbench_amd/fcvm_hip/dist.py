@@ -175,6 +175,11 @@ class DistBackend:
         return t
 
     def dot_t(self, x, y):
+        """owner-weighted dot product of two consistent vectors, result stays on the device"""
+        if hasattr(self.ops, "wdot"):   # one fused pass (fcvm_vec_wdot_dev) instead of two temporaries + a sum
+            out = torch.empty(1, dtype=torch.float64, device=self.device)
+            self.ops.wdot(self.w, x, y, out)
+            return self._allreduce(out)
         return self._allreduce(torch.sum(self.w * x * y).reshape(1))
 
     def dot(self, x, y):
@@ -327,7 +332,9 @@ class DistMG:
     """The three-level V-cycle of the single-GPU solver (tet10 -> tet4 -> aggregates with rigid-body
     modes) on a partitioned mesh.  Vectors are consistent; every local SpMV is followed by the
     shared-node exchange of its level; restriction weights every node by 1/multiplicity so that the
-    partial sums add up; the aggregate level is replicated (one small all-reduce per cycle)."""
+    partial sums add up.  The aggregate level's right-hand side and correction are replicated (two small
+    all-reduces per cycle); its dense inverse is distributed by row blocks, so the number of aggregates can grow
+    with the rank count (about 1000 * world^(2/3): each rank streams n2^2 / world matrix entries per cycle)."""
 
     def __init__(self, be, nocoord_local, k0=1, alpha0=4.0, k1s=2, alpha1s=8.0, target=None, check_every=4, additive=True,
                  weight=1.0):
@@ -417,7 +424,7 @@ class DistMG:
         lo, hi = lo.cpu().numpy(), hi.cpu().numpy()
         ncg = torch.tensor([float(own.sum())], dtype=torch.float64, device=dev)
         ncg = float(be._allreduce(ncg).item())
-        target = self.target if self.target else max(16, int(round(ncg / 1000.0)))
+        target = self.target if self.target else max(16, int(round(ncg / (1000.0 * part.world ** (2.0 / 3.0)))))
         ext = np.maximum(hi - lo, 1e-300)
         live = ext > 1e-9 * ext.max()
         h = (np.prod(ext[live]) / max(1.0, ncg / target)) ** (1.0 / max(1, live.sum()))
@@ -456,35 +463,41 @@ class DistMG:
         cc = np.tile(np.repeat(np.arange(3), 6), self.nc)
         kk = np.tile(np.arange(6), 3 * self.nc)
         Zs = sp.csr_matrix((Z.reshape(-1), (3 * ii + cc, 6 * agg[ii] + kk)), shape=(3 * self.nc, n2))
-        A2 = torch.as_tensor((Zs.T @ (A1 @ Zs)).toarray(), device=dev)
+        A2s = (Zs.T @ (A1 @ Zs)).tocoo()   # sparse: aggregates couple to their neighbours only; densified on the device
+        A2 = torch.zeros(n2, n2, dtype=torch.float64, device=dev)
+        A2.index_put_((torch.as_tensor(A2s.row.astype(np.int64), device=dev), torch.as_tensor(A2s.col.astype(np.int64), device=dev)),
+                      torch.as_tensor(A2s.data, device=dev), accumulate=True)
+        del A2s
         be._allreduce(A2)
-        A2 = A2.cpu().numpy()
         A2 = 0.5 * (A2 + A2.T)
-        A2[np.diag_indices(n2)] += 1e-10 * np.abs(np.diag(A2)).max()
-        # inverted on rank 0 only and broadcast, so that every rank applies bit-identical coarse corrections
-        # (a threaded LAPACK may round differently from process to process)
-        inv_t = torch.empty(n2, n2, dtype=torch.float64, device=dev)
+        A2.diagonal().add_(1e-10 * float(A2.diagonal().abs().max().item()))
+        # every rank factorises the (replicated) matrix on its own device and solves for the rows of the inverse it
+        # applies (the inverse is symmetric: rows = columns), a few thousand right-hand sides at a time.  Ranks never
+        # mix their rows, so differences in rounding between devices cannot make the correction inconsistent.
+        chunk = -(-n2 // part.world)
+        self.row_lo, self.row_hi = min(n2, part.rank * chunk), min(n2, (part.rank + 1) * chunk)
         ok = torch.ones(1, dtype=torch.float64, device=dev)
-        if part.rank == 0:
-            L, info = sla.lapack.dpotrf(A2, lower=1)
-            if info == 0:
-                Li, info = sla.lapack.dpotri(L, lower=1, overwrite_c=1)
-            if info == 0:
-                inv_t.copy_(torch.as_tensor(np.tril(Li) + np.tril(Li, -1).T))
-            else:
-                ok.zero_()
-        if part.world > 1:
-            dist.broadcast(ok, 0, group=part.group)
-            dist.broadcast(inv_t, 0, group=part.group)
+        rows = torch.zeros(self.row_hi - self.row_lo, n2, dtype=torch.float64, device=dev)
+        try:
+            L = torch.linalg.cholesky(A2)
+            for c0 in range(self.row_lo, self.row_hi, 4096):
+                c1 = min(self.row_hi, c0 + 4096)
+                E = torch.zeros(n2, c1 - c0, dtype=torch.float64, device=dev)
+                E[c0:c1] = torch.eye(c1 - c0, dtype=torch.float64, device=dev)
+                rows[c0 - self.row_lo:c1 - self.row_lo] = torch.cholesky_solve(E, L).T
+            del L, E
+        except Exception:
+            ok.zero_()
+        del A2
+        be._allreduce(ok, dist.ReduceOp.MIN)
         if float(ok.item()) == 0.0:
             raise RuntimeError("DistMG: aggregate-level matrix not positive definite")
-        A2inv = inv_t.cpu().numpy()
-        self.ops.mg_set_level2(nagg, np.ascontiguousarray(agg, np.int32), np.ascontiguousarray(Z.reshape(self.nc, 18)),
-                               np.ascontiguousarray(A2inv))
-        self.nagg = nagg
+        self.ops.mg_set_level2(nagg, np.ascontiguousarray(agg, np.int32), np.ascontiguousarray(Z.reshape(self.nc, 18)), rows)
+        del rows
+        self.nagg, self.n2 = nagg, n2
         self.r2 = TVec(torch.zeros(n2, dtype=torch.float64, device=dev))
         self.e2 = TVec(torch.zeros(n2, dtype=torch.float64, device=dev))
-        self.l2_info = dict(aggregates=nagg, unknowns=n2, target=target)
+        self.l2_info = dict(aggregates=nagg, unknowns=n2, target=target, rows=(self.row_lo, self.row_hi))
 
     # -- V-cycle ------------------------------------------------------------------------------
     def _spmv(self, level, x, y):
@@ -520,8 +533,11 @@ class DistMG:
         self._from_zero(1, self.ch1, self.k1s, self.r1, self.x1, self.rr1, self.d1, self.t1)
         torch.mul(self.rr1.t, self.own1, out=self.t1.t)       # owner-weighted: shared nodes count once
         self.ops.mg_l2_restrict(self.t1, self.r2)             # r2 = Z^T (.)  (local part)
-        be._allreduce(self.r2.t)                              # replicated aggregate level
-        self.ops.mg_l2_solve(self.r2, self.e2)
+        be._allreduce(self.r2.t)                              # replicated right-hand side of the aggregate level
+        self.e2.t.zero_()
+        if self.row_hi > self.row_lo:                         # this rank's rows of e2 = A2inv r2 ...
+            self.ops.mg_l2_solve(self.r2, TVec(self.e2.t[self.row_lo:self.row_hi]))
+        be._allreduce(self.e2.t)                              # ... gathered (sum with zeros: bit-identical on every rank)
         self.ops.mg_l2_prolong(self.e2, self.d1)
         self._post(1, self.ch1, self.k1s, self.x1, self.rr1, self.d1, self.t1)
         if self.additive:
@@ -623,6 +639,11 @@ class HipLocalOps:
     def precond(self, r, z):
         self.c.precond(self._p(r), self._p(z))
 
+    def wdot(self, w, x, y, out):
+        """out[0] = sum w x y (torch tensors on this rank's device)"""
+        from ._lib import call
+        call("fcvm_vec_wdot_dev", self.c.h, x.numel(), w.data_ptr(), x.data_ptr(), y.data_ptr(), out.data_ptr())
+
     # -- multigrid building blocks (fcvm_set_precond mode 2 builds the hierarchy at assemble) --
     def mg_enable(self):
         from ._lib import call
@@ -674,19 +695,25 @@ class HipLocalOps:
         from ._lib import call
         call("fcvm_mg_restrict", self.c.h, r0.ptr, r1.ptr)
 
-    def mg_set_level2(self, nagg, agg, Z, A2inv):
+    def mg_set_level2(self, nagg, agg, Z, rows):
+        """rows: this rank's row block [m, 6 nagg] of the aggregate-level inverse (torch f64 on the device);
+        kept in FP32 with rows padded to a multiple of 4 for fcvm_gemv_f32"""
         from ._lib import call
         aoff = 6 * np.arange(nagg + 1, dtype=np.int64)
-        call("fcvm_mg_set_level2", self.c.h, nagg, 6 * nagg, agg.ctypes.data, aoff.ctypes.data, Z.ctypes.data,
-             A2inv.ctypes.data, 3, 8.0)
+        call("fcvm_mg_set_level2", self.c.h, nagg, 6 * nagg, agg.ctypes.data, aoff.ctypes.data, Z.ctypes.data, None, 3, 8.0)
+        m, n = rows.shape
+        self.l2_lda = (n + 3) // 4 * 4
+        self.l2_rows = torch.zeros(max(m, 1), self.l2_lda, dtype=torch.float32, device=rows.device)
+        self.l2_rows[:m, :n] = rows.to(torch.float32)
+        self.l2_m, self.l2_n = m, n
 
     def mg_l2_restrict(self, r1, r2):
         from ._lib import call
         call("fcvm_mg_l2_restrict", self.c.h, r1.ptr, r2.ptr)
 
-    def mg_l2_solve(self, r2, e2):
+    def mg_l2_solve(self, r2, e_rows):
         from ._lib import call
-        call("fcvm_mg_l2_solve", self.c.h, r2.ptr, e2.ptr)
+        call("fcvm_gemv_f32", self.c.h, self.l2_m, self.l2_n, self.l2_lda, self.l2_rows.data_ptr(), r2.ptr, e_rows.ptr)
 
     def mg_l2_prolong(self, e2, d1):
         from ._lib import call

@@ -178,7 +178,9 @@ int fcvm_precond_info(fcvm_ctx *c, double out[8]);
  *   fcvm_mg_coarse_to_coo  [host] scalar COO of the level-1 matrix, 9 * (coarse nnz blocks) entries
  *   fcvm_mg_set_level2     agg int32[nc] aggregate of each level-1 node, aoff int64[nagg+1] first
  *                          level-2 unknown of each aggregate, Z f64[nc][3][6], A2inv f64[n2*n2]
- *                          row-major, k1s/alpha1s: Chebyshev smoothing steps / range on level 1.
+ *                          row-major (NULL: transfer operators only -- the multi-GPU host code keeps a
+ *                          row block of the inverse per rank and applies it with fcvm_gemv_f32),
+ *                          k1s/alpha1s: Chebyshev smoothing steps / range on level 1.
  * Level 2 survives re-assemblies on the same mesh (tangent updates) and is dropped when the mesh or
  * its coordinates change.
  */
@@ -217,6 +219,9 @@ int fcvm_mg_prolong(fcvm_ctx *c, const double *e1, double *d0);
 int fcvm_mg_l2_restrict(fcvm_ctx *c, const double *r1, double *r2);
 int fcvm_mg_l2_solve(fcvm_ctx *c, const double *r2, double *e2);
 int fcvm_mg_l2_prolong(fcvm_ctx *c, const double *e2, double *d1);
+/* y[m] = A x, A f32[m][lda] (device, rows zero-padded to lda = multiple of 4), x f64[n], FP64 accumulation:
+ * one rank's row block of the distributed aggregate-level inverse */
+int fcvm_gemv_f32(fcvm_ctx *c, int64_t m, int64_t n, int64_t lda, const float *A, const double *x, double *y);
 
 #ifdef __cplusplus
 }

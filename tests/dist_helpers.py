@@ -156,19 +156,19 @@ class OracleLocalOps:
         self._hier()
         r1.set(self.Pm.T @ r0.get())
 
-    def mg_set_level2(self, nagg, agg, Z, A2inv):
+    def mg_set_level2(self, nagg, agg, Z, rows):
         nc = len(agg)
         ii = np.repeat(np.arange(nc), 18)
         cc = np.tile(np.repeat(np.arange(3), 6), nc)
         kk = np.tile(np.arange(6), 3 * nc)
         self.Z2 = sp.csr_matrix((Z.reshape(-1), (3 * ii + cc, 6 * agg[ii].astype(np.int64) + kk)), shape=(3 * nc, 6 * nagg))
-        self.A2inv = A2inv.copy()
+        self.A2rows = rows.cpu().numpy().copy()   # this rank's row block of the aggregate-level inverse
 
     def mg_l2_restrict(self, r1, r2):
         r2.set(self.Z2.T @ r1.get())
 
-    def mg_l2_solve(self, r2, e2):
-        e2.set(self.A2inv @ r2.get())
+    def mg_l2_solve(self, r2, e_rows):
+        e_rows.set(self.A2rows @ r2.get())
 
     def mg_l2_prolong(self, e2, d1):
         d1.set(self.Z2 @ e2.get())
