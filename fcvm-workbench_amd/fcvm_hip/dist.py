@@ -456,6 +456,19 @@ class DistMG:
         Z[:, 0, 5], Z[:, 1, 5] = -x[:, 1], x[:, 0]
         free = np.stack([(fm & 1) == 0, (fm & 2) == 0, (fm & 4) == 0], 1).astype(np.float64)
         Z *= free[:, :, None]
+        # orthonormalise the six modes of every aggregate over its (global) node set and drop the combinations that
+        # move nothing (a single line / a single node / clamped nodes): Gram matrices summed over the ranks, symmetric
+        # eigen-decomposition, modes scaled by 1/sqrt(eigenvalue); dropped modes become zero columns, whose (empty)
+        # rows of A2 only see the diagonal shift below.  Without this, near-null combinations get 1e10-sized entries
+        # in the inverse, which FP32 storage cannot cancel.
+        G = np.zeros((nagg, 6, 6))
+        np.add.at(G, agg[own], np.einsum("ncj,nck->njk", Z[own], Z[own]))
+        G_t = torch.as_tensor(G, device=dev)
+        be._allreduce(G_t)
+        lam, V = np.linalg.eigh(G_t.cpu().numpy())
+        keep = lam > 1e-10 * np.maximum(lam.max(axis=1, keepdims=True), 1e-300)
+        T = V * (keep / np.sqrt(np.where(keep, lam, 1.0)))[:, None, :]
+        Z = np.einsum("ncj,njk->nck", Z, T[agg])
         n2 = 6 * nagg
         row, col, val = self.ops.mg_coarse_coo()
         A1 = sp.csr_matrix((val, (row, col)), shape=(3 * self.nc, 3 * self.nc))
@@ -468,9 +481,11 @@ class DistMG:
         A2.index_put_((torch.as_tensor(A2s.row.astype(np.int64), device=dev), torch.as_tensor(A2s.col.astype(np.int64), device=dev)),
                       torch.as_tensor(A2s.data, device=dev), accumulate=True)
         del A2s
-        be._allreduce(A2)
+        step = max(1, (1 << 27) // n2)      # row blocks of at most 1 GiB: some transports count bytes in 32 bits
+        for r0 in range(0, n2, step):
+            be._allreduce(A2[r0:r0 + step])
         A2 = 0.5 * (A2 + A2.T)
-        A2.diagonal().add_(1e-10 * float(A2.diagonal().abs().max().item()))
+        dmax = float(A2.diagonal().abs().max().item())
         # every rank factorises the (replicated) matrix on its own device and solves for the rows of the inverse it
         # applies (the inverse is symmetric: rows = columns), a few thousand right-hand sides at a time.  Ranks never
         # mix their rows, so differences in rounding between devices cannot make the correction inconsistent.
@@ -478,26 +493,39 @@ class DistMG:
         self.row_lo, self.row_hi = min(n2, part.rank * chunk), min(n2, (part.rank + 1) * chunk)
         ok = torch.ones(1, dtype=torch.float64, device=dev)
         rows = torch.zeros(self.row_hi - self.row_lo, n2, dtype=torch.float64, device=dev)
+        why = ""
         try:
-            L = torch.linalg.cholesky(A2)
+            # raw rigid-body modes: aggregates with collinear / fully clamped nodes have zero-energy combinations, which
+            # the diagonal shift turns into harmless tiny pivots; the shift grows until the factorisation goes through
+            # (identical decisions on every rank: the matrix is replicated and info is a property of the matrix)
+            shift, L = 1e-10 * dmax, None
+            for _ in range(4):
+                A2.diagonal().add_(shift)
+                L, info = torch.linalg.cholesky_ex(A2)
+                if int(info.item()) == 0:
+                    break
+                L, shift = None, shift * 100.0
+            if L is None:
+                raise RuntimeError("cholesky_ex info %d after the largest diagonal shift" % int(info.item()))
             for c0 in range(self.row_lo, self.row_hi, 4096):
                 c1 = min(self.row_hi, c0 + 4096)
                 E = torch.zeros(n2, c1 - c0, dtype=torch.float64, device=dev)
                 E[c0:c1] = torch.eye(c1 - c0, dtype=torch.float64, device=dev)
                 rows[c0 - self.row_lo:c1 - self.row_lo] = torch.cholesky_solve(E, L).T
             del L, E
-        except Exception:
+        except Exception as e:  # keep every rank in step: the failure is agreed on below
             ok.zero_()
+            why = repr(e)
         del A2
         be._allreduce(ok, dist.ReduceOp.MIN)
         if float(ok.item()) == 0.0:
-            raise RuntimeError("DistMG: aggregate-level matrix not positive definite")
+            raise RuntimeError("DistMG: aggregate-level inverse failed on some rank (this rank: %s)" % (why or "ok"))
         self.ops.mg_set_level2(nagg, np.ascontiguousarray(agg, np.int32), np.ascontiguousarray(Z.reshape(self.nc, 18)), rows)
         del rows
         self.nagg, self.n2 = nagg, n2
         self.r2 = TVec(torch.zeros(n2, dtype=torch.float64, device=dev))
         self.e2 = TVec(torch.zeros(n2, dtype=torch.float64, device=dev))
-        self.l2_info = dict(aggregates=nagg, unknowns=n2, target=target, rows=(self.row_lo, self.row_hi))
+        self.l2_info = dict(aggregates=nagg, unknowns=n2, target=target, rows=(self.row_lo, self.row_hi), diagonal_shift=shift / dmax)
 
     # -- V-cycle ------------------------------------------------------------------------------
     def _spmv(self, level, x, y):

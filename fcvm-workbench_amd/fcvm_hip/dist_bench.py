@@ -48,6 +48,9 @@ def build_rank_model(rank, world, cells, material, traction, device_index, backe
 def run(args, ctl, material, traction, rtol, hbm_peak, cpu_baseline):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("FCVM_DIST_DEBUG"):   # where does a stuck rank stand? tracebacks of all threads every N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["FCVM_DIST_DEBUG"]), repeat=True)
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     share_gpu = os.environ.get("FCVM_DIST_SHARE_GPU") == "1"  # rehearsal: all ranks on GPU 0 over gloo
     dev_index = 0 if share_gpu else local
