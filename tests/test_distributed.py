@@ -1,4 +1,4 @@
-"""world_size-2 (gloo, CPU) tests of the multi-GPU layer: partition, shared-node exchange,
+"""world_size-2 and -4 (gloo, CPU) tests of the multi-GPU layer: partition, shared-node exchange,
 distributed PCG and the whole Riks analysis on two ranks against the single-process oracle.
 The local element kernels are the oracle's (injected from tests/dist_helpers.py); on the GPU box
 the same driver runs with HipLocalOps."""
@@ -60,6 +60,44 @@ def _worker(rank, world, port, out, use_mg):
         dist.destroy_process_group()
 
 
+def _solve_worker(rank, world, port, out, n):
+    """one elastic solve K u = f with the distributed multigrid PCG (aggregate level split over 4 ranks)"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dist_helpers import OracleLocalOps
+        from fcvm_hip import meshgen
+        from fcvm_hip.dist import DistBackend, DistModel, Partition
+        from fcvm_hip.loads import Loads, external_loads
+        case = small_case(n, prescribed=False)
+        el, xyz = case["elNodes"], case["nocoord"]
+        ne = len(el)
+        lo, hi = rank * ne // world, (rank + 1) * ne // world
+        part = Partition(el[lo:hi])
+        xyz_loc = xyz[part.gnodes - 1]
+        gd = np.array(sorted(case["fix"]), dtype=np.int64)
+        here, ld = part.local_dofs_of(gd)
+        fix_loc = {int(d): case["fix"][int(g)] for d, g in zip(ld, gd[here])}
+        faces = meshgen.boundary_faces_on_plane(el[lo:hi], xyz, 2, 10.0)
+        faces_loc = np.searchsorted(part.gnodes, faces) + 1
+        loads = Loads(ufaces=faces_loc, uloads=np.tile(case["uloads"][0], (len(faces_loc), 1)))
+        ops = OracleLocalOps(part, xyz_loc, case["material"], fix_loc, element_offset=lo)
+        be = DistBackend(part, ops, torch.device("cpu"))
+        be.enable_multigrid(xyz_loc, target=8, check_every=2)
+        model = DistModel(part, be, xyz_loc, case["material"], fix_loc, loads, external_loads)
+        glv, modf, V, _ = model.calc_gsm((0.0, 0.0, -9.81), want_x=False)
+        f = be.array(model.fixdof.get() * glv.get() + modf.get())
+        u, info = be.solve(f, rtol=1e-11, maxit=300)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, dict(gnodes=part.gnodes, u=u.get(), info=info, l2=be.mg.l2_info))
+        if rank == 0:
+            torch.save(gathered, out)
+    finally:
+        dist.destroy_process_group()
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -70,10 +108,10 @@ def _free_port():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("use_mg", [False, True], ids=["block-jacobi", "multigrid"])
-def test_two_rank_analysis_matches_single_process_oracle(orc, tmp_path, use_mg):
+@pytest.mark.parametrize("world,use_mg", [(2, False), (2, True)], ids=["block-jacobi", "multigrid"])
+def test_two_rank_analysis_matches_single_process_oracle(orc, tmp_path, world, use_mg):
     out = str(tmp_path / "res.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out, use_mg), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, use_mg), nprocs=world, join=True)
     got = torch.load(out, weights_only=False)
     case = small_case(3)
     ref = orc.run_analysis(case["elNodes"], case["nocoord"], case["material"], case["fix"],
@@ -89,7 +127,7 @@ def test_two_rank_analysis_matches_single_process_oracle(orc, tmp_path, use_mg):
     assert np.all(owners == 1)
     for g in got:
         assert np.array_equal(g["mult"], holders[g["gnodes"] - 1])
-    assert (holders == 2).sum() > 0
+    assert (holders == 2).sum() > 0 and holders.max() <= world
     rel = lambda a, b: np.abs(np.asarray(a) - b).max() / np.abs(b).max()  # noqa: E731
     for g in got:
         assert len(g["lout"]) == len(ref["lout"])
@@ -102,3 +140,25 @@ def test_two_rank_analysis_matches_single_process_oracle(orc, tmp_path, use_mg):
     assert ref["peeq"].max() > 0
     # ~90 linear solves at rtol 1e-12: ~50 iterations each with the distributed (additive) multigrid cycle, ~190 with block-Jacobi
     assert (got[0]["pcg"] < 8000) if use_mg else (got[0]["pcg"] > 10000), got[0]["pcg"]
+
+
+@pytest.mark.timeout(300)
+def test_four_rank_multigrid_solve(orc, tmp_path):
+    """4 ranks: every rank holds a quarter of the rows of the aggregate-level inverse (uneven split: 64 aggregates x 6
+    modes over 4 ranks of a 6^3-cell cube cut into unequal slabs); the solution equals the oracle's direct solve and
+    the iteration count that of the single-process cycle."""
+    out = str(tmp_path / "solve.pt")
+    mp.spawn(_solve_worker, args=(4, _free_port(), out, 6), nprocs=4, join=True)
+    got = torch.load(out, weights_only=False)
+    case = small_case(6, prescribed=False)
+    stm, row, col, glv, modf, *_ = orc.calcGSM(case["elNodes"], case["nocoord"], case["material"], case["fix"], (0.0, 0.0, -9.81),
+                                               orc.Loads(ufaces=case["ufaces"], uloads=case["uloads"]))
+    ndof = 3 * len(case["nocoord"])
+    fixdof = np.ones(ndof)
+    fixdof[list(case["fix"])] = 0.0
+    ref = orc._Direct(stm, row, col, ndof)(fixdof * glv + modf).reshape(-1, 3)
+    rows = sorted(g["l2"]["rows"] for g in got)
+    assert rows[0][0] == 0 and rows[-1][1] == got[0]["l2"]["unknowns"] and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+    for g in got:
+        assert np.abs(g["u"].reshape(-1, 3) - ref[g["gnodes"] - 1]).max() < 1e-8 * np.abs(ref).max()
+        assert 20 < g["info"]["iterations"] < 80
