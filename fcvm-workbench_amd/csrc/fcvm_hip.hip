@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <thread>
 #include <vector>
@@ -785,6 +786,76 @@ int fcvm_mg_set_level2(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg
     c->nagg = nagg; c->n2 = n2; c->mg_k1s = k1s; c->mg_alpha1s = alpha1s;
     c->l2 = true;
     c->l2_has_inverse = A2inv != nullptr;  // without it only the transfer operators exist (distributed aggregate level)
+    return 0;
+}
+
+// rocSOLVER is loaded on first use only (dlopen): the library has no link-time dependency on it
+namespace {
+struct RocSolver {
+    void *hblas = nullptr, *hsolver = nullptr;
+    int (*create)(void **) = nullptr;
+    int (*destroy)(void *) = nullptr;
+    int (*set_stream)(void *, hipStream_t) = nullptr;
+    int (*dpotrf)(void *, int, int, double *, int, int *) = nullptr;
+    int (*dpotri)(void *, int, int, double *, int, int *) = nullptr;
+    bool tried = false, ok = false;
+    bool load() {
+        if (tried) return ok;
+        tried = true;
+        hblas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!hblas) hblas = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+        hsolver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!hsolver) hsolver = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!hblas || !hsolver) return false;
+        create = (int (*)(void **))dlsym(hblas, "rocblas_create_handle");
+        destroy = (int (*)(void *))dlsym(hblas, "rocblas_destroy_handle");
+        set_stream = (int (*)(void *, hipStream_t))dlsym(hblas, "rocblas_set_stream");
+        dpotrf = (int (*)(void *, int, int, double *, int, int *))dlsym(hsolver, "rocsolver_dpotrf");
+        dpotri = (int (*)(void *, int, int, double *, int, int *))dlsym(hsolver, "rocsolver_dpotri");
+        ok = create && destroy && set_stream && dpotrf && dpotri;
+        return ok;
+    }
+};
+RocSolver g_rocsolver;
+}  // namespace
+
+/* Same as fcvm_mg_set_level2 but takes the SPD matrix A2 itself and inverts it on the device (rocSOLVER potrf + potri,
+ * loaded with dlopen).  Returns 2 (and changes nothing) when rocSOLVER cannot be loaded: the host binding then
+ * inverts with LAPACK and calls fcvm_mg_set_level2. */
+int fcvm_mg_set_level2_spd(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg, const int64_t *aoff, const double *Z,
+                           const double *A2, int k1s, double alpha1s) {
+    NEED(c && A2 && n2 > 0 && n2 < (1 << 30), "fcvm_mg_set_level2_spd: bad arguments");
+    if (!g_rocsolver.load()) {
+        g_err = "fcvm_mg_set_level2_spd: rocSOLVER not available";
+        return 2;
+    }
+    if (fcvm_mg_set_level2(c, nagg, n2, agg, aoff, Z, nullptr, k1s, alpha1s)) return 1;
+    hipStream_t s = c->stream;
+    int *d_info = nullptr;
+    void *h = nullptr;
+    if (dalloc(&c->d_A2inv, n2 * n2) || dalloc(&d_info, 2)) return 1;
+    HCHK(hipMemcpyAsync(c->d_A2inv, A2, sizeof(double) * n2 * n2, hipMemcpyHostToDevice, s));
+    int info[2] = {-1, -1};
+    bool fine = g_rocsolver.create(&h) == 0 && g_rocsolver.set_stream(h, s) == 0;
+    // fill mode 121 = rocblas_fill_upper in column-major terms = the lower triangle of our row-major (symmetric) array
+    fine = fine && g_rocsolver.dpotrf(h, 121, (int)n2, c->d_A2inv, (int)n2, d_info) == 0;
+    fine = fine && g_rocsolver.dpotri(h, 121, (int)n2, c->d_A2inv, (int)n2, d_info + 1) == 0;
+    if (fine) fine = hipMemcpyAsync(info, d_info, sizeof(info), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    if (h) g_rocsolver.destroy(h);
+    dfree(d_info);
+    if (!fine || info[0] != 0 || info[1] != 0) {
+        c->l2 = false;
+        return fail("fcvm_mg_set_level2_spd: aggregate-level matrix not positive definite (potrf info " + std::to_string(info[0]) +
+                    ", potri info " + std::to_string(info[1]) + ")");
+    }
+    // column-major upper = row-major lower: elements [b][a] with a < b are valid; mirror them to [a][b]
+    hipLaunchKernelGGL(k_mirror_lower_to_upper, dim3((unsigned)cdiv(n2 * n2, 256)), dim3(256), 0, s, n2, c->d_A2inv);
+    const int64_t lda = (n2 + 3) / 4 * 4;
+    if (dalloc(&c->d_A2invf, n2 * lda)) return 1;
+    hipLaunchKernelGGL(k_to_f32_padded, dim3((unsigned)cdiv(n2 * lda, 256)), dim3(256), 0, s, n2, lda, c->d_A2inv, c->d_A2invf);
+    HCHK(hipGetLastError());
+    HCHK(hipStreamSynchronize(s));
+    c->l2_has_inverse = true;
     return 0;
 }
 

@@ -312,6 +312,14 @@ __global__ __launch_bounds__(256) void k_gemv_f32x4(int64_t m, int64_t n, int64_
     }
 }
 
+// A[a][b] = A[b][a] for a < b: potri(upper, column-major) leaves the inverse in the row-major lower triangle
+__global__ __launch_bounds__(256) void k_mirror_lower_to_upper(int64_t n, double *A) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * n) return;
+    const int64_t a = i / n, b = i - a * n;
+    if (a < b) A[i] = A[b * n + a];
+}
+
 // FP64 n x n -> FP32 n x lda (zero padded)
 __global__ __launch_bounds__(256) void k_to_f32_padded(int64_t n, int64_t lda, const double *__restrict__ a, float *__restrict__ o) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

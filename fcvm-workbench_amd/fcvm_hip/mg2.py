@@ -8,6 +8,7 @@ import numpy as np
 import scipy.linalg as sla
 import scipy.sparse as sp
 
+from . import _lib
 from ._lib import call
 
 
@@ -71,23 +72,27 @@ def build_level2(ctx, target=250, k1s=2, alpha1s=8.0, rank_tol=1e-8):
     A2 = (Zs.T @ (A1 @ Zs)).toarray()
     A2 = 0.5 * (A2 + A2.T)
     A2[np.diag_indices(n2)] += 1e-13 * np.trace(A2) / n2
-    A2inv = None
-    if os.environ.get("FCVM_L2_TORCH", "0") == "1":  # optional: dense inverse on the GPU through torch
-        try:
-            import torch
-            if torch.cuda.is_available():
-                A2inv = torch.linalg.inv(torch.as_tensor(A2, device="cuda")).cpu().numpy()
-        except Exception:
-            A2inv = None
-    if A2inv is None:  # LAPACK on the host: Cholesky factor + inverse from the factor
-        L, info = sla.lapack.dpotrf(A2, lower=1, overwrite_a=0)
-        if info != 0:
-            raise RuntimeError("build_level2: coarse matrix not positive definite (dpotrf info %d)" % info)
-        Li, info = sla.lapack.dpotri(L, lower=1, overwrite_c=1)
-        A2inv = np.tril(Li) + np.tril(Li, -1).T
-    A2inv = np.ascontiguousarray(0.5 * (A2inv + A2inv.T))
     Zc = np.ascontiguousarray(Z.reshape(nc, 18))
     agg = np.ascontiguousarray(agg, np.int32)
+    where = "host"
+    if os.environ.get("FCVM_L2_DEVICE_INVERSE", "0") == "1":
+        # opt-in: dense SPD inverse on the GPU (rocSOLVER potrf + potri inside the library, 0.5 s faster at 6000
+        # unknowns once rocBLAS is resident -- but its first use on a fresh box was measured at 6 minutes of
+        # library loading, so the default stays the host LAPACK)
+        A2 = np.ascontiguousarray(A2)
+        rc = _lib.load().fcvm_mg_set_level2_spd(ctx.h, nagg, n2, agg.ctypes.data, aoff.ctypes.data, Zc.ctypes.data, A2.ctypes.data,
+                                                int(k1s), float(alpha1s))
+        if rc == 0:
+            return dict(aggregates=nagg, unknowns=n2, target=target, inverse="device")
+        if rc != 2:
+            raise _lib.FcvmError("fcvm_mg_set_level2_spd failed: %s" % _lib.load().fcvm_last_error().decode("utf8", "replace"))
+    # LAPACK on the host: Cholesky factor + inverse from the factor
+    L, info = sla.lapack.dpotrf(A2, lower=1, overwrite_a=0)
+    if info != 0:
+        raise RuntimeError("build_level2: coarse matrix not positive definite (dpotrf info %d)" % info)
+    Li, info = sla.lapack.dpotri(L, lower=1, overwrite_c=1)
+    A2inv = np.tril(Li) + np.tril(Li, -1).T
+    A2inv = np.ascontiguousarray(0.5 * (A2inv + A2inv.T))
     call("fcvm_mg_set_level2", ctx.h, nagg, n2, agg.ctypes.data, aoff.ctypes.data, Zc.ctypes.data, A2inv.ctypes.data,
          int(k1s), float(alpha1s))
-    return dict(aggregates=nagg, unknowns=n2, target=target)
+    return dict(aggregates=nagg, unknowns=n2, target=target, inverse=where)

@@ -188,6 +188,10 @@ int fcvm_mg_coarse_nodes(fcvm_ctx *c, double *coord1, uint8_t *fixmask1);
 int fcvm_mg_coarse_to_coo(fcvm_ctx *c, int64_t *row, int64_t *col, double *val);
 int fcvm_mg_set_level2(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg, const int64_t *aoff,
                        const double *Z, const double *A2inv, int k1s, double alpha1s);
+/* same, but hands over A2 itself (SPD, f64[n2*n2]) and has it inverted on the device by rocSOLVER (dlopen'ed on first
+ * use; return code 2 = not loadable, nothing changed: invert on the host and call fcvm_mg_set_level2) */
+int fcvm_mg_set_level2_spd(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg, const int64_t *aoff,
+                           const double *Z, const double *A2, int k1s, double alpha1s);
 
 /* host-only self check of the sparsity pattern builder (no GPU needed): out[0]=nnz blocks,
  * out[1]=padded slots, out[2]=slices, out[3]=max row length, out[4]=number of violated invariants
