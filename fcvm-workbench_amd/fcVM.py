@@ -245,9 +245,10 @@ def run(name, elNodes, nocoord, materialbyElement, fix, loads=None, control_dir=
 
 
 def run_fcstd(fcstd_path, control_dir, output_dir, name=None):
-    """Box-shaped FreeCAD documents end to end without FreeCAD: <name>.FCStd (mesh + constraints, read by
-    fcvm_hip.fcstd) + <control_dir>/<name>.inp -> <output_dir>/<name>.out / .vtk.  Replaces, for such
-    models, setUpAnalysis + setUpInput (fcVM.py:87-347) in front of the solver path."""
+    """FreeCAD documents end to end without FreeCAD: <name>.FCStd (embedded mesh, BREP geometry and constraints, read
+    by fcvm_hip.fcstd / fcvm_hip.brep: shapes bounded by planes and cylinders) + <control_dir>/<name>.inp ->
+    <output_dir>/<name>.out / .vtk.  Replaces setUpAnalysis + setUpInput (fcVM.py:87-347) in front of the solver
+    path.  The model name written into the .out header is the document's label, as in the macro."""
     from fcvm_hip import fcstd
     m = fcstd.load_model(fcstd_path)
     name = name or os.path.splitext(os.path.basename(fcstd_path))[0]

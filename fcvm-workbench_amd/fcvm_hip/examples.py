@@ -41,8 +41,8 @@ def plate_with_hole(h=10.0):
     """The reference's Plate_with_hole_Example (BASELINE configs[1] and the north-star workload) on a
     synthetic mesh of edge length ~h: its FreeCAD document carries geometry, constraints and material but
     no mesh (FemMesh.unv is empty).  From Document.xml: Cut = Box(200 x 100 x 10) - Cylinder(R 50, axis z
-    through the origin corner); ConstraintDisplacement x on the face x = 0, y on the face x = 200,
-    z on three vertices; ConstraintPressure 100 N/mm^2 (reversed = pulling) on the face x = 200; steel
+    through the origin corner); ConstraintDisplacement x on Face1 (x = 0), y on Face7 (x = 200),
+    z on Vertex1 / 2 / 5 (resolved with fcvm_hip.brep from the document's PartShape2.brp, tests/test_host.py); ConstraintPressure 100 N/mm^2 (reversed = pulling) on the face x = 200; steel
     (E 210000, nu 0.3, 7900 kg/m^3); control file values as shipped (sig_yield 100, 10 arc-length steps).
     The load pulls eccentrically on the ligament x = 0, 50 <= y <= 100 (tension + in-plane bending), which
     is why the reference's .out plateaus at a load factor of about 0.23 and not at the net-section 0.5.
@@ -54,7 +54,7 @@ def plate_with_hole(h=10.0):
         fix[3 * int(n)] = 0.0
     for n in meshgen.nodes_on_plane(xyz, 0, 200.0, tol=1e-7):
         fix[3 * int(n) + 1] = 0.0
-    for p in ((50.0, 0.0, 0.0), (0.0, 100.0, 0.0), (200.0, 0.0, 0.0)):
+    for p in ((0.0, 50.0, 10.0), (0.0, 50.0, 0.0), (50.0, 0.0, 0.0)):   # Vertex1, Vertex2, Vertex5 of the Cut
         n = int(np.argmin(np.abs(xyz - np.array(p)).max(1)))
         assert np.abs(xyz[n] - p).max() < 1e-6
         fix[3 * n + 2] = 0.0

@@ -19,6 +19,7 @@ give the same sets, otherwise the script aborts.
 import json
 import os
 import re
+import shutil
 import sys
 import zipfile
 
@@ -208,18 +209,21 @@ def out_only(name, key):
     print(name, "ne", head["ne"], "rows", len(table))
 
 
-def fcstd_fixture(name, key):
-    """Document.xml + FemMesh.unv of a reference FreeCAD document (data: model definition + mesh),
-    re-zipped without thumbnails / result arrays."""
+def fcstd_fixture(name, key, members=("Document.xml", "FemMesh.unv")):
+    """Document.xml + FemMesh.unv (+ the BREP geometry file of the meshed shape) of a reference FreeCAD document
+    (data: model definition + mesh), re-zipped without thumbnails / result arrays."""
     src = zipfile.ZipFile(os.path.join(REF, "freeCAD files", name + ".FCStd"))
     with zipfile.ZipFile(os.path.join(HERE, key + ".FCStd"), "w", zipfile.ZIP_DEFLATED) as out:
-        for member in ("Document.xml", "FemMesh.unv"):
+        for member in members:
             out.writestr(zipfile.ZipInfo(member, date_time=(2025, 1, 1, 0, 0, 0)), src.read(member), zipfile.ZIP_DEFLATED)
     print(name, "->", key + ".FCStd")
 
 
 if __name__ == "__main__":
     fcstd_fixture("tensile", "tensile")
+    fcstd_fixture("Embankment_with_Ditch_Example", "embankment", ("Document.xml", "FemMesh.unv", "Extrude.Shape.brp"))
+    shutil.copyfile(os.path.join(REF, "output files", "Embankment_with_Ditch_Example.out"), os.path.join(HERE, "embankment_reference.out"))
+    fcstd_fixture("Plate_with_hole_Example", "plate_with_hole", ("Document.xml", "PartShape2.brp"))  # no mesh in this document
     fcstd_fixture("VM_Uniaxial_Tension_Example", "vm_uniaxial")  # BASELINE configs[0]
     inp = [ln.strip() for ln in open(os.path.join(REF, "control files", "VM_Uniaxial_Tension_Example.inp"))]
     json.dump({"name": "VM_Uniaxial_Tension_Example", "inp": [s for s in inp if s != ""]}, open(os.path.join(HERE, "vm_uniaxial.json"), "w"), indent=1)

@@ -359,6 +359,27 @@ def test_gnly_updated_lagrange_analysis_matches_oracle(orc):
     assert rel(res["peeq"], o["peeq"]) < 1e-6
 
 
+def test_embankment_document_in_reference_out_file_out(tmp_path):
+    """Drop-in at file level: the reference's Embankment_with_Ditch_Example document (mesh, BREP, constraints) and its
+    control file go in, the GPU path writes a .out file that is the reference's shipped one byte for byte and a .vtk
+    whose f64 nodal fields match the reference's to 1e-6."""
+    import os
+    import fcVM as ft
+    from conftest import REPO
+    from fcvm_hip import inpout, vtkio
+    g, meta = load_golden("embankment")
+    with open(tmp_path / (meta["name"] + ".inp"), "w") as f:
+        f.write("\n".join(meta["inp"]) + "\n")
+    ft.run_fcstd(os.path.join(REPO, "tests", "golden", "embankment.FCStd"), str(tmp_path), str(tmp_path), name=meta["name"])
+    mine = open(tmp_path / (meta["name"] + ".out")).read()
+    assert mine == open(os.path.join(REPO, "tests", "golden", "embankment_reference.out")).read()
+    pts, cells, data = vtkio.read_vtk(tmp_path / (meta["name"] + ".vtk"))
+    assert np.array_equal(cells + 1, g["elNodes"])
+    assert rel(data["Displacement"], g["vtk_Displacement"]) < 1e-6
+    assert rel(data["Stress_Tensor"], g["vtk_Stress_Tensor"]) < 1e-6
+    assert rel(data["Equivalent_Plastic_Strain\n"], g["vtk_Equivalent_Plastic_Strain"]) < 1e-6
+
+
 @pytest.mark.parametrize("sig_yield", [100.0, 20.0])
 def test_vm_uniaxial_example_config0(orc, tmp_path, sig_yield):
     """BASELINE configs[0] end to end on the GPU: the reference's VM_Uniaxial_Tension_Example document and its

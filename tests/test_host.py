@@ -177,16 +177,75 @@ def test_vm_uniaxial_example_known_answers(orc):
     assert np.abs(res["sigmises"] - 20.0).max() < 1e-9 and res["peeq"].min() > 1e-3
 
 
-def test_fcstd_reader_rejects_non_box_geometry(tmp_path):
+def test_fcstd_reader_rejects_shapes_without_geometry(tmp_path):
+    """a constraint on a shape that is neither a plain Part::Box nor backed by a BREP file in the document"""
     import zipfile
-    import pytest
     from fcvm_hip import fcstd
+    src = zipfile.ZipFile(os.path.join(REPO, "tests", "golden", "tensile.FCStd"))
+    xml = src.read("Document.xml").decode("utf8").replace('type="Part::Box"', 'type="Part::Extrusion"')
     p = tmp_path / "x.FCStd"
     with zipfile.ZipFile(p, "w") as z:
-        z.writestr("Document.xml", '<Document><Objects><Object type="Part::Extrusion" name="Extrude" id="1" /></Objects><ObjectData></ObjectData></Document>')
-        z.writestr("FemMesh.unv", "")
+        z.writestr("Document.xml", xml)
+        z.writestr("FemMesh.unv", src.read("FemMesh.unv"))
     with pytest.raises(NotImplementedError):
         fcstd.load_model(str(p))
+
+
+def test_brep_reader_on_reference_shapes():
+    """fcvm_hip.brep on the geometry files of two reference documents.  Embankment (Part::Extrusion: 12 faces from
+    11 face TShapes -- the two caps share one): the faces its constraints reference select exactly the dofs that
+    are exactly zero in the reference's own displacement result (tests/golden/embankment.npz).  Plate_with_hole
+    (Part::Cut of a box and a cylinder): areas / lengths against closed forms, and the node sets
+    examples.plate_with_hole constrains are those of Face1 / Face7 / Vertex1,2,5 of the document."""
+    import zipfile
+    from fcvm_hip import brep, examples, fcstd
+    g, _ = load_golden("embankment")
+    m = fcstd.load_model(os.path.join(REPO, "tests", "golden", "embankment.FCStd"))
+    assert np.array_equal(m["elNodes"], g["elNodes"]) and np.array_equal(m["nocoord"], g["nocoord"])
+    assert sorted(m["fix"]) == g["fixed_dofs"].tolist() and set(m["fix"].values()) == {0.0}
+    assert np.allclose(m["material"], g["material"])
+    z = zipfile.ZipFile(os.path.join(REPO, "tests", "golden", "embankment.FCStd"))
+    b = brep.BrepShape(z.read("Extrude.Shape.brp").decode())
+    assert (len(b.faces), len(b.edges), len(b.vertices)) == (12, 30, 20)
+    assert b.face(11).area == pytest.approx(5.3e7) and b.face(12).surface[1][1] == pytest.approx(-1000.0)
+    z = zipfile.ZipFile(os.path.join(REPO, "tests", "golden", "plate_with_hole.FCStd"))
+    b = brep.BrepShape(z.read("PartShape2.brp").decode())
+    assert (len(b.faces), len(b.edges), len(b.vertices)) == (7, 15, 10)
+    assert b.face(2).surface[0] == "cylinder" and b.face(2).area == pytest.approx(np.pi * 50.0 / 2.0 * 10.0, rel=1e-9)
+    assert b.face(3).area == pytest.approx(200.0 * 100.0 - np.pi * 2500.0 / 4.0, rel=1e-5)
+    assert sorted(round(b.edge(i).length, 6) for i in range(1, 16))[-1] == 200.0
+    assert b.edge(5).length == pytest.approx(np.pi * 25.0, rel=1e-5)
+    case = examples.plate_with_hole(10.0)
+    xyz = case["nocoord"]
+    fix = {}
+    for n in np.where(b.face(1).nodes(xyz, 1e-6))[0]:
+        fix[3 * int(n)] = 0.0
+    for n in np.where(b.face(7).nodes(xyz, 1e-6))[0]:
+        fix[3 * int(n) + 1] = 0.0
+    for v in (1, 2, 5):
+        (n,) = np.where(b.vertex(v).nodes(xyz, 1e-6))[0]
+        fix[3 * int(n) + 2] = 0.0
+    assert fix == case["fix"]
+    on_hole = b.face(2).nodes(xyz, 1e-6)
+    assert on_hole.sum() > 50 and np.allclose(np.hypot(xyz[on_hole, 0], xyz[on_hole, 1]), 50.0)
+    loaded = b.face(7).nodes(xyz, 1e-6)
+    assert np.array_equal(np.unique(case["ufaces"]), np.where(loaded)[0] + 1)
+
+
+def test_embankment_document_to_out_file_is_the_reference_file(orc, tmp_path):
+    """The whole caller chain on the CPU side: the reference's FreeCAD document (mesh + BREP + constraints) and its
+    control file through fcstd.load_model -> oracle analysis -> inpout.write_out give the reference's shipped .out
+    file byte for byte."""
+    from fcvm_hip import fcstd, inpout
+    g, meta = load_golden("embankment")
+    m = fcstd.load_model(os.path.join(REPO, "tests", "golden", "embankment.FCStd"))
+    ctl = inpout.parse_inp_lines(meta["inp"])
+    res = orc.run_analysis(m["elNodes"], m["nocoord"], m["material"], m["fix"], orc.Loads(), dict(ctl))
+    out = tmp_path / "e.out"
+    inpout.write_out(out, meta["name"], len(m["elNodes"]), len(m["nocoord"]), ctl["gnl"], ctl["nstep"], res["eigenval"], res["loadsum"],
+                     res["crip"], res["x"], res["lout"], res["un"], res["peeqplot"], res["pplot"], res["svmplot"], res["triaxplot"],
+                     res["ecrplot"], res["csrplot"])
+    assert open(out).read() == open(os.path.join(REPO, "tests", "golden", "embankment_reference.out")).read()
 
 
 def test_calcSum_and_avr_format(tmp_path):
