@@ -18,9 +18,14 @@ from ._lib import call
 
 
 def buckling_factors(model, grav, k=2, sigma=0.1, block=6, tol=1e-10, maxit=80, rtol_solve=1e-11, log=None):
-    """Returns (eigenvalues [k] sorted by |lambda - sigma|, eigenvectors host array [ndof, k], ue device
-    vector of the elastic solution).  Leaves the context with the buckling matrices assembled: call
-    model.calc_gsm() again before the next ordinary solve."""
+    """Returns (eigenvalues [k], eigenvectors host array [ndof, k], ue device vector of the elastic solution).
+    Selection as ARPACK's buckling mode makes it (eigsh(K, M=G, sigma, which='LM', mode='buckling'), fcVM.py:1208):
+    largest |nu|, nu = lambda / (lambda - sigma) = 1 + sigma * theta with theta = 1 / (lambda - sigma) the Ritz
+    values of (K - sigma G)^-1 G -- i.e. the smallest factors ABOVE sigma first (nu > 1); negative factors
+    (load reversal, nu < 1) only when there are not enough positive ones.  The block grows until it holds k
+    positive Ritz values (tension-dominated models have negative factors closer to zero than the wanted ones).
+    Leaves the context with the buckling matrices assembled: call model.calc_gsm() again before the next
+    ordinary solve."""
     c = model.ctx
     say = log if log is not None else (lambda *a: None)
     ndof, ne = model.ndof, model.ne
@@ -58,7 +63,7 @@ def buckling_factors(model, grav, k=2, sigma=0.1, block=6, tol=1e-10, maxit=80, 
         Aa = np.array([[c.dot(Z[i], Y[j]) for j in range(m)] for i in range(m)])
         Ga, Aa = 0.5 * (Ga + Ga.T), 0.5 * (Aa + Aa.T)
         th, C = sla.eigh(Ga, Aa)  # Ga c = theta Aa c, Aa SPD (A is SPD below the first buckling load)
-        order = np.argsort(-np.abs(th))
+        order = np.argsort(-np.abs(1.0 + sigma * th), kind="stable")
         th, C = th[order], C[:, order]
         Xn = []
         for j in range(m):  # X_j = sum_i C[i,j] Z_i, scaled to unit max-norm-ish via Aa-normalisation of eigh
@@ -69,8 +74,15 @@ def buckling_factors(model, grav, k=2, sigma=0.1, block=6, tol=1e-10, maxit=80, 
         X = Xn
         lam = sigma + 1.0 / th[:k]
         say("buckling subspace iteration %d: factors %s" % (it, lam))
-        if theta_old is not None and np.all(np.abs(th[:k] - theta_old) <= tol * np.abs(th[:k])):
-            break
+        if theta_old is not None and len(theta_old) == k and np.all(np.abs(th[:k] - theta_old) <= tol * np.abs(th[:k])):
+            if np.all(th[:k] > 0.0) or m >= 4 * block:
+                break
+            # converged onto a block without k positive factors: widen it and go on
+            extra = [c.array(rng.standard_normal(ndof)) for _ in range(block)]
+            X, Y, m = X + extra, Y + [c.empty(ndof) for _ in range(block)], m + block
+            say("buckling subspace: block widened to %d (negative factors nearer to the shift than the wanted ones)" % m)
+            theta_old = None
+            continue
         theta_old = th[:k].copy()
     # ARPACK's buckling mode returns K-normalised vectors (x^T K x = 1; checked against scipy); the Ritz vectors
     # are A-normalised (A = K - sigma G) with x^T G x = theta, so x^T K x = 1 + sigma * theta.  The relative scale of

@@ -68,7 +68,10 @@ def write_out(path, name, ne, nn, gnl, nstep, eigenval, loadsum, crip, x, lout, 
         f.write(_SEP)
         f.write("{0: >8}{1: >10}{2: >10}{3: >10}{4: >10}{5: >10}{6: >10}{7: >10}{8: >10}{9: >10}{10: >10}{11: >10}\n".format(
             "Gauss point", "x", "y", "z", "load", "disp", "peeq", "pressure", "svmises", "triax", "eps_cr", "csr_max"))
-        for i in range(len(crip)):
+        # displacement-controlled runs that stop at the target load carry one load value less than result rows (the
+        # reaction-force history is not extended in that branch, fcVM.py:1486-1510; the macro's loop over len(crip)
+        # then raises IndexError): the complete rows are written
+        for i in range(min(len(crip), len(lout))):
             f.write("{0: 11d}{1: >10.2e}{2: >10.2e}{3: >10.2e}{4: >10.2e}{5: >10.2e}{6: >10.2e}{7: >10.2e}{8: >10.2e}{9: >10.2e}{10: >10.2e}{11: >10.2e}\n".format(
                 int(crip[i]), x[crip[i]][0], x[crip[i]][1], x[crip[i]][2], lout[i], un[i], peeqplot[i], pplot[i],
                 svmplot[i], triaxplot[i], ecrplot[i], csrplot[i]))

@@ -224,6 +224,18 @@ if __name__ == "__main__":
     fcstd_fixture("Embankment_with_Ditch_Example", "embankment", ("Document.xml", "FemMesh.unv", "Extrude.Shape.brp"))
     shutil.copyfile(os.path.join(REF, "output files", "Embankment_with_Ditch_Example.out"), os.path.join(HERE, "embankment_reference.out"))
     fcstd_fixture("Plate_with_hole_Example", "plate_with_hole", ("Document.xml", "PartShape2.brp"))  # no mesh in this document
+    # further documents with an embedded mesh (no shipped result files): inputs for GPU-vs-oracle runs of the whole chain
+    sweep = {}
+    for name, key, members in (("Lug_FaceLoad_Example", "lug_faceload", None), ("Simple Shear", "simple_shear", None),
+                               ("Block_Disp_Control_Example", "block_disp", None), ("Elastica", "elastica", None)):
+        src = zipfile.ZipFile(os.path.join(REF, "freeCAD files", name + ".FCStd"))
+        xml = src.read("Document.xml").decode("utf8", "replace")
+        mesh = [m for n_, m in re.findall(r'<Object name="(FEMMesh[^"]*)".*?<FemMesh file="([^"]+)"', xml[xml.find("<ObjectData"):], re.S)][-1]
+        brps = sorted(set(re.findall(r'file="([^"]+\.brp)"', xml)) & set(src.namelist()))
+        fcstd_fixture(name, key, ("Document.xml", mesh) + tuple(b for b in brps if len(src.read(b)) > 0))
+        inp = [ln.strip() for ln in open(os.path.join(REF, "control files", name + ".inp"))]
+        sweep[key] = {"name": name, "inp": [s for s in inp if s != ""][:21]}
+    json.dump(sweep, open(os.path.join(HERE, "documents.json"), "w"), indent=1)
     fcstd_fixture("VM_Uniaxial_Tension_Example", "vm_uniaxial")  # BASELINE configs[0]
     inp = [ln.strip() for ln in open(os.path.join(REF, "control files", "VM_Uniaxial_Tension_Example.inp"))]
     json.dump({"name": "VM_Uniaxial_Tension_Example", "inp": [s for s in inp if s != ""]}, open(os.path.join(HERE, "vm_uniaxial.json"), "w"), indent=1)

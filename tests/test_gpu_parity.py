@@ -380,6 +380,40 @@ def test_embankment_document_in_reference_out_file_out(tmp_path):
     assert rel(data["Equivalent_Plastic_Strain\n"], g["vtk_Equivalent_Plastic_Strain"]) < 1e-6
 
 
+@pytest.mark.parametrize("key", ["lug_faceload", "simple_shear", "block_disp", "elastica"])
+def test_reference_documents_through_the_whole_chain(orc, tmp_path, key):
+    """More of the reference's FreeCAD documents (with their shipped control files) through fcVM.run_fcstd on the GPU,
+    against the oracle fed by the same reader: Lug_FaceLoad_Example (force on a cylindrical face, linear buckling run),
+    Simple Shear (face forces, vertex supports), Block_Disp_Control_Example (prescribed displacements, reaction-force
+    output, 17-line control file), Elastica (GNLY, 50 steps of large rotation with tangent re-assembly)."""
+    import json
+    import os
+    import fcVM as ft
+    from conftest import REPO
+    from fcvm_hip import fcstd, inpout
+    meta = json.load(open(os.path.join(REPO, "tests", "golden", "documents.json")))[key]
+    with open(tmp_path / (key + ".inp"), "w") as f:
+        f.write("\n".join(meta["inp"]) + "\n")
+    src = os.path.join(REPO, "tests", "golden", key + ".FCStd")
+    res = ft.run_fcstd(src, str(tmp_path), str(tmp_path), name=key)
+    m = fcstd.load_model(src)
+    L = m["loads"]
+    ctl = inpout.parse_inp_lines(meta["inp"])
+    o = orc.run_analysis(m["elNodes"], m["nocoord"], m["material"], m["fix"],
+                         orc.Loads(pfaces=L.pfaces, pvals=L.pvals, ufaces=L.ufaces, uloads=L.uloads, edges=L.edges, eloads=L.eloads,
+                                   vnodes=L.vnodes, vloads=L.vloads), dict(ctl), use_imperfection=True)
+    assert len(res["lout"]) == len(o["lout"])
+    if len(o["lout"]) > 1:
+        assert rel(res["lout"], o["lout"]) < 1e-6
+    assert rel(res["un"], o["un"]) < 1e-6
+    assert rel(res["disp_el"], o["disp_el"]) < 1e-6 and rel(res["displacements"], o["displacements"]) < 1e-6
+    if ctl["gnl"] == "GNLY" and ctl["nstep"] == 1:
+        assert np.allclose(res["eigenval"], o["eigenval"], rtol=1e-6)
+    else:
+        assert rel(res["tet10stress"], o["tet10stress"]) < 1e-6
+    assert os.path.getsize(tmp_path / (key + ".out")) > 0 and os.path.getsize(tmp_path / (key + ".vtk")) > 0
+
+
 @pytest.mark.parametrize("sig_yield", [100.0, 20.0])
 def test_vm_uniaxial_example_config0(orc, tmp_path, sig_yield):
     """BASELINE configs[0] end to end on the GPU: the reference's VM_Uniaxial_Tension_Example document and its

@@ -248,6 +248,24 @@ def test_embankment_document_to_out_file_is_the_reference_file(orc, tmp_path):
     assert open(out).read() == open(os.path.join(REPO, "tests", "golden", "embankment_reference.out")).read()
 
 
+def test_simple_shear_document_known_answer(orc):
+    """The reference's `Simple Shear` document (cube under self-equilibrated shear tractions of 100 N/mm^2 on four faces,
+    ConstraintForce on faces, vertex supports) with its control file: von Mises yields in pure shear at
+    tau = sig_yield / sqrt(3), so the perfectly plastic limit load factor is 0.57735."""
+    from fcvm_hip import fcstd, inpout
+    docs = json.load(open(os.path.join(REPO, "tests", "golden", "documents.json")))
+    m = fcstd.load_model(os.path.join(REPO, "tests", "golden", "simple_shear.FCStd"))
+    ctl = inpout.parse_inp_lines(docs["simple_shear"]["inp"])
+    assert ctl["sig_yield"] == 100.0 and ctl["Et_E"] == 0.0
+    L = m["loads"]
+    assert len(L.ufaces) == 16 and np.allclose(np.abs(L.uloads).max(1), 100.0)
+    res = orc.run_analysis(m["elNodes"], m["nocoord"], m["material"], m["fix"], orc.Loads(ufaces=L.ufaces, uloads=L.uloads), dict(ctl))
+    assert np.abs(res["loadsum"]).max() < 1e-9
+    plateau = np.asarray(res["lout"])[-12:]     # the control file's error_max is 1 %: the steps scatter by that much
+    assert np.abs(plateau - 1.0 / np.sqrt(3.0)).max() < 0.012 and abs(plateau.mean() - 1.0 / np.sqrt(3.0)) < 3e-3
+    assert np.abs(res["sigmises"] - 100.0).max() < 1e-6
+
+
 def test_calcSum_and_avr_format(tmp_path):
     """fcVM.calcSum / .avr writer (host post-processing): exact length / area of a box edge / face,
     averages of linear nodal fields, and the file layout of the reference's shipped .avr files."""
