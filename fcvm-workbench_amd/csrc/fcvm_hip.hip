@@ -443,7 +443,7 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
     if (refresh_precond(c)) return 1;
     if (c->precond_mode >= 1) {
         HCHK(hipStreamSynchronize(s));
-        if (mg_setup(c)) return 1;
+        if (mg_setup(c, sig ? disp : nullptr, sig, pgp, Et_E)) return 1;
     }
     if (volume) {
         HCHK(hipMemcpyAsync(volume, c->d_out8, sizeof(double), hipMemcpyDeviceToHost, s));

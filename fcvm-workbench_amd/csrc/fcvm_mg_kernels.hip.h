@@ -5,14 +5,19 @@
 
 namespace fcvm {
 
-// Linear-tetrahedron stiffness on the corner nodes of the tet10 elements, elastic D, same
-// boundary-condition folding as the fine matrix (unit diagonal per element on fixed dofs).
-// One work-item per (element, row corner a).
+// Linear-tetrahedron stiffness on the corner nodes of the tet10 elements, same boundary-condition folding as the
+// fine matrix (unit diagonal per element on fixed dofs).  One work-item per (element, row corner a).
+// TANGENT: the consistent elastoplastic tangent D - pf s s^T of the element's four Gauss points (as in
+// k_assemble<true>, fcVM.py:983-998) and the displaced corner coordinates -- for straight-sided elements this is the
+// Galerkin operator P^T K_t P of the tangent matrix, so the coarse correction stays consistent with a softened fine level.
+template <bool TANGENT>
 __global__ __launch_bounds__(256) void k_assemble_tet4(int64_t ne, const int32_t *__restrict__ el4,
                                                        const double *__restrict__ coord1,
                                                        const uint8_t *__restrict__ fixmask1,
                                                        const uint32_t *__restrict__ emap4, MatConst mc,
-                                                       double *__restrict__ vals) {
+                                                       double *__restrict__ vals, const int32_t *__restrict__ c2f,
+                                                       const double *__restrict__ disp, const double *__restrict__ sig,
+                                                       const uint8_t *__restrict__ pgp) {
     int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= 4 * ne) return;
     const int64_t e = t >> 2;
@@ -24,6 +29,10 @@ __global__ __launch_bounds__(256) void k_assemble_tet4(int64_t ne, const int32_t
         nd[k] = el4[e * 4 + k];
 #pragma unroll
         for (int c = 0; c < 3; c++) x[k][c] = coord1[3 * (int64_t)nd[k] + c];
+        if (TANGENT && disp) {
+            const double *u = disp + 3 * (int64_t)c2f[nd[k]];
+            x[k][0] += u[0]; x[k][1] += u[1]; x[k][2] += u[2];
+        }
     }
     double e1[3], e2[3], e3[3];
 #pragma unroll
@@ -48,11 +57,48 @@ __global__ __launch_bounds__(256) void k_assemble_tet4(int64_t ne, const int32_t
 #pragma unroll
     for (int k = 0; k < 4; k++)
         if (k == a) { ga[0] = g[k][0]; ga[1] = g[k][1]; ga[2] = g[k][2]; }
+    double S[4][6], pf[4], ta[4][3];
+    if (TANGENT) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            pf[q] = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) S[q][j] = 0.0;
+            if (pgp[4 * e + q]) {
+                const double *s0 = sig + 24 * e + 6 * q;
+                double sd[6] = {s0[0], s0[1], s0[2], s0[3], s0[4], s0[5]};
+                const double p = (sd[0] + sd[1] + sd[2]) / 3.0;
+                sd[0] -= p; sd[1] -= p; sd[2] -= p;
+                double svm = sqrt(1.5 * (sd[0] * sd[0] + sd[1] * sd[1] + sd[2] * sd[2]) + 3.0 * (sd[3] * sd[3] + sd[4] * sd[4] + sd[5] * sd[5]));
+                if (svm == 0.0) svm = 1.0;
+                pf[q] = 0.25 * 3.0 * mc.G / (1.0 + mc.H / 3.0 / mc.G) / (svm * svm);   // 0.25: four equal Gauss weights
+#pragma unroll
+                for (int j = 0; j < 6; j++) S[q][j] = sd[j];
+            }
+            ta[q][0] = ga[0] * S[q][0] + ga[1] * S[q][3] + ga[2] * S[q][4];
+            ta[q][1] = ga[1] * S[q][1] + ga[0] * S[q][3] + ga[2] * S[q][5];
+            ta[q][2] = ga[2] * S[q][2] + ga[0] * S[q][4] + ga[1] * S[q][5];
+        }
+    }
     const int fa = fixmask1[nd[a]];
 #pragma unroll
     for (int b = 0; b < 4; b++) {
         const double *gb = g[b];
         const double dot = ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2];
+        double sub[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (TANGENT) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                double tb[3];
+                tb[0] = gb[0] * S[q][0] + gb[1] * S[q][3] + gb[2] * S[q][4];
+                tb[1] = gb[1] * S[q][1] + gb[0] * S[q][3] + gb[2] * S[q][5];
+                tb[2] = gb[2] * S[q][2] + gb[0] * S[q][4] + gb[1] * S[q][5];
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) sub[r * 3 + c] += pf[q] * ta[q][r] * tb[c];
+            }
+        }
         const int fb = fixmask1[nd[b]];
         double *dst = vals + emap4[(e * 4 + a) * 4 + b];
 #pragma unroll
@@ -64,6 +110,7 @@ __global__ __launch_bounds__(256) void k_assemble_tet4(int64_t ne, const int32_t
                 double v;
                 if (r == c) v = mc.D11 * ga[r] * gb[r] + mc.D44 * (dot - ga[r] * gb[r]);
                 else v = mc.D12 * ga[r] * gb[c] + mc.D44 * ga[c] * gb[r];
+                if (TANGENT) v -= sub[r * 3 + c];
                 if (!rfix && !cfix) atomic_add_f64(dst + (r * 3 + c) * 128, vol * v);
                 else if (rfix && a == b && r == c) atomic_add_f64(dst + (r * 3 + c) * 128, 1.0);
             }
