@@ -245,7 +245,12 @@ class Context:
         if pi["mode"] != "mg" or pi["coarse_nodes"] < self.l2_min_coarse_nodes:
             return None
         if target is None:
-            target = max(16, int(round(pi["coarse_nodes"] / 1000.0)))  # ~1000 aggregates, >= 16 nodes each
+            # nodes per aggregate: at most ~1000 aggregates (the dense inverse costs n^3 at set-up and n^2 per cycle);
+            # the iteration count follows the aggregate SIZE (57 / 66 / 80 PCG iterations for 176 / 350 / 700 nodes on
+            # the 1 M cube), so mid-size meshes keep the 176 of the 1 M case instead of paying for 1000 small
+            # aggregates; small meshes (cheap either way) go down to 16
+            nc = pi["coarse_nodes"]
+            target = max(16, int(round(nc / 1000.0)), int(min(176, nc / 200.0)))
         return mg2.build_level2(self, target=target, k1s=k1s, alpha1s=alpha1s)
 
     def spmv(self, x, y):

@@ -91,8 +91,13 @@ def build_level2(ctx, target=250, k1s=2, alpha1s=8.0, rank_tol=1e-8):
     if info != 0:
         raise RuntimeError("build_level2: coarse matrix not positive definite (dpotrf info %d)" % info)
     Li, info = sla.lapack.dpotri(L, lower=1, overwrite_c=1)
-    A2inv = np.tril(Li) + np.tril(Li, -1).T
-    A2inv = np.ascontiguousarray(0.5 * (A2inv + A2inv.T))
+    if info != 0:
+        raise RuntimeError("build_level2: dpotri info %d" % info)
+    # dpotri fills one triangle (the Fortran-order lower one = the upper one of the C-order view handed over below);
+    # the other triangle still holds the zeros dpotrf left there, so the sum with the transpose is the full inverse
+    A2inv = Li + Li.T
+    A2inv[np.diag_indices(n2)] *= 0.5
+    A2inv = np.ascontiguousarray(A2inv)
     call("fcvm_mg_set_level2", ctx.h, nagg, n2, agg.ctypes.data, aoff.ctypes.data, Zc.ctypes.data, A2inv.ctypes.data,
          int(k1s), float(alpha1s))
     return dict(aggregates=nagg, unknowns=n2, target=target, inverse=where)
