@@ -199,6 +199,56 @@ def buckling():
     print(name, "ne", len(cells), "nn", len(pts), "fixed dofs", len(fd), "loaded faces", len(faces), "factors", ev)
 
 
+def u100():
+    """GNLY run of an extruded U-profile column (gravity + axial and lateral end forces, imperfection 1 mm along the
+    first buckling shape).  The document holds geometry (BREP), constraints and material but no mesh; the mesh is
+    the one of the shipped .vtk, whose points carry the imperfection.  That file was written by the revision of the
+    reference that scales the buckling shapes to max 1, so the imperfection (fcVM.py:1226-1236 with ev2 = 0) is
+    sign * shape1 and the perfect coordinates are points - imperfection: they land on the CAD faces to 1e-13 and the
+    clamped CAD face selects exactly the nodes whose displacement is exactly zero (both asserted here).  The .out
+    table continues past the target load 0.8 after an interactive continuation; rows up to the target are kept."""
+    from fcvm_hip import brep, meshgen
+    name = "buckling_U100_3D"
+    pts, cells, data = read_vtk(os.path.join(REF, "output files", name + ".vtk"))
+    head, table = parse_out(os.path.join(REF, "output files", name + ".out"))
+    ev = [float(v) for v in re.search(r"elastic buckling factors:\s*\[([^\]]*)\]", open(os.path.join(REF, "output files", name + ".out")).read()).group(1).split()]
+    E, nu, rho, xml = material_from_fcstd(os.path.join(REF, "freeCAD files", name + ".FCStd"))
+    inp = [ln.strip() for ln in open(os.path.join(REF, "control files", name + ".inp"))]
+    inp = [s for s in inp if s != ""][:21]
+    b = brep.BrepShape(zipfile.ZipFile(os.path.join(REF, "freeCAD files", name + ".FCStd")).read("PartShape2.brp").decode())
+    s1 = data["Buckling_shape_for_lambda1_=_3.895"].reshape(-1)
+    assert abs(np.abs(s1).max() - 1.0) < 1e-12 and float(inp[18]) == 1.0 and float(inp[20]) == 0.0
+    imper = np.sign(s1[np.argmax(np.abs(s1))]) * s1
+    x0 = pts - imper.reshape(-1, 3)
+    el = (cells + 1).astype(np.int64)
+    bfaces = np.sort(np.concatenate([el[:, list(f)] for f in meshgen.TET_FACES]), axis=1)
+    u, c = np.unique(bfaces, axis=0, return_counts=True)
+    bn = np.unique(u[c == 1]) - 1
+    on_cad = np.zeros(len(x0), bool)
+    for n in range(1, len(b.faces) + 1):
+        on_cad |= b.face(n).nodes(x0, 1e-6)
+    assert on_cad[bn].all() and on_cad.sum() == len(bn), "recovered geometry does not sit on the CAD faces"
+    # constraints of the document: ConstraintFixed on Face11, two ConstraintForce on Face10 (50 kN along -z, 2 kN along +x)
+    assert re.findall(r'<Link obj="Extrude" sub="(Face\d+)"', xml) == ["Face10", "Face10", "Face11"]
+    fixed = np.where(b.face(11).nodes(x0, 1e-6))[0]
+    assert set(fixed) == set(np.where((data["Elastic_Displacement"] == 0.0).all(1))[0])
+    fd = np.array(sorted(3 * int(n) + k for n in fixed for k in range(3)), dtype=np.int64)
+    on = b.face(10).nodes(x0, 1e-6)
+    tf = np.concatenate([el[:, list(f)] for f in meshgen.TET_FACES])
+    tf = tf[on[tf - 1].all(1)]
+    area = b.face(10).area
+    nrow = int(np.argmax(np.isclose(table[:, 4], float(inp[14])))) + 1   # rows up to the target load factor
+    np.savez_compressed(
+        os.path.join(HERE, "u100.npz"),
+        nocoord0=x0, nocoord=pts, elNodes=el, fixed_dofs=fd, fixed_vals=np.zeros(len(fd)), ufaces=tf,
+        uloads=np.tile([2000.0 / area, 0.0, -50000.0 / area], (len(tf), 1)), material=np.array([E, nu, rho]),
+        out_table=table[:nrow], out_loadsum=np.array(head["loadsum"]), buckling_factors=np.array(ev),
+        shape1=data["Buckling_shape_for_lambda1_=_3.895"], shape2=data["Buckling_shape_for_lambda2_=_8.394"],
+        elastic_displacement=data["Elastic_Displacement"])
+    json.dump({"name": name, "inp": inp}, open(os.path.join(HERE, "u100.json"), "w"), indent=1)
+    print(name, "ne", len(cells), "nn", len(pts), "factors", ev, "rows kept", nrow, "loaded faces", len(tf))
+
+
 def out_only(name, key):
     """Control file + .out table of a model whose document holds no mesh (BASELINE configs[1])."""
     head, table = parse_out(os.path.join(REF, "output files", name + ".out"))
@@ -243,5 +293,6 @@ if __name__ == "__main__":
     embankment()
     vtk_only("tensile", "tensile")
     buckling()
+    u100()
     out_only("Plate_with_hole_Example", "plate_with_hole")
     vtk_only("Lug_Pressure_Example", "lug")

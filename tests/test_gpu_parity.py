@@ -592,6 +592,29 @@ def test_gnly_with_buckling_imperfection_full_flow(orc, tmp_path):
     assert np.allclose(r["lout"], tab[:, 4], rtol=2e-2, atol=1e-3) and np.allclose(r["un"], tab[:, 5], rtol=2e-2, atol=1e-2)
 
 
+def test_u100_column_full_gnly_flow_matches_reference_files():
+    """The reference's buckling_U100_3D run from its perfect geometry, entirely on the GPU: buckling factors of the .out
+    header, buckling shapes / imperfect coordinates of the .vtk, and the load / displacement table up to the target
+    load (gravity + two end forces, GNLY with tangent re-assembly)."""
+    from fcvm_hip import inpout
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import run_analysis
+    from test_oracle_golden import sig3
+    g, meta = load_golden("u100")
+    fix = {int(d): float(v) for d, v in zip(g["fixed_dofs"], g["fixed_vals"])}
+    res = run_analysis(g["elNodes"], g["nocoord0"], g["material"], fix, Loads(ufaces=g["ufaces"], uloads=g["uloads"]),
+                       inpout.parse_inp_lines(meta["inp"]), rtol=1e-12)
+    assert np.allclose(res["eigenval"], g["buckling_factors"], rtol=0, atol=6e-6)
+    for i, key in enumerate(("shape1", "shape2")):
+        r, x = g[key].reshape(-1), res["eigenvec"][:, i]
+        assert np.abs((x @ r) / (x @ x) * x - r).max() < 1e-6
+    assert np.abs(res["nocoord"] - g["nocoord"]).max() < 1e-5
+    tab = g["out_table"]
+    assert len(res["lout"]) == len(tab) and res["lout"][-1] == 0.8
+    for col, val in ((4, res["lout"]), (5, res["un"]), (7, res["pplot"]), (8, res["svmplot"]), (9, res["triaxplot"])):
+        assert sig3(val, tab[:, col]), "column %d" % col
+
+
 def test_error_paths_and_mirror_kernels(orc, gpu_ctx):
     """Loud failures (no silent fallback) and the array-level mirrors fcVM.update_stress_load /
     update_PEEQ_CSR / calculate_principal_stress."""

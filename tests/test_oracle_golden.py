@@ -159,3 +159,29 @@ def test_plate_with_hole_collapse_curve(orc):
     assert np.abs(res["lout"][1:] / tab[1:, 4] - 1.0).max() < 0.02
     assert np.abs(res["un"][1:5] / tab[1:5, 5] - 1.0).max() < 0.02  # later step lengths follow the iteration counts
     assert 0.207 < res["lout"][-1] < 0.24
+
+
+def test_u100_column_buckling_and_gnly_run(orc):
+    """Reference 'buckling_U100_3D' model (GNLY): extruded U-profile column, clamped at z = 0, 50 kN axial + 2 kN lateral
+    on the end face, gravity, imperfection 1 mm along the first buckling shape.  From the PERFECT geometry
+    (make_golden.u100): the two buckling factors of the .out header (5 decimals), both buckling shapes of the .vtk
+    (1e-7 of their maximum), the imperfect coordinates the reference wrote (1e-6 mm), its load sums and every row of the
+    load / displacement table up to the target load factor."""
+    g, meta = load_golden("u100")
+    fix = {int(d): float(v) for d, v in zip(g["fixed_dofs"], g["fixed_vals"])}
+    loads = orc.Loads(ufaces=g["ufaces"], uloads=g["uloads"])
+    ctl = orc.read_inp_lines(meta["inp"])
+    assert ctl["gnl"] == "GNLY" and ctl["grav_z"] == -10.0 and ctl["csr_option"] == "CSR"
+    res = orc.run_analysis(g["elNodes"], g["nocoord0"], g["material"], fix, loads, ctl, use_imperfection=True)
+    assert np.allclose(res["eigenval"], g["buckling_factors"], rtol=0, atol=6e-6)
+    for i, key in enumerate(("shape1", "shape2")):
+        r, x = g[key].reshape(-1), res["eigenvec"][:, i]
+        assert np.abs((x @ r) / (x @ x) * x - r).max() < 1e-7
+    assert np.abs(res["nocoord"] - g["nocoord"]).max() < 1e-6
+    assert np.allclose(res["loadsum"], g["out_loadsum"], rtol=2e-3, atol=1e-9)     # printed with 3 digits
+    assert np.abs(res["disp_el"] - g["elastic_displacement"].reshape(-1)).max() < 1e-6 * np.abs(g["elastic_displacement"]).max()
+    tab = g["out_table"]
+    assert len(res["lout"]) == len(tab) == 9 and res["lout"][-1] == 0.8
+    for col, val in ((4, res["lout"]), (5, res["un"]), (7, res["pplot"]), (8, res["svmplot"]), (9, res["triaxplot"]),
+                     (10, res["ecrplot"])):
+        assert sig3(val, tab[:, col]), "column %d" % col
