@@ -54,6 +54,7 @@ struct fcvm_ctx {
     double *d_part_vec = nullptr, *d_part_spmv = nullptr, *d_part_misc = nullptr, *d_out8 = nullptr;
     long long *d_pidx = nullptr;
     int64_t nb_vec = 0, nb_spmv = 0, nb_gp = 0;
+    int spmv_spw = 1;  // waves per SpMV workgroup: 1 keeps the tail of the launch short (long and short slices differ 3x): -5 % vs 4
     double last_spmv_ms = 0, last_total_ms = 0;
     double row_spread = 0.0;
     bool row_order_morton = false;
@@ -138,7 +139,7 @@ static MatView coarse_view(const fcvm_ctx *c) {
 
 template <bool DOT>
 static void launch_spmv_t(fcvm_ctx *c, const MatView &m, const double *x, double *y, double *part, const double *done) {
-    dim3 grid((unsigned)m.nb), block(256);
+    dim3 grid((unsigned)m.nb), block(64 * c->spmv_spw);
     if (m.vals32) {  // FP32-stored matrix, FP64 vectors and accumulation
         hipLaunchKernelGGL((k_spmv<DOT, false, 4, float2>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols,
                            (const float2 *)m.vals32, m.rownode, x, y, part, done, ChebEpi{});
@@ -156,7 +157,7 @@ static void launch_spmv_t(fcvm_ctx *c, const MatView &m, const double *x, double
 }
 // SpMV t = A d fused with a Chebyshev smoother step on the same rows (see ChebEpi); nothing is written but epi's vectors
 static void launch_spmv_cheb(fcvm_ctx *c, const MatView &m, const double *d, const double *done, const ChebEpi &epi) {
-    dim3 grid((unsigned)m.nb), block(256);
+    dim3 grid((unsigned)m.nb), block(64 * c->spmv_spw);
     if (m.vals32)
         hipLaunchKernelGGL((k_spmv<false, false, 4, float2, 1>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols,
                            (const float2 *)m.vals32, m.rownode, d, (double *)nullptr, (double *)nullptr, done, epi);
@@ -206,6 +207,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     fcvm_ctx *c = new fcvm_ctx();
     c->device = device;
     if (const char *v = getenv("FCVM_SPMV_VARIANT")) c->spmv_variant = atoi(v);
+    if (const char *v = getenv("FCVM_SPMV_SPW")) c->spmv_spw = std::min(4, std::max(1, atoi(v)));   // slices (waves) per workgroup
     if (const char *v = getenv("FCVM_MG_ADDITIVE")) c->mg_additive = atoi(v);
     if (const char *v = getenv("FCVM_MG_FP32")) c->mg_fp32 = atoi(v);
     if (const char *v = getenv("FCVM_MG_ADD_W")) c->mg_add_w = atof(v);
@@ -323,7 +325,7 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
         dalloc(&c->d_q, nn * 3))
         return 1;
     c->nb_vec = cdiv(nn, 256);
-    c->nb_spmv = cdiv(p.nslices, 4);
+    c->nb_spmv = cdiv(p.nslices, c->spmv_spw);
     c->nb_gp = cdiv(4 * ne, 256);
     if (dalloc(&c->d_part_vec, 2 * c->nb_vec) || dalloc(&c->d_part_spmv, c->nb_spmv) ||
         dalloc(&c->d_part_misc, 2 * std::max<int64_t>(c->nb_gp, 4096)) || dalloc(&c->d_pidx, c->nb_gp))

@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void k_spmv(int64_t nslices, int64_t nblocks, 
     const int64_t q = nblocks >> 3, r = nblocks & 7, xcd = b & 7;
     const int64_t wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     const int lane = threadIdx.x & 63;
-    const int64_t s = wg * 4 + (threadIdx.x >> 6);
+    const int64_t s = wg * (blockDim.x >> 6) + (threadIdx.x >> 6);   // blockDim.x / 64 slices per workgroup
     double y0 = 0.0, y1 = 0.0, y2 = 0.0;
     int node = -1;
     if (s < nslices) {

@@ -54,7 +54,7 @@ t2 = time.perf_counter()
 print("load factors", np.round(res["lout"], 4).tolist())
 print("max |u|     ", np.round(res["un"], 4).tolist())
 print("%s: %d tet10, %d dof; mesh %.2fs; set-up %.2fs; analysis %.2fs; steps %d; Newton iterations %d (%.1f /s); solves %d; "
-      "PCG iterations %d (%.1f per solve); solve time %.2fs; load factor %.4f; max |u| %.3f; %s" % (
+      "PCG iterations %d (%.1f per solve); solve time %.2fs (fine SpMV %.3f ms each); load factor %.4f; max |u| %.3f; %s" % (
           case["name"], m.ne, m.ndof, t_mesh, t1 - t0, t2 - t1, len(res["lout"]) - 1, st["newton_iterations"],
           st["newton_iterations"] / (t2 - t1), st["solves"], st["pcg_iterations"], st["pcg_iterations"] / max(st["solves"], 1),
-          st["solve_s"], res["lout"][-1], res["un"][-1], m.ctx.precond_info()))
+          st["solve_s"], st.get("spmv_ms", 0.0) / max(st.get("spmv_launches", 0), 1), res["lout"][-1], res["un"][-1], m.ctx.precond_info()))
