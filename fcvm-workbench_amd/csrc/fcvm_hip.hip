@@ -568,7 +568,7 @@ int fcvm_solve(fcvm_ctx *c, const double *f, double *u, double rtol, int64_t max
     HCHK(hipEventRecord(ev0, s));
     hipLaunchKernelGGL(k_pcg_init, dim3((unsigned)nbv), dim3(256), 0, s, nn, c->d_dinv, f, u, c->d_r, c->d_z, c->d_p,
                        c->d_part_vec, nbv);
-    hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(256), 0, s, 0, c->d_part_vec, nbv, c->nb_spmv, c->d_S, rtol);
+    hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(1024), 0, s, 0, c->d_part_vec, nbv, c->nb_spmv, c->d_S, rtol);
     double S[S_COUNT];
     int64_t it = 0, nspmv = 0;
     double spmv_ms = 0.0;
@@ -579,10 +579,10 @@ int fcvm_solve(fcvm_ctx *c, const double *f, double *u, double rtol, int64_t max
             HCHK(hipEventRecord(c->evpool[2 * j], s));
             launch_spmv(c, true, c->d_p, c->d_q, c->d_S + S_DONE);
             HCHK(hipEventRecord(c->evpool[2 * j + 1], s));
-            hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(256), 0, s, 1, c->d_part_spmv, nbv, c->nb_spmv, c->d_S, rtol);
+            hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(1024), 0, s, 1, c->d_part_spmv, nbv, c->nb_spmv, c->d_S, rtol);
             hipLaunchKernelGGL(k_pcg_update_xr, dim3((unsigned)nbv), dim3(256), 0, s, nn, c->d_dinv, c->d_p, c->d_q, u,
                                c->d_r, c->d_z, c->d_part_vec, nbv, c->d_S);
-            hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(256), 0, s, 2, c->d_part_vec, nbv, c->nb_spmv, c->d_S, rtol);
+            hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(1024), 0, s, 2, c->d_part_vec, nbv, c->nb_spmv, c->d_S, rtol);
             hipLaunchKernelGGL(k_pcg_update_p, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, n, c->d_z, c->d_p, c->d_S);
         }
         HCHK(hipGetLastError());

@@ -666,9 +666,9 @@ __device__ __forceinline__ double sum_partials(const double *part, int64_t n, do
 
 // mode 0: after init (rz, rr, threshold); mode 1: after SpMV (pq -> alpha); mode 2: after
 // update_xr (rz_new, rr -> beta, convergence)
-__global__ __launch_bounds__(256) void k_pcg_scalars(int mode, const double *__restrict__ part, int64_t nb_vec, int64_t nb_spmv,
-                                                     double *__restrict__ S, double rtol) {
-    __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void k_pcg_scalars(int mode, const double *__restrict__ part, int64_t nb_vec, int64_t nb_spmv,
+                                                      double *__restrict__ S, double rtol) {
+    __shared__ double sh[16];   // launched with 1024 threads: the SpMV leaves one partial per slice (21 k at 1 M elements)
     if (mode != 0 && S[S_DONE] != 0.0) return;
     if (mode == 1) {
         double pq = sum_partials(part, nb_spmv, sh);
