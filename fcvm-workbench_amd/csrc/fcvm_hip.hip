@@ -46,6 +46,9 @@ struct fcvm_ctx {
     int32_t *d_el = nullptr, *d_cols = nullptr, *d_rownode = nullptr, *d_noce = nullptr;
     int64_t *d_sptr = nullptr;
     uint32_t *d_emap = nullptr, *d_diagoff = nullptr;
+    int64_t *d_nptr = nullptr;   // node -> element incidence for the row-owner assembly
+    int32_t *d_nel = nullptr;
+    int assemble_atomic = 0;     // FCVM_ASSEMBLE_ATOMIC=1: the (element, row) scatter kernel with f64 atomics
     uint8_t *d_fixmask = nullptr;
     double *d_coord = nullptr, *d_fixval = nullptr, *d_vals = nullptr, *d_dblk = nullptr, *d_dinv = nullptr;
     double *d_vals_g = nullptr;  // geometric stiffness (linear buckling), same pattern as d_vals
@@ -207,6 +210,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     fcvm_ctx *c = new fcvm_ctx();
     c->device = device;
     if (const char *v = getenv("FCVM_SPMV_VARIANT")) c->spmv_variant = atoi(v);
+    if (const char *v = getenv("FCVM_ASSEMBLE_ATOMIC")) c->assemble_atomic = atoi(v);
     if (const char *v = getenv("FCVM_SPMV_SPW")) c->spmv_spw = std::min(4, std::max(1, atoi(v)));   // slices (waves) per workgroup
     if (const char *v = getenv("FCVM_MG_ADDITIVE")) c->mg_additive = atoi(v);
     if (const char *v = getenv("FCVM_MG_FP32")) c->mg_fp32 = atoi(v);
@@ -221,6 +225,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
 static void free_mesh(fcvm_ctx *c) {
     dfree(c->d_el); dfree(c->d_cols); dfree(c->d_rownode); dfree(c->d_noce); dfree(c->d_sptr);
     dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
+    dfree(c->d_nptr); dfree(c->d_nel);
     dfree(c->d_vals); dfree(c->d_vals_g); dfree(c->d_dblk); dfree(c->d_dinv); dfree(c->d_r); dfree(c->d_z); dfree(c->d_p);
     dfree(c->d_q); dfree(c->d_part_vec); dfree(c->d_part_spmv); dfree(c->d_part_misc); dfree(c->d_pidx);
     mg_free(c);
@@ -322,7 +327,7 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
         dalloc(&c->d_diagoff, nn) || dalloc(&c->d_fixmask, nn) || dalloc(&c->d_coord, nn * 3) ||
         dalloc(&c->d_fixval, nn * 3) || dalloc(&c->d_vals, p.value_count()) || dalloc(&c->d_dblk, nn * 9) ||
         dalloc(&c->d_dinv, nn * 9) || dalloc(&c->d_r, nn * 3) || dalloc(&c->d_z, nn * 3) || dalloc(&c->d_p, nn * 3) ||
-        dalloc(&c->d_q, nn * 3))
+        dalloc(&c->d_q, nn * 3) || dalloc(&c->d_nptr, nn + 1) || dalloc(&c->d_nel, ne * 10))
         return 1;
     c->nb_vec = cdiv(nn, 256);
     c->nb_spmv = cdiv(p.nslices, c->spmv_spw);
@@ -338,6 +343,8 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     HCHK(hipMemcpyAsync(c->d_sptr, p.sptr.data(), sizeof(int64_t) * (p.nslices + 1), hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_emap, p.emap.data(), sizeof(uint32_t) * ne * 100, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_diagoff, p.diagoff.data(), sizeof(uint32_t) * nn, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_nptr, p.nptr.data(), sizeof(int64_t) * (nn + 1), hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_nel, p.nel.data(), sizeof(int32_t) * ne * 10, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_coord, nocoord, sizeof(double) * nn * 3, hipMemcpyHostToDevice, s));
     HCHK(hipMemsetAsync(c->d_fixmask, 0, nn, s));
     HCHK(hipMemsetAsync(c->d_fixval, 0, sizeof(double) * nn * 3, s));
@@ -433,7 +440,18 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
     HCHK(hipMemsetAsync(c->d_out8, 0, sizeof(double), s));
     MatConst mc = matconst(c, Et_E);
     dim3 grid((unsigned)cdiv(c->ne * 10, 256)), block(256);
-    if (sig)
+    const int64_t nslots = c->pat.nslices * SLICE;
+    dim3 rgrid((unsigned)cdiv(nslots, 256));
+    if (!c->assemble_atomic) {  // one lane per matrix row, no atomics, bitwise reproducible
+        if (sig)
+            hipLaunchKernelGGL(k_assemble_rows<true>, rgrid, block, 0, s, nslots, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord,
+                               disp, c->d_fixmask, c->d_fixval, c->d_emap, sig, pgp, mc, grav[0], grav[1], grav[2], c->d_vals, glv_grav,
+                               modf, xgp, c->d_out8, 0);
+        else
+            hipLaunchKernelGGL(k_assemble_rows<false>, rgrid, block, 0, s, nslots, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord,
+                               disp, c->d_fixmask, c->d_fixval, c->d_emap, (const double *)nullptr, (const uint8_t *)nullptr, mc,
+                               grav[0], grav[1], grav[2], c->d_vals, glv_grav, modf, xgp, c->d_out8, 0);
+    } else if (sig)
         hipLaunchKernelGGL(k_assemble<true>, grid, block, 0, s, c->ne, c->d_el, c->d_coord, disp, c->d_fixmask,
                            c->d_fixval, c->d_emap, sig, pgp, mc, grav[0], grav[1], grav[2], c->d_vals, glv_grav, modf,
                            xgp, c->d_out8, 0);
@@ -988,9 +1006,15 @@ int fcvm_assemble_buckling(fcvm_ctx *c, const double *sig, double shift) {
     HCHK(hipMemsetAsync(c->d_vals_g, 0, sizeof(double) * nv, s));
     MatConst mc = matconst(c, 0.0);
     dim3 grid((unsigned)cdiv(c->ne * 10, 256)), block(256);
-    hipLaunchKernelGGL(k_assemble<false>, grid, block, 0, s, c->ne, c->d_el, c->d_coord, (const double *)nullptr, c->d_fixmask,
-                       c->d_fixval, c->d_emap, (const double *)nullptr, (const uint8_t *)nullptr, mc, 0.0, 0.0, 0.0, c->d_vals,
-                       c->d_r, c->d_z, (double *)nullptr, (double *)nullptr, 1);
+    if (!c->assemble_atomic) {
+        const int64_t nslots = c->pat.nslices * SLICE;
+        hipLaunchKernelGGL(k_assemble_rows<false>, dim3((unsigned)cdiv(nslots, 256)), block, 0, s, nslots, c->d_rownode, c->d_nptr, c->d_nel,
+                           c->d_el, c->d_coord, (const double *)nullptr, c->d_fixmask, c->d_fixval, c->d_emap, (const double *)nullptr,
+                           (const uint8_t *)nullptr, mc, 0.0, 0.0, 0.0, c->d_vals, c->d_r, c->d_z, (double *)nullptr, (double *)nullptr, 1);
+    } else
+        hipLaunchKernelGGL(k_assemble<false>, grid, block, 0, s, c->ne, c->d_el, c->d_coord, (const double *)nullptr, c->d_fixmask,
+                           c->d_fixval, c->d_emap, (const double *)nullptr, (const uint8_t *)nullptr, mc, 0.0, 0.0, 0.0, c->d_vals,
+                           c->d_r, c->d_z, (double *)nullptr, (double *)nullptr, 1);
     hipLaunchKernelGGL(k_assemble_geometric, grid, block, 0, s, c->ne, c->d_el, c->d_coord, c->d_emap, sig, c->d_vals_g);
     if (shift != 0.0)
         hipLaunchKernelGGL(k_axpby, dim3((unsigned)cdiv(nv, 256)), dim3(256), 0, s, nv, 1.0, c->d_vals, shift, c->d_vals_g, c->d_vals);

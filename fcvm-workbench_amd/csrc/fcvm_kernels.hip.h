@@ -249,8 +249,11 @@ __global__ __launch_bounds__(256) void k_update_stress(int64_t ne, const int32_t
 // (element, row node a); it integrates the ten 3x3 blocks K_ab over the four Gauss points and
 // scatters them into the sliced-ELL matrix with the boundary conditions folded in.
 // ---------------------------------------------------------------------------------------------
-template <bool TANGENT>
-__global__ __launch_bounds__(256) void k_assemble(int64_t ne, const int32_t *__restrict__ el,
+// OWNER = false: scatter with f64 atomics (any thread may hold any row).  OWNER = true: the calling lane is the only one
+// that ever touches row nd[a] (k_assemble_rows), so the matrix blocks are plain read-modify-writes in a fixed element
+// order (bitwise reproducible) and the row's gravity / modf / volume sums stay in the caller's registers.
+template <bool TANGENT, bool OWNER>
+__device__ __forceinline__ void assemble_element_row(int64_t e, const int a, const bool valid, const int32_t *__restrict__ el,
                                                   const double *__restrict__ coord,
                                                   const double *__restrict__ disp,
                                                   const uint8_t *__restrict__ fixmask,
@@ -260,12 +263,8 @@ __global__ __launch_bounds__(256) void k_assemble(int64_t ne, const int32_t *__r
                                                   const uint8_t *__restrict__ pgp, MatConst mc, double gx,
                                                   double gy, double gz, double *__restrict__ vals,
                                                   double *__restrict__ glv, double *__restrict__ modf,
-                                                  double *__restrict__ xgp, double *__restrict__ volume, int penalty_bc) {
-    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    int64_t e = t / 10;
-    const int a = (int)(t - e * 10);
-    const bool valid = e < ne;
-    if (!valid) e = ne - 1;
+                                                  double *__restrict__ xgp, double *__restrict__ volume, int penalty_bc,
+                                                  double *racc) {
     int nd[10];
     double cx[10], cy[10], cz[10];
 #pragma unroll
@@ -324,9 +323,13 @@ __global__ __launch_bounds__(256) void k_assemble(int64_t ne, const int32_t *__r
     }
     if (valid) {
         // gravity load (fcVM.py:757-767) and Gauss point coordinates (fcVM.py:761)
-        if (gx != 0.0) atomic_add_f64(glv + 3 * (int64_t)nd[a], gx * mc.rho * gam);
-        if (gy != 0.0) atomic_add_f64(glv + 3 * (int64_t)nd[a] + 1, gy * mc.rho * gam);
-        if (gz != 0.0) atomic_add_f64(glv + 3 * (int64_t)nd[a] + 2, gz * mc.rho * gam);
+        if (OWNER) {
+            racc[0] += gx * mc.rho * gam; racc[1] += gy * mc.rho * gam; racc[2] += gz * mc.rho * gam;
+        } else {
+            if (gx != 0.0) atomic_add_f64(glv + 3 * (int64_t)nd[a], gx * mc.rho * gam);
+            if (gy != 0.0) atomic_add_f64(glv + 3 * (int64_t)nd[a] + 1, gy * mc.rho * gam);
+            if (gz != 0.0) atomic_add_f64(glv + 3 * (int64_t)nd[a] + 2, gz * mc.rho * gam);
+        }
         if (xgp && a < 4) {
             double xi, et, ze;
             gp_point(a, xi, et, ze);
@@ -340,7 +343,9 @@ __global__ __launch_bounds__(256) void k_assemble(int64_t ne, const int32_t *__r
             o[0] = px; o[1] = py; o[2] = pz;
         }
     }
-    if (volume) {
+    if (OWNER) {
+        if (valid && a == 0) racc[6] += vol;
+    } else if (volume) {
         double v = (valid && a == 0) ? vol : 0.0;
         v = wave_sum(v);
         if ((threadIdx.x & 63) == 0 && v != 0.0) atomic_add_f64(volume, v);
@@ -384,22 +389,87 @@ __global__ __launch_bounds__(256) void k_assemble(int64_t ne, const int32_t *__r
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 const bool cfix = (fb >> c) & 1;
+                double add = 0.0;
+                bool has = false;
                 if (penalty_bc) {  // linear-buckling matrices (fcVM.py:1051-1062): no elimination, fixed diagonal x 100
-                    atomic_add_f64(dst + (r * 3 + c) * 128, (rfix && a == b && r == c) ? 100.0 * K[r * 3 + c] : K[r * 3 + c]);
+                    add = (rfix && a == b && r == c) ? 100.0 * K[r * 3 + c] : K[r * 3 + c];
+                    has = true;
                 } else if (!rfix && !cfix) {
-                    atomic_add_f64(dst + (r * 3 + c) * 128, K[r * 3 + c]);
+                    add = K[r * 3 + c];
+                    has = true;
                 } else if (!rfix && cfix) {
                     macc[r] -= K[r * 3 + c] * fixval[3 * (int64_t)nd[b] + c];
                 } else if (rfix && a == b && r == c) {  // fcVM.py:773-778
-                    atomic_add_f64(dst + (r * 3 + c) * 128, 1.0);
+                    add = 1.0;
+                    has = true;
                     macc[r] += fixval[3 * (int64_t)nd[a] + r];
+                }
+                if (has) {
+                    if (OWNER) dst[(r * 3 + c) * 128] += add;
+                    else atomic_add_f64(dst + (r * 3 + c) * 128, add);
                 }
             }
         }
     }
 #pragma unroll
-    for (int r = 0; r < 3; r++)
-        if (macc[r] != 0.0) atomic_add_f64(modf + 3 * (int64_t)nd[a] + r, macc[r]);
+    for (int r = 0; r < 3; r++) {
+        if (OWNER) racc[3 + r] += macc[r];
+        else if (macc[r] != 0.0) atomic_add_f64(modf + 3 * (int64_t)nd[a] + r, macc[r]);
+    }
+}
+
+
+template <bool TANGENT>
+__global__ __launch_bounds__(256) void k_assemble(int64_t ne, const int32_t *__restrict__ el,
+                                                  const double *__restrict__ coord,
+                                                  const double *__restrict__ disp,
+                                                  const uint8_t *__restrict__ fixmask,
+                                                  const double *__restrict__ fixval,
+                                                  const uint32_t *__restrict__ emap,
+                                                  const double *__restrict__ sig,
+                                                  const uint8_t *__restrict__ pgp, MatConst mc, double gx,
+                                                  double gy, double gz, double *__restrict__ vals,
+                                                  double *__restrict__ glv, double *__restrict__ modf,
+                                                  double *__restrict__ xgp, double *__restrict__ volume, int penalty_bc) {
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t e = t / 10;
+    const int a = (int)(t - e * 10);
+    const bool valid = e < ne;
+    if (!valid) e = ne - 1;
+    assemble_element_row<TANGENT, false>(e, a, valid, el, coord, disp, fixmask, fixval, emap, sig, pgp, mc, gx, gy, gz, vals, glv, modf,
+                                         xgp, volume, penalty_bc, nullptr);
+}
+
+// Atomic-free assembly: one lane per matrix row (slot of the sliced-ELL layout, i.e. one node), walking the elements
+// that contain the node (nptr / nel: element << 4 | local index, ascending element order).  The lane owns the storage of
+// its row, so contributions are added with plain loads / stores in a fixed order -- the assembled matrix, gravity vector
+// and modf are bitwise reproducible -- and the 64 lanes of a wave work inside one slice (its blocks are L2 resident).
+template <bool TANGENT>
+__global__ __launch_bounds__(256) void k_assemble_rows(int64_t nslots, const int32_t *__restrict__ rownode,
+                                                       const int64_t *__restrict__ nptr, const int32_t *__restrict__ nel,
+                                                       const int32_t *__restrict__ el, const double *__restrict__ coord,
+                                                       const double *__restrict__ disp, const uint8_t *__restrict__ fixmask,
+                                                       const double *__restrict__ fixval, const uint32_t *__restrict__ emap,
+                                                       const double *__restrict__ sig, const uint8_t *__restrict__ pgp, MatConst mc,
+                                                       double gx, double gy, double gz, double *__restrict__ vals,
+                                                       double *__restrict__ glv, double *__restrict__ modf, double *__restrict__ xgp,
+                                                       double *__restrict__ volume, int penalty_bc) {
+    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int node = slot < nslots ? rownode[slot] : -1;
+    double racc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (node >= 0) {
+        for (int64_t q = nptr[node]; q < nptr[node + 1]; q++) {
+            const int32_t packed = nel[q];
+            assemble_element_row<TANGENT, true>((int64_t)(packed >> 4), packed & 15, true, el, coord, disp, fixmask, fixval, emap, sig, pgp,
+                                                mc, gx, gy, gz, vals, glv, modf, xgp, volume, penalty_bc, racc);
+        }
+        glv[3 * (int64_t)node] = racc[0]; glv[3 * (int64_t)node + 1] = racc[1]; glv[3 * (int64_t)node + 2] = racc[2];
+        modf[3 * (int64_t)node] = racc[3]; modf[3 * (int64_t)node + 1] = racc[4]; modf[3 * (int64_t)node + 2] = racc[5];
+    }
+    if (volume) {
+        const double v = wave_sum(racc[6]);
+        if ((threadIdx.x & 63) == 0 && v != 0.0) atomic_add_f64(volume, v);
+    }
 }
 
 // inverse of the 3x3 diagonal blocks -> dinv[node*9]

@@ -35,14 +35,17 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
     p.nn = nn;
     p.npe = npe;
     // node -> element incidence
-    std::vector<int64_t> nptr(nn + 1, 0);
+    if (ne >= (int64_t(1) << 27)) throw std::runtime_error("more than 2^27 elements per device are not supported");
+    std::vector<int64_t> &nptr = p.nptr;
+    std::vector<int32_t> &nel = p.nel;   // element << 4 | local node index, ascending element order per node
+    nptr.assign(nn + 1, 0);
     for (int64_t i = 0; i < ne * npe; i++) nptr[el[i] + 1]++;
     for (int64_t i = 0; i < nn; i++) nptr[i + 1] += nptr[i];
-    std::vector<int32_t> nel(ne * npe);
+    nel.assign(ne * npe, 0);
     {
         std::vector<int64_t> fill(nptr.begin(), nptr.end() - 1);
         for (int64_t e = 0; e < ne; e++)
-            for (int k = 0; k < npe; k++) nel[fill[el[e * npe + k]]++] = (int32_t)e;
+            for (int k = 0; k < npe; k++) nel[fill[el[e * npe + k]]++] = (int32_t)((e << 4) | k);
     }
     // node -> sorted unique neighbour nodes (diagonal included)
     int nt = std::max(1, nthreads);
@@ -57,7 +60,7 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
         for (int64_t i = b; i < e; i++) {
             tmp.clear();
             for (int64_t q = nptr[i]; q < nptr[i + 1]; q++) {
-                const int32_t *nd = el + (int64_t)nel[q] * npe;
+                const int32_t *nd = el + (int64_t)(nel[q] >> 4) * npe;
                 tmp.insert(tmp.end(), nd, nd + npe);
             }
             if (tmp.empty()) tmp.push_back((int32_t)i);  // isolated node: keep a diagonal block

@@ -25,6 +25,8 @@ struct Pattern {
     std::vector<int32_t> cols;      // [sptr[nslices]*64] column node per (slice, j, lane)
     std::vector<uint32_t> emap;     // [ne*npe*npe] offset (in doubles) of component 0 of block (a,b)
     std::vector<uint32_t> diagoff;  // [nn] offset of component 0 of the diagonal block
+    std::vector<int64_t> nptr;      // [nn+1] node -> element incidence (CSR)
+    std::vector<int32_t> nel;       // [ne*npe] element << 4 | local node index, ascending elements per node
 
     // offset in doubles of component 0 of block j of the row living in `slot`
     inline uint64_t block_offset(int64_t slot, int64_t j) const {
