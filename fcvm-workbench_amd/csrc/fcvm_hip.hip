@@ -46,9 +46,12 @@ struct fcvm_ctx {
     int32_t *d_el = nullptr, *d_cols = nullptr, *d_rownode = nullptr, *d_noce = nullptr;
     int64_t *d_sptr = nullptr;
     uint32_t *d_emap = nullptr, *d_diagoff = nullptr;
-    int64_t *d_nptr = nullptr;   // node -> element incidence for the row-owner assembly
-    int32_t *d_nel = nullptr;
+    int64_t *d_nptr = nullptr, *d_nptr1 = nullptr;   // node -> element incidence for the row-owner assembly (fine / tet4 level)
+    int32_t *d_nel = nullptr, *d_nel1 = nullptr;
     int assemble_atomic = 0;     // FCVM_ASSEMBLE_ATOMIC=1: the (element, row) scatter kernel with f64 atomics
+    int qin_atomic = 0;          // FCVM_QIN_ATOMIC=1: internal forces scattered with f64 atomics
+    double *d_fe = nullptr;      // [ne][10][3] element nodal forces of the last stress update
+    double *d_part_vol = nullptr;  // [nslices] volume partials of the row-owner assembly
     uint8_t *d_fixmask = nullptr;
     double *d_coord = nullptr, *d_fixval = nullptr, *d_vals = nullptr, *d_dblk = nullptr, *d_dinv = nullptr;
     double *d_vals_g = nullptr;  // geometric stiffness (linear buckling), same pattern as d_vals
@@ -211,6 +214,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     c->device = device;
     if (const char *v = getenv("FCVM_SPMV_VARIANT")) c->spmv_variant = atoi(v);
     if (const char *v = getenv("FCVM_ASSEMBLE_ATOMIC")) c->assemble_atomic = atoi(v);
+    if (const char *v = getenv("FCVM_QIN_ATOMIC")) c->qin_atomic = atoi(v);
     if (const char *v = getenv("FCVM_SPMV_SPW")) c->spmv_spw = std::min(4, std::max(1, atoi(v)));   // slices (waves) per workgroup
     if (const char *v = getenv("FCVM_MG_ADDITIVE")) c->mg_additive = atoi(v);
     if (const char *v = getenv("FCVM_MG_FP32")) c->mg_fp32 = atoi(v);
@@ -225,7 +229,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
 static void free_mesh(fcvm_ctx *c) {
     dfree(c->d_el); dfree(c->d_cols); dfree(c->d_rownode); dfree(c->d_noce); dfree(c->d_sptr);
     dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
-    dfree(c->d_nptr); dfree(c->d_nel);
+    dfree(c->d_nptr); dfree(c->d_nel); dfree(c->d_fe); dfree(c->d_part_vol);
     dfree(c->d_vals); dfree(c->d_vals_g); dfree(c->d_dblk); dfree(c->d_dinv); dfree(c->d_r); dfree(c->d_z); dfree(c->d_p);
     dfree(c->d_q); dfree(c->d_part_vec); dfree(c->d_part_spmv); dfree(c->d_part_misc); dfree(c->d_pidx);
     mg_free(c);
@@ -327,7 +331,7 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
         dalloc(&c->d_diagoff, nn) || dalloc(&c->d_fixmask, nn) || dalloc(&c->d_coord, nn * 3) ||
         dalloc(&c->d_fixval, nn * 3) || dalloc(&c->d_vals, p.value_count()) || dalloc(&c->d_dblk, nn * 9) ||
         dalloc(&c->d_dinv, nn * 9) || dalloc(&c->d_r, nn * 3) || dalloc(&c->d_z, nn * 3) || dalloc(&c->d_p, nn * 3) ||
-        dalloc(&c->d_q, nn * 3) || dalloc(&c->d_nptr, nn + 1) || dalloc(&c->d_nel, ne * 10))
+        dalloc(&c->d_q, nn * 3) || dalloc(&c->d_nptr, nn + 1) || dalloc(&c->d_nel, ne * 10) || dalloc(&c->d_part_vol, p.nslices))
         return 1;
     c->nb_vec = cdiv(nn, 256);
     c->nb_spmv = cdiv(p.nslices, c->spmv_spw);
@@ -446,11 +450,12 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
         if (sig)
             hipLaunchKernelGGL(k_assemble_rows<true>, rgrid, block, 0, s, nslots, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord,
                                disp, c->d_fixmask, c->d_fixval, c->d_emap, sig, pgp, mc, grav[0], grav[1], grav[2], c->d_vals, glv_grav,
-                               modf, xgp, c->d_out8, 0);
+                               modf, xgp, c->d_part_vol, 0);
         else
             hipLaunchKernelGGL(k_assemble_rows<false>, rgrid, block, 0, s, nslots, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord,
                                disp, c->d_fixmask, c->d_fixval, c->d_emap, (const double *)nullptr, (const uint8_t *)nullptr, mc,
-                               grav[0], grav[1], grav[2], c->d_vals, glv_grav, modf, xgp, c->d_out8, 0);
+                               grav[0], grav[1], grav[2], c->d_vals, glv_grav, modf, xgp, c->d_part_vol, 0);
+        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, s, c->d_part_vol, c->pat.nslices, c->d_out8);
     } else if (sig)
         hipLaunchKernelGGL(k_assemble<true>, grid, block, 0, s, c->ne, c->d_el, c->d_coord, disp, c->d_fixmask,
                            c->d_fixval, c->d_emap, sig, pgp, mc, grav[0], grav[1], grav[2], c->d_vals, glv_grav, modf,
@@ -480,15 +485,27 @@ int fcvm_update_stress_load(fcvm_ctx *c, const double *sig_yield, const double *
     NEED(sig_yield && du && sig_old && sig_new && sig_test && qin && pgp, "fcvm_update_stress_load: null array");
     NEED(!LD || disp_new, "fcvm_update_stress_load: disp_new required when LD");
     hipStream_t s = c->stream;
-    HCHK(hipMemsetAsync(qin, 0, sizeof(double) * 3 * c->nn, s));
     MatConst mc = matconst(c, Et_E);
     dim3 grid((unsigned)cdiv(c->ne * 4, 256)), block(256);
+    if (!c->qin_atomic) {   // per-element nodal forces + fixed-order gather per node: no atomics, reproducible residuals
+        if (!c->d_fe && dalloc(&c->d_fe, c->ne * 30)) return 1;
+        if (LD)
+            hipLaunchKernelGGL((k_update_stress<true, true>), grid, block, 0, s, c->ne, c->d_el, c->d_coord, disp_new, du, sig_old,
+                               sig_new, sig_test, sig_yield, pgp, qin, mc, c->d_fe);
+        else
+            hipLaunchKernelGGL((k_update_stress<false, true>), grid, block, 0, s, c->ne, c->d_el, c->d_coord, disp_new, du, sig_old,
+                               sig_new, sig_test, sig_yield, pgp, qin, mc, c->d_fe);
+        hipLaunchKernelGGL(k_gather_qin, dim3((unsigned)cdiv(c->nn, 256)), block, 0, s, c->nn, c->d_nptr, c->d_nel, c->d_fe, qin);
+        HCHK(hipGetLastError());
+        return 0;
+    }
+    HCHK(hipMemsetAsync(qin, 0, sizeof(double) * 3 * c->nn, s));
     if (LD)
-        hipLaunchKernelGGL(k_update_stress<true>, grid, block, 0, s, c->ne, c->d_el, c->d_coord, disp_new, du, sig_old,
-                           sig_new, sig_test, sig_yield, pgp, qin, mc);
+        hipLaunchKernelGGL((k_update_stress<true, false>), grid, block, 0, s, c->ne, c->d_el, c->d_coord, disp_new, du, sig_old,
+                           sig_new, sig_test, sig_yield, pgp, qin, mc, (double *)nullptr);
     else
-        hipLaunchKernelGGL(k_update_stress<false>, grid, block, 0, s, c->ne, c->d_el, c->d_coord, disp_new, du,
-                           sig_old, sig_new, sig_test, sig_yield, pgp, qin, mc);
+        hipLaunchKernelGGL((k_update_stress<false, false>), grid, block, 0, s, c->ne, c->d_el, c->d_coord, disp_new, du,
+                           sig_old, sig_new, sig_test, sig_yield, pgp, qin, mc, (double *)nullptr);
     HCHK(hipGetLastError());
     return 0;
 }
@@ -522,7 +539,7 @@ int fcvm_map_stresses(fcvm_ctx *c, int averaged, const double *sig, const double
     HCHK(hipMemsetAsync(t10csr, 0, sizeof(double) * c->nn, s));
     HCHK(hipMemsetAsync(t10svm, 0, sizeof(double) * c->nn, s));
     HCHK(hipMemsetAsync(t10triax, 0, sizeof(double) * c->nn, s));
-    hipLaunchKernelGGL(k_map_corners, dim3((unsigned)cdiv(4 * c->ne, 256)), dim3(256), 0, s, c->ne, c->d_el, c->d_noce,
+    hipLaunchKernelGGL(k_map_corners, dim3((unsigned)cdiv(c->nn, 256)), dim3(256), 0, s, c->nn, c->d_nptr, c->d_nel, c->d_noce,
                        averaged, sig, peeq, sigvm, csr, sig_yield, t10s, t10peeq, t10csr, t10svm, t10triax);
     hipLaunchKernelGGL(k_map_midside, dim3((unsigned)cdiv(6 * c->ne, 256)), dim3(256), 0, s, c->ne, c->d_el, t10s,
                        t10peeq, t10csr, t10svm, t10triax);

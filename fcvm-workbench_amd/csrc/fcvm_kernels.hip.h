@@ -116,7 +116,9 @@ struct MatConst {
     double D11, D12, D44, G, H, Et, rho;
 };
 
-template <bool LD>
+// GATHER = false: internal forces scattered into qin with f64 atomics.  GATHER = true: the element's 10 x 3 nodal
+// forces go to fe[e][30] and k_gather_qin sums them per node in a fixed order (bitwise reproducible residuals).
+template <bool LD, bool GATHER>
 __global__ __launch_bounds__(256) void k_update_stress(int64_t ne, const int32_t *__restrict__ el,
                                                        const double *__restrict__ coord,
                                                        const double *__restrict__ disp_new,
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void k_update_stress(int64_t ne, const int32_t
                                                        double *__restrict__ sig_test,
                                                        const double *__restrict__ sig_yield,
                                                        uint8_t *__restrict__ pgp, double *__restrict__ qin,
-                                                       MatConst mc) {
+                                                       MatConst mc, double *__restrict__ fe) {
     int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t e = t >> 2;
     const int g = (int)(t & 3);
@@ -236,12 +238,31 @@ __global__ __launch_bounds__(256) void k_update_stress(int64_t ne, const int32_t
         f0 += __shfl_xor(f0, 1, 64); f1 += __shfl_xor(f1, 1, 64); f2 += __shfl_xor(f2, 1, 64);
         f0 += __shfl_xor(f0, 2, 64); f1 += __shfl_xor(f1, 2, 64); f2 += __shfl_xor(f2, 2, 64);
         if (valid && g == (k & 3)) {
-            double *q = qin + 3 * (int64_t)nd[k];
-            atomic_add_f64(q, f0);
-            atomic_add_f64(q + 1, f1);
-            atomic_add_f64(q + 2, f2);
+            if (GATHER) {
+                double *q = fe + 30 * e + 3 * k;
+                q[0] = f0; q[1] = f1; q[2] = f2;
+            } else {
+                double *q = qin + 3 * (int64_t)nd[k];
+                atomic_add_f64(q, f0);
+                atomic_add_f64(q + 1, f1);
+                atomic_add_f64(q + 2, f2);
+            }
         }
     }
+}
+
+// qin[node] = sum over the elements containing the node (ascending element order) of their nodal force fe[e][a][3]
+__global__ __launch_bounds__(256) void k_gather_qin(int64_t nn, const int64_t *__restrict__ nptr, const int32_t *__restrict__ nel,
+                                                    const double *__restrict__ fe, double *__restrict__ qin) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nn) return;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int64_t q = nptr[i]; q < nptr[i + 1]; q++) {
+        const int32_t packed = nel[q];
+        const double *f = fe + 30 * (int64_t)(packed >> 4) + 3 * (packed & 15);
+        a0 += f[0]; a1 += f[1]; a2 += f[2];
+    }
+    qin[3 * i] = a0; qin[3 * i + 1] = a1; qin[3 * i + 2] = a2;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -466,9 +487,9 @@ __global__ __launch_bounds__(256) void k_assemble_rows(int64_t nslots, const int
         glv[3 * (int64_t)node] = racc[0]; glv[3 * (int64_t)node + 1] = racc[1]; glv[3 * (int64_t)node + 2] = racc[2];
         modf[3 * (int64_t)node] = racc[3]; modf[3 * (int64_t)node + 1] = racc[4]; modf[3 * (int64_t)node + 2] = racc[5];
     }
-    if (volume) {
+    if (volume) {   // one partial per wavefront (= slice), summed in a fixed order by k_sum_final
         const double v = wave_sum(racc[6]);
-        if ((threadIdx.x & 63) == 0 && v != 0.0) atomic_add_f64(volume, v);
+        if ((threadIdx.x & 63) == 0) volume[slot >> 6] = v;
     }
 }
 
@@ -910,32 +931,37 @@ __global__ __launch_bounds__(256) void k_peeq_csr_final(int64_t nb, const double
 // ---------------------------------------------------------------------------------------------
 // mapStresses (fcVM.py:2497-2554)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_map_corners(int64_t ne, const int32_t *__restrict__ el, const int32_t *__restrict__ noce,
-                                                     int averaged, const double *__restrict__ sig, const double *__restrict__ peeq,
-                                                     const double *__restrict__ svm, const double *__restrict__ csr, double sig_yield,
-                                                     double *__restrict__ t10s, double *__restrict__ t10peeq, double *__restrict__ t10csr,
+// corner nodes: lane per node, gathering the Gauss-point values of the incident elements (Gauss point a of an element
+// maps to its corner a, fcVM.py:2510-2540) in ascending element order -- the reference's own summation order, no atomics
+__global__ __launch_bounds__(256) void k_map_corners(int64_t nn, const int64_t *__restrict__ nptr, const int32_t *__restrict__ nel,
+                                                     const int32_t *__restrict__ noce, int averaged, const double *__restrict__ sig,
+                                                     const double *__restrict__ peeq, const double *__restrict__ svm,
+                                                     const double *__restrict__ csr, double sig_yield, double *__restrict__ t10s,
+                                                     double *__restrict__ t10peeq, double *__restrict__ t10csr,
                                                      double *__restrict__ t10svm, double *__restrict__ t10triax) {
-    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= 4 * ne) return;
-    const int64_t e = t >> 2;
-    const int c = (int)(t & 3);
-    const int64_t nd = el[e * 10 + c];
+    const int64_t nd = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (nd >= nn) return;
     const double cnt = (double)noce[nd];
-    const double *s = sig + 6 * t;
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double ap = 0.0, ac = 0.0, av = 0.0, at = 0.0;
+    for (int64_t q = nptr[nd]; q < nptr[nd + 1]; q++) {
+        const int32_t packed = nel[q];
+        const int a = packed & 15;
+        if (a >= 4) continue;
+        const int64_t t = 4 * (int64_t)(packed >> 4) + a;
+        const double *s = sig + 6 * t;
 #pragma unroll
-    for (int k = 0; k < 6; k++) atomic_add_f64(t10s + 6 * nd + k, s[k] / cnt);
-    const double tr = (s[0] + s[1] + s[2]) / 3.0 / sig_yield;
-    if (averaged) {
-        atomic_add_f64(t10peeq + nd, peeq[t] / cnt);
-        atomic_add_f64(t10csr + nd, csr[t] / cnt);
-        atomic_add_f64(t10svm + nd, svm[t] / cnt);
-        atomic_add_f64(t10triax + nd, tr / cnt);
-    } else {
-        atomic_fmax_f64(t10peeq + nd, peeq[t]);
-        atomic_fmax_f64(t10csr + nd, csr[t]);
-        atomic_fmax_f64(t10svm + nd, svm[t]);
-        atomic_fmax_f64(t10triax + nd, tr);
+        for (int k = 0; k < 6; k++) acc[k] += s[k] / cnt;
+        const double tr = (s[0] + s[1] + s[2]) / 3.0 / sig_yield;
+        if (averaged) {
+            ap += peeq[t] / cnt; ac += csr[t] / cnt; av += svm[t] / cnt; at += tr / cnt;
+        } else {
+            ap = fmax(ap, peeq[t]); ac = fmax(ac, csr[t]); av = fmax(av, svm[t]); at = fmax(at, tr);
+        }
     }
+#pragma unroll
+    for (int k = 0; k < 6; k++) t10s[6 * nd + k] = acc[k];
+    t10peeq[nd] = ap; t10csr[nd] = ac; t10svm[nd] = av; t10triax[nd] = at;
 }
 
 __global__ __launch_bounds__(256) void k_map_midside(int64_t ne, const int32_t *__restrict__ el, double *__restrict__ t10s,

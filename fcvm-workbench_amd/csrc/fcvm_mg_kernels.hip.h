@@ -10,18 +10,14 @@ namespace fcvm {
 // TANGENT: the consistent elastoplastic tangent D - pf s s^T of the element's four Gauss points (as in
 // k_assemble<true>, fcVM.py:983-998) and the displaced corner coordinates -- for straight-sided elements this is the
 // Galerkin operator P^T K_t P of the tangent matrix, so the coarse correction stays consistent with a softened fine level.
-template <bool TANGENT>
-__global__ __launch_bounds__(256) void k_assemble_tet4(int64_t ne, const int32_t *__restrict__ el4,
+template <bool TANGENT, bool OWNER>
+__device__ __forceinline__ void tet4_element_row(const int64_t e, const int a, const int32_t *__restrict__ el4,
                                                        const double *__restrict__ coord1,
                                                        const uint8_t *__restrict__ fixmask1,
                                                        const uint32_t *__restrict__ emap4, MatConst mc,
                                                        double *__restrict__ vals, const int32_t *__restrict__ c2f,
                                                        const double *__restrict__ disp, const double *__restrict__ sig,
                                                        const uint8_t *__restrict__ pgp) {
-    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= 4 * ne) return;
-    const int64_t e = t >> 2;
-    const int a = (int)(t & 3);
     int nd[4];
     double x[4][3];
 #pragma unroll
@@ -111,10 +107,34 @@ __global__ __launch_bounds__(256) void k_assemble_tet4(int64_t ne, const int32_t
                 if (r == c) v = mc.D11 * ga[r] * gb[r] + mc.D44 * (dot - ga[r] * gb[r]);
                 else v = mc.D12 * ga[r] * gb[c] + mc.D44 * ga[c] * gb[r];
                 if (TANGENT) v -= sub[r * 3 + c];
-                if (!rfix && !cfix) atomic_add_f64(dst + (r * 3 + c) * 128, vol * v);
-                else if (rfix && a == b && r == c) atomic_add_f64(dst + (r * 3 + c) * 128, 1.0);
+                double add = 0.0;
+                if (!rfix && !cfix) add = vol * v;
+                else if (rfix && a == b && r == c) add = 1.0;
+                else continue;
+                if (OWNER) dst[(r * 3 + c) * 128] += add;
+                else atomic_add_f64(dst + (r * 3 + c) * 128, add);
             }
         }
+    }
+}
+
+// one lane per row of the level-1 matrix (slot -> coarse node), walking the elements at that corner: no atomics, the
+// coarse operator -- and with it the preconditioner and every PCG iterate -- is bitwise reproducible
+template <bool TANGENT>
+__global__ __launch_bounds__(256) void k_assemble_tet4_rows(int64_t nslots, const int32_t *__restrict__ rownode1,
+                                                            const int64_t *__restrict__ nptr1, const int32_t *__restrict__ nel1,
+                                                            const int32_t *__restrict__ el4, const double *__restrict__ coord1,
+                                                            const uint8_t *__restrict__ fixmask1, const uint32_t *__restrict__ emap4,
+                                                            MatConst mc, double *__restrict__ vals, const int32_t *__restrict__ c2f,
+                                                            const double *__restrict__ disp, const double *__restrict__ sig,
+                                                            const uint8_t *__restrict__ pgp) {
+    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (slot >= nslots) return;
+    const int node = rownode1[slot];
+    if (node < 0) return;
+    for (int64_t q = nptr1[node]; q < nptr1[node + 1]; q++) {
+        const int32_t packed = nel1[q];
+        tet4_element_row<TANGENT, true>((int64_t)(packed >> 4), packed & 15, el4, coord1, fixmask1, emap4, mc, vals, c2f, disp, sig, pgp);
     }
 }
 

@@ -615,6 +615,29 @@ def test_u100_column_full_gnly_flow_matches_reference_files():
         assert sig3(val, tab[:, col]), "column %d" % col
 
 
+def test_reruns_are_bitwise_identical():
+    """No floating-point atomics anywhere on the path (row-owner assembly, per-element internal forces gathered in a fixed
+    order, fixed-order reductions in the solver): two runs of an elastoplastic analysis in fresh contexts give bitwise
+    identical load histories, displacements, stresses and iteration counts."""
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import run_analysis
+    case = small_case(5, prescribed=False)
+    ctl = dict(sig_yield=4.0, grav_x=0.0, grav_y=0.0, grav_z=-9.81, nstep=4, iterat_max=20, error_max=1e-4, relax=1.2,
+               scale_re=2.0, scale_up=1.2, scale_dn=1.2, disp_output="total", ultimate_strain=0.25, Et_E=0.02, target_LF=10.0,
+               csr_option="PEEQ", averaged_option="unaveraged", gnl="GNLN", maxImp="0.0", ev1="1.0", ev2="0.0")
+    runs = []
+    for _ in range(2):
+        r = run_analysis(case["elNodes"], case["nocoord"], case["material"], case["fix"],
+                         Loads(ufaces=case["ufaces"], uloads=case["uloads"]), dict(ctl))
+        runs.append(r)
+        r["model"].ctx.close()
+    a, b = runs
+    assert a["peeq"].max() > 0
+    for k in ("lout", "un", "displacements", "stresses", "peeq", "tet10stress"):
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+    assert a["stats"]["pcg_iterations"] == b["stats"]["pcg_iterations"]
+
+
 def test_error_paths_and_mirror_kernels(orc, gpu_ctx):
     """Loud failures (no silent fallback) and the array-level mirrors fcVM.update_stress_load /
     update_PEEQ_CSR / calculate_principal_stress."""
