@@ -1032,7 +1032,11 @@ int fcvm_assemble_buckling(fcvm_ctx *c, const double *sig, double shift) {
         hipLaunchKernelGGL(k_assemble<false>, grid, block, 0, s, c->ne, c->d_el, c->d_coord, (const double *)nullptr, c->d_fixmask,
                            c->d_fixval, c->d_emap, (const double *)nullptr, (const uint8_t *)nullptr, mc, 0.0, 0.0, 0.0, c->d_vals,
                            c->d_r, c->d_z, (double *)nullptr, (double *)nullptr, 1);
-    hipLaunchKernelGGL(k_assemble_geometric, grid, block, 0, s, c->ne, c->d_el, c->d_coord, c->d_emap, sig, c->d_vals_g);
+    {
+        const int64_t nslots = c->pat.nslices * SLICE;
+        hipLaunchKernelGGL(k_assemble_geometric, dim3((unsigned)cdiv(nslots, 256)), block, 0, s, nslots, c->d_rownode, c->d_nptr, c->d_nel,
+                           c->d_el, c->d_coord, c->d_emap, sig, c->d_vals_g);
+    }
     if (shift != 0.0)
         hipLaunchKernelGGL(k_axpby, dim3((unsigned)cdiv(nv, 256)), dim3(256), 0, s, nv, 1.0, c->d_vals, shift, c->d_vals_g, c->d_vals);
     HCHK(hipGetLastError());

@@ -1040,14 +1040,11 @@ __global__ __launch_bounds__(256) void k_to_f32(int64_t n, const double *__restr
 }
 
 // geometric stiffness of calcTSM(nstep = 1), fcVM.py:1002-1006: Kg_ab = (sum_gp w ga . sigma . gb) I3, scattered into a
-// second value array that shares the pattern of the stiffness matrix.  One work-item per (element, row node a).
-__global__ __launch_bounds__(256) void k_assemble_geometric(int64_t ne, const int32_t *__restrict__ el,
-                                                            const double *__restrict__ coord, const uint32_t *__restrict__ emap,
-                                                            const double *__restrict__ sig, double *__restrict__ vals_g) {
-    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    int64_t e = t / 10;
-    const int a = (int)(t - e * 10);
-    if (e >= ne) return;
+// second value array that shares the pattern of the stiffness matrix.  One lane per matrix row walking its elements
+// (as k_assemble_rows: plain read-modify-writes in a fixed order, no atomics).
+__device__ __forceinline__ void geometric_element_row(const int64_t e, const int a, const int32_t *__restrict__ el,
+                                                      const double *__restrict__ coord, const uint32_t *__restrict__ emap,
+                                                      const double *__restrict__ sig, double *__restrict__ vals_g) {
     int nd[10];
     double cx[10], cy[10], cz[10];
 #pragma unroll
@@ -1093,9 +1090,24 @@ __global__ __launch_bounds__(256) void k_assemble_geometric(int64_t ne, const in
             v += w[g] * (sa[g][0] * g0 + sa[g][1] * g1 + sa[g][2] * g2);
         }
         double *dst = vals_g + em[b];
-        atomic_add_f64(dst, v);
-        atomic_add_f64(dst + 4 * 128, v);
-        atomic_add_f64(dst + 8 * 128, v);
+        dst[0] += v;
+        dst[4 * 128] += v;
+        dst[8 * 128] += v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_assemble_geometric(int64_t nslots, const int32_t *__restrict__ rownode,
+                                                            const int64_t *__restrict__ nptr, const int32_t *__restrict__ nel,
+                                                            const int32_t *__restrict__ el, const double *__restrict__ coord,
+                                                            const uint32_t *__restrict__ emap, const double *__restrict__ sig,
+                                                            double *__restrict__ vals_g) {
+    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (slot >= nslots) return;
+    const int node = rownode[slot];
+    if (node < 0) return;
+    for (int64_t q = nptr[node]; q < nptr[node + 1]; q++) {
+        const int32_t packed = nel[q];
+        geometric_element_row((int64_t)(packed >> 4), packed & 15, el, coord, emap, sig, vals_g);
     }
 }
 
