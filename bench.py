@@ -38,8 +38,8 @@ MATERIAL = (210000.0, 0.3, 7.8e-6)
 TRACTION = (20.0, 0.0, 200.0)
 RTOL = 1.0e-10
 # HBM bytes per SpMV launch of the 55^3-cell cube from the PMC counters (separate rocprofv3 passes, gfx950 correction
-# applied), see profiles/r01b_spmv_pmc.txt; bench.py cannot collect counters itself
-SPMV_TRAFFIC_BYTES = 3.170e9
+# applied), see profiles/r01h_spmv_pmc.txt; bench.py cannot collect counters itself
+SPMV_TRAFFIC_BYTES = 3.163e9
 
 
 def cpu_baseline(cells=12, iters=5):
@@ -189,7 +189,7 @@ def run_single(args):
         "roofline": {"bound": "hbm", "kernel": "k_spmv<true> (sliced-ELL 3x3-block SpMV + p.Ap partials)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": SPMV_TRAFFIC_BYTES if n == 55 else None,
-                     "traffic_source": "profiles/r01b_spmv_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH+WRITE)",
+                     "traffic_source": "profiles/r01h_spmv_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH+WRITE)",
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
                      "launches_timed": spmv_launches, "padded_matrix_bytes": info["matrix_bytes"],
                      "csr_equivalent_GBs": (info["nnz_blocks"] * 9 * 12 + 2 * ndof * 8) / (avg_ms * 1e-3) / 1e9},
