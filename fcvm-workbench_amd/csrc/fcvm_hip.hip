@@ -960,6 +960,31 @@ int fcvm_mg_restrict(fcvm_ctx *c, const double *r0, double *r1) {
     return 0;
 }
 
+int fcvm_mg_restrict_weighted(fcvm_ctx *c, const double *r0, const double *wgt, double *r1) {
+    NEED(c && c->mg_topo && wgt, "fcvm_mg_restrict_weighted: no multigrid hierarchy / weights");
+    hipLaunchKernelGGL(k_restrict, dim3((unsigned)cdiv(c->nc, 256)), dim3(256), 0, c->stream, c->nc, c->d_c2f, c->d_mptr, c->d_mids,
+                       c->d_fixmask, r0, r1, (const double *)nullptr, wgt);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_mg_prolong_add(fcvm_ctx *c, const double *e1, const double *z0, double *z) {
+    NEED(c && c->mg_topo, "fcvm_mg_prolong_add: no multigrid hierarchy");
+    hipLaunchKernelGGL(k_prolong_add, dim3((unsigned)cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_pa, c->d_pb, c->d_fixmask, e1,
+                       z0, z);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_pcg_update_xr_z0(fcvm_ctx *c, const double *alpha_dev, const double *p, const double *q, double *x, double *r, double *z0,
+                          double weight) {
+    NEED(c && c->have_mesh && alpha_dev, "fcvm_pcg_update_xr_z0: no mesh");
+    hipLaunchKernelGGL(k_update_xr_z0_ext, dim3((unsigned)cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, alpha_dev, p, q, x, r, c->d_dinv,
+                       z0, weight);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
 int fcvm_mg_prolong(fcvm_ctx *c, const double *e1, double *d0) {
     NEED(c && c->mg_topo, "fcvm_mg_prolong: no multigrid hierarchy");
     hipLaunchKernelGGL(k_prolong, dim3((unsigned)cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_pa, c->d_pb, c->d_fixmask, e1,

@@ -140,22 +140,26 @@ __global__ __launch_bounds__(256) void k_assemble_tet4_rows(int64_t nslots, cons
 
 // r1 = M1 P^T M0 r0 : coarse node c collects its own fine node and half of every mid-side node
 // on an edge ending in c (CSR lists, fixed order -> deterministic); M = free-dof masks.
+// wgt (optional, per fine dof): partition-of-unity weights of the multi-GPU cycle (1 / ranks holding the node).
 __global__ __launch_bounds__(256) void k_restrict(int64_t nc, const int32_t *__restrict__ c2f,
                                                   const int64_t *__restrict__ mptr, const int32_t *__restrict__ mids,
                                                   const uint8_t *__restrict__ fixmask0, const double *__restrict__ r0,
-                                                  double *__restrict__ r1, const double *__restrict__ done) {
+                                                  double *__restrict__ r1, const double *__restrict__ done,
+                                                  const double *__restrict__ wgt = nullptr) {
     if (done && *done != 0.0) return;
     int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= nc) return;
     const int64_t f = c2f[c];
     const int fm = fixmask0[f];
     double a0 = r0[3 * f], a1 = r0[3 * f + 1], a2 = r0[3 * f + 2];
+    if (wgt) { a0 *= wgt[3 * f]; a1 *= wgt[3 * f + 1]; a2 *= wgt[3 * f + 2]; }
     for (int64_t q = mptr[c]; q < mptr[c + 1]; q++) {
         const int64_t m = mids[q];
         const int mm = fixmask0[m];
-        if (!(mm & 1)) a0 += 0.5 * r0[3 * m];
-        if (!(mm & 2)) a1 += 0.5 * r0[3 * m + 1];
-        if (!(mm & 4)) a2 += 0.5 * r0[3 * m + 2];
+        const double w0 = wgt ? wgt[3 * m] : 1.0, w1 = wgt ? wgt[3 * m + 1] : 1.0, w2 = wgt ? wgt[3 * m + 2] : 1.0;
+        if (!(mm & 1)) a0 += 0.5 * w0 * r0[3 * m];
+        if (!(mm & 2)) a1 += 0.5 * w1 * r0[3 * m + 1];
+        if (!(mm & 4)) a2 += 0.5 * w2 * r0[3 * m + 2];
     }
     r1[3 * c] = (fm & 1) ? 0.0 : a0;
     r1[3 * c + 1] = (fm & 2) ? 0.0 : a1;
@@ -180,6 +184,40 @@ __global__ __launch_bounds__(256) void k_prolong(int64_t nn, const int32_t *__re
     d0[3 * i] = (fm & 1) ? 0.0 : v0;
     d0[3 * i + 1] = (fm & 2) ? 0.0 : v1;
     d0[3 * i + 2] = (fm & 4) ? 0.0 : v2;
+}
+
+// z = z0 + M0 P M1 e1 (the additive cycle's second half without the inner products: multi-GPU host code)
+__global__ __launch_bounds__(256) void k_prolong_add(int64_t nn, const int32_t *__restrict__ pa, const int32_t *__restrict__ pb,
+                                                     const uint8_t *__restrict__ fixmask0, const double *__restrict__ e1,
+                                                     const double *__restrict__ z0, double *__restrict__ z) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nn) return;
+    const int64_t a = pa[i], b = pb[i];
+    const int fm = fixmask0[i];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double v = (a >= 0 && !((fm >> c) & 1)) ? 0.5 * (e1[3 * a + c] + e1[3 * b + c]) : 0.0;
+        z[3 * i + c] = z0[3 * i + c] + v;
+    }
+}
+
+// x += alpha p ; r -= alpha q ; z0 = w * Dinv r, alpha read from device memory (multi-GPU host code)
+__global__ __launch_bounds__(256) void k_update_xr_z0_ext(int64_t nn, const double *__restrict__ alpha_ptr, const double *__restrict__ p,
+                                                          const double *__restrict__ q, double *__restrict__ x, double *__restrict__ r,
+                                                          const double *__restrict__ dinv, double *__restrict__ z0, double w) {
+    const double alpha = *alpha_ptr;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nn) return;
+    double rn[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        x[3 * i + c] += alpha * p[3 * i + c];
+        rn[c] = r[3 * i + c] - alpha * q[3 * i + c];
+        r[3 * i + c] = rn[c];
+    }
+    double a0, a1, a2;
+    apply_dinv(dinv + i * 9, rn[0], rn[1], rn[2], a0, a1, a2);
+    z0[3 * i] = w * a0; z0[3 * i + 1] = w * a1; z0[3 * i + 2] = w * a2;
 }
 
 // start of a Chebyshev sweep from the zero vector: x = 0, r = b, d = c0 * Dinv b

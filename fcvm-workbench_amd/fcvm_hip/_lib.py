@@ -69,6 +69,9 @@ SIGNATURES = {
     "fcvm_mg_cheb_step": [_vp, _int, _vp, _vp, _vp, _vp, _f64, _f64, _int],
     "fcvm_mg_restrict": [_vp, _vp, _vp],
     "fcvm_mg_prolong": [_vp, _vp, _vp],
+    "fcvm_mg_restrict_weighted": [_vp, _vp, _vp, _vp],
+    "fcvm_mg_prolong_add": [_vp, _vp, _vp, _vp],
+    "fcvm_pcg_update_xr_z0": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64],
     "fcvm_mg_l2_restrict": [_vp, _vp, _vp],
     "fcvm_mg_l2_solve": [_vp, _vp, _vp],
     "fcvm_gemv_f32": [_vp, _i64, _i64, _i64, _vp, _vp, _vp],

@@ -286,13 +286,17 @@ class DistBackend:
             return u, info
         thresh = rtol * rtol * bb_h
         it = 0
+        fused = self.mg is not None and self.mg.ready and self.mg.additive
         while it < maxit:
             for _ in range(self.check_every):
                 self.spmv(p, q)
-                alpha = rz / self.dot_t(p.t, q.t)
-                x.addcmul_(p.t, alpha)                      # x += alpha p   (alpha stays on the device)
-                r.addcmul_(q.t, -alpha)                     # r -= alpha q
-                self.precond(TVec(r), z)
+                alpha = rz / self.dot_t(p.t, q.t)           # stays on the device
+                if fused:
+                    self.mg.update_and_vcycle(alpha, p, q, TVec(x), TVec(r), z)
+                else:
+                    x.addcmul_(p.t, alpha)                  # x += alpha p
+                    r.addcmul_(q.t, -alpha)                 # r -= alpha q
+                    self.precond(TVec(r), z)
                 rz_new = self.dot_t(r, z.t)
                 torch.addcmul(z.t, p.t, rz_new / rz, out=p.t)  # p = z + beta p
                 rz = rz_new
@@ -366,7 +370,7 @@ class DistMG:
         self.c2f = c2f
         n0, n1 = 3 * part.nn, 3 * self.nc
         mk = lambda n: TVec(torch.zeros(n, dtype=torch.float64, device=dev))  # noqa: E731
-        self.r0, self.d0, self.t0, self.rw = mk(n0), mk(n0), mk(n0), mk(n0)
+        self.r0, self.d0, self.t0 = mk(n0), mk(n0), mk(n0)
         self.r1, self.x1, self.rr1, self.d1, self.t1 = mk(n1), mk(n1), mk(n1), mk(n1), mk(n1)
         self.topo = True
 
@@ -548,15 +552,10 @@ class DistMG:
             else:
                 self.ops.mg_cheb_step(level, None, x, r, d, 0.0, 0.0, False)
 
-    def vcycle(self, b, x):
-        """x = M^-1 b (consistent fine vectors)"""
+    def _coarse(self, r):
+        """x1 = M1^-1 P^T (w0 r): weighted restriction of a consistent fine vector, level-1 / aggregate cycle"""
         be = self.be
-        if self.additive:   # x = w c0 Dinv b + P M1^-1 P^T b : no fine-level SpMV / exchange in the preconditioner
-            self.ops.mg_cheb_init(0, b, x, self.r0, self.d0, self.weight * self.ch0.c0)
-        else:
-            self._from_zero(0, self.ch0, self.k0, b, x, self.r0, self.d0, self.t0)
-        torch.mul(self.r0.t, self.w0, out=self.rw.t)
-        self.ops.mg_restrict(self.rw, self.r1)
+        self.ops.mg_restrict_weighted(r, TVec(self.w0), self.r1)
         self.ex1.interface_sum(self.r1.t, 3)
         self._from_zero(1, self.ch1, self.k1s, self.r1, self.x1, self.rr1, self.d1, self.t1)
         torch.mul(self.rr1.t, self.own1, out=self.t1.t)       # owner-weighted: shared nodes count once
@@ -568,12 +567,25 @@ class DistMG:
         be._allreduce(self.e2.t)                              # ... gathered (sum with zeros: bit-identical on every rank)
         self.ops.mg_l2_prolong(self.e2, self.d1)
         self._post(1, self.ch1, self.k1s, self.x1, self.rr1, self.d1, self.t1)
-        if self.additive:
-            self.ops.mg_prolong(self.x1, self.t0)
-            torch.add(self.d0.t, self.t0.t, out=x.t)
+
+    def vcycle(self, b, x):
+        """x = M^-1 b (consistent fine vectors)"""
+        if self.additive:   # x = w c0 Dinv b + P M1^-1 P^T b : no fine-level SpMV / exchange in the preconditioner
+            self.ops.mg_cheb_init(0, b, x, self.r0, self.d0, self.weight * self.ch0.c0)
+            self._coarse(b)
+            self.ops.mg_prolong_add(self.x1, self.d0, x)
             return
+        self._from_zero(0, self.ch0, self.k0, b, x, self.r0, self.d0, self.t0)
+        self._coarse(self.r0)
         self.ops.mg_prolong(self.x1, self.d0)
         self._post(0, self.ch0, self.k0, x, self.r0, self.d0, self.t0)
+
+    def update_and_vcycle(self, alpha, p, q, x, r, z):
+        """additive cycle fused with the PCG update: x += alpha p, r -= alpha q, z = w c0 Dinv r + P M1^-1 P^T r
+        (alpha: 1-element device tensor)"""
+        self.ops.pcg_update_xr_z0(alpha, p, q, x, r, self.d0, self.weight * self.ch0.c0)
+        self._coarse(r)
+        self.ops.mg_prolong_add(self.x1, self.d0, z)
 
 
 class DistModel:
@@ -722,6 +734,18 @@ class HipLocalOps:
     def mg_restrict(self, r0, r1):
         from ._lib import call
         call("fcvm_mg_restrict", self.c.h, r0.ptr, r1.ptr)
+
+    def mg_restrict_weighted(self, r0, w, r1):
+        from ._lib import call
+        call("fcvm_mg_restrict_weighted", self.c.h, r0.ptr, w.ptr, r1.ptr)
+
+    def mg_prolong_add(self, e1, z0, z):
+        from ._lib import call
+        call("fcvm_mg_prolong_add", self.c.h, e1.ptr, z0.ptr, z.ptr)
+
+    def pcg_update_xr_z0(self, alpha, p, q, x, r, z0, weight):
+        from ._lib import call
+        call("fcvm_pcg_update_xr_z0", self.c.h, alpha.data_ptr(), p.ptr, q.ptr, x.ptr, r.ptr, z0.ptr, float(weight))
 
     def mg_set_level2(self, nagg, agg, Z, rows):
         """rows: this rank's row block [m, 6 nagg] of the aggregate-level inverse (torch f64 on the device);

@@ -219,6 +219,12 @@ int fcvm_mg_cheb_step(fcvm_ctx *c, int level, const double *t, double *x, double
                       double cdr, int update_d);
 int fcvm_mg_restrict(fcvm_ctx *c, const double *r0, double *r1);
 int fcvm_mg_prolong(fcvm_ctx *c, const double *e1, double *d0);
+/* fused forms for the host-driven (multi-GPU) additive cycle: restriction with per-dof partition-of-unity weights;
+ * z = z0 + M0 P M1 e1; x += alpha p, r -= alpha q, z0 = weight * Dinv r with alpha read from device memory */
+int fcvm_mg_restrict_weighted(fcvm_ctx *c, const double *r0, const double *wgt, double *r1);
+int fcvm_mg_prolong_add(fcvm_ctx *c, const double *e1, const double *z0, double *z);
+int fcvm_pcg_update_xr_z0(fcvm_ctx *c, const double *alpha_dev, const double *p, const double *q, double *x, double *r,
+                          double *z0, double weight);
 /* aggregate level after fcvm_mg_set_level2: r2 = Z^T r1 (f64[n2]), e2 = A2inv r2, d1 = Z e2 */
 int fcvm_mg_l2_restrict(fcvm_ctx *c, const double *r1, double *r2);
 int fcvm_mg_l2_solve(fcvm_ctx *c, const double *r2, double *e2);

@@ -156,6 +156,21 @@ class OracleLocalOps:
         self._hier()
         r1.set(self.Pm.T @ r0.get())
 
+    def mg_restrict_weighted(self, r0, w, r1):
+        self._hier()
+        r1.set(self.Pm.T @ (w.get() * r0.get()))
+
+    def mg_prolong_add(self, e1, z0, z):
+        self._hier()
+        z.set(z0.get() + self.Pm @ e1.get())
+
+    def pcg_update_xr_z0(self, alpha, p, q, x, r, z0, weight):
+        a = float(alpha.item())
+        x.set(x.get() + a * p.get())
+        rn = r.get() - a * q.get()
+        r.set(rn)
+        z0.set(weight * self._dinv(0, rn))
+
     def mg_set_level2(self, nagg, agg, Z, rows):
         nc = len(agg)
         ii = np.repeat(np.arange(nc), 18)
