@@ -119,7 +119,7 @@ struct MatConst {
 // GATHER = false: internal forces scattered into qin with f64 atomics.  GATHER = true: the element's 10 x 3 nodal
 // forces go to fe[e][30] and k_gather_qin sums them per node in a fixed order (bitwise reproducible residuals).
 template <bool LD, bool GATHER>
-__global__ __launch_bounds__(256) void k_update_stress(int64_t ne, const int32_t *__restrict__ el,
+__global__ __launch_bounds__(256, 4) void k_update_stress(int64_t ne, const int32_t *__restrict__ el,
                                                        const double *__restrict__ coord,
                                                        const double *__restrict__ disp_new,
                                                        const double *__restrict__ du,
