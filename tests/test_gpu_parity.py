@@ -274,14 +274,15 @@ def test_cube_analysis_matches_oracle(orc):
     assert np.array_equal(res["crip"], o["crip"])
 
 
-def test_size_independent_properties_100k_elements(gpu_ctx):
-    """Properties that need no oracle, at a size the CPU restatement would take minutes for:
-    K symmetric (<x,Ky> = <y,Kx>), rigid translations in the null space of the unconstrained K,
-    elastic internal force == K du, PCG solution satisfies K u = f."""
+@pytest.mark.parametrize("cells", [26, 55], ids=["105k", "998k-bench-size"])
+def test_size_independent_properties(gpu_ctx, cells):
+    """Properties that need no oracle, at sizes the CPU restatement would take minutes / hours for (55 = the mesh of
+    the benchmark, 998,250 tet10): K symmetric (<x,Ky> = <y,Kx>), rigid translations in the null space of the
+    unconstrained K, elastic internal force == K du, PCG solution satisfies K u = f."""
     from fcvm_hip import meshgen
     from fcvm_hip.loads import Loads
     from fcvm_hip.solver import GpuModel
-    el, xyz = meshgen.cube_tet10(26, 26, 26, 50.0, 50.0, 50.0)
+    el, xyz = meshgen.cube_tet10(cells, cells, cells, 50.0, 50.0, 50.0)
     mat = (210000.0, 0.3, 7.8e-6)
     m = GpuModel(el, xyz, mat, {}, Loads())
     c = m.ctx
