@@ -616,6 +616,34 @@ def test_u100_column_full_gnly_flow_matches_reference_files():
         assert sig3(val, tab[:, col]), "column %d" % col
 
 
+def test_plate_with_hole_configs1_and_north_star_sizes():
+    """BASELINE configs[1] (Plate_with_hole_Example, ~50k tet10, reference control file, 10 arc-length steps to collapse)
+    and the north-star size (1.0 M tet10) on the GPU.  No oracle at these sizes; checked are the physics the
+    reference's own .out shows (load history of its 395-element mesh within 5 % row by row, same plateau) and mesh
+    independence of the collapse load (50k vs 1M within 0.3 %)."""
+    import json
+    import os
+    from conftest import REPO
+    from fcvm_hip import examples
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import GpuModel, calc_disp
+    ref = json.load(open(os.path.join(REPO, "tests", "golden", "plate_with_hole.json")))
+    tab = np.array(ref["out_table"])
+    out = {}
+    for h in (4.0, 1.45):
+        case = examples.plate_with_hole(h)
+        m = GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"], Loads(ufaces=case["ufaces"], uloads=case["uloads"]))
+        res = calc_disp(m, case["ctl"])
+        out[h] = (m.ne, np.asarray(res["lout"]), np.asarray(res["un"]))
+        assert np.allclose(res["loadsum"], ref["loadsum"], atol=1e-6)
+        m.ctx.close()
+    (ne_a, la, ua), (ne_b, lb, ub) = out[4.0], out[1.45]
+    assert 45000 < ne_a < 55000 and 0.95e6 < ne_b < 1.1e6
+    assert len(la) == len(lb) == len(tab) == 11
+    assert np.abs(la[1:] / tab[1:, 4] - 1.0).max() < 0.05 and np.abs(ua[1:4] / tab[1:4, 5] - 1.0).max() < 0.02
+    assert abs(la[-1] / lb[-1] - 1.0) < 3e-3 and 0.215 < lb[-1] < 0.23
+
+
 def test_reruns_are_bitwise_identical():
     """No floating-point atomics anywhere on the path (row-owner assembly, per-element internal forces gathered in a fixed
     order, fixed-order reductions in the solver): two runs of an elastoplastic analysis in fresh contexts give bitwise
