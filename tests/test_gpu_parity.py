@@ -644,6 +644,26 @@ def test_plate_with_hole_configs1_and_north_star_sizes():
     assert abs(la[-1] / lb[-1] - 1.0) < 3e-3 and 0.215 < lb[-1] < 0.23
 
 
+def test_command_line_entry_point(tmp_path):
+    """python -m fcvm_hip <document> --control DIR --output DIR: the reference's Embankment document and control file in,
+    the reference's .out file out (model name = the document's label, as in the macro)."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    from conftest import REPO
+    g, meta = load_golden("embankment")
+    with open(tmp_path / (meta["name"] + ".inp"), "w") as f:
+        f.write("\n".join(meta["inp"]) + "\n")
+    doc = tmp_path / "model.FCStd"
+    shutil.copyfile(os.path.join(REPO, "tests", "golden", "embankment.FCStd"), doc)
+    env = dict(os.environ, PYTHONPATH=os.path.join(REPO, "fcvm-workbench_amd"))
+    r = subprocess.run([sys.executable, "-m", "fcvm_hip", str(doc), "--control", str(tmp_path), "--output", str(tmp_path)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(tmp_path / (meta["name"] + ".out")).read() == open(os.path.join(REPO, "tests", "golden", "embankment_reference.out")).read()
+
+
 def test_reruns_are_bitwise_identical():
     """No floating-point atomics anywhere on the path (row-owner assembly, per-element internal forces gathered in a fixed
     order, fixed-order reductions in the solver): two runs of an elastoplastic analysis in fresh contexts give bitwise
