@@ -59,7 +59,9 @@ def run(args, ctl, material, traction, rtol, hbm_peak, cpu_baseline):
     backend = os.environ.get("FCVM_DIST_BACKEND", "gloo" if share_gpu else "nccl")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
-    dist.init_process_group(backend, rank=rank, world_size=world)
+    import datetime
+    # a stuck collective should end the run with an error well inside the caller's time limit, not sit out the default 10 min
+    dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=4))
     try:
         model, be, ops = build_rank_model(rank, world, args.cells, material, traction, dev_index, device)
         stats = {}
