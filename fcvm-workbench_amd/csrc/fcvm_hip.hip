@@ -731,11 +731,9 @@ int fcvm_host_pattern_check(int64_t ne, int64_t nn, const int64_t *elNodes, int6
     for (int64_t e = 0; e < ne; e++)
         for (int a = 0; a < 10; a++)
             for (int b = 0; b < 10; b++) {
-                uint64_t off = p.emap[e * 100 + a * 10 + b];
-                int64_t j0 = (int64_t)(off & 1), rest = (int64_t)(off >> 1);
-                int64_t l = rest % SLICE, jp = rest / SLICE;  // jp = (sptr/2 + j/2) * 9
-                if (jp % 9 != 0) { bad++; continue; }
-                int64_t jglob = (jp / 9) * 2 + j0;  // = sptr[s] + j
+                const uint32_t em = p.emap[e * 100 + a * 10 + b];   // packed: pair row << 7 | lane << 1 | (j & 1)
+                const int64_t j0 = em & 1, l = (em >> 1) & 63;
+                const int64_t jglob = (int64_t)(em >> 7) * 2 + j0;  // = sptr[s] + j
                 int64_t slot = p.slotof[el[e * 10 + a]];
                 int64_t s = slot / SLICE;
                 if (slot % SLICE != l || jglob < p.sptr[s] || jglob >= p.sptr[s + 1]) { bad++; continue; }

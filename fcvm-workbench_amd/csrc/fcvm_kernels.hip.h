@@ -97,6 +97,11 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
 
 __device__ __forceinline__ void atomic_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
 
+// packed block location (Pattern::pack_offset) -> offset in doubles of component 0 of the 3x3 block
+__device__ __forceinline__ int64_t unpack_offset(uint32_t em) {
+    return (((int64_t)(em >> 7) * 576 + (int64_t)((em >> 1) & 63)) << 1) + (int64_t)(em & 1);
+}
+
 __device__ __forceinline__ void atomic_fmax_f64(double *addr, double v) {
     unsigned long long *a = (unsigned long long *)addr;
     unsigned long long old = *a, assumed;
@@ -403,7 +408,7 @@ __device__ __forceinline__ void assemble_element_row(int64_t e, const int a, con
                 }
         }
         const int fb = fixmask[nd[b]];
-        double *dst = vals + em[b];
+        double *dst = vals + unpack_offset(em[b]);
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const bool rfix = (fa >> r) & 1;
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(256) void k_diag_get(int64_t nn, const uint32_t *__
                                                   const double *__restrict__ vals, double *__restrict__ dblk) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nn) return;
-    const double *v = vals + diagoff[i];
+    const double *v = vals + unpack_offset(diagoff[i]);
 #pragma unroll
     for (int c = 0; c < 9; c++) dblk[i * 9 + c] = v[c * 128];
 }
@@ -1089,7 +1094,7 @@ __device__ __forceinline__ void geometric_element_row(const int64_t e, const int
             to_global(xsi[g], d0, d1, d2, g0, g1, g2);
             v += w[g] * (sa[g][0] * g0 + sa[g][1] * g1 + sa[g][2] * g2);
         }
-        double *dst = vals_g + em[b];
+        double *dst = vals_g + unpack_offset(em[b]);
         dst[0] += v;
         dst[4 * 128] += v;
         dst[8 * 128] += v;

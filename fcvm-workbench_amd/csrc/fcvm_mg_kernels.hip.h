@@ -96,7 +96,7 @@ __device__ __forceinline__ void tet4_element_row(const int64_t e, const int a, c
             }
         }
         const int fb = fixmask1[nd[b]];
-        double *dst = vals + emap4[(e * 4 + a) * 4 + b];
+        double *dst = vals + unpack_offset(emap4[(e * 4 + a) * 4 + b]);
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const bool rfix = (fa >> r) & 1;

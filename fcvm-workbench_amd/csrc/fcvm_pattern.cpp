@@ -107,8 +107,8 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
         p.sptr[s + 1] = p.sptr[s] + m;
     }
     p.nslots = p.sptr[p.nslices] * SLICE;
-    if ((uint64_t)p.value_count() >= (1ull << 32))
-        throw std::runtime_error("matrix too large for 32-bit slot offsets on one GPU");
+    if ((uint64_t)(p.sptr[p.nslices] / 2) >= (1ull << 25))
+        throw std::runtime_error("matrix too large for the packed 32-bit block locations (2^25 pair rows)");
     p.cols.assign(p.nslots, 0);
     parallel_for(p.nslices, nt, [&](int64_t b, int64_t e, int) {
         for (int64_t s = b; s < e; s++) {
@@ -134,7 +134,7 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
                 int64_t slot = p.slotof[nd[a]];
                 for (int c = 0; c < npe; c++) {
                     int64_t j = std::lower_bound(rb, re, nd[c]) - rb;
-                    p.emap[(k * npe + a) * npe + c] = (uint32_t)p.block_offset(slot, j);
+                    p.emap[(k * npe + a) * npe + c] = p.pack_offset(slot, j);
                 }
             }
         }
@@ -144,7 +144,7 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
         const int32_t *rb = p.colidx.data() + p.rowptr[i];
         const int32_t *re = p.colidx.data() + p.rowptr[i + 1];
         int64_t j = std::lower_bound(rb, re, (int32_t)i) - rb;
-        p.diagoff[i] = (uint32_t)p.block_offset(p.slotof[i], j);
+        p.diagoff[i] = p.pack_offset(p.slotof[i], j);
     }
 }
 

@@ -23,8 +23,8 @@ struct Pattern {
     std::vector<int32_t> rownode;   // [nslices*64] node of slot, -1 = padding
     std::vector<int32_t> slotof;    // [nn] slot (slice*64+lane) of node
     std::vector<int32_t> cols;      // [sptr[nslices]*64] column node per (slice, j, lane)
-    std::vector<uint32_t> emap;     // [ne*npe*npe] offset (in doubles) of component 0 of block (a,b)
-    std::vector<uint32_t> diagoff;  // [nn] offset of component 0 of the diagonal block
+    std::vector<uint32_t> emap;     // [ne*npe*npe] packed location of component 0 of block (a,b), see pack_offset
+    std::vector<uint32_t> diagoff;  // [nn] packed location of component 0 of the diagonal block
     std::vector<int64_t> nptr;      // [nn+1] node -> element incidence (CSR)
     std::vector<int32_t> nel;       // [ne*npe] element << 4 | local node index, ascending elements per node
 
@@ -34,6 +34,13 @@ struct Pattern {
         return (uint64_t)(((sptr[s] / 2 + (j >> 1)) * 9 * SLICE + l) * 2 + (j & 1));
     }
     int64_t value_count() const { return sptr[nslices] * SLICE * 9; }
+    // 32-bit form of block_offset for the device tables: pair row P = sptr[s]/2 + j/2 (25 bits), lane (6 bits), j & 1;
+    // offset in doubles = ((P * 9 * 64) + lane) * 2 + (j & 1)  (unpack_offset in fcvm_kernels.hip.h).  2^25 pair rows
+    // = 309 GB of values: beyond the HBM of one GPU.
+    inline uint32_t pack_offset(int64_t slot, int64_t j) const {
+        int64_t s = slot / SLICE, l = slot % SLICE;
+        return (uint32_t)((((uint64_t)(sptr[s] / 2 + (j >> 1))) << 7) | ((uint64_t)l << 1) | (uint64_t)(j & 1));
+    }
 };
 
 // elnodes0: 0-based int32 [ne*10].  Throws std::runtime_error on bad input.
