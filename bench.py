@@ -162,6 +162,7 @@ def run_single(args):
         drv.iteration()
     c.sync()
     dt = time.perf_counter() - t0
+    stream_gbs = c.membench(3 << 30)
     spmv_launches = stats["spmv_launches"] - s0["spmv_launches"]
     spmv_ms = stats["spmv_ms"] - s0["spmv_ms"]
     pcg_its = stats["pcg_iterations"] - s0["pcg_iterations"]
@@ -192,6 +193,9 @@ def run_single(args):
                      "traffic_source": "profiles/r01h_spmv_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH+WRITE)",
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
                      "launches_timed": spmv_launches, "padded_matrix_bytes": info["matrix_bytes"],
+                     # what this box's HBM delivers for a plain 16 B/lane streaming read of a fresh 3 GB buffer, measured right
+                     # after the timed region (boxes of the pool differ: 5.1 .. 6.3 TB/s): context for `frac`
+                     "stream_read_GBs_this_box": stream_gbs,
                      "csr_equivalent_GBs": (info["nnz_blocks"] * 9 * 12 + 2 * ndof * 8) / (avg_ms * 1e-3) / 1e9},
     }
     if not args.no_cpu:

@@ -842,6 +842,34 @@ int fcvm_host_pattern_check(int64_t ne, int64_t nn, const int64_t *elNodes, int6
     return 0;
 }
 
+int fcvm_membench(fcvm_ctx *c, int64_t nbytes, double out[2]) {
+    NEED(c && nbytes >= (1 << 20), "fcvm_membench: bad arguments");
+    hipStream_t s = c->stream;
+    const int64_t n2 = nbytes / 16;
+    double2 *buf = nullptr;
+    double *sink = nullptr;
+    if (dalloc(&buf, n2) || dalloc(&sink, 1)) return 1;
+    HCHK(hipMemsetAsync(buf, 0, (size_t)n2 * 16, s));
+    hipEvent_t e0, e1;
+    HCHK(hipEventCreate(&e0));
+    HCHK(hipEventCreate(&e1));
+    const unsigned grid = 256 * 16;   // 16 workgroups of 4 waves per CU
+    for (int k = 0; k < 3; k++) hipLaunchKernelGGL(k_stream_read, dim3(grid), dim3(256), 0, s, n2, buf, sink);
+    HCHK(hipEventRecord(e0, s));
+    for (int k = 0; k < 10; k++) hipLaunchKernelGGL(k_stream_read, dim3(grid), dim3(256), 0, s, n2, buf, sink);
+    HCHK(hipEventRecord(e1, s));
+    HCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HCHK(hipEventElapsedTime(&ms, e0, e1));
+    out[0] = (double)n2 * 16.0 / (ms / 10.0 * 1e-3) / 1e9;   // GB/s read
+    out[1] = ms / 10.0;
+    HCHK(hipEventDestroy(e0));
+    HCHK(hipEventDestroy(e1));
+    dfree(buf);
+    dfree(sink);
+    return 0;
+}
+
 int fcvm_mg_coarse_nodes(fcvm_ctx *c, double *coord1, uint8_t *fixmask1) {
     NEED(c && c->mg_topo, "fcvm_mg_coarse_nodes: assemble with the multigrid preconditioner first");
     HCHK(hipMemcpyAsync(coord1, c->d_coord1, sizeof(double) * 3 * c->nc, hipMemcpyDeviceToHost, c->stream));

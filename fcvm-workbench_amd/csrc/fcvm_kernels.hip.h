@@ -1044,6 +1044,16 @@ __global__ __launch_bounds__(256) void k_to_f32(int64_t n, const double *__restr
     if (i < n) o[i] = (float)a[i];
 }
 
+// plain streaming read (16 B per lane, nontemporal, grid-stride): the HBM rate a box delivers, for comparison with the SpMV
+__global__ __launch_bounds__(256) void k_stream_read(int64_t n2, const double2 *__restrict__ a, double *__restrict__ out) {
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+        const double2 v = ld_val<true>(a + i);
+        s += v.x + v.y;
+    }
+    if (s == 1.2345e300) out[0] = s;   // never true: keeps the loads alive
+}
+
 // geometric stiffness of calcTSM(nstep = 1), fcVM.py:1002-1006: Kg_ab = (sum_gp w ga . sigma . gb) I3, scattered into a
 // second value array that shares the pattern of the stiffness matrix.  One lane per matrix row walking its elements
 // (as k_assemble_rows: plain read-modify-writes in a fixed order, no atomics).

@@ -74,6 +74,7 @@ SIGNATURES = {
     "fcvm_pcg_update_xr_z0": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64],
     "fcvm_mg_l2_restrict": [_vp, _vp, _vp],
     "fcvm_mg_l2_solve": [_vp, _vp, _vp],
+    "fcvm_membench": [_vp, _i64, _vp],
     "fcvm_gemv_f32": [_vp, _i64, _i64, _i64, _vp, _vp, _vp],
     "fcvm_mg_l2_prolong": [_vp, _vp, _vp],
 }

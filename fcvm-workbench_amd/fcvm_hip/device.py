@@ -221,6 +221,12 @@ class Context:
         call("fcvm_solve_timing", self.h, t)
         return dict(spmv_ms=t[0], total_ms=t[1], spmv_timed=int(t[2]), coarse_spmv=int(t[3]))
 
+    def membench(self, nbytes=3 << 30):
+        """streaming read rate (GB/s) of a fresh buffer: what the HBM of this GPU delivers right now"""
+        o = (C.c_double * 2)()
+        call("fcvm_membench", self.h, int(nbytes), o)
+        return o[0]
+
     def set_precond(self, mode="mg", k0=1, k1=60, alpha0=4.0, alpha1=1000.0):
         """mode "bj": 3x3 block-Jacobi; "mg": p-multigrid V-cycle (takes effect at the next assemble)."""
         call("fcvm_set_precond", self.h, 1 if mode == "mg" else 0, int(k0), int(k1), float(alpha0), float(alpha1))

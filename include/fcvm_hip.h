@@ -193,6 +193,10 @@ int fcvm_mg_set_level2(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg
 int fcvm_mg_set_level2_spd(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg, const int64_t *aoff,
                            const double *Z, const double *A2, int k1s, double alpha1s);
 
+/* diagnostic: streaming read rate of a freshly allocated buffer of nbytes (16 B per lane, nontemporal): out[0] = GB/s,
+ * out[1] = ms per pass.  The HBM rate this GPU delivers right now, to put a measured SpMV time into perspective. */
+int fcvm_membench(fcvm_ctx *c, int64_t nbytes, double out[2]);
+
 /* host-only self check of the sparsity pattern builder (no GPU needed): out[0]=nnz blocks,
  * out[1]=padded slots, out[2]=slices, out[3]=max row length, out[4]=number of violated invariants
  * (must be 0), out[5]=value count, out[6]=sum of slice lengths */
