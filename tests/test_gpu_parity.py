@@ -644,6 +644,32 @@ def test_plate_with_hole_configs1_and_north_star_sizes():
     assert abs(la[-1] / lb[-1] - 1.0) < 3e-3 and 0.215 < lb[-1] < 0.23
 
 
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the driver's keys plus the roofline / cpu_baseline objects (tiny workload)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--cells", "10", "--steps", "2", "--warmup", "1", "--no-plate"],
+                       capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["unit"] == "elements*GP/s" and "workload" in d["config"] and "model" not in d["config"]
+    ro = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in ro, k
+    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+
+
 def test_command_line_entry_point(tmp_path):
     """python -m fcvm_hip <document> --control DIR --output DIR: the reference's Embankment document and control file in,
     the reference's .out file out (model name = the document's label, as in the macro)."""
