@@ -44,7 +44,9 @@ struct fcvm_ctx {
     double E = 0, nu = 0, rho = 0;
     // device mesh
     int32_t *d_el = nullptr, *d_cols = nullptr, *d_rownode = nullptr, *d_noce = nullptr;
-    int64_t *d_sptr = nullptr;
+    int64_t *d_sptr = nullptr, *d_gptr = nullptr, *d_gptr1 = nullptr;   // slice lengths; gang tables (Pattern::chunk)
+    uint32_t *d_goff = nullptr, *d_goff1 = nullptr;
+    int spmv_gang = 64;          // slices per gang of interleaved chunks (FCVM_SPMV_GANG; 1 = slice after slice)
     uint32_t *d_emap = nullptr, *d_diagoff = nullptr;
     int64_t *d_nptr = nullptr, *d_nptr1 = nullptr;   // node -> element incidence for the row-owner assembly (fine / tet4 level)
     int32_t *d_nel = nullptr, *d_nel1 = nullptr;
@@ -64,7 +66,7 @@ struct fcvm_ctx {
     double last_spmv_ms = 0, last_total_ms = 0;
     double row_spread = 0.0;
     bool row_order_morton = false;
-    int spmv_variant = 4;  // 0 plain, 1 nontemporal matrix loads, 2 unroll x2, 3 nt + x2, 4 nt + x4 (fastest measured)
+    int spmv_variant = 4;  // 0 plain loads, one pair per iteration; 4 nontemporal matrix loads, four pairs in flight (shipped)
     double last_spmv_timed = 0;
     // host copies needed to build the coarse level
     std::vector<int32_t> h_el;
@@ -136,40 +138,49 @@ struct MatView {
     const int32_t *cols;
     const double *vals;
     const int32_t *rownode;
+    ChunkMap cm;
     const float *vals32 = nullptr;  // optional FP32 copy of the values (coarse multigrid level)
 };
-static MatView fine_view(const fcvm_ctx *c) { return {c->pat.nslices, c->nb_spmv, c->d_sptr, c->d_cols, c->d_vals, c->d_rownode}; }
-static MatView coarse_view(const fcvm_ctx *c) {
-    return {c->pat1.nslices, c->nb_spmv1, c->d_sptr1, c->d_cols1, c->d_vals1, c->d_rownode1, c->mg_fp32 ? c->d_vals1f : nullptr};
+static ChunkMap chunk_map(const Pattern &p, const int64_t *d_gptr, const uint32_t *d_goff) {
+    int sh = -1;
+    if (p.gang > 1)
+        for (sh = 0; (1 << sh) < p.gang; sh++) {}
+    return {sh, d_gptr, d_goff};
 }
+static MatView fine_view(const fcvm_ctx *c) {
+    return {c->pat.nslices, c->nb_spmv, c->d_sptr, c->d_cols, c->d_vals, c->d_rownode, chunk_map(c->pat, c->d_gptr, c->d_goff)};
+}
+static MatView coarse_view(const fcvm_ctx *c) {
+    return {c->pat1.nslices, c->nb_spmv1, c->d_sptr1, c->d_cols1, c->d_vals1, c->d_rownode1, chunk_map(c->pat1, c->d_gptr1, c->d_goff1),
+            c->mg_fp32 ? c->d_vals1f : nullptr};
+}
+
+#define FCVM_SPMV_LAUNCH(DOT_, NT_, UN_, V2_, EPI_, vals_, epi_)                                                                      \
+    do {                                                                                                                            \
+        if (m.cm.gshift >= 0)                                                                                                       \
+            hipLaunchKernelGGL((k_spmv<DOT_, NT_, UN_, V2_, EPI_, true>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols, \
+                               (const V2_ *)(vals_), m.rownode, x, y, part, done, epi_, m.cm);                                       \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((k_spmv<DOT_, NT_, UN_, V2_, EPI_, false>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols, \
+                               (const V2_ *)(vals_), m.rownode, x, y, part, done, epi_, m.cm);                                       \
+    } while (0)
 
 template <bool DOT>
 static void launch_spmv_t(fcvm_ctx *c, const MatView &m, const double *x, double *y, double *part, const double *done) {
     dim3 grid((unsigned)m.nb), block(64 * c->spmv_spw);
     if (m.vals32) {  // FP32-stored matrix, FP64 vectors and accumulation
-        hipLaunchKernelGGL((k_spmv<DOT, false, 4, float2>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols,
-                           (const float2 *)m.vals32, m.rownode, x, y, part, done, ChebEpi{});
+        FCVM_SPMV_LAUNCH(DOT, false, 4, float2, 0, m.vals32, ChebEpi{});
         return;
     }
-#define FCVM_SPMV_ARGS m.nslices, m.nb, m.sptr, m.cols, (const double2 *)m.vals, m.rownode, x, y, part, done, ChebEpi{}
-    switch (c->spmv_variant) {
-        case 0: hipLaunchKernelGGL((k_spmv<DOT, false, 1>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
-        case 1: hipLaunchKernelGGL((k_spmv<DOT, true, 1>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
-        case 2: hipLaunchKernelGGL((k_spmv<DOT, false, 2>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
-        case 3: hipLaunchKernelGGL((k_spmv<DOT, true, 2>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
-        default: hipLaunchKernelGGL((k_spmv<DOT, true, 4>), grid, block, 0, c->stream, FCVM_SPMV_ARGS); break;
-    }
-#undef FCVM_SPMV_ARGS
+    if (c->spmv_variant == 0) FCVM_SPMV_LAUNCH(DOT, false, 1, double2, 0, m.vals, ChebEpi{});
+    else FCVM_SPMV_LAUNCH(DOT, true, 4, double2, 0, m.vals, ChebEpi{});
 }
 // SpMV t = A d fused with a Chebyshev smoother step on the same rows (see ChebEpi); nothing is written but epi's vectors
-static void launch_spmv_cheb(fcvm_ctx *c, const MatView &m, const double *d, const double *done, const ChebEpi &epi) {
+static void launch_spmv_cheb(fcvm_ctx *c, const MatView &m, const double *x, const double *done, const ChebEpi &epi) {
     dim3 grid((unsigned)m.nb), block(64 * c->spmv_spw);
-    if (m.vals32)
-        hipLaunchKernelGGL((k_spmv<false, false, 4, float2, 1>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols,
-                           (const float2 *)m.vals32, m.rownode, d, (double *)nullptr, (double *)nullptr, done, epi);
-    else
-        hipLaunchKernelGGL((k_spmv<false, true, 4, double2, 1>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols,
-                           (const double2 *)m.vals, m.rownode, d, (double *)nullptr, (double *)nullptr, done, epi);
+    double *y = nullptr, *part = nullptr;
+    if (m.vals32) FCVM_SPMV_LAUNCH(false, false, 4, float2, 1, m.vals32, epi);
+    else FCVM_SPMV_LAUNCH(false, true, 4, double2, 1, m.vals, epi);
 }
 static void launch_gemv_f32(fcvm_ctx *c, const double *r2, double *e2, const double *done) {
     hipLaunchKernelGGL(k_gemv_f32x4, dim3((unsigned)cdiv(c->n2, 16)), dim3(256), 0, c->stream, c->n2, c->n2, (c->n2 + 3) / 4 * 4,
@@ -306,6 +317,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_SPMV_VARIANT")) c->spmv_variant = atoi(v);
     if (const char *v = getenv("FCVM_ASSEMBLE_ATOMIC")) c->assemble_atomic = atoi(v);
     if (const char *v = getenv("FCVM_QIN_ATOMIC")) c->qin_atomic = atoi(v);
+    if (const char *v = getenv("FCVM_SPMV_GANG")) c->spmv_gang = std::max(1, atoi(v));
     if (const char *v = getenv("FCVM_SPMV_SPW")) c->spmv_spw = std::min(4, std::max(1, atoi(v)));   // slices (waves) per workgroup
     if (const char *v = getenv("FCVM_MG_ADDITIVE")) c->mg_additive = atoi(v);
     if (const char *v = getenv("FCVM_MG_FP32")) c->mg_fp32 = atoi(v);
@@ -318,7 +330,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
 }
 
 static void free_mesh(fcvm_ctx *c) {
-    dfree(c->d_el); dfree(c->d_cols); dfree(c->d_rownode); dfree(c->d_noce); dfree(c->d_sptr);
+    dfree(c->d_el); dfree(c->d_cols); dfree(c->d_rownode); dfree(c->d_noce); dfree(c->d_sptr); dfree(c->d_gptr); dfree(c->d_goff);
     dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
     dfree(c->d_nptr); dfree(c->d_nel); dfree(c->d_fe); dfree(c->d_part_vol);
     dfree(c->d_vals); dfree(c->d_vals_g); dfree(c->d_dblk); dfree(c->d_dinv); dfree(c->d_r); dfree(c->d_z); dfree(c->d_p);
@@ -405,7 +417,7 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
         std::vector<int32_t> order;
         if (use_morton) order = morton_order(nn, nocoord);
         c->row_order_morton = use_morton;
-        build_pattern(ne, nn, el.data(), c->pat, nt, win, 10, use_morton ? order.data() : nullptr);
+        build_pattern(ne, nn, el.data(), c->pat, nt, win, 10, use_morton ? order.data() : nullptr, c->spmv_gang);
     } catch (const std::exception &ex) {
         return fail(std::string("fcvm_set_mesh: ") + ex.what());
     }
@@ -422,7 +434,8 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
         dalloc(&c->d_diagoff, nn) || dalloc(&c->d_fixmask, nn) || dalloc(&c->d_coord, nn * 3) ||
         dalloc(&c->d_fixval, nn * 3) || dalloc(&c->d_vals, p.value_count()) || dalloc(&c->d_dblk, nn * 9) ||
         dalloc(&c->d_dinv, nn * 9) || dalloc(&c->d_r, nn * 3) || dalloc(&c->d_z, nn * 3) || dalloc(&c->d_p, nn * 3) ||
-        dalloc(&c->d_q, nn * 3) || dalloc(&c->d_nptr, nn + 1) || dalloc(&c->d_nel, ne * 10) || dalloc(&c->d_part_vol, p.nslices))
+        dalloc(&c->d_q, nn * 3) || dalloc(&c->d_nptr, nn + 1) || dalloc(&c->d_nel, ne * 10) || dalloc(&c->d_part_vol, p.nslices) ||
+        dalloc(&c->d_gptr, (int64_t)p.gptr.size()) || dalloc(&c->d_goff, (int64_t)p.goff.size()))
         return 1;
     c->nb_vec = cdiv(nn, 256);
     c->nb_spmv = cdiv(p.nslices, c->spmv_spw);
@@ -436,6 +449,8 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     HCHK(hipMemcpyAsync(c->d_rownode, p.rownode.data(), sizeof(int32_t) * p.nslices * SLICE, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_noce, noce.data(), sizeof(int32_t) * nn, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_sptr, p.sptr.data(), sizeof(int64_t) * (p.nslices + 1), hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_gptr, p.gptr.data(), sizeof(int64_t) * p.gptr.size(), hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_goff, p.goff.data(), sizeof(uint32_t) * p.goff.size(), hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_emap, p.emap.data(), sizeof(uint32_t) * ne * 100, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_diagoff, p.diagoff.data(), sizeof(uint32_t) * nn, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_nptr, p.nptr.data(), sizeof(int64_t) * (nn + 1), hipMemcpyHostToDevice, s));
@@ -815,30 +830,44 @@ int fcvm_host_pattern_check(int64_t ne, int64_t nn, const int64_t *elNodes, int6
     }
     Pattern p;
     try {
-        build_pattern(ne, nn, el.data(), p, 4, SORT_WINDOW);
+        int gang = 64;
+        if (const char *v = getenv("FCVM_SPMV_GANG")) gang = std::max(1, atoi(v));
+        build_pattern(ne, nn, el.data(), p, 4, SORT_WINDOW, 10, nullptr, gang);
     } catch (const std::exception &ex) {
         return fail(std::string("fcvm_host_pattern_check: ") + ex.what());
     }
     int64_t bad = 0;
-    // every element block must land on a slot whose column is the block's column node and whose
-    // row slot belongs to the block's row node
+    // every element block must land on a chunk of its row's slice whose column entry is the block's column node,
+    // in the lane of the block's row node; no two blocks of a row may share a location
     for (int64_t e = 0; e < ne; e++)
         for (int a = 0; a < 10; a++)
             for (int b = 0; b < 10; b++) {
-                const uint32_t em = p.emap[e * 100 + a * 10 + b];   // packed: pair row << 7 | lane << 1 | (j & 1)
-                const int64_t j0 = em & 1, l = (em >> 1) & 63;
-                const int64_t jglob = (int64_t)(em >> 7) * 2 + j0;  // = sptr[s] + j
-                int64_t slot = p.slotof[el[e * 10 + a]];
-                int64_t s = slot / SLICE;
-                if (slot % SLICE != l || jglob < p.sptr[s] || jglob >= p.sptr[s + 1]) { bad++; continue; }
-                if (p.cols[jglob * SLICE + l] != el[e * 10 + b]) bad++;
+                const uint32_t em = p.emap[e * 100 + a * 10 + b];   // packed: chunk << 7 | lane << 1 | (j & 1)
+                const int64_t j0 = em & 1, l = (em >> 1) & 63, chunk = em >> 7;
+                const int64_t slot = p.slotof[el[e * 10 + a]], s = slot / SLICE;
+                if (slot % SLICE != l) { bad++; continue; }
+                const int64_t np = (p.sptr[s + 1] - p.sptr[s]) / 2;
+                bool found = false;
+                for (int64_t pp = 0; pp < np && !found; pp++) found = p.chunk(s, pp) == chunk;
+                if (!found) { bad++; continue; }
+                if (p.cols[(chunk * 2 + j0) * SLICE + l] != el[e * 10 + b]) bad++;
             }
+    {   // the chunks of all slices tile [0, total) exactly once
+        std::vector<uint8_t> seen(p.sptr[p.nslices] / 2, 0);
+        for (int64_t s = 0; s < p.nslices; s++)
+            for (int64_t pp = 0; pp < (p.sptr[s + 1] - p.sptr[s]) / 2; pp++) {
+                const int64_t ch = p.chunk(s, pp);
+                if (ch < 0 || ch >= (int64_t)seen.size() || seen[ch]) bad++;
+                else seen[ch] = 1;
+            }
+        for (uint8_t v : seen) bad += v ? 0 : 1;
+    }
     for (int64_t i = 0; i < nn; i++) {
         int64_t slot = p.slotof[i];
         if (slot < 0 || p.rownode[slot] != i) bad++;
     }
     out[0] = p.nnzb; out[1] = p.nslots; out[2] = p.nslices; out[3] = p.maxlen; out[4] = bad;
-    out[5] = p.value_count(); out[6] = p.sptr[p.nslices]; out[7] = 0;
+    out[5] = p.value_count(); out[6] = p.sptr[p.nslices]; out[7] = p.gang;
     return 0;
 }
 

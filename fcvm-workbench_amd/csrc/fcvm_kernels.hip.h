@@ -586,14 +586,22 @@ struct ChebEpi {
 };
 __device__ __forceinline__ void apply_dinv(const double *d, double r0, double r1, double r2, double &z0, double &z1, double &z2);
 
-template <bool DOT, bool NT, int UNROLL, class V2 = double2, int EPI = 0>
-__global__ __launch_bounds__(256) void k_spmv(int64_t nslices, int64_t nblocks, const int64_t *__restrict__ sptr,
+// Where the chunks (block pairs) of the slices live: see Pattern::chunk (fcvm_pattern.h).  gshift < 0: plain order,
+// chunk(s, p) = sptr[s] / 2 + p.  Otherwise gangs of 1 << gshift slices with interleaved chunks.
+struct ChunkMap {
+    int gshift;
+    const int64_t *gptr;
+    const uint32_t *goff;
+};
+
+template <bool DOT, bool NT, int UNROLL, class V2 = double2, int EPI = 0, bool GANGED = false>
+__global__ __launch_bounds__(256, (sizeof(V2) == 16 ? 4 : 1)) void k_spmv(int64_t nslices, int64_t nblocks, const int64_t *__restrict__ sptr,
                                               const int32_t *__restrict__ cols,
                                               const V2 *__restrict__ vals,
                                               const int32_t *__restrict__ rownode,
                                               const double *__restrict__ x, double *__restrict__ y,
                                               double *__restrict__ partial, const double *__restrict__ done,
-                                              ChebEpi epi) {
+                                              ChebEpi epi, ChunkMap cm) {
     __shared__ double sh[4];
     if (done && *done != 0.0) return;
     // XCD-aware remap: workgroups b, b+8, b+16.. share an XCD (and its L2); give each XCD a
@@ -602,41 +610,56 @@ __global__ __launch_bounds__(256) void k_spmv(int64_t nslices, int64_t nblocks, 
     const int64_t q = nblocks >> 3, r = nblocks & 7, xcd = b & 7;
     const int64_t wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     const int lane = threadIdx.x & 63;
-    const int64_t s = wg * (blockDim.x >> 6) + (threadIdx.x >> 6);   // blockDim.x / 64 slices per workgroup
+    // one slice per wavefront: the slice number is wave-uniform (scalar registers, scalar loads of the slice tables)
+    const int64_t s = wg * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double y0 = 0.0, y1 = 0.0, y2 = 0.0;
     int node = -1;
     if (s < nslices) {
         const int64_t jb = sptr[s], je = sptr[s + 1];
-        const int32_t *cp = cols + jb * 64 + lane;
-        const V2 *vp = vals + (jb >> 1) * (9 * 64) + lane;
         int64_t np = (je - jb) >> 1;
+        // chunk(s, p) = cbase + (GANGED ? go[p] : p)
+        int64_t cbase = jb >> 1;
+        const uint32_t *go = nullptr;
+        if (GANGED) {
+            const int64_t g = s >> cm.gshift;
+            cbase = (sptr[g << cm.gshift] >> 1) + (s - (g << cm.gshift));
+            go = cm.goff + cm.gptr[g];
+        }
+        const int32_t *cp = cols + cbase * 128 + lane;
+        const V2 *vp = vals + cbase * (9 * 64) + lane;
+#define FCVM_CP(o) (cp + (int64_t)(o) * 128)
+#define FCVM_VP(o) (vp + (int64_t)(o) * (9 * 64))
+        int64_t p = 0;
         if (UNROLL == 4) {
             double z0 = 0.0, z1 = 0.0, z2 = 0.0, u0 = 0.0, u1 = 0.0, u2 = 0.0, w0 = 0.0, w1 = 0.0, w2 = 0.0;
-            for (; np >= 4; np -= 4) {
-                spmv_pair<NT, V2>(cp, vp, x, y0, y1, y2);
-                spmv_pair<NT, V2>(cp + 128, vp + 9 * 64, x, z0, z1, z2);
-                spmv_pair<NT, V2>(cp + 256, vp + 18 * 64, x, u0, u1, u2);
-                spmv_pair<NT, V2>(cp + 384, vp + 27 * 64, x, w0, w1, w2);
-                cp += 512;
-                vp += 36 * 64;
+            // chunk offsets of the next unrolled iteration are fetched (scalar loads) before this one's matrix loads
+            uint32_t o0 = GANGED ? go[0] : 0u, o1 = GANGED ? go[1] : 1u, o2 = GANGED ? go[2] : 2u, o3 = GANGED ? go[3] : 3u;
+            for (; np - p >= 4; p += 4) {
+                const uint32_t n0 = GANGED ? go[p + 4] : (uint32_t)(p + 4), n1 = GANGED ? go[p + 5] : (uint32_t)(p + 5),
+                               n2 = GANGED ? go[p + 6] : (uint32_t)(p + 6), n3 = GANGED ? go[p + 7] : (uint32_t)(p + 7);
+                spmv_pair<NT, V2>(FCVM_CP(o0), FCVM_VP(o0), x, y0, y1, y2);
+                spmv_pair<NT, V2>(FCVM_CP(o1), FCVM_VP(o1), x, z0, z1, z2);
+                spmv_pair<NT, V2>(FCVM_CP(o2), FCVM_VP(o2), x, u0, u1, u2);
+                spmv_pair<NT, V2>(FCVM_CP(o3), FCVM_VP(o3), x, w0, w1, w2);
+                o0 = n0; o1 = n1; o2 = n2; o3 = n3;
             }
             y0 += z0 + u0 + w0; y1 += z1 + u1 + w1; y2 += z2 + u2 + w2;
         }
         if (UNROLL >= 2) {
             double z0 = 0.0, z1 = 0.0, z2 = 0.0;
-            for (; np >= 2; np -= 2) {
-                spmv_pair<NT, V2>(cp, vp, x, y0, y1, y2);
-                spmv_pair<NT, V2>(cp + 128, vp + 9 * 64, x, z0, z1, z2);
-                cp += 256;
-                vp += 18 * 64;
+            for (; np - p >= 2; p += 2) {
+                const uint32_t o0 = GANGED ? go[p] : (uint32_t)p, o1 = GANGED ? go[p + 1] : (uint32_t)(p + 1);
+                spmv_pair<NT, V2>(FCVM_CP(o0), FCVM_VP(o0), x, y0, y1, y2);
+                spmv_pair<NT, V2>(FCVM_CP(o1), FCVM_VP(o1), x, z0, z1, z2);
             }
             y0 += z0; y1 += z1; y2 += z2;
         }
-        for (; np > 0; np--) {
-            spmv_pair<NT, V2>(cp, vp, x, y0, y1, y2);
-            cp += 128;
-            vp += 9 * 64;
+        for (; p < np; p++) {
+            const uint32_t o0 = GANGED ? go[p] : (uint32_t)p;
+            spmv_pair<NT, V2>(FCVM_CP(o0), FCVM_VP(o0), x, y0, y1, y2);
         }
+#undef FCVM_CP
+#undef FCVM_VP
         node = rownode[s * 64 + lane];
         if (EPI == 0) {
             if (node >= 0) {
