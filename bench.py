@@ -37,29 +37,37 @@ CTL = dict(sig_yield=120.0, grav_x=0.0, grav_y=0.0, grav_z=0.0, nstep=2, iterat_
 MATERIAL = (210000.0, 0.3, 7.8e-6)
 TRACTION = (20.0, 0.0, 200.0)
 RTOL = 1.0e-10
-# HBM bytes per SpMV launch of the 55^3-cell cube from the PMC counters (separate rocprofv3 passes, gfx950 correction
-# applied), see profiles/r01h_spmv_pmc.txt; bench.py cannot collect counters itself
-SPMV_TRAFFIC_BYTES = 3.163e9
+# HBM bytes per SpMV launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes, gfx950
+# correction applied): bench.py cannot collect counters itself, so the measured figure is kept in a file together with
+# the layout it was measured for (cells, storage order, kernel variant, commit) and is only quoted when this run uses
+# that layout; otherwise `traffic` is null.
+SPMV_TRAFFIC_FILE = os.path.join(REPO, "profiles", "spmv_traffic.json")
 
 
-def cpu_baseline(cells=12, iters=5):
-    """The oracle (C restatement + SuperLU in place of CHOLMOD) on this host: one Newton iteration =
-    back substitution + update_stress_load, factorisation outside (as in the reference)."""
-    from fcvm_hip import meshgen
-    from oracle import oracle as orc
-    case = meshgen.cube_case(cells, l=100.0, traction=TRACTION)
-    el, xyz = case["elNodes"], case["nocoord"]
-    loads = orc.Loads(ufaces=case["ufaces"], uloads=case["uloads"])
-    mat = np.array(MATERIAL)
+def spmv_traffic(cells, gang, variant):
+    try:
+        t = json.load(open(SPMV_TRAFFIC_FILE))
+    except (OSError, ValueError):
+        return None, None
+    for e in t.get("measurements", []):
+        if e.get("cells") == cells and e.get("gang") == gang and e.get("variant") == variant:
+            return float(e["traffic_bytes_per_launch"]), "%s (commit %s, %s)" % (e.get("source", SPMV_TRAFFIC_FILE), e.get("commit", "?"), e.get("method", ""))
+    return None, None
+
+
+def _cpu_newton_iterations(orc, el, xyz, mat, fix, loads, iters):
+    """The oracle (C restatement + SuperLU in place of CHOLMOD) on this host: one Newton iteration = back substitution +
+    update_stress_load, factorisation outside (the reference factorises once, fcVM.py:1121).  Returns
+    (seconds per iteration, calcGSM seconds, factorisation seconds)."""
     ne, nn = len(el), len(xyz)
     t0 = time.perf_counter()
-    stm, row, col, glv, modf, *_ = orc.calcGSM(el, xyz, mat, case["fix"], (0, 0, 0), loads)
+    stm, row, col, glv, modf, *_ = orc.calcGSM(el, xyz, mat, fix, (0, 0, 0), loads)
     t_asm = time.perf_counter() - t0
     t0 = time.perf_counter()
     factor = orc._Direct(stm, row, col, 3 * nn)
     t_fac = time.perf_counter() - t0
     fixdof = np.ones(3 * nn)
-    fixdof[list(case["fix"].keys())] = 0.0
+    fixdof[list(fix.keys())] = 0.0
     ue = factor(fixdof * glv + modf)
     du = 0.5 * ue
     sig_old, sig_new, sig_test = np.zeros(24 * ne), np.zeros(24 * ne), np.zeros(24 * ne)
@@ -77,12 +85,48 @@ def cpu_baseline(cells=12, iters=5):
         orc.update_stress_load(el, xyz, mat, sy, disp, du, sig_old, sig_new, sig_test, qin, 0.0, False, pgp)
         r = fixdof * (0.5 * glv - qin)
         np.linalg.norm(r)
-    dt = (time.perf_counter() - t0) / iters
-    return {"value": ne * 4 / dt, "unit": "elements*GP/s", "cores": 1, "kind": "port",
-            "newton_iterations_per_s": 1.0 / dt,
-            "sample": "%d^3-cell cube = %d tet10 / %d dof, %d Newton iterations (SuperLU back-substitution + "
-                      "update_stress_load); one-time calcGSM %.1fs and factorisation %.1fs excluded" %
-                      (cells, ne, 3 * nn, iters, t_asm, t_fac)}
+    return (time.perf_counter() - t0) / iters, t_asm, t_fac
+
+
+def cpu_baseline(cells=12, iters=5, plate_h=6.0):
+    """cpu_baseline leg (rank 0, N = 1): the oracle port timed on this host's cores on two bounded samples --
+    (1) the benchmark's own cube geometry at 12^3 cells (the 1 M-element cube would take SuperLU hours), in the
+    headline unit; (2) `same_mesh`: the reference's Plate_with_hole_Example (BASELINE configs[1] / north-star geometry,
+    shipped control file) on ONE mesh for both sides: CPU Newton iterations/s from the oracle, GPU Newton iterations/s from
+    the whole collapse analysis through the C-ABI, so that the north_star's ">= 10x CPU Newton iterations/s" reads off
+    one object.  plate_h = 6.0 gives 16,830 tet10 (17 s of factorisation); bench.py --cpu-plate-h 4.0 runs the
+    configs[1] size (48,600 tet10: 160 s of factorisation, profiles/r02_same_mesh_48k.json holds such a run)."""
+    from fcvm_hip import examples, meshgen
+    from oracle import oracle as orc
+    case = meshgen.cube_case(cells, l=100.0, traction=TRACTION)
+    el, xyz = case["elNodes"], case["nocoord"]
+    ne, nn = len(el), len(xyz)
+    dt, t_asm, t_fac = _cpu_newton_iterations(orc, el, xyz, np.array(MATERIAL), case["fix"],
+                                              orc.Loads(ufaces=case["ufaces"], uloads=case["uloads"]), iters)
+    out = {"value": ne * 4 / dt, "unit": "elements*GP/s", "cores": 1, "kind": "port",
+           "newton_iterations_per_s": 1.0 / dt,
+           "sample": "%d^3-cell cube = %d tet10 / %d dof, %d Newton iterations (SuperLU back-substitution + "
+                     "update_stress_load); one-time calcGSM %.1fs and factorisation %.1fs excluded" %
+                     (cells, ne, 3 * nn, iters, t_asm, t_fac)}
+    if plate_h:
+        pc = examples.plate_with_hole(plate_h)
+        pdt, p_asm, p_fac = _cpu_newton_iterations(orc, pc["elNodes"], pc["nocoord"], pc["material"], pc["fix"],
+                                                   orc.Loads(ufaces=pc["ufaces"], uloads=pc["uloads"]), iters)
+        gpu = plate_with_hole_run(plate_h)
+        out["same_mesh"] = {
+            "workload": "%s: %d tet10 / %d dof" % (pc["name"], len(pc["elNodes"]), 3 * len(pc["nocoord"])),
+            "cpu_newton_iterations_per_s": 1.0 / pdt, "cpu_cores": 1, "cpu_kind": "port",
+            "cpu_sample": "%d Newton iterations (SuperLU back-substitution + update_stress_load)" % iters,
+            "cpu_one_time_s": {"calcGSM": p_asm, "factorisation": p_fac},
+            "gpu_newton_iterations_per_s": gpu["newton_iterations_per_s"],
+            "gpu_sample": "whole analysis (%d steps, %d Newton iterations, %d linear solves, %.1f PCG iterations per solve) incl. "
+                          "assembly and multigrid set-up: %.2f s" % (gpu["steps"], gpu["newton_iterations"], gpu["linear_solves"],
+                                                                   gpu["pcg_iterations_per_solve"], gpu["analysis_s"]),
+            "gpu_over_cpu_newton_iterations_per_s": gpu["newton_iterations_per_s"] * pdt,
+            "gpu_whole_analysis_s": gpu["analysis_s"],
+            "cpu_whole_analysis_estimate_s": p_asm + p_fac + gpu["newton_iterations"] * pdt,
+            "collapse_load_factor_gpu": gpu["collapse_load_factor"]}
+    return out
 
 
 def precond_label(c):
@@ -174,6 +218,7 @@ def run_single(args):
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     plastic = int(drv.pgp.get().sum())
     ne = model.ne
+    traffic, traffic_src = spmv_traffic(n, info["gang"], info["spmv_variant"])
     out = {
         "metric": "elements*GP/s over Newton iterations (Newton iterations/s x elements x 4 GP), 1M tet10",
         "value": ne * 4 * args.steps / dt, "unit": "elements*GP/s", "n_gpus": 1, "steps": args.steps,
@@ -189,8 +234,8 @@ def run_single(args):
         "setup_s": {"mesh": t_mesh, "pattern_host": model.t_pattern, "assembly_plus_preconditioner_hierarchy": t_setup},
         "roofline": {"bound": "hbm", "kernel": "k_spmv<true> (sliced-ELL 3x3-block SpMV + p.Ap partials)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": SPMV_TRAFFIC_BYTES if n == 55 else None,
-                     "traffic_source": "profiles/r01h_spmv_pmc.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 2*FETCH+WRITE)",
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "storage_order": "sliced-ELL 64 x 3x3 blocks, gangs of %d slices with interleaved 9 KiB chunks" % info["gang"],
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
                      "launches_timed": spmv_launches, "padded_matrix_bytes": info["matrix_bytes"],
                      # what this box's HBM delivers for a plain 16 B/lane streaming read of a fresh 3 GB buffer, measured right
@@ -199,7 +244,7 @@ def run_single(args):
                      "csr_equivalent_GBs": (info["nnz_blocks"] * 9 * 12 + 2 * ndof * 8) / (avg_ms * 1e-3) / 1e9},
     }
     if not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline()
+        out["cpu_baseline"] = cpu_baseline(plate_h=args.cpu_plate_h)
     if not args.no_plate:
         del drv, model
         out["north_star_workload"] = plate_with_hole_run(args.plate_h)
@@ -213,11 +258,34 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cells", type=int, default=55, help="cells per cube edge (55 -> 998,250 tet10)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-plate-h", type=float, default=6.0,
+                    help="mesh size of the same-mesh CPU / GPU comparison on Plate_with_hole (6.0 -> 16,830 tet10; 4.0 -> 48,600 = configs[1]; 0 = skip)")
     ap.add_argument("--no-plate", action="store_true", help="skip the Plate_with_hole whole-analysis leg (N = 1 only)")
     ap.add_argument("--plate-h", type=float, default=1.45, help="mesh size of the Plate_with_hole leg (1.45 -> 1,006,434 tet10)")
     args = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU under
+        # torch.distributed.run) BEFORE anything in this process touches the GPU, and pass their exit code on
+        import socket
+        import subprocess
+        import torch
+        have = torch.cuda.device_count()   # counting devices does not initialise HIP
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) visible" % (args.gpus, have))
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    world = int(world_env) if world_env is not None else 1
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d does not match WORLD_SIZE=%d; launch with `python -m torch.distributed.run "
+                         "--nnodes=1 --nproc-per-node %d bench.py --gpus %d ...` or plain `python bench.py --gpus %d`"
+                         % (args.gpus, world, args.gpus, args.gpus, args.gpus))
+    if world > 1:
         from fcvm_hip import dist_bench
         dist_bench.run(args, CTL, MATERIAL, TRACTION, RTOL, HBM_PEAK_GBS, cpu_baseline)
     else:

@@ -14,6 +14,7 @@
 
 #include "fcvm_kernels.hip.h"
 #include "fcvm_mg_kernels.hip.h"
+#include "fcvm_assemble_lds.hip.h"
 #include "fcvm_pattern.h"
 
 using namespace fcvm;
@@ -46,11 +47,17 @@ struct fcvm_ctx {
     int32_t *d_el = nullptr, *d_cols = nullptr, *d_rownode = nullptr, *d_noce = nullptr;
     int64_t *d_sptr = nullptr, *d_gptr = nullptr, *d_gptr1 = nullptr;   // slice lengths; gang tables (Pattern::chunk)
     uint32_t *d_goff = nullptr, *d_goff1 = nullptr;
-    int spmv_gang = 64;          // slices per gang of interleaved chunks (FCVM_SPMV_GANG; 1 = slice after slice)
+    int spmv_gang = 1;           // slices per gang of interleaved chunks (FCVM_SPMV_GANG); 1 = slice after slice: measured equal (r02a)
     uint32_t *d_emap = nullptr, *d_diagoff = nullptr;
     int64_t *d_nptr = nullptr, *d_nptr1 = nullptr;   // node -> element incidence for the row-owner assembly (fine / tet4 level)
     int32_t *d_nel = nullptr, *d_nel1 = nullptr;
     int assemble_atomic = 0;     // FCVM_ASSEMBLE_ATOMIC=1: the (element, row) scatter kernel with f64 atomics
+    int assemble_lds = 1;        // rows accumulated in LDS, one coalesced write per value (FCVM_ASSEMBLE_LDS=0: global read-modify-writes)
+    // work items of k_assemble_lds (slice * 4 + quarter), grouped by the LDS a quarter slice needs
+    static constexpr int ASM_BUCKETS = 5;
+    int32_t *d_asm_items = nullptr;
+    int64_t asm_count[ASM_BUCKETS] = {0, 0, 0, 0, 0}, asm_first[ASM_BUCKETS] = {0, 0, 0, 0, 0};
+    bool asm_lds_ok = false;
     int qin_atomic = 0;          // FCVM_QIN_ATOMIC=1: internal forces scattered with f64 atomics
     double *d_fe = nullptr;      // [ne][10][3] element nodal forces of the last stress update
     double *d_part_vol = nullptr;  // [nslices] volume partials of the row-owner assembly
@@ -292,6 +299,53 @@ static int tune_matrix_placement(fcvm_ctx *c) {
     return 0;
 }
 
+// slice-length classes of k_assemble_lds: a quarter slice (16 rows) needs 16 * (9 len + 1) * 8 bytes of LDS
+static const int64_t ASM_LEN_LIMIT[fcvm_ctx::ASM_BUCKETS] = {20, 28, 40, 68, 138};   // 23 / 32 / 46 / 78 / 159 KiB
+
+static int build_asm_items(fcvm_ctx *c) {
+    const Pattern &p = c->pat;
+    c->asm_lds_ok = false;
+    dfree(c->d_asm_items);
+    if (p.gang != 1 || p.maxlen + 1 > ASM_LEN_LIMIT[fcvm_ctx::ASM_BUCKETS - 1]) return 0;   // block locations must be cbase + pair; rows must fit the LDS
+    std::vector<int32_t> items[fcvm_ctx::ASM_BUCKETS];
+    NEED(p.nslices < (int64_t(1) << 29), "too many slices for 32-bit assembly work items");
+    for (int64_t s = 0; s < p.nslices; s++) {
+        const int64_t len = p.sptr[s + 1] - p.sptr[s];
+        int b = 0;
+        while (len > ASM_LEN_LIMIT[b]) b++;
+        for (int q = 0; q < 4; q++) items[b].push_back((int32_t)(s * 4 + q));
+    }
+    std::vector<int32_t> all;
+    for (int b = 0; b < fcvm_ctx::ASM_BUCKETS; b++) {
+        c->asm_first[b] = (int64_t)all.size();
+        c->asm_count[b] = (int64_t)items[b].size();
+        all.insert(all.end(), items[b].begin(), items[b].end());
+    }
+    if (dalloc(&c->d_asm_items, (int64_t)all.size())) return 1;
+    HCHK(hipMemcpyAsync(c->d_asm_items, all.data(), sizeof(int32_t) * all.size(), hipMemcpyHostToDevice, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+    for (int b = 0; b < fcvm_ctx::ASM_BUCKETS; b++) {   // dynamic LDS beyond 64 KiB has to be requested per kernel
+        const int bytes = (int)asm_lds_bytes(ASM_LEN_LIMIT[b]);
+        if (bytes <= 64 * 1024) continue;
+        HCHK(hipFuncSetAttribute((const void *)k_assemble_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HCHK(hipFuncSetAttribute((const void *)k_assemble_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    }
+    c->asm_lds_ok = true;
+    return 0;
+}
+
+template <bool TANGENT>
+static void launch_assemble_lds(fcvm_ctx *c, const double *disp, const double *sig, const uint8_t *pgp, const MatConst &mc,
+                                const double grav[3], double *glv, double *modf, double *xgp, double *vol_part, int penalty_bc) {
+    for (int b = 0; b < fcvm_ctx::ASM_BUCKETS; b++) {
+        if (!c->asm_count[b]) continue;
+        hipLaunchKernelGGL(k_assemble_lds<TANGENT>, dim3((unsigned)c->asm_count[b]), dim3(64), (size_t)asm_lds_bytes(ASM_LEN_LIMIT[b]), c->stream,
+                           c->d_asm_items + c->asm_first[b], c->d_sptr, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord, disp, c->d_fixmask,
+                           c->d_fixval, c->d_emap, sig, pgp, mc, grav[0], grav[1], grav[2], c->d_vals, glv, modf, xgp,
+                           vol_part ? vol_part + c->asm_first[b] : nullptr, penalty_bc);
+    }
+}
+
 extern "C" {
 
 const char *fcvm_last_error(void) { return g_err.c_str(); }
@@ -316,6 +370,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     c->device = device;
     if (const char *v = getenv("FCVM_SPMV_VARIANT")) c->spmv_variant = atoi(v);
     if (const char *v = getenv("FCVM_ASSEMBLE_ATOMIC")) c->assemble_atomic = atoi(v);
+    if (const char *v = getenv("FCVM_ASSEMBLE_LDS")) c->assemble_lds = atoi(v);
     if (const char *v = getenv("FCVM_QIN_ATOMIC")) c->qin_atomic = atoi(v);
     if (const char *v = getenv("FCVM_SPMV_GANG")) c->spmv_gang = std::max(1, atoi(v));
     if (const char *v = getenv("FCVM_SPMV_SPW")) c->spmv_spw = std::min(4, std::max(1, atoi(v)));   // slices (waves) per workgroup
@@ -332,7 +387,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
 static void free_mesh(fcvm_ctx *c) {
     dfree(c->d_el); dfree(c->d_cols); dfree(c->d_rownode); dfree(c->d_noce); dfree(c->d_sptr); dfree(c->d_gptr); dfree(c->d_goff);
     dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
-    dfree(c->d_nptr); dfree(c->d_nel); dfree(c->d_fe); dfree(c->d_part_vol);
+    dfree(c->d_nptr); dfree(c->d_nel); dfree(c->d_fe); dfree(c->d_part_vol); dfree(c->d_asm_items);
     dfree(c->d_vals); dfree(c->d_vals_g); dfree(c->d_dblk); dfree(c->d_dinv); dfree(c->d_r); dfree(c->d_z); dfree(c->d_p);
     dfree(c->d_q); dfree(c->d_part_vec); dfree(c->d_part_spmv); dfree(c->d_part_misc); dfree(c->d_pidx);
     mg_free(c);
@@ -434,7 +489,7 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
         dalloc(&c->d_diagoff, nn) || dalloc(&c->d_fixmask, nn) || dalloc(&c->d_coord, nn * 3) ||
         dalloc(&c->d_fixval, nn * 3) || dalloc(&c->d_vals, p.value_count()) || dalloc(&c->d_dblk, nn * 9) ||
         dalloc(&c->d_dinv, nn * 9) || dalloc(&c->d_r, nn * 3) || dalloc(&c->d_z, nn * 3) || dalloc(&c->d_p, nn * 3) ||
-        dalloc(&c->d_q, nn * 3) || dalloc(&c->d_nptr, nn + 1) || dalloc(&c->d_nel, ne * 10) || dalloc(&c->d_part_vol, p.nslices) ||
+        dalloc(&c->d_q, nn * 3) || dalloc(&c->d_nptr, nn + 1) || dalloc(&c->d_nel, ne * 10) || dalloc(&c->d_part_vol, 4 * p.nslices) ||
         dalloc(&c->d_gptr, (int64_t)p.gptr.size()) || dalloc(&c->d_goff, (int64_t)p.goff.size()))
         return 1;
     c->nb_vec = cdiv(nn, 256);
@@ -462,6 +517,7 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     HCHK(hipStreamSynchronize(s));
     c->ne = ne;
     c->nn = nn;
+    if (build_asm_items(c)) return 1;
     if (tune_matrix_placement(c)) return 1;
     // the element->slot map is only needed on the device from here on
     c->pat.emap.clear();
@@ -504,12 +560,13 @@ int fcvm_set_fix(fcvm_ctx *c, int64_t nfix, const int64_t *dofs, const double *v
     return 0;
 }
 
-int fcvm_pattern_info(fcvm_ctx *c, int64_t out[6]) {
+int fcvm_pattern_info(fcvm_ctx *c, int64_t out[8]) {
     NEED(c && c->have_mesh, "fcvm_pattern_info: no mesh");
     const Pattern &p = c->pat;
     out[0] = p.nnzb; out[1] = p.nslots; out[2] = p.nslices;
     out[3] = p.value_count() * 8 + p.nslots * 4;
     out[4] = p.maxlen; out[5] = 3 * p.nn;
+    out[6] = p.gang; out[7] = c->spmv_variant;
     return 0;
 }
 
@@ -547,7 +604,8 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
     NEED(glv_grav && modf, "fcvm_assemble: glv_grav and modf are required");
     NEED((sig == nullptr) == (pgp == nullptr), "fcvm_assemble: sig and pgp go together");
     hipStream_t s = c->stream;
-    HCHK(hipMemsetAsync(c->d_vals, 0, sizeof(double) * c->pat.value_count(), s));
+    const bool use_lds = !c->assemble_atomic && c->assemble_lds && c->asm_lds_ok;
+    if (!use_lds) HCHK(hipMemsetAsync(c->d_vals, 0, sizeof(double) * c->pat.value_count(), s));   // the LDS kernel writes every value once
     HCHK(hipMemsetAsync(glv_grav, 0, sizeof(double) * 3 * c->nn, s));
     HCHK(hipMemsetAsync(modf, 0, sizeof(double) * 3 * c->nn, s));
     HCHK(hipMemsetAsync(c->d_out8, 0, sizeof(double), s));
@@ -555,6 +613,11 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
     dim3 grid((unsigned)cdiv(c->ne * 10, 256)), block(256);
     const int64_t nslots = c->pat.nslices * SLICE;
     dim3 rgrid((unsigned)cdiv(nslots, 256));
+    if (use_lds) {  // quarter slices accumulated in LDS, written once (fcvm_assemble_lds.hip.h)
+        if (sig) launch_assemble_lds<true>(c, disp, sig, pgp, mc, grav, glv_grav, modf, xgp, c->d_part_vol, 0);
+        else launch_assemble_lds<false>(c, disp, nullptr, nullptr, mc, grav, glv_grav, modf, xgp, c->d_part_vol, 0);
+        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, s, c->d_part_vol, 4 * c->pat.nslices, c->d_out8);
+    } else
     if (!c->assemble_atomic) {  // one lane per matrix row, no atomics, bitwise reproducible
         if (sig)
             hipLaunchKernelGGL(k_assemble_rows<true>, rgrid, block, 0, s, nslots, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord,
@@ -830,7 +893,7 @@ int fcvm_host_pattern_check(int64_t ne, int64_t nn, const int64_t *elNodes, int6
     }
     Pattern p;
     try {
-        int gang = 64;
+        int gang = 1;
         if (const char *v = getenv("FCVM_SPMV_GANG")) gang = std::max(1, atoi(v));
         build_pattern(ne, nn, el.data(), p, 4, SORT_WINDOW, 10, nullptr, gang);
     } catch (const std::exception &ex) {
@@ -1193,11 +1256,15 @@ int fcvm_assemble_buckling(fcvm_ctx *c, const double *sig, double shift) {
     hipStream_t s = c->stream;
     const int64_t nv = c->pat.value_count();
     if (!c->d_vals_g && dalloc(&c->d_vals_g, nv)) return 1;
-    HCHK(hipMemsetAsync(c->d_vals, 0, sizeof(double) * nv, s));
+    const bool use_lds = !c->assemble_atomic && c->assemble_lds && c->asm_lds_ok;
+    if (!use_lds) HCHK(hipMemsetAsync(c->d_vals, 0, sizeof(double) * nv, s));
     HCHK(hipMemsetAsync(c->d_vals_g, 0, sizeof(double) * nv, s));
     MatConst mc = matconst(c, 0.0);
     dim3 grid((unsigned)cdiv(c->ne * 10, 256)), block(256);
-    if (!c->assemble_atomic) {
+    if (use_lds) {
+        const double g0[3] = {0.0, 0.0, 0.0};
+        launch_assemble_lds<false>(c, nullptr, nullptr, nullptr, mc, g0, c->d_r, c->d_z, nullptr, nullptr, 1);
+    } else if (!c->assemble_atomic) {
         const int64_t nslots = c->pat.nslices * SLICE;
         hipLaunchKernelGGL(k_assemble_rows<false>, dim3((unsigned)cdiv(nslots, 256)), block, 0, s, nslots, c->d_rownode, c->d_nptr, c->d_nel,
                            c->d_el, c->d_coord, (const double *)nullptr, c->d_fixmask, c->d_fixval, c->d_emap, (const double *)nullptr,

@@ -128,13 +128,29 @@ def calcDisp(elNodes, nocoord, fixdof, movdof, modf, materialbyElement, stm, row
 _model_cache = {}
 
 
+def _digest(a, dtype):
+    import hashlib
+    return hashlib.blake2b(np.ascontiguousarray(a, dtype=dtype).reshape(-1).view(np.uint8), digest_size=16).digest()
+
+
 def _model_for(elNodes, nocoord, materialbyElement, fix=None):
-    key = (id(elNodes), id(nocoord), np.shape(elNodes), float(np.asarray(materialbyElement)[0][0]))
+    """GPU model for the host-array mirrors below, cached on CONTENT: connectivity, the whole material row and the
+    supports select the model; coordinates are compared on every hit and re-uploaded when they changed (calcDisp
+    itself adds the imperfection to nocoord in place, as the reference does, fcVM.py:1240)."""
+    mat = tuple(float(v) for v in np.asarray(materialbyElement, dtype=np.float64)[0][:3])
+    key = (_digest(elNodes, np.int64), mat, tuple(sorted((int(k), float(v)) for k, v in (fix or {}).items())))
+    xyz = np.ascontiguousarray(nocoord, dtype=np.float64)
+    dx = _digest(xyz, np.float64)
     m = _model_cache.get(key)
     if m is None:
         _model_cache.clear()
-        m = GpuModel(elNodes, nocoord, np.asarray(materialbyElement)[0], fix or {}, device=settings["device"])
+        m = GpuModel(elNodes, xyz, mat, fix or {}, device=settings["device"])
+        m._el_digest, m._xyz_digest = key[0], dx
         _model_cache[key] = m
+    elif m._xyz_digest != dx:
+        m.ctx.set_coords(xyz)
+        m.nocoord = xyz.copy()
+        m._xyz_digest = dx
     return m
 
 
@@ -172,8 +188,9 @@ def update_PEEQ_CSR(nelem, materialbyElement, sig_test, sig_new, sig_yield, ulti
 
 def mapStresses(averaged, elNodes, nocoord, sig, peeq, sigvm, csr, noce, sig_yield, materialbyElement=((1.0, 0.0, 0.0),)):
     """fcVM.py:2497-2554.  Returns (tet10stress [nn,6], tet10peeq, tet10csr, tet10svm, tet10triax)."""
-    for m in _model_cache.values():
-        if m.ne == len(elNodes) and m.nn == len(nocoord):
+    de = _digest(elNodes, np.int64)
+    for m in _model_cache.values():   # node -> element incidence is all this needs: any cached model of the same connectivity
+        if m._el_digest == de and m.nn == len(nocoord):
             break
     else:
         m = _model_for(elNodes, nocoord, materialbyElement)

@@ -158,10 +158,10 @@ class Context:
         call("fcvm_set_fix", self.h, len(dofs), dofs.ctypes.data, vals.ctypes.data)
 
     def pattern_info(self):
-        out = (C.c_int64 * 6)()
+        out = (C.c_int64 * 8)()
         call("fcvm_pattern_info", self.h, out)
         return dict(nnz_blocks=out[0], padded_slots=out[1], slices=out[2], matrix_bytes=out[3],
-                    max_row_blocks=out[4], ndof=out[5])
+                    max_row_blocks=out[4], ndof=out[5], gang=out[6], spmv_variant=out[7])
 
     def matrix_coo(self):
         nnz = 9 * self.pattern_info()["nnz_blocks"]

@@ -269,8 +269,23 @@ class DistBackend:
             self.ops.precond(r, z)
         return z
 
-    # -- distributed block-Jacobi PCG ---------------------------------------------------------
+    # -- distributed PCG ----------------------------------------------------------------------
+    def dot2_t(self, r, z):
+        """(r.z, r.r), owner-weighted, one all-reduce for both; stays on the device"""
+        out = torch.empty(2, dtype=torch.float64, device=self.device)
+        if hasattr(self.ops, "wdot"):
+            self.ops.wdot(self.w, r, z, out[0:1])
+            self.ops.wdot(self.w, r, r, out[1:2])
+        else:
+            wr = self.w * r
+            out[0], out[1] = torch.sum(wr * z), torch.sum(wr * r)
+        return self._allreduce(out)
+
     def solve(self, f, u=None, rtol=1e-10, maxit=20000):
+        """Preconditioned CG on consistent vectors.  Convergence is decided on the device every iteration: once
+        r.r <= (rtol ||f||)^2 (in particular r.r == 0) the updates are masked out (alpha = beta = 0), so x and r stay
+        what they were at convergence however many iterations the host has already queued; the host reads the flag
+        after 1, 1, 2, 4 ... check_every iterations (a Newton step whose start vector is nearly exact converges in one)."""
         if u is None:
             u = self.empty(f.n)
         x, r = u.t, f.t.clone()
@@ -278,36 +293,54 @@ class DistBackend:
         z, q = self.empty(f.n), self.empty(f.n)
         self.precond(TVec(r), z)
         p = TVec(z.t.clone())
-        rz = self.dot_t(r, z.t)
-        bb = self.dot_t(r, r)
+        both = self.dot2_t(r, z.t)
+        rz, bb = both[0:1].clone(), both[1:2].clone()
         bb_h = float(bb.item())
         info = dict(iterations=0, rel_residual=0.0, spmv=0)
         if bb_h == 0.0:
             return u, info
-        thresh = rtol * rtol * bb_h
-        it = 0
+        if not np.isfinite(bb_h):
+            raise RuntimeError("distributed PCG: non-finite right-hand side")
+        dev = self.device
+        thresh = torch.full((1,), rtol * rtol * bb_h, dtype=torch.float64, device=dev)
+        zero, one = torch.zeros(1, dtype=torch.float64, device=dev), torch.ones(1, dtype=torch.float64, device=dev)
+        done = torch.zeros(1, dtype=torch.bool, device=dev)
+        it_t = torch.zeros(1, dtype=torch.float64, device=dev)
+        rr = bb.clone()
         fused = self.mg is not None and self.mg.ready and self.mg.additive
-        while it < maxit:
-            for _ in range(self.check_every):
+        queued, chunk, spmvs = 0, 1, 0
+        finished = False
+        while queued < maxit and not finished:
+            n = min(chunk, maxit - queued)
+            for _ in range(n):
                 self.spmv(p, q)
-                alpha = rz / self.dot_t(p.t, q.t)           # stays on the device
+                spmvs += 1
+                pq = self.dot_t(p.t, q.t)
+                live = ~done
+                alpha = torch.where(live & (pq != 0.0), rz / torch.where(pq != 0.0, pq, one), zero)
                 if fused:
                     self.mg.update_and_vcycle(alpha, p, q, TVec(x), TVec(r), z)
                 else:
                     x.addcmul_(p.t, alpha)                  # x += alpha p
                     r.addcmul_(q.t, -alpha)                 # r -= alpha q
                     self.precond(TVec(r), z)
-                rz_new = self.dot_t(r, z.t)
-                torch.addcmul(z.t, p.t, rz_new / rz, out=p.t)  # p = z + beta p
-                rz = rz_new
-                it += 1
-            rr = float(self.dot_t(r, r).item())
-            if not np.isfinite(rr):
-                raise RuntimeError("distributed PCG broke down")
-            if rr <= thresh:
-                break
-        info.update(iterations=it, rel_residual=float(np.sqrt(rr / bb_h)), spmv=it)
-        if rr > thresh:
+                both = self.dot2_t(r, z.t)
+                rz_new, rr_new = both[0:1], both[1:2]
+                beta = torch.where(live & (rz != 0.0), rz_new / torch.where(rz != 0.0, rz, one), zero)
+                torch.addcmul(z.t, p.t, beta, out=p.t)     # p = z + beta p
+                rz = torch.where(live, rz_new, rz)
+                rr = torch.where(live, rr_new, rr)
+                it_t += live
+                done = done | (rr <= thresh) | ~torch.isfinite(rr)
+            queued += n
+            chunk = min(self.check_every, 2 * chunk) if queued >= 2 else 1
+            finished = bool(done.item())
+        it = int(it_t.item())
+        rr_h = float(rr.item())
+        info.update(iterations=it, rel_residual=float(np.sqrt(rr_h / bb_h)) if np.isfinite(rr_h) else float("nan"), spmv=spmvs)
+        if not np.isfinite(rr_h):
+            raise RuntimeError("distributed PCG broke down")
+        if rr_h > float(thresh.item()):
             raise RuntimeError("distributed PCG did not converge in %d iterations" % maxit)
         return u, info
 

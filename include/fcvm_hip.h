@@ -59,8 +59,9 @@ int fcvm_set_fix(fcvm_ctx *c, int64_t nfix, const int64_t *dofs, const double *v
 int fcvm_set_coords(fcvm_ctx *c, const double *nocoord);
 
 /* pattern statistics: out[0]=nnz blocks, out[1]=padded block slots, out[2]=slices,
- * out[3]=matrix bytes (values+cols), out[4]=max row length, out[5]=ndof */
-int fcvm_pattern_info(fcvm_ctx *c, int64_t out[6]);
+ * out[3]=matrix bytes (values+cols), out[4]=max row length, out[5]=ndof, out[6]=slices per gang of interleaved
+ * chunks (storage order of the SpMV stream, 1 = slice after slice), out[7]=SpMV kernel variant */
+int fcvm_pattern_info(fcvm_ctx *c, int64_t out[8]);
 /* host copy of the assembled matrix as scalar COO (row, col, val) of the FULL symmetric matrix,
  * nnz = 9 * nnz blocks; for tests.  Arrays must hold 9*out[0] entries. */
 int fcvm_matrix_to_coo(fcvm_ctx *c, int64_t *row, int64_t *col, double *val);

@@ -214,7 +214,9 @@ class _Direct:
     def __init__(self, stm, row, col, ndof):
         low = sp.csc_matrix((stm, (row, col)), shape=(ndof, ndof))
         full = low + sp.tril(low, -1).T
-        self.lu = spla.splu(full.tocsc())
+        # symmetric-mode SuperLU (minimum degree on A + A^T, diagonal pivots): same solution, about half the fill of the
+        # default column ordering on these SPD matrices
+        self.lu = spla.splu(full.tocsc(), permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
 
     def __call__(self, f):
         return self.lu.solve(f)
@@ -443,7 +445,7 @@ def read_inp_lines(lines):
                 csr_option=t[15], averaged_option=t[16], gnl=t[17], maxImp=t[18], ev1=t[19], ev2=t[20])
 
 
-def run_analysis(elNodes, nocoord, material, fix, loads, ctl, log=None, use_imperfection=False):
+def run_analysis(elNodes, nocoord, material, fix, loads, ctl, log=None, use_imperfection=False, max_passes=1):
     """fcVM.FCMacro:118-175: calcGSM -> calcDisp -> mapStresses, no FreeCAD objects.
     use_imperfection: run the GNLY buckling pre-analysis and apply ctl["maxImp"] (fcVM.py:1199-1296);
     default False = the given coordinates are used as they are."""
@@ -462,7 +464,7 @@ def run_analysis(elNodes, nocoord, material, fix, loads, ctl, log=None, use_impe
     res = calcDisp(elNodes, nocoord, fixdof, movdof, modf, material, stm, row, col, glv, ctl["nstep"],
                    ctl["iterat_max"], ctl["error_max"], ctl["relax"], ctl["scale_re"], ctl["scale_up"],
                    ctl["scale_dn"], ctl["sig_yield"], ctl["disp_output"], ctl["ultimate_strain"],
-                   ctl["Et_E"], ctl["target_LF"], x, noce, fix, grav, loads, gnl=ctl["gnl"], log=log,
+                   ctl["Et_E"], ctl["target_LF"], x, noce, fix, grav, loads, gnl=ctl["gnl"], log=log, max_passes=max_passes,
                    maxImp=ctl.get("maxImp", 0.0) if use_imperfection else 0.0, ev1=ctl.get("ev1", 1.0), ev2=ctl.get("ev2", 0.0))
     nocoord = res["nocoord"]
     t10 = mapStresses(False, elNodes, nocoord, res["stresses"], res["peeq"], res["sigmises"],

@@ -128,6 +128,58 @@ def vtk_only(name, key):
     print(name, "ne", len(cells), "nn", len(pts), "E nu rho", E, nu, rho, "fields", list(data))
 
 
+def lug_pressure():
+    """Lug_Pressure_Example: the document holds geometry + constraints but no mesh, the .vtk holds the mesh the
+    reference solved.  Constraint node sets are resolved on the vtk mesh from the document's BREP shapes
+    (ConstraintFixed on Extrude:Face1, ConstraintPressure 100 N/mm2 on the two half-cylinders Fusion001:Face15/16 of
+    the hole), the pressure faces are the 6-node tet faces lying on those cylinders, oriented with the outward
+    normal like the surface elements FreeCAD hands to the reference (fcVM.py:270-287; sign -1 = not reversed).
+    Cross-checks: the fixed nodes are exactly the nodes with zero displacement in the reference's result, and the
+    load sum of the .out header is reproduced by the face integrals (tests/test_oracle_golden.py).  The .out of
+    this model has 61 rows: two passes of nstep = 30 (continuation after the plot window, fcVM.py:1304-1308, 1615)."""
+    from fcvm_hip import fcstd, meshgen
+    from fcvm_hip.brep import BrepShape
+    name = "Lug_Pressure_Example"
+    vtk_only(name, "lug")
+    g = dict(np.load(os.path.join(HERE, "lug.npz")))
+    xyz, el = g["nocoord"], g["elNodes"]
+    z = zipfile.ZipFile(os.path.join(REF, "freeCAD files", name + ".FCStd"))
+    xml = z.read("Document.xml").decode("utf8", "replace")
+    objs = fcstd._objects(xml)
+
+    def shape_of(obj):
+        m = re.search(r'<Part [^>]*file="([^"]+\.brp)"', fcstd._prop(objs[obj][1], "Shape") or "")
+        return BrepShape(z.read(m.group(1)).decode("ascii", "replace"))
+
+    refs = {n: re.findall(r'<Link obj="([^"]+)" sub="([^"]+)"', fcstd._prop(b, "References") or "") for n, (t, b) in objs.items()
+            if t.startswith("Fem::Constraint")}
+    assert refs == {"ConstraintFixed001": [("Extrude", "Face1")], "ConstraintPressure": [("Fusion001", "Face16"), ("Fusion001", "Face15")]}
+    assert fcstd._float(objs["ConstraintPressure"][1], "Pressure") == 100.0 and not fcstd._bool(objs["ConstraintPressure"][1], "Reversed")
+    tol = 1e-6 * float(np.ptp(xyz, axis=0).max())
+    fixed = np.where(shape_of("Extrude").element("Face1").nodes(xyz, tol))[0]
+    assert set(fixed) == set(np.where((g["vtk_Displacement"] == 0.0).all(1))[0])
+    fus = shape_of("Fusion001")
+    on = np.zeros(len(xyz), bool)
+    for f in ("Face16", "Face15"):
+        sub = fus.element(f)
+        assert sub.surface[0] == "cylinder"
+        on |= sub.nodes(xyz, tol)
+    faces = []
+    for f in meshgen.TET_FACES:
+        opp = [k for k in range(4) if k not in f[:3]][0]
+        for e in np.where(on[el[:, list(f)] - 1].all(1))[0]:
+            n6 = el[e, list(f)]
+            p, o = xyz[n6[:3] - 1], xyz[el[e, opp] - 1]
+            if np.dot(np.cross(p[1] - p[0], p[2] - p[0]), p[0] - o) < 0:   # normal towards the element: turn the face round
+                n6 = n6[[0, 2, 1, 5, 4, 3]]
+            faces.append(n6)
+    faces = np.array(faces, dtype=np.int64)
+    g["fixed_dofs"] = np.array(sorted(3 * int(n) + k for n in fixed for k in range(3)), dtype=np.int64)
+    g["pfaces"], g["pvals"] = faces, np.full(len(faces), -100.0)
+    np.savez_compressed(os.path.join(HERE, "lug.npz"), **g)
+    print(name, "fixed nodes", len(fixed), "pressure faces", len(faces), "rows", len(g["out_table"]))
+
+
 def barbuckling():
     """GNLY (geometrically non-linear) reference run: 1000 x 10 x 10 bar (Part::Box), clamped at x = 0,
     axial force at x = L, imperfection of 10 mm along the first buckling shape.  Mesh, constraints and
@@ -295,4 +347,4 @@ if __name__ == "__main__":
     buckling()
     u100()
     out_only("Plate_with_hole_Example", "plate_with_hole")
-    vtk_only("Lug_Pressure_Example", "lug")
+    lug_pressure()

@@ -251,6 +251,22 @@ def test_embankment_analysis_matches_reference_files(orc, embankment):
     assert rel(res["lout"], o["lout"]) < tol and rel(res["un"], o["un"]) < tol
 
 
+def test_lug_pressure_example_matches_reference_files():
+    """The reference's Lug_Pressure_Example through the C-ABI: pressure on the two cylindrical faces of the hole
+    (face integrals with the element normals, fcVM.py:649-672), disp_output = incremental, two passes of 30 steps
+    (continuation, fcVM.py:1304-1308) -- every column of all 61 rows of the reference's .out and the f64 nodal fields
+    of its .vtk (north_star tolerance 1e-6)."""
+    from fcvm_hip import inpout
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import run_analysis
+    from test_oracle_golden import check_lug_against_reference_files, lug_pressure_case
+    g, meta = load_golden("lug")
+    fix, pf, pv, inp = lug_pressure_case(g, meta)
+    ctl = inpout.parse_inp_lines(inp)
+    res = run_analysis(g["elNodes"], g["nocoord"], g["material"], fix, Loads(pfaces=pf, pvals=pv), ctl, rtol=1e-11, max_passes=2)
+    check_lug_against_reference_files(res, g, 1e-6)
+
+
 def test_cube_analysis_matches_oracle(orc):
     """Traction-loaded cube with prescribed displacements (moving boundary => reaction-force
     output, fcVM.py:1169-1177, 1522-1523), hardening, 6 load steps."""

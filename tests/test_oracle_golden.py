@@ -60,13 +60,45 @@ def test_principal_stress_against_reference_vtk(orc):
             assert (not gap.any()) or d[gap].max() < 1e-6 * scale
 
 
-def test_elastic_stress_recovery_lug(orc):
-    """Lug_Pressure_Example is loaded to LF 1 in the reference (yield 240, mostly elastic): the
-    reference's nodal von Mises field never exceeds the yield stress and the stress tensor is
-    consistent with its own von Mises field at the corner nodes."""
+def lug_pressure_case(g, meta, orc_or_none=None):
+    """Lug_Pressure_Example from the fixture: (fix, pressure faces, pressure values, control dict lines)."""
+    fix = {int(d): 0.0 for d in g["fixed_dofs"]}
+    return fix, g["pfaces"], g["pvals"], meta["inp"]
+
+
+def check_lug_against_reference_files(res, g, tol):
+    """all 61 rows of the reference's .out (two passes of 30 steps), every column, and the f64 fields of its .vtk"""
+    tab = g["out_table"]
+    assert len(res["lout"]) == len(tab) == 61
+    assert np.array_equal(np.asarray(res["crip"]), tab[:, 0].astype(int))
+    x = res["x"][np.asarray(res["crip"])]
+    for col, val in ((1, x[:, 0]), (2, x[:, 1]), (3, x[:, 2]), (4, res["lout"]), (5, res["un"]), (6, res["peeqplot"]),
+                     (7, res["pplot"]), (8, res["svmplot"]), (9, res["triaxplot"]), (10, res["ecrplot"]), (11, res["csrplot"])):
+        assert sig3(val, tab[:, col]), "column %d" % col
+    assert sig3(res["loadsum"][0], g["out_loadsum"][0]) and abs(res["loadsum"][1]) < 1e-6 and abs(res["loadsum"][2]) < 1e-6
+    rel = lambda a, b: np.abs(np.asarray(a) - b).max() / np.abs(b).max()  # noqa: E731
+    # disp_output = incremental (fcVM.py:1631-1634): the file holds the displacement increment of the last step
+    assert rel(np.asarray(res["displacements"]).reshape(-1, 3), g["vtk_Displacement"]) < tol
+    assert rel(res["tet10stress"], g["vtk_Stress_Tensor"]) < tol
+    assert rel(res["tet10peeq"], g["vtk_Equivalent_Plastic_Strain"]) < tol
+    assert rel(res["tet10csr"], g["vtk_Critical_Strain_Ratio"]) < tol
+    assert rel(res["tet10svm"], g["vtk_von_Mises_Stress"]) < tol
+    assert rel(res["tet10triax"], g["vtk_Triaxiality"]) < tol
+
+
+def test_lug_pressure_example_out_and_vtk(orc):
+    """Pressure loads on curved faces (face integrals with the element normal, fcVM.py:649-672), `incremental`
+    displacement output and the continuation pass after the plot window (fcVM.py:1304-1308, 1615), pinned on the
+    reference's own Lug_Pressure_Example.out / .vtk: 100 N/mm2 on the two half-cylinders of the hole, 2 x 30 steps."""
     g, meta = load_golden("lug")
-    sy = float(meta["inp"][0])
-    assert g["vtk_von_Mises_Stress"].max() <= sy * (1 + 1e-9)
+    fix, pf, pv, inp = lug_pressure_case(g, meta)
+    ctl = orc.read_inp_lines(inp)
+    assert ctl["disp_output"] == "incremental" and ctl["nstep"] == 30
+    res = orc.run_analysis(g["elNodes"], g["nocoord"], g["material"], fix, orc.Loads(pfaces=pf, pvals=pv), ctl, max_passes=2)
+    check_lug_against_reference_files(res, g, 1e-9)
+    # one pass only = the first 31 rows
+    one = orc.run_analysis(g["elNodes"], g["nocoord"], g["material"], fix, orc.Loads(pfaces=pf, pvals=pv), ctl)
+    assert len(one["lout"]) == 31 and np.array_equal(one["lout"], res["lout"][:31])
 
 
 def _bar(orc):
@@ -134,7 +166,7 @@ def test_buckling_model_equilibrium_and_factors(orc):
     for i, key in enumerate(("vtk_Buckling_shape_for_lambda1__4263", "vtk_Buckling_shape_for_lambda2__38524")):
         r, x = g[key].reshape(-1), v[:, i]
         s = (x @ r) / (x @ x)
-        assert np.abs(s * x - r).max() < 2e-6
+        assert np.abs(s * x - r).max() < 5e-6   # shapes ~0.5; the stresses behind K_g come from a solve with cond(K) ~ 1e9
 
 
 def test_plate_with_hole_collapse_curve(orc):

@@ -19,6 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cells", type=int, default=55)
 ap.add_argument("--reps", type=int, default=50)
 ap.add_argument("--pcg", type=int, default=25, help="PCG iterations of the extra solve (0 = skip)")
+ap.add_argument("--membench", action="store_true", help="also run the plain streaming-read kernel (3 GiB)")
 a = ap.parse_args()
 case = meshgen.cube_case(a.cells, l=100.0, traction=(20.0, 0.0, 200.0))
 m = GpuModel(case["elNodes"], case["nocoord"], (210000.0, 0.3, 7.8e-6), case["fix"],
@@ -40,6 +41,8 @@ alg = info["nnz_blocks"] * 76 + 2 * info["ndof"] * 8
 print("elements %d ndof %d nnzb %d padded_slots %d  spmv %.4f ms  %.1f GB/s algorithmic (%.1f GB/s incl. padding)" %
       (m.ne, m.ndof, info["nnz_blocks"], info["padded_slots"], ms, alg / ms / 1e6,
        (info["matrix_bytes"] + 2 * info["ndof"] * 8) / ms / 1e6))
+if a.membench:
+    print("stream read %.0f GB/s" % c.membench(3 << 30))
 if a.pcg:
     f = c.mul(m.fixdof, glv)
     try:
