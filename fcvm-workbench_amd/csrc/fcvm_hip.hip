@@ -66,6 +66,8 @@ struct fcvm_ctx {
     double *d_vals_g = nullptr;  // geometric stiffness (linear buckling), same pattern as d_vals
     // pcg work
     double *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_q = nullptr, *d_S = nullptr;
+    double *d_p4 = nullptr;      // the PCG direction with 4 doubles per node: what the fine SpMV gathers from (FCVM_SPMV_XPAD=0: off)
+    int spmv_xpad = 1;
     double *d_part_vec = nullptr, *d_part_spmv = nullptr, *d_part_misc = nullptr, *d_out8 = nullptr;
     long long *d_pidx = nullptr;
     int64_t nb_vec = 0, nb_spmv = 0, nb_gp = 0;
@@ -162,41 +164,54 @@ static MatView coarse_view(const fcvm_ctx *c) {
             c->mg_fp32 ? c->d_vals1f : nullptr};
 }
 
-#define FCVM_SPMV_LAUNCH(DOT_, NT_, UN_, V2_, EPI_, vals_, epi_)                                                                      \
+#define FCVM_SPMV_LAUNCH(DOT_, NT_, UN_, V2_, EPI_, XP_, vals_, epi_)                                                                  \
     do {                                                                                                                            \
         if (m.cm.gshift >= 0)                                                                                                       \
-            hipLaunchKernelGGL((k_spmv<DOT_, NT_, UN_, V2_, EPI_, true>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols, \
+            hipLaunchKernelGGL((k_spmv<DOT_, NT_, UN_, V2_, EPI_, true, XP_>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols, \
                                (const V2_ *)(vals_), m.rownode, x, y, part, done, epi_, m.cm);                                       \
         else                                                                                                                        \
-            hipLaunchKernelGGL((k_spmv<DOT_, NT_, UN_, V2_, EPI_, false>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols, \
+            hipLaunchKernelGGL((k_spmv<DOT_, NT_, UN_, V2_, EPI_, false, XP_>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols, \
                                (const V2_ *)(vals_), m.rownode, x, y, part, done, epi_, m.cm);                                       \
     } while (0)
 
+// xpad: x holds 4 doubles per node (only the FP64 fine-level kernel has that form)
 template <bool DOT>
-static void launch_spmv_t(fcvm_ctx *c, const MatView &m, const double *x, double *y, double *part, const double *done) {
+static void launch_spmv_t(fcvm_ctx *c, const MatView &m, const double *x, double *y, double *part, const double *done, bool xpad = false) {
     dim3 grid((unsigned)m.nb), block(64 * c->spmv_spw);
     if (m.vals32) {  // FP32-stored matrix, FP64 vectors and accumulation
-        FCVM_SPMV_LAUNCH(DOT, false, 4, float2, 0, m.vals32, ChebEpi{});
+        FCVM_SPMV_LAUNCH(DOT, false, 4, float2, 0, false, m.vals32, ChebEpi{});
         return;
     }
-    if (c->spmv_variant == 0) FCVM_SPMV_LAUNCH(DOT, false, 1, double2, 0, m.vals, ChebEpi{});
-    else FCVM_SPMV_LAUNCH(DOT, true, 4, double2, 0, m.vals, ChebEpi{});
+    if (xpad) FCVM_SPMV_LAUNCH(DOT, true, 4, double2, 0, true, m.vals, ChebEpi{});
+    else if (c->spmv_variant == 0) FCVM_SPMV_LAUNCH(DOT, false, 1, double2, 0, false, m.vals, ChebEpi{});
+    else FCVM_SPMV_LAUNCH(DOT, true, 4, double2, 0, false, m.vals, ChebEpi{});
 }
 // SpMV t = A d fused with a Chebyshev smoother step on the same rows (see ChebEpi); nothing is written but epi's vectors
 static void launch_spmv_cheb(fcvm_ctx *c, const MatView &m, const double *x, const double *done, const ChebEpi &epi) {
     dim3 grid((unsigned)m.nb), block(64 * c->spmv_spw);
     double *y = nullptr, *part = nullptr;
-    if (m.vals32) FCVM_SPMV_LAUNCH(false, false, 4, float2, 1, m.vals32, epi);
-    else FCVM_SPMV_LAUNCH(false, true, 4, double2, 1, m.vals, epi);
+    if (m.vals32) FCVM_SPMV_LAUNCH(false, false, 4, float2, 1, false, m.vals32, epi);
+    else FCVM_SPMV_LAUNCH(false, true, 4, double2, 1, false, m.vals, epi);
 }
 static void launch_gemv_f32(fcvm_ctx *c, const double *r2, double *e2, const double *done) {
     hipLaunchKernelGGL(k_gemv_f32x4, dim3((unsigned)cdiv(c->n2, 16)), dim3(256), 0, c->stream, c->n2, c->n2, (c->n2 + 3) / 4 * 4,
                        c->d_A2invf, r2, e2, done);
 }
-static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done) {
-    if (dot) launch_spmv_t<true>(c, fine_view(c), x, y, c->d_part_spmv, done);
-    else launch_spmv_t<false>(c, fine_view(c), x, y, nullptr, done);
+static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done, bool xpad = false) {
+    if (dot) launch_spmv_t<true>(c, fine_view(c), x, y, c->d_part_spmv, done, xpad);
+    else launch_spmv_t<false>(c, fine_view(c), x, y, nullptr, done, xpad);
 }
+// p = z + beta p of the PCG loops (and the padded copy of p the fine SpMV gathers from)
+static void launch_update_p(fcvm_ctx *c) {
+    if (c->spmv_xpad)
+        hipLaunchKernelGGL(k_pcg_update_p4, dim3((unsigned)cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_z, c->d_p, c->d_p4, c->d_S);
+    else
+        hipLaunchKernelGGL(k_pcg_update_p, dim3((unsigned)cdiv(3 * c->nn, 256)), dim3(256), 0, c->stream, 3 * c->nn, c->d_z, c->d_p, c->d_S);
+}
+static void launch_pad_p(fcvm_ctx *c) {
+    if (c->spmv_xpad) hipLaunchKernelGGL(k_pad4, dim3((unsigned)cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_p, c->d_p4);
+}
+static const double *pcg_dir(const fcvm_ctx *c) { return c->spmv_xpad ? c->d_p4 : c->d_p; }
 
 static int dot_common(fcvm_ctx *c, int64_t n, const double *w, const double *x, const double *y, double *result_dev) {
     NEED(c && c->d_part_misc, "vector reductions need a mesh (work buffers)");
@@ -372,6 +387,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_ASSEMBLE_ATOMIC")) c->assemble_atomic = atoi(v);
     if (const char *v = getenv("FCVM_ASSEMBLE_LDS")) c->assemble_lds = atoi(v);
     if (const char *v = getenv("FCVM_QIN_ATOMIC")) c->qin_atomic = atoi(v);
+    if (const char *v = getenv("FCVM_SPMV_XPAD")) c->spmv_xpad = atoi(v);
     if (const char *v = getenv("FCVM_SPMV_GANG")) c->spmv_gang = std::max(1, atoi(v));
     if (const char *v = getenv("FCVM_SPMV_SPW")) c->spmv_spw = std::min(4, std::max(1, atoi(v)));   // slices (waves) per workgroup
     if (const char *v = getenv("FCVM_MG_ADDITIVE")) c->mg_additive = atoi(v);
@@ -389,7 +405,7 @@ static void free_mesh(fcvm_ctx *c) {
     dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
     dfree(c->d_nptr); dfree(c->d_nel); dfree(c->d_fe); dfree(c->d_part_vol); dfree(c->d_asm_items);
     dfree(c->d_vals); dfree(c->d_vals_g); dfree(c->d_dblk); dfree(c->d_dinv); dfree(c->d_r); dfree(c->d_z); dfree(c->d_p);
-    dfree(c->d_q); dfree(c->d_part_vec); dfree(c->d_part_spmv); dfree(c->d_part_misc); dfree(c->d_pidx);
+    dfree(c->d_q); dfree(c->d_p4); dfree(c->d_part_vec); dfree(c->d_part_spmv); dfree(c->d_part_misc); dfree(c->d_pidx);
     mg_free(c);
     c->have_mesh = c->assembled = false;
 }
@@ -489,7 +505,7 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
         dalloc(&c->d_diagoff, nn) || dalloc(&c->d_fixmask, nn) || dalloc(&c->d_coord, nn * 3) ||
         dalloc(&c->d_fixval, nn * 3) || dalloc(&c->d_vals, p.value_count()) || dalloc(&c->d_dblk, nn * 9) ||
         dalloc(&c->d_dinv, nn * 9) || dalloc(&c->d_r, nn * 3) || dalloc(&c->d_z, nn * 3) || dalloc(&c->d_p, nn * 3) ||
-        dalloc(&c->d_q, nn * 3) || dalloc(&c->d_nptr, nn + 1) || dalloc(&c->d_nel, ne * 10) || dalloc(&c->d_part_vol, 4 * p.nslices) ||
+        dalloc(&c->d_q, nn * 3) || dalloc(&c->d_p4, nn * 4) || dalloc(&c->d_nptr, nn + 1) || dalloc(&c->d_nel, ne * 10) || dalloc(&c->d_part_vol, 4 * p.nslices) ||
         dalloc(&c->d_gptr, (int64_t)p.gptr.size()) || dalloc(&c->d_goff, (int64_t)p.goff.size()))
         return 1;
     c->nb_vec = cdiv(nn, 256);
@@ -735,6 +751,14 @@ int fcvm_spmv(fcvm_ctx *c, const double *x, double *y) {
     return 0;
 }
 
+int fcvm_spmv_x4(fcvm_ctx *c, const double *x4, double *y) {
+    NEED(c && c->have_mesh, "fcvm_spmv_x4: no mesh");
+    NEED(x4 != y, "fcvm_spmv_x4: x and y must not alias");
+    launch_spmv(c, false, x4, y, nullptr, true);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
 int fcvm_precond(fcvm_ctx *c, const double *r, double *z) {
     NEED(c && c->have_mesh, "fcvm_precond: no mesh");
     hipLaunchKernelGGL(k_precond, dim3((unsigned)c->nb_vec), dim3(256), 0, c->stream, c->nn, c->d_dinv, r, z);
@@ -762,7 +786,7 @@ int fcvm_solve(fcvm_ctx *c, const double *f, double *u, double rtol, int64_t max
     if (c->precond_mode == 1) return mg_pcg(c, f, u, rtol, maxit, info);
     NEED(c->precond_mode == 0, "fcvm_solve: in hierarchy-only mode the solve is driven by the host (multi-GPU)");
     hipStream_t s = c->stream;
-    const int64_t nn = c->nn, n = 3 * nn, nbv = c->nb_vec;
+    const int64_t nn = c->nn, nbv = c->nb_vec;
     const int CHUNK = 25;
     if (c->evpool.size() < (size_t)(2 * CHUNK + 2)) {
         while (c->evpool.size() < (size_t)(2 * CHUNK + 2)) {
@@ -776,6 +800,7 @@ int fcvm_solve(fcvm_ctx *c, const double *f, double *u, double rtol, int64_t max
     hipLaunchKernelGGL(k_pcg_init, dim3((unsigned)nbv), dim3(256), 0, s, nn, c->d_dinv, f, u, c->d_r, c->d_z, c->d_p,
                        c->d_part_vec, nbv);
     hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(1024), 0, s, 0, c->d_part_vec, nbv, c->nb_spmv, c->d_S, rtol);
+    launch_pad_p(c);
     double S[S_COUNT];
     int64_t it = 0, nspmv = 0;
     double spmv_ms = 0.0;
@@ -784,13 +809,13 @@ int fcvm_solve(fcvm_ctx *c, const double *f, double *u, double rtol, int64_t max
         int k = (int)std::min<int64_t>(CHUNK, maxit - it);
         for (int j = 0; j < k; j++) {
             HCHK(hipEventRecord(c->evpool[2 * j], s));
-            launch_spmv(c, true, c->d_p, c->d_q, c->d_S + S_DONE);
+            launch_spmv(c, true, pcg_dir(c), c->d_q, c->d_S + S_DONE, c->spmv_xpad != 0);
             HCHK(hipEventRecord(c->evpool[2 * j + 1], s));
             hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(1024), 0, s, 1, c->d_part_spmv, nbv, c->nb_spmv, c->d_S, rtol);
             hipLaunchKernelGGL(k_pcg_update_xr, dim3((unsigned)nbv), dim3(256), 0, s, nn, c->d_dinv, c->d_p, c->d_q, u,
                                c->d_r, c->d_z, c->d_part_vec, nbv, c->d_S);
             hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(1024), 0, s, 2, c->d_part_vec, nbv, c->nb_spmv, c->d_S, rtol);
-            hipLaunchKernelGGL(k_pcg_update_p, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, n, c->d_z, c->d_p, c->d_S);
+            launch_update_p(c);
         }
         HCHK(hipGetLastError());
         HCHK(hipMemcpyAsync(S, c->d_S, sizeof(S), hipMemcpyDeviceToHost, s));

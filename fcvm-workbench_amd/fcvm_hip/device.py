@@ -269,6 +269,11 @@ class Context:
         call("fcvm_spmv", self.h, x.ptr, y.ptr)
         return y
 
+    def spmv4(self, x4, y):
+        """y = K x with x given as 4 doubles per node (x, y, z, 0)"""
+        call("fcvm_spmv_x4", self.h, x4.ptr, y.ptr)
+        return y
+
     def precond(self, r, z):
         call("fcvm_precond", self.h, r.ptr, z.ptr)
         return z

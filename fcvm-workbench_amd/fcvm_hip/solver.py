@@ -340,6 +340,17 @@ class RiksDriver:
             self.record()
         return False
 
+    def next_pass(self, new_target=None):
+        """What the reference's plot window does between two passes when "add" is clicked, optionally after a new target
+        load factor was typed in (fcVM.py:1664-1672, 1686): the step restarts from 1 / nstep of the elastic solution
+        when the old target lies at or behind the current load level."""
+        new_t = self.target_LF if new_target is None else float(new_target)
+        LF = self.lbd[-1]
+        if (self.target_LF - LF) * (new_t - LF) <= 0.0:
+            self.dl = float(np.sign(new_t - LF)) / self.nstep
+            self.c.axpby(self.dl, self.ue, 0.0, None, out=self.du)
+        self.target_LF = new_t
+
     def result(self):
         lout = self.rfl if self.model.moving else self.lbd
         if self.elastic_only:
@@ -358,10 +369,11 @@ class RiksDriver:
                     eigenvec=self.eigenvec, nocoord=self.model.nocoord, nocoord_old=self.nocoord_old)
 
 
-def calc_disp(model, ctl, log=None, rtol=1e-10, maxit=50000, max_passes=1, stats=None):
+def calc_disp(model, ctl, log=None, rtol=1e-10, maxit=50000, max_passes=1, stats=None, pass_targets=None):
     """GPU calcDisp (fcVM.py:1083-1635).  ctl: dict as read from the .inp control file
     (inpout.read_inp).  The interactive plot() between passes (fcVM.py:1615) is replaced by
-    "stop after max_passes passes of nstep steps"."""
+    "continue ('add') until max_passes passes of nstep steps are done"; pass_targets[i] is the target load factor
+    typed into the window after pass i + 1 (None / missing: left alone)."""
     d = RiksDriver(model, ctl, log=log, rtol=rtol, maxit=maxit, stats=stats)
     cnt = not d.elastic_only
     passes = 0
@@ -379,15 +391,17 @@ def calc_disp(model, ctl, log=None, rtol=1e-10, maxit=50000, max_passes=1, stats
                 break
         passes += 1
         cnt = passes < max_passes and not d.mrr
+        if cnt:
+            d.next_pass(pass_targets[passes - 1] if pass_targets is not None and passes - 1 < len(pass_targets) else None)
     return d.result()
 
 
-def run_analysis(elNodes, nocoord, material, fix, loads, ctl, device=0, log=None, rtol=1e-10, model=None, max_passes=1):
+def run_analysis(elNodes, nocoord, material, fix, loads, ctl, device=0, log=None, rtol=1e-10, model=None, max_passes=1, pass_targets=None):
     """fcVM.FCMacro:118-175 without FreeCAD: calcGSM -> calcDisp -> mapStresses (all on the GPU).
     Returns the calc_disp dict extended with the nodal (tet10) result fields on the host."""
     if model is None:
         model = GpuModel(elNodes, nocoord, material, fix, loads, device=device)
-    res = calc_disp(model, ctl, log=log, rtol=rtol, max_passes=max_passes)
+    res = calc_disp(model, ctl, log=log, rtol=rtol, max_passes=max_passes, pass_targets=pass_targets)
     c = model.ctx
     t10 = c.map_stresses(False, res["stresses"], res["peeq"], res["sigmises"], res["csr"], float(ctl["sig_yield"]))
     ps, pv = c.principal_stress(t10[0])

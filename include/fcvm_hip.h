@@ -134,6 +134,9 @@ int fcvm_spmv_geometric(fcvm_ctx *c, const double *x, double *y);
 
 /* y = K x on the assembled matrix ([dev] f64[3nn]); building block of the multi-GPU solver */
 int fcvm_spmv(fcvm_ctx *c, const double *x, double *y);
+/* the same with x stored as 4 doubles per node (x, y, z, 0): the form the PCG loop feeds the kernel (one 16-byte and one
+ * 8-byte gather per node instead of three 8-byte ones) */
+int fcvm_spmv_x4(fcvm_ctx *c, const double *x4, double *y);
 /* z = M^-1 r with the 3x3 block-Jacobi preconditioner */
 int fcvm_precond(fcvm_ctx *c, const double *r, double *z);
 /* diagonal 3x3 blocks [dev] f64[nn*9]: get (for the interface sum across ranks) / set+invert */

@@ -225,7 +225,7 @@ class _Direct:
 def calcDisp(elNodes, nocoord, fixdof, movdof, modf, material, stm, row, col, glv, nstep,
              iterat_max, error_max, relax, scale_re, scale_up, scale_dn, sig_yield_inp,
              disp_output, ultimate_strain, Et_E, target_LF, x, noce, fix, grav, loads, gnl="GNLN",
-             log=None, max_passes=1, maxImp=0.0, ev1=1.0, ev2=0.0):
+             log=None, max_passes=1, maxImp=0.0, ev1=1.0, ev2=0.0, pass_targets=None):
     """Restatement of fcVM.py:1083-1635 (calcDisp) for gnl == "GNLN" plus the tangent-update
     part of "GNLY".  The GUI hooks (progress bar, matplotlib `plot`, fcVM.py:1104-1108, 1615)
     are replaced by "stop after `max_passes` passes of nstep steps" (the reference's result
@@ -425,6 +425,16 @@ def calcDisp(elNodes, nocoord, fixdof, movdof, modf, material, stm, row, col, gl
         cnt = False  # headless stand-in for plot(): stop (fcVM.py:1615)
         if passes < max_passes and not mrr:
             cnt = True
+            # "add" button of the plot window, with the target load factor typed into it beforehand (fcVM.py:1664-1672,
+            # 1686): pass_targets[i] = the value entered after pass i + 1 (None: field left alone)
+            new_t = target_LF
+            if pass_targets is not None and passes - 1 < len(pass_targets) and pass_targets[passes - 1] is not None:
+                new_t = float(pass_targets[passes - 1])
+            LF = lbd[-1]
+            if (target_LF - LF) * (new_t - LF) <= 0.0:
+                dl = np.sign(new_t - LF) * 1.0 / nstep
+                du = dl * ue
+            target_LF = new_t
     res = disp_new if disp_output == "total" else disp_new - disp_old
     return dict(displacements=res, disp_el=disp_el, stresses=sig_new, peeq=peeq, sigmises=sigmises,
                 csr=csr, lout=np.asarray(lout), un=np.asarray(un), crip=np.asarray(crip),
@@ -445,7 +455,7 @@ def read_inp_lines(lines):
                 csr_option=t[15], averaged_option=t[16], gnl=t[17], maxImp=t[18], ev1=t[19], ev2=t[20])
 
 
-def run_analysis(elNodes, nocoord, material, fix, loads, ctl, log=None, use_imperfection=False, max_passes=1):
+def run_analysis(elNodes, nocoord, material, fix, loads, ctl, log=None, use_imperfection=False, max_passes=1, pass_targets=None):
     """fcVM.FCMacro:118-175: calcGSM -> calcDisp -> mapStresses, no FreeCAD objects.
     use_imperfection: run the GNLY buckling pre-analysis and apply ctl["maxImp"] (fcVM.py:1199-1296);
     default False = the given coordinates are used as they are."""
@@ -464,7 +474,7 @@ def run_analysis(elNodes, nocoord, material, fix, loads, ctl, log=None, use_impe
     res = calcDisp(elNodes, nocoord, fixdof, movdof, modf, material, stm, row, col, glv, ctl["nstep"],
                    ctl["iterat_max"], ctl["error_max"], ctl["relax"], ctl["scale_re"], ctl["scale_up"],
                    ctl["scale_dn"], ctl["sig_yield"], ctl["disp_output"], ctl["ultimate_strain"],
-                   ctl["Et_E"], ctl["target_LF"], x, noce, fix, grav, loads, gnl=ctl["gnl"], log=log, max_passes=max_passes,
+                   ctl["Et_E"], ctl["target_LF"], x, noce, fix, grav, loads, gnl=ctl["gnl"], log=log, max_passes=max_passes, pass_targets=pass_targets,
                    maxImp=ctl.get("maxImp", 0.0) if use_imperfection else 0.0, ev1=ctl.get("ev1", 1.0), ev2=ctl.get("ev2", 0.0))
     nocoord = res["nocoord"]
     t10 = mapStresses(False, elNodes, nocoord, res["stresses"], res["peeq"], res["sigmises"],

@@ -294,7 +294,7 @@ def u100():
         os.path.join(HERE, "u100.npz"),
         nocoord0=x0, nocoord=pts, elNodes=el, fixed_dofs=fd, fixed_vals=np.zeros(len(fd)), ufaces=tf,
         uloads=np.tile([2000.0 / area, 0.0, -50000.0 / area], (len(tf), 1)), material=np.array([E, nu, rho]),
-        out_table=table[:nrow], out_loadsum=np.array(head["loadsum"]), buckling_factors=np.array(ev),
+        out_table=table[:nrow], out_table_full=table, out_loadsum=np.array(head["loadsum"]), buckling_factors=np.array(ev),
         shape1=data["Buckling_shape_for_lambda1_=_3.895"], shape2=data["Buckling_shape_for_lambda2_=_8.394"],
         elastic_displacement=data["Elastic_Displacement"])
     json.dump({"name": name, "inp": inp}, open(os.path.join(HERE, "u100.json"), "w"), indent=1)

@@ -611,8 +611,8 @@ def test_gnly_with_buckling_imperfection_full_flow(orc, tmp_path):
 
 def test_u100_column_full_gnly_flow_matches_reference_files():
     """The reference's buckling_U100_3D run from its perfect geometry, entirely on the GPU: buckling factors of the .out
-    header, buckling shapes / imperfect coordinates of the .vtk, and the load / displacement table up to the target
-    load (gravity + two end forces, GNLY with tangent re-assembly)."""
+    header, buckling shapes / imperfect coordinates of the .vtk, and every row of the load / displacement table over the
+    three passes of the reference's session (gravity + two end forces, GNLY with tangent re-assembly, post-peak branch)."""
     from fcvm_hip import inpout
     from fcvm_hip.loads import Loads
     from fcvm_hip.solver import run_analysis
@@ -620,15 +620,17 @@ def test_u100_column_full_gnly_flow_matches_reference_files():
     g, meta = load_golden("u100")
     fix = {int(d): float(v) for d, v in zip(g["fixed_dofs"], g["fixed_vals"])}
     res = run_analysis(g["elNodes"], g["nocoord0"], g["material"], fix, Loads(ufaces=g["ufaces"], uloads=g["uloads"]),
-                       inpout.parse_inp_lines(meta["inp"]), rtol=1e-12)
+                       inpout.parse_inp_lines(meta["inp"]), rtol=1e-12, max_passes=3, pass_targets=[1.0, 1000.0])
     assert np.allclose(res["eigenval"], g["buckling_factors"], rtol=0, atol=6e-6)
     for i, key in enumerate(("shape1", "shape2")):
         r, x = g[key].reshape(-1), res["eigenvec"][:, i]
         assert np.abs((x @ r) / (x @ x) * x - r).max() < 1e-6
     assert np.abs(res["nocoord"] - g["nocoord"]).max() < 1e-5
-    tab = g["out_table"]
-    assert len(res["lout"]) == len(tab) and res["lout"][-1] == 0.8
-    for col, val in ((4, res["lout"]), (5, res["un"]), (7, res["pplot"]), (8, res["svmplot"]), (9, res["triaxplot"])):
+    tab = g["out_table_full"]   # three passes: to 0.8, to 1.0 (new target typed into the plot window), over the peak load
+    assert len(res["lout"]) == len(tab) == 22 and res["lout"][8] == 0.8 and res["lout"][11] == 1.0
+    assert np.array_equal(res["crip"], tab[:, 0].astype(int))
+    for col, val in ((4, res["lout"]), (5, res["un"]), (6, res["peeqplot"]), (7, res["pplot"]), (8, res["svmplot"]),
+                     (9, res["triaxplot"]), (10, res["ecrplot"]), (11, res["csrplot"])):
         assert sig3(val, tab[:, col]), "column %d" % col
 
 

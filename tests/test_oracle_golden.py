@@ -198,13 +198,16 @@ def test_u100_column_buckling_and_gnly_run(orc):
     on the end face, gravity, imperfection 1 mm along the first buckling shape.  From the PERFECT geometry
     (make_golden.u100): the two buckling factors of the .out header (5 decimals), both buckling shapes of the .vtk
     (1e-7 of their maximum), the imperfect coordinates the reference wrote (1e-6 mm), its load sums and every row of the
-    load / displacement table up to the target load factor."""
+    load / displacement table: all three passes of the reference's session (multi-pass continuation with new targets)."""
     g, meta = load_golden("u100")
     fix = {int(d): float(v) for d, v in zip(g["fixed_dofs"], g["fixed_vals"])}
     loads = orc.Loads(ufaces=g["ufaces"], uloads=g["uloads"])
     ctl = orc.read_inp_lines(meta["inp"])
     assert ctl["gnl"] == "GNLY" and ctl["grav_z"] == -10.0 and ctl["csr_option"] == "CSR"
-    res = orc.run_analysis(g["elNodes"], g["nocoord0"], g["material"], fix, loads, ctl, use_imperfection=True)
+    # three passes like the reference's session: target 0.8 from the control file, then 1.0 typed into the plot window
+    # ("add": restart with 1 / nstep of the elastic solution, fcVM.py:1664-1672), then a target beyond the peak load
+    res = orc.run_analysis(g["elNodes"], g["nocoord0"], g["material"], fix, loads, ctl, use_imperfection=True, max_passes=3,
+                           pass_targets=[1.0, 1000.0])
     assert np.allclose(res["eigenval"], g["buckling_factors"], rtol=0, atol=6e-6)
     for i, key in enumerate(("shape1", "shape2")):
         r, x = g[key].reshape(-1), res["eigenvec"][:, i]
@@ -212,8 +215,9 @@ def test_u100_column_buckling_and_gnly_run(orc):
     assert np.abs(res["nocoord"] - g["nocoord"]).max() < 1e-6
     assert np.allclose(res["loadsum"], g["out_loadsum"], rtol=2e-3, atol=1e-9)     # printed with 3 digits
     assert np.abs(res["disp_el"] - g["elastic_displacement"].reshape(-1)).max() < 1e-6 * np.abs(g["elastic_displacement"]).max()
-    tab = g["out_table"]
-    assert len(res["lout"]) == len(tab) == 9 and res["lout"][-1] == 0.8
-    for col, val in ((4, res["lout"]), (5, res["un"]), (7, res["pplot"]), (8, res["svmplot"]), (9, res["triaxplot"]),
-                     (10, res["ecrplot"])):
+    tab = g["out_table_full"]    # all 22 rows: 8 steps to 0.8, 3 steps to 1.0, 10 steps over the peak (1.19) down to 1.13
+    assert len(res["lout"]) == len(tab) == 22 and res["lout"][8] == 0.8 and res["lout"][11] == 1.0
+    assert np.array_equal(res["crip"], tab[:, 0].astype(int))
+    for col, val in ((4, res["lout"]), (5, res["un"]), (6, res["peeqplot"]), (7, res["pplot"]), (8, res["svmplot"]),
+                     (9, res["triaxplot"]), (10, res["ecrplot"]), (11, res["csrplot"])):
         assert sig3(val, tab[:, col]), "column %d" % col

@@ -24,6 +24,7 @@ ap.add_argument("--mesh", default="cube", help="cube | embankment3 | plate")
 ap.add_argument("--variants", nargs="+", default=["FCVM_SPMV_GANG=1", "FCVM_SPMV_GANG=64"])
 ap.add_argument("--rounds", type=int, default=12)
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--x4", action="store_true", help="also time the padded-x form of every variant")
 a = ap.parse_args()
 
 if a.mesh == "cube":
@@ -52,26 +53,31 @@ for v in a.variants:
             del os.environ[k]
         else:
             os.environ[k] = old
-    x = ctx.array(np.random.default_rng(0).standard_normal(m.ndof))
+    xh = np.random.default_rng(0).standard_normal(m.ndof)
+    x = ctx.array(xh)
     y = ctx.empty(m.ndof)
-    models.append((v, m, x, y))
+    models.append((v, m, x, y, False))
+    if a.x4:   # the same matrix, x gathered from the 4-doubles-per-node copy (what the PCG loop uses)
+        x4 = ctx.array(np.concatenate([xh.reshape(-1, 3), np.zeros((m.nn, 1))], axis=1).reshape(-1))
+        models.append((v + " x4", m, x4, ctx.empty(m.ndof), True))
 
 info = models[0][1].ctx.pattern_info()
 alg = info["nnz_blocks"] * 76 + 2 * info["ndof"] * 8
 ref = None
 times = {v: [] for v, *_ in models}
 for r in range(a.rounds + 1):
-    for v, m, x, y in models:
+    for v, m, x, y, pad in models:
         c = m.ctx
-        c.spmv(x, y)
+        f = c.spmv4 if pad else c.spmv
+        f(x, y)
         c.sync()
         t0 = time.perf_counter()
         for _ in range(a.reps):
-            c.spmv(x, y)
+            f(x, y)
         c.sync()
         if r > 0:
             times[v].append((time.perf_counter() - t0) / a.reps * 1e3)
-for v, m, x, y in models:
+for v, m, x, y, pad in models:
     yy = y.get()
     if ref is None:
         ref = yy
