@@ -44,13 +44,13 @@ RTOL = 1.0e-10
 SPMV_TRAFFIC_FILE = os.path.join(REPO, "profiles", "spmv_traffic.json")
 
 
-def spmv_traffic(cells, gang, variant):
+def spmv_traffic(cells, variant):
     try:
         t = json.load(open(SPMV_TRAFFIC_FILE))
     except (OSError, ValueError):
         return None, None
     for e in t.get("measurements", []):
-        if e.get("cells") == cells and e.get("gang") == gang and e.get("variant") == variant:
+        if e.get("cells") == cells and e.get("variant") == variant:
             return float(e["traffic_bytes_per_launch"]), "%s (commit %s, %s)" % (e.get("source", SPMV_TRAFFIC_FILE), e.get("commit", "?"), e.get("method", ""))
     return None, None
 
@@ -218,7 +218,7 @@ def run_single(args):
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     plastic = int(drv.pgp.get().sum())
     ne = model.ne
-    traffic, traffic_src = spmv_traffic(n, info["gang"], info["spmv_variant"])
+    traffic, traffic_src = spmv_traffic(n, info["spmv_variant"])
     out = {
         "metric": "elements*GP/s over Newton iterations (Newton iterations/s x elements x 4 GP), 1M tet10",
         "value": ne * 4 * args.steps / dt, "unit": "elements*GP/s", "n_gpus": 1, "steps": args.steps,
@@ -235,7 +235,6 @@ def run_single(args):
         "roofline": {"bound": "hbm", "kernel": "k_spmv<true> (sliced-ELL 3x3-block SpMV + p.Ap partials)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
-                     "storage_order": "sliced-ELL 64 x 3x3 blocks, gangs of %d slices with interleaved 9 KiB chunks" % info["gang"],
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
                      "launches_timed": spmv_launches, "padded_matrix_bytes": info["matrix_bytes"],
                      # what this box's HBM delivers for a plain 16 B/lane streaming read of a fresh 3 GB buffer, measured right

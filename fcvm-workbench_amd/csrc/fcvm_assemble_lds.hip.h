@@ -7,8 +7,9 @@
 // until every element of every row has been visited; the finished quarter slice then leaves in one pass of coalesced
 // 16-byte nontemporal stores (each value written exactly once, no memset of the 3 GB array, no atomics, fixed
 // summation order => bitwise reproducible).  Four lanes share a row:
-//   * lane h of the quad evaluates the Jacobian of Gauss point h of the visited element, the quad exchanges the four
-//     inverse Jacobians / weights with lane shuffles (each Jacobian is computed once per visit instead of four times);
+//   * lane h of the quad evaluates the Jacobian of Gauss point h of the visited element and leaves it in LDS for the
+//     other three (each Jacobian is computed once per visit instead of four times); shape-function derivatives at
+//     the Gauss points come from a 1.3 KB LDS table instead of per-lane switch statements;
 //   * lane h integrates the blocks K_ab of the local columns b = h, h + 4, h + 8 and adds them to the row's LDS image;
 //   * element connectivity, node coordinates, block locations and support flags of visit v + 1 (and the
 //     connectivity of visit v + 2) are in flight while visit v is integrated.
@@ -20,17 +21,28 @@
 namespace fcvm {
 
 constexpr int ASM_ROWS = 16;                       // rows per wavefront (4 lanes each)
+#ifndef ASM_RELOAD_DN
+#define ASM_RELOAD_DN true
+#endif
+#ifndef ASM_RELOAD_DB
+#define ASM_RELOAD_DB TANGENT
+#endif
+// LDS of a work item: shape-function tables | Jacobians of the visited elements (one per row and Gauss point) | rows
+constexpr int ASM_TAB = 160;                       // doubles: dN/dxi at the 4 Gauss points [4][10][3], then N [4][10]
+constexpr int ASM_JREC = 20;                       // doubles per (row, Gauss point): xsi[9], w, vol, pf, s[6], 2 unused
+constexpr int ASM_JAC = ASM_ROWS * 4 * ASM_JREC;   // doubles
 __host__ __device__ inline int64_t asm_row_stride(int64_t len) { return len * 9 + 1; }   // doubles; odd: rows spread over the LDS banks
-__host__ __device__ inline int64_t asm_lds_bytes(int64_t len) { return ASM_ROWS * asm_row_stride(len) * 8; }
+__host__ __device__ inline int64_t asm_lds_bytes(int64_t len) { return (ASM_TAB + ASM_JAC + ASM_ROWS * asm_row_stride(len)) * 8; }
 
-__device__ __forceinline__ double quad_get(double v, int lane_in_quad) {
-    return __shfl(v, (int)((threadIdx.x & 60u) | (unsigned)lane_in_quad), 64);
+// Hides where a pointer came from, so that loads through it are not hoisted out of the visit loop: every lane always
+// uses the same table entries (its Gauss point, its three local columns: 66 doubles), and keeping all of them in
+// registers for the whole loop costs more (spills) than re-reading them from LDS.
+template <bool ON, class T>
+__device__ __forceinline__ T *reload_each_time(T *p) {
+    if (ON) asm volatile("" : "+v"(p));
+    return p;
 }
 
-struct AsmVisit {     // what a lane needs of one (element, row node) visit
-    int32_t packed;   // element << 4 | local index of the row node, -1: no visit (lanes of shorter rows)
-    int nd[10];
-};
 struct AsmGeom {
     double cx[10], cy[10], cz[10];
     uint32_t em[3];   // packed block location of local column b = h + 4 t
@@ -48,7 +60,8 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                                                      const uint8_t *__restrict__ pgp, MatConst mc, double gx, double gy, double gz,
                                                      double *__restrict__ vals, double *__restrict__ glv, double *__restrict__ modf,
                                                      double *__restrict__ xgp, double *__restrict__ volume, int penalty_bc) {
-    extern __shared__ double rowbuf[];
+    extern __shared__ double lds[];
+    double *tab = lds, *jac = lds + ASM_TAB, *rowbuf = lds + ASM_TAB + ASM_JAC;
     // XCD-aware remap (as k_spmv): the workgroups of one XCD take a contiguous range of work items, whose rows share
     // elements and nodes, so that their gathers meet in one L2
     const int64_t nb = gridDim.x, bq = nb >> 3, br = nb & 7, xcd = blockIdx.x & 7;
@@ -60,6 +73,14 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
     const int64_t jb = sptr[s], len = sptr[s + 1] - jb, cbase = jb >> 1;
     const int64_t S = asm_row_stride(len);
     for (int64_t i = lane; i < ASM_ROWS * S; i += 64) rowbuf[i] = 0.0;
+    if (lane < 40) {   // shape-function tables (fcVM.py:365-424 at the Gauss points of fcVM.py:587-596)
+        const int g = lane / 10, k = lane - 10 * g;
+        double xi, et, ze, d0, d1, d2;
+        gp_point(g, xi, et, ze);
+        dshp_k(k, xi, et, ze, d0, d1, d2);
+        tab[3 * lane] = d0; tab[3 * lane + 1] = d1; tab[3 * lane + 2] = d2;
+        tab[120 + lane] = shp_k(k, xi, et, ze);
+    }
     const int64_t slot = s * 64 + qd * ASM_ROWS + rowl;
     const int node = rownode[slot];
     const int64_t q0 = node >= 0 ? nptr[node] : 0;
@@ -69,195 +90,182 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
     for (int o = 32; o > 0; o >>= 1) maxvis = max(maxvis, __shfl_xor(maxvis, o, 64));
     const int fa = node >= 0 ? fixmask[node] : 0;
     double *myrow = rowbuf + rowl * S;
+    double *myjac = jac + (rowl * 4 + h) * ASM_JREC;         // this lane's Gauss point of this row's visited element
+    const double *rowjac = jac + rowl * 4 * ASM_JREC;        // all four
+    const double *mydn = tab + 30 * h;                       // dN/dxi at Gauss point h
     __syncthreads();
 
+    // packed visit: element << 4 | local index of the row node, -1: no visit (lanes of shorter rows)
     auto load_packed = [&](int v) -> int32_t { return v < nvis ? nel[q0 + v] : -1; };
-    auto load_nodes = [&](int32_t packed, AsmVisit &V) {
-        V.packed = packed;
+    int nd[10];       // element nodes of the visit whose coordinates are fetched next
+    auto load_nodes = [&](int32_t packed) {
         const int64_t e = packed >= 0 ? (int64_t)(packed >> 4) : 0;   // idle lanes read element 0 (valid memory), results unused
         const int2 *p = (const int2 *)(el + e * 10);                  // 40-byte rows: 8-byte aligned
 #pragma unroll
         for (int k = 0; k < 5; k++) {
             const int2 t = p[k];
-            V.nd[2 * k] = t.x;
-            V.nd[2 * k + 1] = t.y;
+            nd[2 * k] = t.x;
+            nd[2 * k + 1] = t.y;
         }
     };
-    auto load_geom = [&](const AsmVisit &V, AsmGeom &G) {
+    auto load_geom = [&](int32_t packed, AsmGeom &G) {
 #pragma unroll
         for (int k = 0; k < 10; k++) {
-            const double *c = coord + 3 * (int64_t)V.nd[k];
+            const double *c = coord + 3 * (int64_t)nd[k];
             G.cx[k] = c[0]; G.cy[k] = c[1]; G.cz[k] = c[2];
         }
         if (disp) {
 #pragma unroll
             for (int k = 0; k < 10; k++) {
-                const double *u = disp + 3 * (int64_t)V.nd[k];
+                const double *u = disp + 3 * (int64_t)nd[k];
                 G.cx[k] += u[0]; G.cy[k] += u[1]; G.cz[k] += u[2];
             }
         }
-        const int64_t e = V.packed >= 0 ? (int64_t)(V.packed >> 4) : 0;
-        const int a = V.packed >= 0 ? (V.packed & 15) : 0;
+        const int64_t e = packed >= 0 ? (int64_t)(packed >> 4) : 0;
+        const int a = packed >= 0 ? (packed & 15) : 0;
 #pragma unroll
         for (int t = 0; t < 3; t++) {
             const int b = min(h + 4 * t, 9);
-            // column node of block t: nd[4 t + h] without a runtime-indexed register array
-            int nb = V.nd[min(4 * t, 9)];
-            if (h == 1) nb = V.nd[min(4 * t + 1, 9)];
-            if (h == 2) nb = V.nd[min(4 * t + 2, 9)];
-            if (h == 3) nb = V.nd[min(4 * t + 3, 9)];
-            G.ndb[t] = nb;
+            // column node of block t = nd[4 t + h]: read again from the (cached) connectivity row -- selecting it from the
+            // registers makes the compiler index the array at run time, which puts it into scratch memory
+            const int nb_ = el[e * 10 + b];
+            G.ndb[t] = nb_;
             G.em[t] = emap[e * 100 + a * 10 + b];
-            G.fb[t] = fixmask[nb];
+            G.fb[t] = fixmask[nb_];
         }
     };
 
-    AsmVisit V0, V1, V2;
-    AsmGeom G0, G1;
-    load_nodes(load_packed(0), V0);
-    load_nodes(load_packed(1), V1);
-    int32_t pk2 = load_packed(2);
-    load_geom(V0, G0);
-
     double racc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // gravity (3), modf (3), volume
-    for (int v = 0; v < maxvis; v++) {
-        // loads of the next stages first: they are in flight while this visit is integrated
-        load_geom(V1, G1);
-        load_nodes(pk2, V2);
-        pk2 = load_packed(v + 3);
-
-        const bool active = V0.packed >= 0;
-        const int64_t e = active ? (int64_t)(V0.packed >> 4) : 0;
-        const int a = active ? (V0.packed & 15) : 0;
-        // ---- Jacobian of Gauss point h (fcVM.py:436-453), shared inside the quad ----
-        double xsi[4][9], w[4], vol = 0.0;
+    auto integrate = [&](const int32_t pk, const AsmGeom &G0) {
+        const bool active = pk >= 0;
+        const int64_t e = active ? (int64_t)(pk >> 4) : 0;
+        const int a = active ? (pk & 15) : 0;
+        // ---- Jacobian of Gauss point h (fcVM.py:436-453) -> LDS record of (row, h) ----
         {
-            double xi, et, ze;
-            gp_point(h, xi, et, ze);
             double xs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const double *dn = reload_each_time<ASM_RELOAD_DN>(mydn);
 #pragma unroll
             for (int k = 0; k < 10; k++) {
-                double d0, d1, d2;
-                dshp_k(k, xi, et, ze, d0, d1, d2);
+                const double d0 = dn[3 * k], d1 = dn[3 * k + 1], d2 = dn[3 * k + 2];
                 xs[0] += G0.cx[k] * d0; xs[1] += G0.cx[k] * d1; xs[2] += G0.cx[k] * d2;
                 xs[3] += G0.cy[k] * d0; xs[4] += G0.cy[k] * d1; xs[5] += G0.cy[k] * d2;
                 xs[6] += G0.cz[k] * d0; xs[7] += G0.cz[k] * d1; xs[8] += G0.cz[k] * d2;
             }
             double mine[9];
             const double xsj = jac_inverse(xs, mine);
-            const double wm = FCVM_GPW * fabs(xsj), vm = xsj * FCVM_GPW;
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
+            for (int k = 0; k < 9; k++) myjac[k] = mine[k];
+            myjac[9] = FCVM_GPW * fabs(xsj);
+            myjac[10] = xsj * FCVM_GPW;
+            if (TANGENT) {   // deviatoric stress and plastic factor of Gauss point h (fcVM.py:983-998)
+                double sd[6] = {0, 0, 0, 0, 0, 0}, pfm = 0.0;
+                if (active && pgp[4 * e + h]) {
+                    const double *s0 = sig + 24 * e + 6 * h;
 #pragma unroll
-                for (int k = 0; k < 9; k++) xsi[g][k] = quad_get(mine[k], g);
-                w[g] = quad_get(wm, g);
-                vol += quad_get(vm, g);
+                    for (int j = 0; j < 6; j++) sd[j] = s0[j];
+                    const double p = (sd[0] + sd[1] + sd[2]) / 3.0;
+                    sd[0] -= p; sd[1] -= p; sd[2] -= p;
+                    double svm = sqrt(1.5 * (sd[0] * sd[0] + sd[1] * sd[1] + sd[2] * sd[2]) + 3.0 * (sd[3] * sd[3] + sd[4] * sd[4] + sd[5] * sd[5]));
+                    if (svm == 0.0) svm = 1.0;
+                    pfm = 3.0 * mc.G / (1.0 + mc.H / 3.0 / mc.G) / (svm * svm);
+                }
+                myjac[11] = pfm;
+#pragma unroll
+                for (int j = 0; j < 6; j++) myjac[12 + j] = sd[j];
             }
         }
         // Gauss point coordinates (fcVM.py:761): lane 3 of the quad (it integrates one block less)
         if (xgp && active && a < 4 && h == 3) {
-            double xi, et, ze;
-            gp_point(a, xi, et, ze);
+            const double *nsa = tab + 120 + 10 * a;
             double px = 0, py = 0, pz = 0;
 #pragma unroll
             for (int k = 0; k < 10; k++) {
-                const double n = shp_k(k, xi, et, ze);
+                const double n = nsa[k];
                 px += G0.cx[k] * n; py += G0.cy[k] * n; pz += G0.cz[k] * n;
             }
             double *o = xgp + 3 * (4 * e + a);
             o[0] = px; o[1] = py; o[2] = pz;
         }
-        // ---- row node a: global gradients, gravity weight, tangent terms ----
-        double ga[4][3], gam = 0.0;
-        double Sg[4][6], pf[4], ta[4][3];
-        if (TANGENT) {   // lane h fetches the stresses of Gauss point h (fcVM.py:983-998), the quad shares them
-            double sd[6] = {0, 0, 0, 0, 0, 0}, pfm = 0.0;
-            if (active && pgp[4 * e + h]) {
-                const double *s0 = sig + 24 * e + 6 * h;
+        __syncthreads();   // one wavefront: orders the LDS records of the quad before they are read
+        // ---- blocks K_ab, b = h, h + 4, h + 8, Gauss points outermost ----
+        double M[3][9];
 #pragma unroll
-                for (int j = 0; j < 6; j++) sd[j] = s0[j];
-                const double p = (sd[0] + sd[1] + sd[2]) / 3.0;
-                sd[0] -= p; sd[1] -= p; sd[2] -= p;
-                double svm = sqrt(1.5 * (sd[0] * sd[0] + sd[1] * sd[1] + sd[2] * sd[2]) + 3.0 * (sd[3] * sd[3] + sd[4] * sd[4] + sd[5] * sd[5]));
-                if (svm == 0.0) svm = 1.0;
-                pfm = 3.0 * mc.G / (1.0 + mc.H / 3.0 / mc.G) / (svm * svm);
-            }
+        for (int t = 0; t < 3; t++)
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-#pragma unroll
-                for (int j = 0; j < 6; j++) Sg[g][j] = quad_get(sd[j], g);
-                pf[g] = quad_get(pfm, g);
-            }
-        }
+            for (int k = 0; k < 9; k++) M[t][k] = 0.0;
+        double gam = 0.0, vol = 0.0;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            double xi, et, ze, d0, d1, d2;
-            gp_point(g, xi, et, ze);
-            dshp_k(a, xi, et, ze, d0, d1, d2);
-            to_global(xsi[g], d0, d1, d2, ga[g][0], ga[g][1], ga[g][2]);
-            gam += w[g] * shp_k(a, xi, et, ze);
+            const double *J = rowjac + g * ASM_JREC;
+            double xsi[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) xsi[k] = J[k];
+            const double wg_ = J[9];
+            vol += J[10];
+            const double *da = tab + 30 * g + 3 * a;
+            double ga[3];
+            to_global(xsi, da[0], da[1], da[2], ga[0], ga[1], ga[2]);
+            gam += wg_ * tab[120 + 10 * g + a];
+            double pf = 0.0, Sg[6], ta[3];
             if (TANGENT) {
-                ta[g][0] = ga[g][0] * Sg[g][0] + ga[g][1] * Sg[g][3] + ga[g][2] * Sg[g][4];
-                ta[g][1] = ga[g][1] * Sg[g][1] + ga[g][0] * Sg[g][3] + ga[g][2] * Sg[g][5];
-                ta[g][2] = ga[g][2] * Sg[g][2] + ga[g][0] * Sg[g][4] + ga[g][1] * Sg[g][5];
+                pf = J[11];
+#pragma unroll
+                for (int j = 0; j < 6; j++) Sg[j] = J[12 + j];
+                ta[0] = ga[0] * Sg[0] + ga[1] * Sg[3] + ga[2] * Sg[4];
+                ta[1] = ga[1] * Sg[1] + ga[0] * Sg[3] + ga[2] * Sg[5];
+                ta[2] = ga[2] * Sg[2] + ga[0] * Sg[4] + ga[1] * Sg[5];
+            }
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const int b = min(h + 4 * t, 9);
+                const double *db = reload_each_time<ASM_RELOAD_DB>(tab + 30 * g + 3 * b);
+                double gb[3];
+                to_global(xsi, db[0], db[1], db[2], gb[0], gb[1], gb[2]);
+                if (!TANGENT) {
+                    // constant D over the Gauss points: only M = sum_g w_g ga_g gb_g^T is integrated, D is applied below
+                    const double a0 = wg_ * ga[0], a1 = wg_ * ga[1], a2 = wg_ * ga[2];
+                    M[t][0] += a0 * gb[0]; M[t][1] += a0 * gb[1]; M[t][2] += a0 * gb[2];
+                    M[t][3] += a1 * gb[0]; M[t][4] += a1 * gb[1]; M[t][5] += a1 * gb[2];
+                    M[t][6] += a2 * gb[0]; M[t][7] += a2 * gb[1]; M[t][8] += a2 * gb[2];
+                } else {
+                    const double dot = ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2];
+                    double tb[3];
+                    tb[0] = gb[0] * Sg[0] + gb[1] * Sg[3] + gb[2] * Sg[4];
+                    tb[1] = gb[1] * Sg[1] + gb[0] * Sg[3] + gb[2] * Sg[5];
+                    tb[2] = gb[2] * Sg[2] + gb[0] * Sg[4] + gb[1] * Sg[5];
+#pragma unroll
+                    for (int r = 0; r < 3; r++)
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            double val;
+                            if (r == c) val = mc.D11 * ga[r] * gb[r] + mc.D44 * (dot - ga[r] * gb[r]);
+                            else val = mc.D12 * ga[r] * gb[c] + mc.D44 * ga[c] * gb[r];
+                            val -= pf * ta[r] * tb[c];
+                            M[t][r * 3 + c] += wg_ * val;
+                        }
+                }
             }
         }
         if (active && h == 0) {   // gravity load (fcVM.py:757-767) and volume
             racc[0] += gx * mc.rho * gam; racc[1] += gy * mc.rho * gam; racc[2] += gz * mc.rho * gam;
             if (a == 0) racc[6] += vol;
         }
-        // ---- blocks K_ab, b = h, h + 4, h + 8 ----
 #pragma unroll
         for (int t = 0; t < 3; t++) {
             const int b = h + 4 * t;
             if (active && b < 10) {
                 double K[9];
-                if (!TANGENT) {
-                    // constant D over the Gauss points: K = D12 M + D44 M^T + (D11 - D12 - D44) diag(M) + D44 tr(M) I with
-                    // M = sum_g w_g ga_g gb_g^T (the same numbers as fcVM.py:769-771, summed in a different order)
-                    double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        double xi, et, ze, d0, d1, d2, gb0, gb1, gb2;
-                        gp_point(g, xi, et, ze);
-                        dshp_k(b, xi, et, ze, d0, d1, d2);
-                        to_global(xsi[g], d0, d1, d2, gb0, gb1, gb2);
-                        const double a0 = w[g] * ga[g][0], a1 = w[g] * ga[g][1], a2 = w[g] * ga[g][2];
-                        M[0] += a0 * gb0; M[1] += a0 * gb1; M[2] += a0 * gb2;
-                        M[3] += a1 * gb0; M[4] += a1 * gb1; M[5] += a1 * gb2;
-                        M[6] += a2 * gb0; M[7] += a2 * gb1; M[8] += a2 * gb2;
-                    }
-                    const double tr = M[0] + M[4] + M[8];
+                if (!TANGENT) {   // K = D12 M + D44 M^T + (D11 - D12 - D44) diag(M) + D44 tr(M) I (fcVM.py:769-771 regrouped)
+                    const double tr = M[t][0] + M[t][4] + M[t][8];
 #pragma unroll
                     for (int r = 0; r < 3; r++)
 #pragma unroll
                         for (int c = 0; c < 3; c++)
-                            K[r * 3 + c] = (r == c) ? mc.D11 * M[r * 3 + r] + mc.D44 * (tr - M[r * 3 + r])
-                                                    : mc.D12 * M[r * 3 + c] + mc.D44 * M[c * 3 + r];
+                            K[r * 3 + c] = (r == c) ? mc.D11 * M[t][r * 3 + r] + mc.D44 * (tr - M[t][r * 3 + r])
+                                                    : mc.D12 * M[t][r * 3 + c] + mc.D44 * M[t][c * 3 + r];
                 } else {
 #pragma unroll
-                    for (int k = 0; k < 9; k++) K[k] = 0.0;
-#pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        double xi, et, ze, d0, d1, d2, gb[3], tb[3];
-                        gp_point(g, xi, et, ze);
-                        dshp_k(b, xi, et, ze, d0, d1, d2);
-                        to_global(xsi[g], d0, d1, d2, gb[0], gb[1], gb[2]);
-                        const double dot = ga[g][0] * gb[0] + ga[g][1] * gb[1] + ga[g][2] * gb[2];
-                        tb[0] = gb[0] * Sg[g][0] + gb[1] * Sg[g][3] + gb[2] * Sg[g][4];
-                        tb[1] = gb[1] * Sg[g][1] + gb[0] * Sg[g][3] + gb[2] * Sg[g][5];
-                        tb[2] = gb[2] * Sg[g][2] + gb[0] * Sg[g][4] + gb[1] * Sg[g][5];
-#pragma unroll
-                        for (int r = 0; r < 3; r++)
-#pragma unroll
-                            for (int c = 0; c < 3; c++) {
-                                double val;
-                                if (r == c) val = mc.D11 * ga[g][r] * gb[r] + mc.D44 * (dot - ga[g][r] * gb[r]);
-                                else val = mc.D12 * ga[g][r] * gb[c] + mc.D44 * ga[g][c] * gb[r];
-                                val -= pf[g] * ta[g][r] * tb[c];
-                                K[r * 3 + c] += w[g] * val;
-                            }
-                    }
+                    for (int k = 0; k < 9; k++) K[k] = M[t][k];
                 }
                 // boundary conditions folded in (fcVM.py:773-800) and accumulation into the row's LDS image
                 const uint32_t em = G0.em[t];
@@ -265,38 +273,65 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                 double *dst = myrow + jj * 9;
                 const int fb = G0.fb[t];
                 const bool diag = (a == b);
+                if (penalty_bc) {   // linear-buckling matrices (fcVM.py:1051-1062): no elimination, fixed diagonal x 100
 #pragma unroll
-                for (int r = 0; r < 3; r++) {
-                    const bool rfix = (fa >> r) & 1;
+                    for (int r = 0; r < 3; r++)
 #pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        const bool cfix = (fb >> c) & 1;
-                        double add = 0.0;
-                        bool has = false;
-                        if (penalty_bc) {   // linear-buckling matrices (fcVM.py:1051-1062): no elimination, fixed diagonal x 100
-                            add = (rfix && diag && r == c) ? 100.0 * K[r * 3 + c] : K[r * 3 + c];
-                            has = true;
-                        } else if (!rfix && !cfix) {
-                            add = K[r * 3 + c];
-                            has = true;
-                        } else if (!rfix && cfix) {
-                            racc[3 + r] -= K[r * 3 + c] * fixval[3 * (int64_t)G0.ndb[t] + c];
-                        } else if (rfix && diag && r == c) {   // fcVM.py:773-778: unit diagonal per element occurrence
-                            add = 1.0;
-                            has = true;
-                            racc[3 + r] += fixval[3 * (int64_t)node + r];
+                        for (int c = 0; c < 3; c++)
+                            dst[r * 3 + c] += (((fa >> r) & 1) && diag && r == c) ? 100.0 * K[r * 3 + c] : K[r * 3 + c];
+                } else if ((fa | fb) == 0) {   // no supports at either node: the whole block
+#pragma unroll
+                    for (int k = 0; k < 9; k++) dst[k] += K[k];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 3; r++) {
+                        const bool rfix = (fa >> r) & 1;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            const bool cfix = (fb >> c) & 1;
+                            if (!rfix && !cfix) {
+                                dst[r * 3 + c] += K[r * 3 + c];
+                            } else if (!rfix && cfix) {
+                                racc[3 + r] -= K[r * 3 + c] * fixval[3 * (int64_t)G0.ndb[t] + c];
+                            } else if (rfix && diag && r == c) {   // fcVM.py:773-778: unit diagonal per element occurrence
+                                dst[r * 3 + c] += 1.0;
+                                racc[3 + r] += fixval[3 * (int64_t)node + r];
+                            }
                         }
-                        if (has) dst[r * 3 + c] += add;
                     }
                 }
             }
         }
-        V0 = V1; V1 = V2; G0 = G1;
+        __syncthreads();   // the Jacobian records are rewritten by the next visit
+    };
+
+    // software pipeline over the visits, two per trip so that the two coordinate sets swap roles without copies:
+    // while visit v is integrated, the coordinates / block locations of visit v + 1 and the connectivity of visit
+    // v + 2 are in flight
+    AsmGeom GA, GB;
+    int32_t pk0 = load_packed(0), pk1 = load_packed(1), pk2 = load_packed(2);
+    load_nodes(pk0);
+    load_geom(pk0, GA);
+    load_nodes(pk1);
+    for (int v = 0; v < maxvis; v += 2) {
+        load_geom(pk1, GB);
+        load_nodes(pk2);
+        const int32_t pk3 = load_packed(v + 3);
+        integrate(pk0, GA);
+        int32_t pk4 = -1;
+        if (v + 1 < maxvis) {
+            load_geom(pk2, GA);
+            load_nodes(pk3);
+            pk4 = load_packed(v + 4);
+            integrate(pk1, GB);
+        }
+        pk0 = pk2; pk1 = pk3; pk2 = pk4;
     }
     // ---- per-row sums: quad reduction in a fixed order, lane 0 of the quad writes ----
 #pragma unroll
     for (int k = 3; k < 6; k++) {
-        const double v0 = quad_get(racc[k], 0), v1 = quad_get(racc[k], 1), v2 = quad_get(racc[k], 2), v3 = quad_get(racc[k], 3);
+        const int qb = lane & 60;
+        const double v0 = __shfl(racc[k], qb, 64), v1 = __shfl(racc[k], qb + 1, 64), v2 = __shfl(racc[k], qb + 2, 64), v3 = __shfl(racc[k], qb + 3, 64);
         racc[k] = (v0 + v1) + (v2 + v3);
     }
     if (node >= 0 && h == 0) {

@@ -45,9 +45,7 @@ struct fcvm_ctx {
     double E = 0, nu = 0, rho = 0;
     // device mesh
     int32_t *d_el = nullptr, *d_cols = nullptr, *d_rownode = nullptr, *d_noce = nullptr;
-    int64_t *d_sptr = nullptr, *d_gptr = nullptr, *d_gptr1 = nullptr;   // slice lengths; gang tables (Pattern::chunk)
-    uint32_t *d_goff = nullptr, *d_goff1 = nullptr;
-    int spmv_gang = 1;           // slices per gang of interleaved chunks (FCVM_SPMV_GANG); 1 = slice after slice: measured equal (r02a)
+    int64_t *d_sptr = nullptr;
     uint32_t *d_emap = nullptr, *d_diagoff = nullptr;
     int64_t *d_nptr = nullptr, *d_nptr1 = nullptr;   // node -> element incidence for the row-owner assembly (fine / tet4 level)
     int32_t *d_nel = nullptr, *d_nel1 = nullptr;
@@ -66,8 +64,6 @@ struct fcvm_ctx {
     double *d_vals_g = nullptr;  // geometric stiffness (linear buckling), same pattern as d_vals
     // pcg work
     double *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_q = nullptr, *d_S = nullptr;
-    double *d_p4 = nullptr;      // the PCG direction with 4 doubles per node: what the fine SpMV gathers from (FCVM_SPMV_XPAD=0: off)
-    int spmv_xpad = 1;
     double *d_part_vec = nullptr, *d_part_spmv = nullptr, *d_part_misc = nullptr, *d_out8 = nullptr;
     long long *d_pidx = nullptr;
     int64_t nb_vec = 0, nb_spmv = 0, nb_gp = 0;
@@ -147,71 +143,42 @@ struct MatView {
     const int32_t *cols;
     const double *vals;
     const int32_t *rownode;
-    ChunkMap cm;
     const float *vals32 = nullptr;  // optional FP32 copy of the values (coarse multigrid level)
 };
-static ChunkMap chunk_map(const Pattern &p, const int64_t *d_gptr, const uint32_t *d_goff) {
-    int sh = -1;
-    if (p.gang > 1)
-        for (sh = 0; (1 << sh) < p.gang; sh++) {}
-    return {sh, d_gptr, d_goff};
-}
-static MatView fine_view(const fcvm_ctx *c) {
-    return {c->pat.nslices, c->nb_spmv, c->d_sptr, c->d_cols, c->d_vals, c->d_rownode, chunk_map(c->pat, c->d_gptr, c->d_goff)};
-}
+static MatView fine_view(const fcvm_ctx *c) { return {c->pat.nslices, c->nb_spmv, c->d_sptr, c->d_cols, c->d_vals, c->d_rownode}; }
 static MatView coarse_view(const fcvm_ctx *c) {
-    return {c->pat1.nslices, c->nb_spmv1, c->d_sptr1, c->d_cols1, c->d_vals1, c->d_rownode1, chunk_map(c->pat1, c->d_gptr1, c->d_goff1),
-            c->mg_fp32 ? c->d_vals1f : nullptr};
+    return {c->pat1.nslices, c->nb_spmv1, c->d_sptr1, c->d_cols1, c->d_vals1, c->d_rownode1, c->mg_fp32 ? c->d_vals1f : nullptr};
 }
 
-#define FCVM_SPMV_LAUNCH(DOT_, NT_, UN_, V2_, EPI_, XP_, vals_, epi_)                                                                  \
-    do {                                                                                                                            \
-        if (m.cm.gshift >= 0)                                                                                                       \
-            hipLaunchKernelGGL((k_spmv<DOT_, NT_, UN_, V2_, EPI_, true, XP_>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols, \
-                               (const V2_ *)(vals_), m.rownode, x, y, part, done, epi_, m.cm);                                       \
-        else                                                                                                                        \
-            hipLaunchKernelGGL((k_spmv<DOT_, NT_, UN_, V2_, EPI_, false, XP_>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols, \
-                               (const V2_ *)(vals_), m.rownode, x, y, part, done, epi_, m.cm);                                       \
-    } while (0)
+#define FCVM_SPMV_LAUNCH(DOT_, NT_, UN_, V2_, EPI_, vals_, epi_)                                                               \
+    hipLaunchKernelGGL((k_spmv<DOT_, NT_, UN_, V2_, EPI_>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols, \
+                       (const V2_ *)(vals_), m.rownode, x, y, part, done, epi_)
 
-// xpad: x holds 4 doubles per node (only the FP64 fine-level kernel has that form)
 template <bool DOT>
-static void launch_spmv_t(fcvm_ctx *c, const MatView &m, const double *x, double *y, double *part, const double *done, bool xpad = false) {
+static void launch_spmv_t(fcvm_ctx *c, const MatView &m, const double *x, double *y, double *part, const double *done) {
     dim3 grid((unsigned)m.nb), block(64 * c->spmv_spw);
     if (m.vals32) {  // FP32-stored matrix, FP64 vectors and accumulation
-        FCVM_SPMV_LAUNCH(DOT, false, 4, float2, 0, false, m.vals32, ChebEpi{});
+        FCVM_SPMV_LAUNCH(DOT, false, 4, float2, 0, m.vals32, ChebEpi{});
         return;
     }
-    if (xpad) FCVM_SPMV_LAUNCH(DOT, true, 4, double2, 0, true, m.vals, ChebEpi{});
-    else if (c->spmv_variant == 0) FCVM_SPMV_LAUNCH(DOT, false, 1, double2, 0, false, m.vals, ChebEpi{});
-    else FCVM_SPMV_LAUNCH(DOT, true, 4, double2, 0, false, m.vals, ChebEpi{});
+    if (c->spmv_variant == 0) FCVM_SPMV_LAUNCH(DOT, false, 1, double2, 0, m.vals, ChebEpi{});
+    else FCVM_SPMV_LAUNCH(DOT, true, 4, double2, 0, m.vals, ChebEpi{});
 }
 // SpMV t = A d fused with a Chebyshev smoother step on the same rows (see ChebEpi); nothing is written but epi's vectors
 static void launch_spmv_cheb(fcvm_ctx *c, const MatView &m, const double *x, const double *done, const ChebEpi &epi) {
     dim3 grid((unsigned)m.nb), block(64 * c->spmv_spw);
     double *y = nullptr, *part = nullptr;
-    if (m.vals32) FCVM_SPMV_LAUNCH(false, false, 4, float2, 1, false, m.vals32, epi);
-    else FCVM_SPMV_LAUNCH(false, true, 4, double2, 1, false, m.vals, epi);
+    if (m.vals32) FCVM_SPMV_LAUNCH(false, false, 4, float2, 1, m.vals32, epi);
+    else FCVM_SPMV_LAUNCH(false, true, 4, double2, 1, m.vals, epi);
 }
 static void launch_gemv_f32(fcvm_ctx *c, const double *r2, double *e2, const double *done) {
     hipLaunchKernelGGL(k_gemv_f32x4, dim3((unsigned)cdiv(c->n2, 16)), dim3(256), 0, c->stream, c->n2, c->n2, (c->n2 + 3) / 4 * 4,
                        c->d_A2invf, r2, e2, done);
 }
-static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done, bool xpad = false) {
-    if (dot) launch_spmv_t<true>(c, fine_view(c), x, y, c->d_part_spmv, done, xpad);
-    else launch_spmv_t<false>(c, fine_view(c), x, y, nullptr, done, xpad);
+static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done) {
+    if (dot) launch_spmv_t<true>(c, fine_view(c), x, y, c->d_part_spmv, done);
+    else launch_spmv_t<false>(c, fine_view(c), x, y, nullptr, done);
 }
-// p = z + beta p of the PCG loops (and the padded copy of p the fine SpMV gathers from)
-static void launch_update_p(fcvm_ctx *c) {
-    if (c->spmv_xpad)
-        hipLaunchKernelGGL(k_pcg_update_p4, dim3((unsigned)cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_z, c->d_p, c->d_p4, c->d_S);
-    else
-        hipLaunchKernelGGL(k_pcg_update_p, dim3((unsigned)cdiv(3 * c->nn, 256)), dim3(256), 0, c->stream, 3 * c->nn, c->d_z, c->d_p, c->d_S);
-}
-static void launch_pad_p(fcvm_ctx *c) {
-    if (c->spmv_xpad) hipLaunchKernelGGL(k_pad4, dim3((unsigned)cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_p, c->d_p4);
-}
-static const double *pcg_dir(const fcvm_ctx *c) { return c->spmv_xpad ? c->d_p4 : c->d_p; }
 
 static int dot_common(fcvm_ctx *c, int64_t n, const double *w, const double *x, const double *y, double *result_dev) {
     NEED(c && c->d_part_misc, "vector reductions need a mesh (work buffers)");
@@ -321,7 +288,7 @@ static int build_asm_items(fcvm_ctx *c) {
     const Pattern &p = c->pat;
     c->asm_lds_ok = false;
     dfree(c->d_asm_items);
-    if (p.gang != 1 || p.maxlen + 1 > ASM_LEN_LIMIT[fcvm_ctx::ASM_BUCKETS - 1]) return 0;   // block locations must be cbase + pair; rows must fit the LDS
+    if (p.maxlen + 1 > ASM_LEN_LIMIT[fcvm_ctx::ASM_BUCKETS - 1]) return 0;   // the rows must fit the LDS
     std::vector<int32_t> items[fcvm_ctx::ASM_BUCKETS];
     NEED(p.nslices < (int64_t(1) << 29), "too many slices for 32-bit assembly work items");
     for (int64_t s = 0; s < p.nslices; s++) {
@@ -387,8 +354,6 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_ASSEMBLE_ATOMIC")) c->assemble_atomic = atoi(v);
     if (const char *v = getenv("FCVM_ASSEMBLE_LDS")) c->assemble_lds = atoi(v);
     if (const char *v = getenv("FCVM_QIN_ATOMIC")) c->qin_atomic = atoi(v);
-    if (const char *v = getenv("FCVM_SPMV_XPAD")) c->spmv_xpad = atoi(v);
-    if (const char *v = getenv("FCVM_SPMV_GANG")) c->spmv_gang = std::max(1, atoi(v));
     if (const char *v = getenv("FCVM_SPMV_SPW")) c->spmv_spw = std::min(4, std::max(1, atoi(v)));   // slices (waves) per workgroup
     if (const char *v = getenv("FCVM_MG_ADDITIVE")) c->mg_additive = atoi(v);
     if (const char *v = getenv("FCVM_MG_FP32")) c->mg_fp32 = atoi(v);
@@ -401,11 +366,11 @@ int fcvm_create(int device, fcvm_ctx **out) {
 }
 
 static void free_mesh(fcvm_ctx *c) {
-    dfree(c->d_el); dfree(c->d_cols); dfree(c->d_rownode); dfree(c->d_noce); dfree(c->d_sptr); dfree(c->d_gptr); dfree(c->d_goff);
+    dfree(c->d_el); dfree(c->d_cols); dfree(c->d_rownode); dfree(c->d_noce); dfree(c->d_sptr);
     dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
     dfree(c->d_nptr); dfree(c->d_nel); dfree(c->d_fe); dfree(c->d_part_vol); dfree(c->d_asm_items);
     dfree(c->d_vals); dfree(c->d_vals_g); dfree(c->d_dblk); dfree(c->d_dinv); dfree(c->d_r); dfree(c->d_z); dfree(c->d_p);
-    dfree(c->d_q); dfree(c->d_p4); dfree(c->d_part_vec); dfree(c->d_part_spmv); dfree(c->d_part_misc); dfree(c->d_pidx);
+    dfree(c->d_q); dfree(c->d_part_vec); dfree(c->d_part_spmv); dfree(c->d_part_misc); dfree(c->d_pidx);
     mg_free(c);
     c->have_mesh = c->assembled = false;
 }
@@ -488,7 +453,7 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
         std::vector<int32_t> order;
         if (use_morton) order = morton_order(nn, nocoord);
         c->row_order_morton = use_morton;
-        build_pattern(ne, nn, el.data(), c->pat, nt, win, 10, use_morton ? order.data() : nullptr, c->spmv_gang);
+        build_pattern(ne, nn, el.data(), c->pat, nt, win, 10, use_morton ? order.data() : nullptr);
     } catch (const std::exception &ex) {
         return fail(std::string("fcvm_set_mesh: ") + ex.what());
     }
@@ -505,8 +470,7 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
         dalloc(&c->d_diagoff, nn) || dalloc(&c->d_fixmask, nn) || dalloc(&c->d_coord, nn * 3) ||
         dalloc(&c->d_fixval, nn * 3) || dalloc(&c->d_vals, p.value_count()) || dalloc(&c->d_dblk, nn * 9) ||
         dalloc(&c->d_dinv, nn * 9) || dalloc(&c->d_r, nn * 3) || dalloc(&c->d_z, nn * 3) || dalloc(&c->d_p, nn * 3) ||
-        dalloc(&c->d_q, nn * 3) || dalloc(&c->d_p4, nn * 4) || dalloc(&c->d_nptr, nn + 1) || dalloc(&c->d_nel, ne * 10) || dalloc(&c->d_part_vol, 4 * p.nslices) ||
-        dalloc(&c->d_gptr, (int64_t)p.gptr.size()) || dalloc(&c->d_goff, (int64_t)p.goff.size()))
+        dalloc(&c->d_q, nn * 3) || dalloc(&c->d_nptr, nn + 1) || dalloc(&c->d_nel, ne * 10) || dalloc(&c->d_part_vol, 4 * p.nslices))
         return 1;
     c->nb_vec = cdiv(nn, 256);
     c->nb_spmv = cdiv(p.nslices, c->spmv_spw);
@@ -520,8 +484,6 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     HCHK(hipMemcpyAsync(c->d_rownode, p.rownode.data(), sizeof(int32_t) * p.nslices * SLICE, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_noce, noce.data(), sizeof(int32_t) * nn, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_sptr, p.sptr.data(), sizeof(int64_t) * (p.nslices + 1), hipMemcpyHostToDevice, s));
-    HCHK(hipMemcpyAsync(c->d_gptr, p.gptr.data(), sizeof(int64_t) * p.gptr.size(), hipMemcpyHostToDevice, s));
-    HCHK(hipMemcpyAsync(c->d_goff, p.goff.data(), sizeof(uint32_t) * p.goff.size(), hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_emap, p.emap.data(), sizeof(uint32_t) * ne * 100, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_diagoff, p.diagoff.data(), sizeof(uint32_t) * nn, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_nptr, p.nptr.data(), sizeof(int64_t) * (nn + 1), hipMemcpyHostToDevice, s));
@@ -582,7 +544,7 @@ int fcvm_pattern_info(fcvm_ctx *c, int64_t out[8]) {
     out[0] = p.nnzb; out[1] = p.nslots; out[2] = p.nslices;
     out[3] = p.value_count() * 8 + p.nslots * 4;
     out[4] = p.maxlen; out[5] = 3 * p.nn;
-    out[6] = p.gang; out[7] = c->spmv_variant;
+    out[6] = 1; out[7] = c->spmv_variant;
     return 0;
 }
 
@@ -751,14 +713,6 @@ int fcvm_spmv(fcvm_ctx *c, const double *x, double *y) {
     return 0;
 }
 
-int fcvm_spmv_x4(fcvm_ctx *c, const double *x4, double *y) {
-    NEED(c && c->have_mesh, "fcvm_spmv_x4: no mesh");
-    NEED(x4 != y, "fcvm_spmv_x4: x and y must not alias");
-    launch_spmv(c, false, x4, y, nullptr, true);
-    HCHK(hipGetLastError());
-    return 0;
-}
-
 int fcvm_precond(fcvm_ctx *c, const double *r, double *z) {
     NEED(c && c->have_mesh, "fcvm_precond: no mesh");
     hipLaunchKernelGGL(k_precond, dim3((unsigned)c->nb_vec), dim3(256), 0, c->stream, c->nn, c->d_dinv, r, z);
@@ -800,7 +754,6 @@ int fcvm_solve(fcvm_ctx *c, const double *f, double *u, double rtol, int64_t max
     hipLaunchKernelGGL(k_pcg_init, dim3((unsigned)nbv), dim3(256), 0, s, nn, c->d_dinv, f, u, c->d_r, c->d_z, c->d_p,
                        c->d_part_vec, nbv);
     hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(1024), 0, s, 0, c->d_part_vec, nbv, c->nb_spmv, c->d_S, rtol);
-    launch_pad_p(c);
     double S[S_COUNT];
     int64_t it = 0, nspmv = 0;
     double spmv_ms = 0.0;
@@ -809,13 +762,13 @@ int fcvm_solve(fcvm_ctx *c, const double *f, double *u, double rtol, int64_t max
         int k = (int)std::min<int64_t>(CHUNK, maxit - it);
         for (int j = 0; j < k; j++) {
             HCHK(hipEventRecord(c->evpool[2 * j], s));
-            launch_spmv(c, true, pcg_dir(c), c->d_q, c->d_S + S_DONE, c->spmv_xpad != 0);
+            launch_spmv(c, true, c->d_p, c->d_q, c->d_S + S_DONE);
             HCHK(hipEventRecord(c->evpool[2 * j + 1], s));
             hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(1024), 0, s, 1, c->d_part_spmv, nbv, c->nb_spmv, c->d_S, rtol);
             hipLaunchKernelGGL(k_pcg_update_xr, dim3((unsigned)nbv), dim3(256), 0, s, nn, c->d_dinv, c->d_p, c->d_q, u,
                                c->d_r, c->d_z, c->d_part_vec, nbv, c->d_S);
             hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(1024), 0, s, 2, c->d_part_vec, nbv, c->nb_spmv, c->d_S, rtol);
-            launch_update_p(c);
+            hipLaunchKernelGGL(k_pcg_update_p, dim3((unsigned)cdiv(3 * nn, 256)), dim3(256), 0, s, 3 * nn, c->d_z, c->d_p, c->d_S);
         }
         HCHK(hipGetLastError());
         HCHK(hipMemcpyAsync(S, c->d_S, sizeof(S), hipMemcpyDeviceToHost, s));
@@ -918,44 +871,30 @@ int fcvm_host_pattern_check(int64_t ne, int64_t nn, const int64_t *elNodes, int6
     }
     Pattern p;
     try {
-        int gang = 1;
-        if (const char *v = getenv("FCVM_SPMV_GANG")) gang = std::max(1, atoi(v));
-        build_pattern(ne, nn, el.data(), p, 4, SORT_WINDOW, 10, nullptr, gang);
+        build_pattern(ne, nn, el.data(), p, 4, SORT_WINDOW);
     } catch (const std::exception &ex) {
         return fail(std::string("fcvm_host_pattern_check: ") + ex.what());
     }
     int64_t bad = 0;
-    // every element block must land on a chunk of its row's slice whose column entry is the block's column node,
-    // in the lane of the block's row node; no two blocks of a row may share a location
+    // every element block must land on a slot whose column is the block's column node and whose
+    // row slot belongs to the block's row node
     for (int64_t e = 0; e < ne; e++)
         for (int a = 0; a < 10; a++)
             for (int b = 0; b < 10; b++) {
-                const uint32_t em = p.emap[e * 100 + a * 10 + b];   // packed: chunk << 7 | lane << 1 | (j & 1)
-                const int64_t j0 = em & 1, l = (em >> 1) & 63, chunk = em >> 7;
-                const int64_t slot = p.slotof[el[e * 10 + a]], s = slot / SLICE;
-                if (slot % SLICE != l) { bad++; continue; }
-                const int64_t np = (p.sptr[s + 1] - p.sptr[s]) / 2;
-                bool found = false;
-                for (int64_t pp = 0; pp < np && !found; pp++) found = p.chunk(s, pp) == chunk;
-                if (!found) { bad++; continue; }
-                if (p.cols[(chunk * 2 + j0) * SLICE + l] != el[e * 10 + b]) bad++;
+                const uint32_t em = p.emap[e * 100 + a * 10 + b];   // packed: pair row << 7 | lane << 1 | (j & 1)
+                const int64_t j0 = em & 1, l = (em >> 1) & 63;
+                const int64_t jglob = (int64_t)(em >> 7) * 2 + j0;  // = sptr[s] + j
+                int64_t slot = p.slotof[el[e * 10 + a]];
+                int64_t s = slot / SLICE;
+                if (slot % SLICE != l || jglob < p.sptr[s] || jglob >= p.sptr[s + 1]) { bad++; continue; }
+                if (p.cols[jglob * SLICE + l] != el[e * 10 + b]) bad++;
             }
-    {   // the chunks of all slices tile [0, total) exactly once
-        std::vector<uint8_t> seen(p.sptr[p.nslices] / 2, 0);
-        for (int64_t s = 0; s < p.nslices; s++)
-            for (int64_t pp = 0; pp < (p.sptr[s + 1] - p.sptr[s]) / 2; pp++) {
-                const int64_t ch = p.chunk(s, pp);
-                if (ch < 0 || ch >= (int64_t)seen.size() || seen[ch]) bad++;
-                else seen[ch] = 1;
-            }
-        for (uint8_t v : seen) bad += v ? 0 : 1;
-    }
     for (int64_t i = 0; i < nn; i++) {
         int64_t slot = p.slotof[i];
         if (slot < 0 || p.rownode[slot] != i) bad++;
     }
     out[0] = p.nnzb; out[1] = p.nslots; out[2] = p.nslices; out[3] = p.maxlen; out[4] = bad;
-    out[5] = p.value_count(); out[6] = p.sptr[p.nslices]; out[7] = p.gang;
+    out[5] = p.value_count(); out[6] = p.sptr[p.nslices]; out[7] = 0;
     return 0;
 }
 

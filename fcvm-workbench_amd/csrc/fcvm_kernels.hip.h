@@ -559,28 +559,16 @@ __device__ __forceinline__ int32_t ld_col(const int32_t *p) {
     return NT ? __builtin_nontemporal_load(p) : *p;
 }
 
-// XPAD: the gathered vector holds 4 doubles per node (x, y, z, 0): a node is one 16-byte and one 8-byte load instead of
-// three 8-byte loads.  The address / L1 pipeline (TA) is 87 % busy in this kernel and the x gathers are two thirds of
-// its work (profiles/r02c_pmc_*: TA_TA_BUSY 292 M of 336 M cycles, 61 cycles per wave-instruction against 33 for a
-// coalesced 16-byte stream load), so the kernel's time follows the shader clock of the box, not its HBM.
-template <bool NT, class V2, bool XPAD>
+template <bool NT, class V2>
 __device__ __forceinline__ void spmv_pair(const int32_t *cp, const V2 *vp, const double *__restrict__ x,
                                           double &y0, double &y1, double &y2) {
     const int32_t c0 = ld_col<NT>(cp), c1 = ld_col<NT>(cp + 64);
     double2 v[9];
 #pragma unroll
     for (int c = 0; c < 9; c++) v[c] = ld_val<NT>(vp + c * 64);
-    double a0, a1, a2, b0, b1, b2;
-    if (XPAD) {
-        const double *xa = x + 4 * (int64_t)c0, *xb = x + 4 * (int64_t)c1;
-        const double2 a01 = *(const double2 *)xa, b01 = *(const double2 *)xb;
-        a0 = a01.x; a1 = a01.y; a2 = xa[2];
-        b0 = b01.x; b1 = b01.y; b2 = xb[2];
-    } else {
-        const double *xa = x + 3 * (int64_t)c0, *xb = x + 3 * (int64_t)c1;
-        a0 = xa[0]; a1 = xa[1]; a2 = xa[2];
-        b0 = xb[0]; b1 = xb[1]; b2 = xb[2];
-    }
+    const double *xa = x + 3 * (int64_t)c0, *xb = x + 3 * (int64_t)c1;
+    const double a0 = xa[0], a1 = xa[1], a2 = xa[2];
+    const double b0 = xb[0], b1 = xb[1], b2 = xb[2];
     y0 += v[0].x * a0 + v[1].x * a1 + v[2].x * a2 + v[0].y * b0 + v[1].y * b1 + v[2].y * b2;
     y1 += v[3].x * a0 + v[4].x * a1 + v[5].x * a2 + v[3].y * b0 + v[4].y * b1 + v[5].y * b2;
     y2 += v[6].x * a0 + v[7].x * a1 + v[8].x * a2 + v[6].y * b0 + v[7].y * b1 + v[8].y * b2;
@@ -598,22 +586,14 @@ struct ChebEpi {
 };
 __device__ __forceinline__ void apply_dinv(const double *d, double r0, double r1, double r2, double &z0, double &z1, double &z2);
 
-// Where the chunks (block pairs) of the slices live: see Pattern::chunk (fcvm_pattern.h).  gshift < 0: plain order,
-// chunk(s, p) = sptr[s] / 2 + p.  Otherwise gangs of 1 << gshift slices with interleaved chunks.
-struct ChunkMap {
-    int gshift;
-    const int64_t *gptr;
-    const uint32_t *goff;
-};
-
-template <bool DOT, bool NT, int UNROLL, class V2 = double2, int EPI = 0, bool GANGED = false, bool XPAD = false>
+template <bool DOT, bool NT, int UNROLL, class V2 = double2, int EPI = 0>
 __global__ __launch_bounds__(256, (sizeof(V2) == 16 ? 4 : 1)) void k_spmv(int64_t nslices, int64_t nblocks, const int64_t *__restrict__ sptr,
                                               const int32_t *__restrict__ cols,
                                               const V2 *__restrict__ vals,
                                               const int32_t *__restrict__ rownode,
                                               const double *__restrict__ x, double *__restrict__ y,
                                               double *__restrict__ partial, const double *__restrict__ done,
-                                              ChebEpi epi, ChunkMap cm) {
+                                              ChebEpi epi) {
     __shared__ double sh[4];
     if (done && *done != 0.0) return;
     // XCD-aware remap: workgroups b, b+8, b+16.. share an XCD (and its L2); give each XCD a
@@ -622,56 +602,42 @@ __global__ __launch_bounds__(256, (sizeof(V2) == 16 ? 4 : 1)) void k_spmv(int64_
     const int64_t q = nblocks >> 3, r = nblocks & 7, xcd = b & 7;
     const int64_t wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     const int lane = threadIdx.x & 63;
-    // one slice per wavefront: the slice number is wave-uniform (scalar registers, scalar loads of the slice tables)
+    // one slice per wavefront: the slice number is wave-uniform (scalar registers, scalar loads of the slice table)
     const int64_t s = wg * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double y0 = 0.0, y1 = 0.0, y2 = 0.0;
     int node = -1;
     if (s < nslices) {
         const int64_t jb = sptr[s], je = sptr[s + 1];
+        const int32_t *cp = cols + jb * 64 + lane;
+        const V2 *vp = vals + (jb >> 1) * (9 * 64) + lane;
         int64_t np = (je - jb) >> 1;
-        // chunk(s, p) = cbase + (GANGED ? go[p] : p)
-        int64_t cbase = jb >> 1;
-        const uint32_t *go = nullptr;
-        if (GANGED) {
-            const int64_t g = s >> cm.gshift;
-            cbase = (sptr[g << cm.gshift] >> 1) + (s - (g << cm.gshift));
-            go = cm.goff + cm.gptr[g];
-        }
-        const int32_t *cp = cols + cbase * 128 + lane;
-        const V2 *vp = vals + cbase * (9 * 64) + lane;
-#define FCVM_CP(o) (cp + (int64_t)(o) * 128)
-#define FCVM_VP(o) (vp + (int64_t)(o) * (9 * 64))
-        int64_t p = 0;
         if (UNROLL == 4) {
             double z0 = 0.0, z1 = 0.0, z2 = 0.0, u0 = 0.0, u1 = 0.0, u2 = 0.0, w0 = 0.0, w1 = 0.0, w2 = 0.0;
-            // chunk offsets of the next unrolled iteration are fetched (scalar loads) before this one's matrix loads
-            uint32_t o0 = GANGED ? go[0] : 0u, o1 = GANGED ? go[1] : 1u, o2 = GANGED ? go[2] : 2u, o3 = GANGED ? go[3] : 3u;
-            for (; np - p >= 4; p += 4) {
-                const uint32_t n0 = GANGED ? go[p + 4] : (uint32_t)(p + 4), n1 = GANGED ? go[p + 5] : (uint32_t)(p + 5),
-                               n2 = GANGED ? go[p + 6] : (uint32_t)(p + 6), n3 = GANGED ? go[p + 7] : (uint32_t)(p + 7);
-                spmv_pair<NT, V2, XPAD>(FCVM_CP(o0), FCVM_VP(o0), x, y0, y1, y2);
-                spmv_pair<NT, V2, XPAD>(FCVM_CP(o1), FCVM_VP(o1), x, z0, z1, z2);
-                spmv_pair<NT, V2, XPAD>(FCVM_CP(o2), FCVM_VP(o2), x, u0, u1, u2);
-                spmv_pair<NT, V2, XPAD>(FCVM_CP(o3), FCVM_VP(o3), x, w0, w1, w2);
-                o0 = n0; o1 = n1; o2 = n2; o3 = n3;
+            for (; np >= 4; np -= 4) {
+                spmv_pair<NT, V2>(cp, vp, x, y0, y1, y2);
+                spmv_pair<NT, V2>(cp + 128, vp + 9 * 64, x, z0, z1, z2);
+                spmv_pair<NT, V2>(cp + 256, vp + 18 * 64, x, u0, u1, u2);
+                spmv_pair<NT, V2>(cp + 384, vp + 27 * 64, x, w0, w1, w2);
+                cp += 512;
+                vp += 36 * 64;
             }
             y0 += z0 + u0 + w0; y1 += z1 + u1 + w1; y2 += z2 + u2 + w2;
         }
         if (UNROLL >= 2) {
             double z0 = 0.0, z1 = 0.0, z2 = 0.0;
-            for (; np - p >= 2; p += 2) {
-                const uint32_t o0 = GANGED ? go[p] : (uint32_t)p, o1 = GANGED ? go[p + 1] : (uint32_t)(p + 1);
-                spmv_pair<NT, V2, XPAD>(FCVM_CP(o0), FCVM_VP(o0), x, y0, y1, y2);
-                spmv_pair<NT, V2, XPAD>(FCVM_CP(o1), FCVM_VP(o1), x, z0, z1, z2);
+            for (; np >= 2; np -= 2) {
+                spmv_pair<NT, V2>(cp, vp, x, y0, y1, y2);
+                spmv_pair<NT, V2>(cp + 128, vp + 9 * 64, x, z0, z1, z2);
+                cp += 256;
+                vp += 18 * 64;
             }
             y0 += z0; y1 += z1; y2 += z2;
         }
-        for (; p < np; p++) {
-            const uint32_t o0 = GANGED ? go[p] : (uint32_t)p;
-            spmv_pair<NT, V2, XPAD>(FCVM_CP(o0), FCVM_VP(o0), x, y0, y1, y2);
+        for (; np > 0; np--) {
+            spmv_pair<NT, V2>(cp, vp, x, y0, y1, y2);
+            cp += 128;
+            vp += 9 * 64;
         }
-#undef FCVM_CP
-#undef FCVM_VP
         node = rownode[s * 64 + lane];
         if (EPI == 0) {
             if (node >= 0) {
@@ -679,8 +645,8 @@ __global__ __launch_bounds__(256, (sizeof(V2) == 16 ? 4 : 1)) void k_spmv(int64_
                 yo[0] = y0; yo[1] = y1; yo[2] = y2;
             }
         } else if (node >= 0) {
-            const int64_t o = 3 * (int64_t)node, ox = (XPAD ? 4 : 3) * (int64_t)node;
-            const double d0 = x[ox], d1 = x[ox + 1], d2 = x[ox + 2];
+            const int64_t o = 3 * (int64_t)node;
+            const double d0 = x[o], d1 = x[o + 1], d2 = x[o + 2];
             const double r0 = epi.r[o] - y0, r1 = epi.r[o + 1] - y1, r2 = epi.r[o + 2] - y2;
             epi.r[o] = r0; epi.r[o + 1] = r1; epi.r[o + 2] = r2;
             double a0 = d0, a1 = d1, a2 = d2;
@@ -697,7 +663,7 @@ __global__ __launch_bounds__(256, (sizeof(V2) == 16 ? 4 : 1)) void k_spmv(int64_
     if (DOT) {
         double d = 0.0;
         if (node >= 0) {
-            const double *xo = x + (XPAD ? 4 : 3) * (int64_t)node;
+            const double *xo = x + 3 * (int64_t)node;
             d = y0 * xo[0] + y1 * xo[1] + y2 * xo[2];
         }
         d = block_sum(d, sh);
@@ -787,27 +753,6 @@ __global__ __launch_bounds__(256) void k_pcg_update_p(int64_t n, const double *_
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = z[i] + beta * p[i];
 }
-// the same per node, also writing the 4-doubles-per-node copy the SpMV gathers from (k_spmv<XPAD>)
-__global__ __launch_bounds__(256) void k_pcg_update_p4(int64_t nn, const double *__restrict__ z, double *__restrict__ p,
-                                                       double *__restrict__ p4, const double *__restrict__ S) {
-    if (S[S_DONE] != 0.0) return;
-    const double beta = S[S_BETA];
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= nn) return;
-    const double a = z[3 * i] + beta * p[3 * i], b = z[3 * i + 1] + beta * p[3 * i + 1], c = z[3 * i + 2] + beta * p[3 * i + 2];
-    p[3 * i] = a; p[3 * i + 1] = b; p[3 * i + 2] = c;
-    double2 *o = (double2 *)(p4 + 4 * i);
-    o[0] = double2{a, b};
-    o[1] = double2{c, 0.0};
-}
-__global__ __launch_bounds__(256) void k_pad4(int64_t nn, const double *__restrict__ p, double *__restrict__ p4) {
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= nn) return;
-    double2 *o = (double2 *)(p4 + 4 * i);
-    o[0] = double2{p[3 * i], p[3 * i + 1]};
-    o[1] = double2{p[3 * i + 2], 0.0};
-}
-
 // fixed-order sum of n partials (single workgroup); result valid in thread 0
 __device__ __forceinline__ double sum_partials(const double *part, int64_t n, double *sh) {
     double v = 0.0;

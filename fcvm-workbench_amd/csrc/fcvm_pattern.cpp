@@ -27,7 +27,7 @@ static void parallel_for(int64_t n, int nthreads, const std::function<void(int64
 }
 
 void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nthreads, int sort_window, int npe,
-                   const int32_t *row_order, int gang) {
+                   const int32_t *row_order) {
     if (ne <= 0 || nn <= 0) throw std::runtime_error("empty mesh");
     for (int64_t i = 0; i < ne * npe; i++)
         if (el[i] < 0 || el[i] >= nn) throw std::runtime_error("element node index out of range");
@@ -107,34 +107,6 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
         p.sptr[s + 1] = p.sptr[s] + m;
     }
     p.nslots = p.sptr[p.nslices] * SLICE;
-    // gangs: largest power of two <= the request that divides the sort window (lengths inside a gang are then sorted)
-    {
-        int g = 1;
-        while (g * 2 <= gang && sort_window % (g * 2) == 0) g *= 2;
-        p.gang = g;
-        const int64_t ngangs = (p.nslices + g - 1) / g;
-        p.gptr.assign(ngangs + 1, 0);
-        p.goff.clear();
-        for (int64_t q = 0; q < ngangs; q++) {
-            const int64_t s0 = q * g, s1 = std::min(p.nslices, s0 + g);
-            int64_t maxp = 0;
-            for (int64_t s = s0; s < s1; s++) {
-                const int64_t np = (p.sptr[s + 1] - p.sptr[s]) / 2;
-                if (s > s0 && np > (p.sptr[s] - p.sptr[s - 1]) / 2) throw std::runtime_error("gang with unsorted slice lengths");
-                maxp = std::max(maxp, np);
-            }
-            p.gptr[q] = (int64_t)p.goff.size();
-            uint32_t acc = 0;
-            for (int64_t pp = 0; pp < maxp + GOFF_PAD; pp++) {
-                p.goff.push_back(acc);
-                uint32_t cnt = 0;
-                for (int64_t s = s0; s < s1; s++)
-                    if ((p.sptr[s + 1] - p.sptr[s]) / 2 > pp) cnt++;
-                acc += cnt;
-            }
-        }
-        p.gptr[ngangs] = (int64_t)p.goff.size();
-    }
     if ((uint64_t)(p.sptr[p.nslices] / 2) >= (1ull << 25))
         throw std::runtime_error("matrix too large for the packed 32-bit block locations (2^25 pair rows)");
     p.cols.assign(p.nslots, 0);
@@ -146,7 +118,7 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
                 for (int64_t j = 0; j < L; j++) {
                     int32_t c = 0;
                     if (nd >= 0) c = (j < len[nd]) ? p.colidx[p.rowptr[nd] + j] : nd;
-                    p.cols[p.col_index(s * SLICE + l, j)] = c;
+                    p.cols[(p.sptr[s] + j) * SLICE + l] = c;
                 }
             }
         }

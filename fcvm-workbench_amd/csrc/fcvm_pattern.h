@@ -9,7 +9,6 @@ namespace fcvm {
 constexpr int SLICE = 64;           // rows (nodes) per slice = one wavefront, one row per lane
 constexpr int SORT_WINDOW = 64;     // slices per length-sorting window (4096 rows); measured: 8 -> 64 = -4% bytes
 constexpr int64_t VSTRIDE = 2 * SLICE;  // doubles between two components of one 3x3 block
-constexpr int GOFF_PAD = 8;         // the SpMV reads its chunk offsets one unrolled iteration ahead
 
 struct Pattern {
     int64_t ne = 0, nn = 0;
@@ -21,16 +20,6 @@ struct Pattern {
     std::vector<int64_t> rowptr;    // [nn+1] CSR over nodes (sorted columns, diagonal included)
     std::vector<int32_t> colidx;    // [nnzb]
     std::vector<int64_t> sptr;      // [nslices+1] cumulative slice lengths (blocks per lane, even)
-    // Storage order of the 9 KiB value chunks (one chunk = one block pair of one slice = 9 x 64 double2) and of the
-    // matching 512 B column chunks: slices are grouped in gangs of `gang` consecutive slices (a power of two that
-    // divides the sort window, so slice lengths inside a gang never increase); inside a gang the chunks are
-    // interleaved -- pair 0 of every slice, then pair 1 of every slice that has one, ... -- so that the wavefronts of
-    // a gang, which run at the same time, stream through the same pages instead of `gang` regions of 100-300 KB each.
-    // chunk(s, p) = sptr[g * gang] / 2 + goff[gptr[g] + p] + s % gang with g = s / gang; gang = 1 is the plain
-    // slice-after-slice order (goff[p] = p).
-    int gang = 1;
-    std::vector<int64_t> gptr;      // [ngangs+1] start of each gang's offset table in goff
-    std::vector<uint32_t> goff;     // per gang: chunks of the gang stored before pair p (padded by GOFF_PAD entries)
     std::vector<int32_t> rownode;   // [nslices*64] node of slot, -1 = padding
     std::vector<int32_t> slotof;    // [nn] slot (slice*64+lane) of node
     std::vector<int32_t> cols;      // [sptr[nslices]*64] column node per (slice, j, lane)
@@ -39,33 +28,24 @@ struct Pattern {
     std::vector<int64_t> nptr;      // [nn+1] node -> element incidence (CSR)
     std::vector<int32_t> nel;       // [ne*npe] element << 4 | local node index, ascending elements per node
 
-    inline int64_t chunk(int64_t s, int64_t p) const {
-        const int64_t g = s / gang;
-        return sptr[g * gang] / 2 + (int64_t)goff[gptr[g] + p] + s % gang;
-    }
     // offset in doubles of component 0 of block j of the row living in `slot`
     inline uint64_t block_offset(int64_t slot, int64_t j) const {
         int64_t s = slot / SLICE, l = slot % SLICE;
-        return (uint64_t)((chunk(s, j >> 1) * 9 * SLICE + l) * 2 + (j & 1));
-    }
-    // position in `cols` of the column index of block j of the row living in `slot`
-    inline int64_t col_index(int64_t slot, int64_t j) const {
-        int64_t s = slot / SLICE, l = slot % SLICE;
-        return (chunk(s, j >> 1) * 2 + (j & 1)) * SLICE + l;
+        return (uint64_t)(((sptr[s] / 2 + (j >> 1)) * 9 * SLICE + l) * 2 + (j & 1));
     }
     int64_t value_count() const { return sptr[nslices] * SLICE * 9; }
-    // 32-bit form of block_offset for the device tables: pair row (chunk) P = chunk(s, j/2) (25 bits), lane (6 bits), j & 1;
+    // 32-bit form of block_offset for the device tables: pair row P = sptr[s]/2 + j/2 (25 bits), lane (6 bits), j & 1;
     // offset in doubles = ((P * 9 * 64) + lane) * 2 + (j & 1)  (unpack_offset in fcvm_kernels.hip.h).  2^25 pair rows
     // = 309 GB of values: beyond the HBM of one GPU.
     inline uint32_t pack_offset(int64_t slot, int64_t j) const {
         int64_t s = slot / SLICE, l = slot % SLICE;
-        return (uint32_t)((((uint64_t)chunk(s, j >> 1)) << 7) | ((uint64_t)l << 1) | (uint64_t)(j & 1));
+        return (uint32_t)((((uint64_t)(sptr[s] / 2 + (j >> 1))) << 7) | ((uint64_t)l << 1) | (uint64_t)(j & 1));
     }
 };
 
 // elnodes0: 0-based int32 [ne*10].  Throws std::runtime_error on bad input.
 void build_pattern(int64_t ne, int64_t nn, const int32_t *elnodes0, Pattern &p, int nthreads,
-                   int sort_window = SORT_WINDOW, int npe = 10, const int32_t *row_order = nullptr, int gang = 1);
+                   int sort_window = SORT_WINDOW, int npe = 10, const int32_t *row_order = nullptr);
 
 // nodes sorted along a Morton (Z-order) curve through their coordinates: a locality-preserving order in which
 // the SpMV walks the rows when the caller's node numbering has none (unstructured meshes)

@@ -42,7 +42,6 @@ SIGNATURES = {
     "fcvm_principal_stress": [_vp, _i64, _vp, _vp, _vp],
     "fcvm_solve": [_vp, _vp, _vp, _f64, _i64, _pf64],
     "fcvm_spmv": [_vp, _vp, _vp],
-    "fcvm_spmv_x4": [_vp, _vp, _vp],
     "fcvm_assemble_buckling": [_vp, _vp, _f64],
     "fcvm_spmv_geometric": [_vp, _vp, _vp],
     "fcvm_precond": [_vp, _vp, _vp],

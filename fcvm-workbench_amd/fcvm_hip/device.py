@@ -161,7 +161,7 @@ class Context:
         out = (C.c_int64 * 8)()
         call("fcvm_pattern_info", self.h, out)
         return dict(nnz_blocks=out[0], padded_slots=out[1], slices=out[2], matrix_bytes=out[3],
-                    max_row_blocks=out[4], ndof=out[5], gang=out[6], spmv_variant=out[7])
+                    max_row_blocks=out[4], ndof=out[5], spmv_variant=out[7])
 
     def matrix_coo(self):
         nnz = 9 * self.pattern_info()["nnz_blocks"]
@@ -267,11 +267,6 @@ class Context:
 
     def spmv(self, x, y):
         call("fcvm_spmv", self.h, x.ptr, y.ptr)
-        return y
-
-    def spmv4(self, x4, y):
-        """y = K x with x given as 4 doubles per node (x, y, z, 0)"""
-        call("fcvm_spmv_x4", self.h, x4.ptr, y.ptr)
         return y
 
     def precond(self, r, z):

@@ -59,8 +59,8 @@ int fcvm_set_fix(fcvm_ctx *c, int64_t nfix, const int64_t *dofs, const double *v
 int fcvm_set_coords(fcvm_ctx *c, const double *nocoord);
 
 /* pattern statistics: out[0]=nnz blocks, out[1]=padded block slots, out[2]=slices,
- * out[3]=matrix bytes (values+cols), out[4]=max row length, out[5]=ndof, out[6]=slices per gang of interleaved
- * chunks (storage order of the SpMV stream, 1 = slice after slice), out[7]=SpMV kernel variant */
+ * out[3]=matrix bytes (values+cols), out[4]=max row length, out[5]=ndof, out[6]=1 (reserved),
+ * out[7]=SpMV kernel variant */
 int fcvm_pattern_info(fcvm_ctx *c, int64_t out[8]);
 /* host copy of the assembled matrix as scalar COO (row, col, val) of the FULL symmetric matrix,
  * nnz = 9 * nnz blocks; for tests.  Arrays must hold 9*out[0] entries. */
@@ -134,9 +134,6 @@ int fcvm_spmv_geometric(fcvm_ctx *c, const double *x, double *y);
 
 /* y = K x on the assembled matrix ([dev] f64[3nn]); building block of the multi-GPU solver */
 int fcvm_spmv(fcvm_ctx *c, const double *x, double *y);
-/* the same with x stored as 4 doubles per node (x, y, z, 0): the form the PCG loop feeds the kernel (one 16-byte and one
- * 8-byte gather per node instead of three 8-byte ones) */
-int fcvm_spmv_x4(fcvm_ctx *c, const double *x4, double *y);
 /* z = M^-1 r with the 3x3 block-Jacobi preconditioner */
 int fcvm_precond(fcvm_ctx *c, const double *r, double *z);
 /* diagonal 3x3 blocks [dev] f64[nn*9]: get (for the interface sum across ranks) / set+invert */

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """A/B of SpMV storage orders in ONE process (interleaved rounds, median / min per variant): the same mesh is set up in
-several contexts that differ only in environment knobs read at context creation (FCVM_SPMV_GANG, FCVM_VALS_TRIES, ...).
+several contexts that differ only in environment knobs read at context creation (FCVM_SPMV_VARIANT, FCVM_VALS_TRIES, ...).
 
-  python3 tools/spmv_ab.py --cells 55 --variants "FCVM_SPMV_GANG=1" "FCVM_SPMV_GANG=64" --rounds 12 --reps 20
+  python3 tools/spmv_ab.py --cells 55 --variants "FCVM_SPMV_VARIANT=4" "FCVM_SPMV_VARIANT=0" --rounds 12 --reps 20
 """
 import argparse
 import os
@@ -21,10 +21,9 @@ from fcvm_hip.solver import GpuModel  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--cells", type=int, default=55)
 ap.add_argument("--mesh", default="cube", help="cube | embankment3 | plate")
-ap.add_argument("--variants", nargs="+", default=["FCVM_SPMV_GANG=1", "FCVM_SPMV_GANG=64"])
+ap.add_argument("--variants", nargs="+", default=["FCVM_SPMV_VARIANT=4", "FCVM_SPMV_VARIANT=0"])
 ap.add_argument("--rounds", type=int, default=12)
 ap.add_argument("--reps", type=int, default=20)
-ap.add_argument("--x4", action="store_true", help="also time the padded-x form of every variant")
 a = ap.parse_args()
 
 if a.mesh == "cube":
@@ -57,9 +56,6 @@ for v in a.variants:
     x = ctx.array(xh)
     y = ctx.empty(m.ndof)
     models.append((v, m, x, y, False))
-    if a.x4:   # the same matrix, x gathered from the 4-doubles-per-node copy (what the PCG loop uses)
-        x4 = ctx.array(np.concatenate([xh.reshape(-1, 3), np.zeros((m.nn, 1))], axis=1).reshape(-1))
-        models.append((v + " x4", m, x4, ctx.empty(m.ndof), True))
 
 info = models[0][1].ctx.pattern_info()
 alg = info["nnz_blocks"] * 76 + 2 * info["ndof"] * 8
@@ -68,7 +64,7 @@ times = {v: [] for v, *_ in models}
 for r in range(a.rounds + 1):
     for v, m, x, y, pad in models:
         c = m.ctx
-        f = c.spmv4 if pad else c.spmv
+        f = c.spmv
         f(x, y)
         c.sync()
         t0 = time.perf_counter()
