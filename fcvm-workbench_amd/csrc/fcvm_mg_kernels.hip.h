@@ -166,6 +166,44 @@ __global__ __launch_bounds__(256) void k_restrict(int64_t nc, const int32_t *__r
     r1[3 * c + 2] = (fm & 4) ? 0.0 : a2;
 }
 
+// The V-cycle's form of the restriction: four lanes per coarse node share the list of mid-side nodes (fixed partition,
+// fixed reduction tree => deterministic), and the start of the level-1 Chebyshev sweep (k_cheb_init: x = 0, r = b,
+// d = c0 Dinv b) rides on it: the restricted residual goes straight to r, x and d.
+__global__ __launch_bounds__(256) void k_restrict_init(int64_t nc, const int32_t *__restrict__ c2f, const int64_t *__restrict__ mptr,
+                                                       const int32_t *__restrict__ mids, const uint8_t *__restrict__ fixmask0,
+                                                       const double *__restrict__ r0, const double *__restrict__ dinv1, double c0,
+                                                       double *__restrict__ x1, double *__restrict__ r1, double *__restrict__ d1,
+                                                       const double *__restrict__ done) {
+    if (done && *done != 0.0) return;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t c = t >> 2;
+    const int q = (int)(t & 3);
+    const bool valid = c < nc;
+    if (!valid) c = nc - 1;
+    const int64_t f = c2f[c];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (q == 0) { a0 = r0[3 * f]; a1 = r0[3 * f + 1]; a2 = r0[3 * f + 2]; }
+    for (int64_t k = mptr[c] + q; k < mptr[c + 1]; k += 4) {
+        const int64_t m = mids[k];
+        const int mm = fixmask0[m];
+        if (!(mm & 1)) a0 += 0.5 * r0[3 * m];
+        if (!(mm & 2)) a1 += 0.5 * r0[3 * m + 1];
+        if (!(mm & 4)) a2 += 0.5 * r0[3 * m + 2];
+    }
+    a0 += __shfl_xor(a0, 1, 64); a1 += __shfl_xor(a1, 1, 64); a2 += __shfl_xor(a2, 1, 64);
+    a0 += __shfl_xor(a0, 2, 64); a1 += __shfl_xor(a1, 2, 64); a2 += __shfl_xor(a2, 2, 64);
+    if (!valid || q != 0) return;
+    const int fm = fixmask0[f];
+    if (fm & 1) a0 = 0.0;
+    if (fm & 2) a1 = 0.0;
+    if (fm & 4) a2 = 0.0;
+    double z0, z1, z2;
+    apply_dinv(dinv1 + c * 9, a0, a1, a2, z0, z1, z2);
+    x1[3 * c] = 0.0; x1[3 * c + 1] = 0.0; x1[3 * c + 2] = 0.0;
+    r1[3 * c] = a0; r1[3 * c + 1] = a1; r1[3 * c + 2] = a2;
+    d1[3 * c] = c0 * z0; d1[3 * c + 1] = c0 * z1; d1[3 * c + 2] = c0 * z2;
+}
+
 // d0 = M0 P M1 e1 : fine corner nodes copy, mid-side nodes average their two edge ends
 __global__ __launch_bounds__(256) void k_prolong(int64_t nn, const int32_t *__restrict__ pa, const int32_t *__restrict__ pb,
                                                  const uint8_t *__restrict__ fixmask0, const double *__restrict__ e1,
