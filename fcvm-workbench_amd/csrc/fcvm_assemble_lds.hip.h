@@ -29,10 +29,12 @@ constexpr int ASM_ROWS = 16;                       // rows per wavefront (4 lane
 #endif
 // LDS of a work item: shape-function tables | Jacobians of the visited elements (one per row and Gauss point) | rows
 constexpr int ASM_TAB = 160;                       // doubles: dN/dxi at the 4 Gauss points [4][10][3], then N [4][10]
-constexpr int ASM_JREC = 20;                       // doubles per (row, Gauss point): xsi[9], w, vol, pf, s[6], 2 unused
+constexpr int ASM_JREC = 10;                       // doubles per (row, Gauss point): xsi[9], GPW * det J (signed)
 constexpr int ASM_JAC = ASM_ROWS * 4 * ASM_JREC;   // doubles
-__host__ __device__ inline int64_t asm_row_stride(int64_t len) { return len * 9 + 1; }   // doubles; odd: rows spread over the LDS banks
-__host__ __device__ inline int64_t asm_lds_bytes(int64_t len) { return (ASM_TAB + ASM_JAC + ASM_ROWS * asm_row_stride(len)) * 8; }
+// rlen = blocks of the longest row of the slice (the slice stores rlen rounded up to even: the padding block is written
+// as zeros without passing through LDS); row stride in doubles, odd so that the 16 rows spread over the LDS banks
+__host__ __device__ inline int64_t asm_row_stride(int64_t rlen) { return rlen * 9 + ((rlen & 1) ? 0 : 1); }
+__host__ __device__ inline int64_t asm_lds_bytes(int64_t rlen) { return (ASM_TAB + ASM_JAC + ASM_ROWS * asm_row_stride(rlen)) * 8; }
 
 // Hides where a pointer came from, so that loads through it are not hoisted out of the visit loop: every lane always
 // uses the same table entries (its Gauss point, its three local columns: 66 doubles), and keeping all of them in
@@ -51,7 +53,7 @@ struct AsmGeom {
 };
 
 template <bool TANGENT>
-__global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__ items, const int64_t *__restrict__ sptr,
+__global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__ items, const int32_t *__restrict__ rlens, const int64_t *__restrict__ sptr,
                                                      const int32_t *__restrict__ rownode, const int64_t *__restrict__ nptr,
                                                      const int32_t *__restrict__ nel, const int32_t *__restrict__ el,
                                                      const double *__restrict__ coord, const double *__restrict__ disp,
@@ -71,7 +73,8 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
     const int qd = item & 3;
     const int lane = threadIdx.x, rowl = lane >> 2, h = lane & 3;
     const int64_t jb = sptr[s], len = sptr[s + 1] - jb, cbase = jb >> 1;
-    const int64_t S = asm_row_stride(len);
+    const int64_t rlen = rlens[s];
+    const int64_t S = asm_row_stride(rlen);
     for (int64_t i = lane; i < ASM_ROWS * S; i += 64) rowbuf[i] = 0.0;
     if (lane < 40) {   // shape-function tables (fcVM.py:365-424 at the Gauss points of fcVM.py:587-596)
         const int g = lane / 10, k = lane - 10 * g;
@@ -155,24 +158,7 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
             const double xsj = jac_inverse(xs, mine);
 #pragma unroll
             for (int k = 0; k < 9; k++) myjac[k] = mine[k];
-            myjac[9] = FCVM_GPW * fabs(xsj);
-            myjac[10] = xsj * FCVM_GPW;
-            if (TANGENT) {   // deviatoric stress and plastic factor of Gauss point h (fcVM.py:983-998)
-                double sd[6] = {0, 0, 0, 0, 0, 0}, pfm = 0.0;
-                if (active && pgp[4 * e + h]) {
-                    const double *s0 = sig + 24 * e + 6 * h;
-#pragma unroll
-                    for (int j = 0; j < 6; j++) sd[j] = s0[j];
-                    const double p = (sd[0] + sd[1] + sd[2]) / 3.0;
-                    sd[0] -= p; sd[1] -= p; sd[2] -= p;
-                    double svm = sqrt(1.5 * (sd[0] * sd[0] + sd[1] * sd[1] + sd[2] * sd[2]) + 3.0 * (sd[3] * sd[3] + sd[4] * sd[4] + sd[5] * sd[5]));
-                    if (svm == 0.0) svm = 1.0;
-                    pfm = 3.0 * mc.G / (1.0 + mc.H / 3.0 / mc.G) / (svm * svm);
-                }
-                myjac[11] = pfm;
-#pragma unroll
-                for (int j = 0; j < 6; j++) myjac[12 + j] = sd[j];
-            }
+            myjac[9] = xsj * FCVM_GPW;
         }
         // Gauss point coordinates (fcVM.py:761): lane 3 of the quad (it integrates one block less)
         if (xgp && active && a < 4 && h == 3) {
@@ -200,17 +186,24 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
             double xsi[9];
 #pragma unroll
             for (int k = 0; k < 9; k++) xsi[k] = J[k];
-            const double wg_ = J[9];
-            vol += J[10];
+            const double wg_ = fabs(J[9]);
+            vol += J[9];
             const double *da = tab + 30 * g + 3 * a;
             double ga[3];
             to_global(xsi, da[0], da[1], da[2], ga[0], ga[1], ga[2]);
             gam += wg_ * tab[120 + 10 * g + a];
-            double pf = 0.0, Sg[6], ta[3];
-            if (TANGENT) {
-                pf = J[11];
+            double pf = 0.0, Sg[6] = {0, 0, 0, 0, 0, 0}, ta[3];
+            if (TANGENT) {   // deviatoric stress and plastic factor of Gauss point g (fcVM.py:983-998); same address in the quad
+                if (active && pgp[4 * e + g]) {
+                    const double *s0 = sig + 24 * e + 6 * g;
 #pragma unroll
-                for (int j = 0; j < 6; j++) Sg[j] = J[12 + j];
+                    for (int j = 0; j < 6; j++) Sg[j] = s0[j];
+                    const double p = (Sg[0] + Sg[1] + Sg[2]) / 3.0;
+                    Sg[0] -= p; Sg[1] -= p; Sg[2] -= p;
+                    double svm = sqrt(1.5 * (Sg[0] * Sg[0] + Sg[1] * Sg[1] + Sg[2] * Sg[2]) + 3.0 * (Sg[3] * Sg[3] + Sg[4] * Sg[4] + Sg[5] * Sg[5]));
+                    if (svm == 0.0) svm = 1.0;
+                    pf = 3.0 * mc.G / (1.0 + mc.H / 3.0 / mc.G) / (svm * svm);
+                }
                 ta[0] = ga[0] * Sg[0] + ga[1] * Sg[3] + ga[2] * Sg[4];
                 ta[1] = ga[1] * Sg[1] + ga[0] * Sg[3] + ga[2] * Sg[5];
                 ta[2] = ga[2] * Sg[2] + ga[0] * Sg[4] + ga[1] * Sg[5];
@@ -355,7 +348,7 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
         while (p < npairs) {
             v2d d;
             d.x = src[(2 * p) * 9 + c];
-            d.y = src[(2 * p + 1) * 9 + c];
+            d.y = (2 * p + 1 < rlen) ? src[(2 * p + 1) * 9 + c] : 0.0;   // the padding block of an odd-length slice
             __builtin_nontemporal_store(d, out + (p * 9 + c) * 64);
             c += 4;
             if (c >= 9) { c -= 9; p++; }

@@ -1,0 +1,262 @@
+// Dense FP64 kernels for the aggregate level of the multigrid hierarchy (no reference counterpart: the reference
+// factorises the sparse matrix with CHOLMOD, fcVM.py:1121): A2 = Z^T A1 Z from the sliced-ELL level-1 matrix and the
+// explicit inverse of that SPD matrix (blocked Cholesky, triangular inverse, X^T X), so that the hierarchy set-up
+// needs neither host LAPACK nor a vendor solver library.  Matrices are row-major with a leading dimension that is
+// a multiple of TB; the caller pads with an identity block.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fcvm_kernels.hip.h"
+
+namespace fcvm {
+
+constexpr int TB = 64;     // tile edge
+constexpr int TK = 16;     // k-slab staged through LDS
+constexpr int TPAD = 4;    // LDS row padding (doubles)
+
+// acc[4][4] += sum_k A(r, k) * B(c, k) for the 64 x 64 tile of a 16 x 16 thread grid (thread (ty, tx) owns rows
+// 4 ty.., columns 4 tx..).  TA = false: A(r, k) = A[r * lda + k]; TA = true: A(r, k) = A[k * lda + r]; same for B.
+// K is a multiple of TK.  sA / sB: [TK][TB + TPAD] each.
+template <bool TA, bool TBt>
+__device__ __forceinline__ void tile_mac(double (&acc)[4][4], const double *__restrict__ A, int64_t lda, const double *__restrict__ B,
+                                         int64_t ldb, int K, double (*sA)[TB + TPAD], double (*sB)[TB + TPAD]) {
+    const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
+    for (int k0 = 0; k0 < K; k0 += TK) {
+        __syncthreads();
+        if (!TA) {   // 64 rows x 16 k, k contiguous: thread -> (row, 4 k)
+            const int r = t >> 2, kq = (t & 3) * 4;
+            const double *p = A + (int64_t)r * lda + k0 + kq;
+#pragma unroll
+            for (int u = 0; u < 4; u++) sA[kq + u][r] = p[u];
+        } else {     // 16 k-rows x 64 r, r contiguous: thread -> (k, 4 r)
+            const int q = t >> 4, r4 = (t & 15) * 4;
+            const double *p = A + (int64_t)(k0 + q) * lda + r4;
+#pragma unroll
+            for (int u = 0; u < 4; u++) sA[q][r4 + u] = p[u];
+        }
+        if (!TBt) {
+            const int r = t >> 2, kq = (t & 3) * 4;
+            const double *p = B + (int64_t)r * ldb + k0 + kq;
+#pragma unroll
+            for (int u = 0; u < 4; u++) sB[kq + u][r] = p[u];
+        } else {
+            const int q = t >> 4, r4 = (t & 15) * 4;
+            const double *p = B + (int64_t)(k0 + q) * ldb + r4;
+#pragma unroll
+            for (int u = 0; u < 4; u++) sB[q][r4 + u] = p[u];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TK; k++) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { a[u] = sA[k][4 * ty + u]; b[u] = sB[k][4 * tx + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int v = 0; v < 4; v++) acc[u][v] += a[u] * b[v];
+        }
+    }
+}
+
+// Cholesky factor of the diagonal tile k (lower, in place, upper part of the tile zeroed) and the inverse of that factor
+// (lower triangular) into Linv[k].  One workgroup.  info[0] = 1 + row of the first non-positive pivot.
+__global__ __launch_bounds__(256) void k_chol_diag(double *__restrict__ M, int64_t ld, int k, double *__restrict__ Linv, int *__restrict__ info) {
+    __shared__ double T[TB][TB + 1];
+    __shared__ double X[TB][TB + 1];
+    const int t = threadIdx.x;
+    double *blk = M + ((int64_t)k * TB) * ld + (int64_t)k * TB;
+    for (int e = t; e < TB * TB; e += 256) T[e >> 6][e & 63] = blk[(int64_t)(e >> 6) * ld + (e & 63)];
+    __syncthreads();
+    for (int j = 0; j < TB; j++) {
+        const double d = T[j][j];
+        if (!(d > 0.0)) {
+            if (t == 0 && atomicCAS(info, 0, k * TB + j + 1) == 0) {}
+            return;
+        }
+        const double s = sqrt(d);
+        __syncthreads();
+        if (t > j && t < TB) T[t][j] /= s;
+        if (t == j) T[j][j] = s;
+        __syncthreads();
+        // trailing update of the lower triangle: rows i > j, columns j < m <= i
+        for (int e = t; e < TB * TB; e += 256) {
+            const int i = e >> 6, m = e & 63;
+            if (m > j && i >= m) T[i][m] -= T[i][j] * T[m][j];
+        }
+        __syncthreads();
+    }
+    // inverse of the lower-triangular factor, one column per thread (forward substitution)
+    if (t < TB) {
+        const int c = t;
+        for (int i = 0; i < TB; i++) {
+            double v = (i == c) ? 1.0 : 0.0;
+            if (i >= c) {
+                for (int m = c; m < i; m++) v -= T[i][m] * X[m][c];
+                v /= T[i][i];
+            } else {
+                v = 0.0;
+            }
+            X[i][c] = v;
+        }
+    }
+    __syncthreads();
+    double *li = Linv + (int64_t)k * TB * TB;
+    for (int e = t; e < TB * TB; e += 256) {
+        const int i = e >> 6, m = e & 63;
+        blk[(int64_t)i * ld + m] = (m <= i) ? T[i][m] : 0.0;
+        li[e] = X[i][m];
+    }
+}
+
+// panel below the diagonal tile k: L_ik = A_ik Linv_kk^T
+__global__ __launch_bounds__(256) void k_chol_panel(double *__restrict__ M, int64_t ld, int k, const double *__restrict__ Linv) {
+    __shared__ double sA[TK][TB + TPAD], sB[TK][TB + TPAD];
+    const int i = k + 1 + blockIdx.x;
+    double *A = M + ((int64_t)i * TB) * ld + (int64_t)k * TB;
+    double acc[4][4] = {};
+    tile_mac<false, false>(acc, A, ld, Linv + (int64_t)k * TB * TB, TB, TB, sA, sB);
+    __syncthreads();   // every thread has read its part of A_ik before it is overwritten
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) A[(int64_t)(4 * ty + u) * ld + 4 * tx + v] = acc[u][v];
+}
+
+// trailing update after panel k: A_ij -= L_ik L_jk^T for k < j <= i (grid: (i - k - 1, j - k - 1), upper half exits)
+__global__ __launch_bounds__(256) void k_chol_trailing(double *__restrict__ M, int64_t ld, int k) {
+    __shared__ double sA[TK][TB + TPAD], sB[TK][TB + TPAD];
+    const int i = k + 1 + blockIdx.y, j = k + 1 + blockIdx.x;
+    if (j > i) return;
+    const double *Li = M + ((int64_t)i * TB) * ld + (int64_t)k * TB;
+    const double *Lj = M + ((int64_t)j * TB) * ld + (int64_t)k * TB;
+    double acc[4][4] = {};
+    tile_mac<false, false>(acc, Li, ld, Lj, ld, TB, sA, sB);
+    double *C = M + ((int64_t)i * TB) * ld + (int64_t)j * TB;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) C[(int64_t)(4 * ty + u) * ld + 4 * tx + v] -= acc[u][v];
+}
+
+// block row i of X = L^-1: X_ii = Linv_ii, X_ij = - Linv_ii sum_{j <= m < i} L_im X_mj (grid: j = 0 .. i; block i itself copies)
+__global__ __launch_bounds__(256) void k_trinv_row(const double *__restrict__ M, double *__restrict__ Xm, int64_t ld, int i, const double *__restrict__ Linv) {
+    __shared__ double sA[TK][TB + TPAD], sB[TK][TB + TPAD];
+    __shared__ double sT[TB][TB + TPAD];
+    const int j = blockIdx.x;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    double *out = Xm + ((int64_t)i * TB) * ld + (int64_t)j * TB;
+    const double *li = Linv + (int64_t)i * TB * TB;
+    if (j == i) {
+        for (int e = threadIdx.x; e < TB * TB; e += 256) out[(int64_t)(e >> 6) * ld + (e & 63)] = li[e];
+        return;
+    }
+    // S = sum_m L_im X_mj : A(r, k) = L[i-row r][m-col k] (k contiguous), B(c, k) = X[m-row k][j-col c] (c contiguous => transposed form)
+    double acc[4][4] = {};
+    tile_mac<false, true>(acc, M + ((int64_t)i * TB) * ld + (int64_t)j * TB, ld, Xm + ((int64_t)j * TB) * ld + (int64_t)j * TB, ld, (i - j) * TB, sA, sB);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) sT[4 * ty + u][4 * tx + v] = acc[u][v];
+    __syncthreads();
+    // X_ij = - Linv_ii S : rows r, columns c, sum over q: Linv[r][q] S[q][c]
+    double o[4][4] = {};
+    for (int q = 0; q < TB; q++) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a[u] = li[(4 * ty + u) * TB + q]; b[u] = sT[q][4 * tx + u]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int v = 0; v < 4; v++) o[u][v] += a[u] * b[v];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) out[(int64_t)(4 * ty + u) * ld + 4 * tx + v] = -o[u][v];
+}
+
+// Ainv = X^T X for lower block-triangular X: tile (a, b), b <= a: sum over block rows m >= a of X_ma^T X_mb; both
+// (a, b) and its transpose (b, a) are written
+__global__ __launch_bounds__(256) void k_xtx(const double *__restrict__ Xm, double *__restrict__ Out, int64_t ld, int nt) {
+    __shared__ double sA[TK][TB + TPAD], sB[TK][TB + TPAD];
+    const int a = blockIdx.y, b = blockIdx.x;
+    if (b > a) return;
+    double acc[4][4] = {};
+    // A(r, k) = X[row a*TB + k .. ][col a-tile r] -> element X[(a TB + k) ld + a TB + r]: transposed form, K = (nt - a) TB
+    tile_mac<true, true>(acc, Xm + ((int64_t)a * TB) * ld + (int64_t)a * TB, ld, Xm + ((int64_t)a * TB) * ld + (int64_t)b * TB, ld, (nt - a) * TB, sA, sB);
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int64_t r = (int64_t)a * TB + 4 * ty + u, c = (int64_t)b * TB + 4 * tx + v;
+            Out[r * ld + c] = acc[u][v];
+            Out[c * ld + r] = acc[u][v];
+        }
+}
+
+// dst (n x n, leading dimension ldd) = 0.5 (src + src^T) of the leading n x n part of src (leading dimension lds),
+// plus shift on the diagonal; entries outside n x n of dst (up to np) = identity
+__global__ __launch_bounds__(256) void k_sym_pad(int64_t n, int64_t np, const double *__restrict__ src, int64_t lds, double shift,
+                                                 double *__restrict__ dst, int64_t ldd) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= np * np) return;
+    const int64_t r = e / np, c = e - r * np;
+    double v;
+    if (r < n && c < n) v = 0.5 * (src[r * lds + c] + src[c * lds + r]) + (r == c ? shift : 0.0);
+    else v = (r == c) ? 1.0 : 0.0;
+    dst[r * ldd + c] = v;
+}
+
+__global__ __launch_bounds__(256) void k_copy_block(int64_t n, const double *__restrict__ src, int64_t lds, double *__restrict__ dst, int64_t ldd) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * n) return;
+    const int64_t r = e / n, c = e - r * n;
+    dst[r * ldd + c] = src[r * lds + c];
+}
+
+// trace of the leading n x n part (single workgroup, fixed order)
+__global__ __launch_bounds__(256) void k_trace(int64_t n, const double *__restrict__ A, int64_t ld, double *__restrict__ out) {
+    __shared__ double sh[4];
+    double v = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) v += A[i * ld + i];
+    v = block_sum(v, sh);
+    if (threadIdx.x == 0) *out = v;
+}
+
+// A2 = Z^T A1 Z, one workgroup per aggregate g.  The (row node, column node) blocks of A1 whose row lies in g are
+// listed per neighbouring aggregate ("slot") by the host; accumulator (slot, k, k') belongs to one thread, which adds
+// the entries of its slot in list order: no atomics, bitwise reproducible.
+__global__ __launch_bounds__(256) void k_galerkin_rows(const int64_t *__restrict__ sptr_g, const int32_t *__restrict__ slot_agg,
+                                                       const int64_t *__restrict__ eptr, const int32_t *__restrict__ ent_i,
+                                                       const int32_t *__restrict__ ent_j, const uint32_t *__restrict__ ent_loc,
+                                                       const double *__restrict__ vals1, const double *__restrict__ Z,
+                                                       const int64_t *__restrict__ aoff, double *__restrict__ A2, int64_t ld) {
+    const int64_t g = blockIdx.x;
+    const int64_t s0 = sptr_g[g], ns = sptr_g[g + 1] - s0;
+    const int64_t og = aoff[g], ng = aoff[g + 1] - og;
+    for (int64_t a = threadIdx.x; a < ns * 36; a += 256) {
+        const int64_t sl = s0 + a / 36;
+        const int kk = (int)(a % 36), k = kk / 6, kp = kk - 6 * k;
+        const int64_t h = slot_agg[sl], oh = aoff[h], nh = aoff[h + 1] - oh;
+        if (k >= ng || kp >= nh) continue;
+        double acc = 0.0;
+        for (int64_t e = eptr[sl]; e < eptr[sl + 1]; e++) {
+            const double *zi = Z + (int64_t)ent_i[e] * 18, *zj = Z + (int64_t)ent_j[e] * 18;
+            const double *v = vals1 + unpack_offset(ent_loc[e]);
+            const double z0 = zj[kp], z1 = zj[6 + kp], z2 = zj[12 + kp];
+            const double t0 = v[0] * z0 + v[128] * z1 + v[256] * z2;
+            const double t1 = v[384] * z0 + v[512] * z1 + v[640] * z2;
+            const double t2 = v[768] * z0 + v[896] * z1 + v[1024] * z2;
+            acc += zi[k] * t0 + zi[6 + k] * t1 + zi[12 + k] * t2;
+        }
+        A2[(og + k) * ld + oh + kp] = acc;
+    }
+}
+
+}  // namespace fcvm

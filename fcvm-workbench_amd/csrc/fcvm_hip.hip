@@ -15,6 +15,7 @@
 #include "fcvm_kernels.hip.h"
 #include "fcvm_mg_kernels.hip.h"
 #include "fcvm_assemble_lds.hip.h"
+#include "fcvm_dense.hip.h"
 #include "fcvm_pattern.h"
 
 using namespace fcvm;
@@ -53,7 +54,7 @@ struct fcvm_ctx {
     int assemble_lds = 1;        // rows accumulated in LDS, one coalesced write per value (FCVM_ASSEMBLE_LDS=0: global read-modify-writes)
     // work items of k_assemble_lds (slice * 4 + quarter), grouped by the LDS a quarter slice needs
     static constexpr int ASM_BUCKETS = 5;
-    int32_t *d_asm_items = nullptr;
+    int32_t *d_asm_items = nullptr, *d_asm_rlen = nullptr;   // work items; blocks of the longest row of every slice
     int64_t asm_count[ASM_BUCKETS] = {0, 0, 0, 0, 0}, asm_first[ASM_BUCKETS] = {0, 0, 0, 0, 0};
     bool asm_lds_ok = false;
     int qin_atomic = 0;          // FCVM_QIN_ATOMIC=1: internal forces scattered with f64 atomics
@@ -78,6 +79,7 @@ struct fcvm_ctx {
     std::vector<int32_t> h_el;
     std::vector<double> h_coord;
     std::vector<uint8_t> h_fixmask;
+    std::vector<int32_t> h_c2f;   // level-1 node -> fine node
     // p-multigrid preconditioner (mode 1): level 1 = linear tets on the corner nodes
     int precond_mode = 0, mg_k0 = 1, mg_k1 = 60;
     double mg_alpha0 = 4.0, mg_alpha1 = 1000.0, mg_lmax0 = 0, mg_lmax1 = 0;
@@ -298,20 +300,26 @@ static int tune_matrix_placement(fcvm_ctx *c) {
     return 0;
 }
 
-// slice-length classes of k_assemble_lds: a quarter slice (16 rows) needs 16 * (9 len + 1) * 8 bytes of LDS
-static const int64_t ASM_LEN_LIMIT[fcvm_ctx::ASM_BUCKETS] = {20, 28, 40, 68, 138};   // 23 / 32 / 46 / 78 / 159 KiB
+// slice-length classes of k_assemble_lds (blocks of the longest row): a quarter slice needs asm_lds_bytes() of LDS
+static const int64_t ASM_LEN_LIMIT[fcvm_ctx::ASM_BUCKETS] = {19, 27, 41, 65, 133};   // 28 / 37 / 54 / 81 / 160 KiB: 5 / 4 / 3 / 2 / 1 per CU
 
 static int build_asm_items(fcvm_ctx *c) {
     const Pattern &p = c->pat;
     c->asm_lds_ok = false;
     dfree(c->d_asm_items);
-    if (p.maxlen + 1 > ASM_LEN_LIMIT[fcvm_ctx::ASM_BUCKETS - 1]) return 0;   // the rows must fit the LDS
-    std::vector<int32_t> items[fcvm_ctx::ASM_BUCKETS];
+    dfree(c->d_asm_rlen);
+    if (p.maxlen > ASM_LEN_LIMIT[fcvm_ctx::ASM_BUCKETS - 1]) return 0;   // a row that does not fit the LDS: global read-modify-write kernel
+    std::vector<int32_t> items[fcvm_ctx::ASM_BUCKETS], rlen(p.nslices, 0);
     NEED(p.nslices < (int64_t(1) << 29), "too many slices for 32-bit assembly work items");
     for (int64_t s = 0; s < p.nslices; s++) {
-        const int64_t len = p.sptr[s + 1] - p.sptr[s];
+        int64_t m = 1;
+        for (int l = 0; l < SLICE; l++) {
+            const int32_t nd = p.rownode[s * SLICE + l];
+            if (nd >= 0) m = std::max(m, p.rowptr[nd + 1] - p.rowptr[nd]);
+        }
+        rlen[s] = (int32_t)m;
         int b = 0;
-        while (len > ASM_LEN_LIMIT[b]) b++;
+        while (m > ASM_LEN_LIMIT[b]) b++;
         for (int q = 0; q < 4; q++) items[b].push_back((int32_t)(s * 4 + q));
     }
     std::vector<int32_t> all;
@@ -320,12 +328,13 @@ static int build_asm_items(fcvm_ctx *c) {
         c->asm_count[b] = (int64_t)items[b].size();
         all.insert(all.end(), items[b].begin(), items[b].end());
     }
-    if (dalloc(&c->d_asm_items, (int64_t)all.size())) return 1;
+    if (dalloc(&c->d_asm_items, (int64_t)all.size()) || dalloc(&c->d_asm_rlen, p.nslices)) return 1;
     HCHK(hipMemcpyAsync(c->d_asm_items, all.data(), sizeof(int32_t) * all.size(), hipMemcpyHostToDevice, c->stream));
+    HCHK(hipMemcpyAsync(c->d_asm_rlen, rlen.data(), sizeof(int32_t) * rlen.size(), hipMemcpyHostToDevice, c->stream));
     HCHK(hipStreamSynchronize(c->stream));
     for (int b = 0; b < fcvm_ctx::ASM_BUCKETS; b++) {   // dynamic LDS beyond 64 KiB has to be requested per kernel
         const int bytes = (int)asm_lds_bytes(ASM_LEN_LIMIT[b]);
-        if (bytes <= 64 * 1024) continue;
+        if (bytes <= 64 * 1024 || !c->asm_count[b]) continue;
         HCHK(hipFuncSetAttribute((const void *)k_assemble_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HCHK(hipFuncSetAttribute((const void *)k_assemble_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
@@ -339,7 +348,7 @@ static void launch_assemble_lds(fcvm_ctx *c, const double *disp, const double *s
     for (int b = 0; b < fcvm_ctx::ASM_BUCKETS; b++) {
         if (!c->asm_count[b]) continue;
         hipLaunchKernelGGL(k_assemble_lds<TANGENT>, dim3((unsigned)c->asm_count[b]), dim3(64), (size_t)asm_lds_bytes(ASM_LEN_LIMIT[b]), c->stream,
-                           c->d_asm_items + c->asm_first[b], c->d_sptr, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord, disp, c->d_fixmask,
+                           c->d_asm_items + c->asm_first[b], c->d_asm_rlen, c->d_sptr, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord, disp, c->d_fixmask,
                            c->d_fixval, c->d_emap, sig, pgp, mc, grav[0], grav[1], grav[2], c->d_vals, glv, modf, xgp,
                            vol_part ? vol_part + c->asm_first[b] : nullptr, penalty_bc);
     }
@@ -386,7 +395,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
 static void free_mesh(fcvm_ctx *c) {
     dfree(c->d_el); dfree(c->d_cols); dfree(c->d_rownode); dfree(c->d_noce); dfree(c->d_sptr);
     dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
-    dfree(c->d_nptr); dfree(c->d_nel); dfree(c->d_fe); dfree(c->d_part_vol); dfree(c->d_asm_items);
+    dfree(c->d_nptr); dfree(c->d_nel); dfree(c->d_fe); dfree(c->d_part_vol); dfree(c->d_asm_items); dfree(c->d_asm_rlen);
     dfree(c->d_vals); dfree(c->d_vals_g); dfree(c->d_dblk); dfree(c->d_dinv); dfree(c->d_r); dfree(c->d_z); dfree(c->d_p);
     dfree(c->d_q); dfree(c->d_part_vec); dfree(c->d_part_spmv); dfree(c->d_part_misc); dfree(c->d_pidx);
     mg_free(c);
@@ -1020,74 +1029,27 @@ int fcvm_mg_set_level2(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg
     return 0;
 }
 
-// rocSOLVER is loaded on first use only (dlopen): the library has no link-time dependency on it
-namespace {
-struct RocSolver {
-    void *hblas = nullptr, *hsolver = nullptr;
-    int (*create)(void **) = nullptr;
-    int (*destroy)(void *) = nullptr;
-    int (*set_stream)(void *, hipStream_t) = nullptr;
-    int (*dpotrf)(void *, int, int, double *, int, int *) = nullptr;
-    int (*dpotri)(void *, int, int, double *, int, int *) = nullptr;
-    bool tried = false, ok = false;
-    bool load() {
-        if (tried) return ok;
-        tried = true;
-        hblas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!hblas) hblas = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-        hsolver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!hsolver) hsolver = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-        if (!hblas || !hsolver) return false;
-        create = (int (*)(void **))dlsym(hblas, "rocblas_create_handle");
-        destroy = (int (*)(void *))dlsym(hblas, "rocblas_destroy_handle");
-        set_stream = (int (*)(void *, hipStream_t))dlsym(hblas, "rocblas_set_stream");
-        dpotrf = (int (*)(void *, int, int, double *, int, int *))dlsym(hsolver, "rocsolver_dpotrf");
-        dpotri = (int (*)(void *, int, int, double *, int, int *))dlsym(hsolver, "rocsolver_dpotri");
-        ok = create && destroy && set_stream && dpotrf && dpotri;
-        return ok;
-    }
-};
-RocSolver g_rocsolver;
-}  // namespace
+}  // extern "C"
+#include "fcvm_level2.inc"
+extern "C" {
 
-/* Same as fcvm_mg_set_level2 but takes the SPD matrix A2 itself and inverts it on the device (rocSOLVER potrf + potri,
- * loaded with dlopen).  Returns 2 (and changes nothing) when rocSOLVER cannot be loaded: the host binding then
- * inverts with LAPACK and calls fcvm_mg_set_level2. */
-int fcvm_mg_set_level2_spd(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg, const int64_t *aoff, const double *Z,
-                           const double *A2, int k1s, double alpha1s) {
-    NEED(c && A2 && n2 > 0 && n2 < (1 << 30), "fcvm_mg_set_level2_spd: bad arguments");
-    if (!g_rocsolver.load()) {
-        g_err = "fcvm_mg_set_level2_spd: rocSOLVER not available";
-        return 2;
-    }
-    if (fcvm_mg_set_level2(c, nagg, n2, agg, aoff, Z, nullptr, k1s, alpha1s)) return 1;
-    hipStream_t s = c->stream;
-    int *d_info = nullptr;
-    void *h = nullptr;
-    if (dalloc(&c->d_A2inv, n2 * n2) || dalloc(&d_info, 2)) return 1;
-    HCHK(hipMemcpyAsync(c->d_A2inv, A2, sizeof(double) * n2 * n2, hipMemcpyHostToDevice, s));
-    int info[2] = {-1, -1};
-    bool fine = g_rocsolver.create(&h) == 0 && g_rocsolver.set_stream(h, s) == 0;
-    // fill mode 121 = rocblas_fill_upper in column-major terms = the lower triangle of our row-major (symmetric) array
-    fine = fine && g_rocsolver.dpotrf(h, 121, (int)n2, c->d_A2inv, (int)n2, d_info) == 0;
-    fine = fine && g_rocsolver.dpotri(h, 121, (int)n2, c->d_A2inv, (int)n2, d_info + 1) == 0;
-    if (fine) fine = hipMemcpyAsync(info, d_info, sizeof(info), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-    if (h) g_rocsolver.destroy(h);
-    dfree(d_info);
-    if (!fine || info[0] != 0 || info[1] != 0) {
-        c->l2 = false;
-        return fail("fcvm_mg_set_level2_spd: aggregate-level matrix not positive definite (potrf info " + std::to_string(info[0]) +
-                    ", potri info " + std::to_string(info[1]) + ")");
-    }
-    // column-major upper = row-major lower: elements [b][a] with a < b are valid; mirror them to [a][b]
-    hipLaunchKernelGGL(k_mirror_lower_to_upper, dim3((unsigned)cdiv(n2 * n2, 256)), dim3(256), 0, s, n2, c->d_A2inv);
-    const int64_t lda = (n2 + 3) / 4 * 4;
-    if (dalloc(&c->d_A2invf, n2 * lda)) return 1;
-    hipLaunchKernelGGL(k_to_f32_padded, dim3((unsigned)cdiv(n2 * lda, 256)), dim3(256), 0, s, n2, lda, c->d_A2inv, c->d_A2invf);
-    HCHK(hipGetLastError());
-    HCHK(hipStreamSynchronize(s));
-    c->l2_has_inverse = true;
+/* Third multigrid level built inside the library: aggregates (uniform bins of about `target` level-1 nodes), rigid-body
+ * modes, A2 = Z^T A1 Z and its dense inverse on the device.  out[0] = aggregates, out[1] = unknowns. */
+int fcvm_mg_build_level2(fcvm_ctx *c, int64_t target, int k1s, double alpha1s, int64_t out[2]) {
+    NEED(c && c->mg_topo, "fcvm_mg_build_level2: assemble with the multigrid preconditioner first");
+    NEED(target >= 1 && k1s >= 1 && alpha1s > 1.0, "fcvm_mg_build_level2: bad parameters");
+    HCHK(hipSetDevice(c->device));
+    if (mg_build_level2(c, target, k1s, alpha1s, 1e-6)) return 1;
+    if (out) { out[0] = c->nagg; out[1] = c->n2; }
     return 0;
+}
+
+/* dst = inverse of the symmetric positive definite n x n matrix src (both row-major on the device, may not alias):
+ * blocked Cholesky, triangular inverse and X^T X in HIP kernels (fcvm_dense.hip.h) */
+int fcvm_spd_inverse(fcvm_ctx *c, int64_t n, const double *src, double *dst) {
+    NEED(c && n > 0 && src && dst && src != dst, "fcvm_spd_inverse: bad arguments");
+    HCHK(hipSetDevice(c->device));
+    return spd_inverse_device(c, n, src, dst, 0.0);
 }
 
 /* ---- fine-grained multigrid building blocks for the host-driven multi-GPU V-cycle ---- */

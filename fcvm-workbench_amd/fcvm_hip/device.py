@@ -245,8 +245,8 @@ class Context:
 
     def build_level2(self, target=None, k1s=None, alpha1s=None):
         """Third multigrid level (aggregates of tet4 nodes); call after assemble().  Skipped for
-        small coarse levels where the long Chebyshev sweep is cheap anyway."""
-        from . import mg2
+        small coarse levels where the long Chebyshev sweep is cheap anyway.  Built inside the library
+        (fcvm_mg_build_level2: bookkeeping in C++, Z^T A1 Z and the dense SPD inverse in HIP kernels)."""
         pi = self.precond_info()
         if pi["mode"] != "mg" or pi["coarse_nodes"] < self.l2_min_coarse_nodes:
             return None
@@ -263,7 +263,9 @@ class Context:
             k1s = 2 if target <= 250 else (3 if target <= 1000 else 4)
         if alpha1s is None:
             alpha1s = 4.0 * k1s
-        return mg2.build_level2(self, target=target, k1s=k1s, alpha1s=alpha1s)
+        out = (C.c_int64 * 2)()
+        call("fcvm_mg_build_level2", self.h, int(target), int(k1s), float(alpha1s), out)
+        return dict(aggregates=out[0], unknowns=out[1], target=target, inverse="device")
 
     def spmv(self, x, y):
         call("fcvm_spmv", self.h, x.ptr, y.ptr)

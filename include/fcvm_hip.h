@@ -189,10 +189,12 @@ int fcvm_mg_coarse_nodes(fcvm_ctx *c, double *coord1, uint8_t *fixmask1);
 int fcvm_mg_coarse_to_coo(fcvm_ctx *c, int64_t *row, int64_t *col, double *val);
 int fcvm_mg_set_level2(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg, const int64_t *aoff,
                        const double *Z, const double *A2inv, int k1s, double alpha1s);
-/* same, but hands over A2 itself (SPD, f64[n2*n2]) and has it inverted on the device by rocSOLVER (dlopen'ed on first
- * use; return code 2 = not loadable, nothing changed: invert on the host and call fcvm_mg_set_level2) */
-int fcvm_mg_set_level2_spd(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg, const int64_t *aoff,
-                           const double *Z, const double *A2, int k1s, double alpha1s);
+/* Third multigrid level built inside the library (host bookkeeping in C++, triple product and dense SPD inverse in HIP
+ * kernels): aggregates = uniform bins of about `target` level-1 nodes, six orthonormalised rigid-body modes each,
+ * A2 = Z^T A1 Z, explicit inverse kept in FP32.  out[0] = aggregates, out[1] = unknowns.  Call after fcvm_assemble. */
+int fcvm_mg_build_level2(fcvm_ctx *c, int64_t target, int k1s, double alpha1s, int64_t out[2]);
+/* dst = inverse of the SPD n x n matrix src (row-major, device pointers, no aliasing) */
+int fcvm_spd_inverse(fcvm_ctx *c, int64_t n, const double *src, double *dst);
 
 /* diagnostic: streaming read rate of a freshly allocated buffer of nbytes (16 B per lane, nontemporal): out[0] = GB/s,
  * out[1] = ms per pass.  The HBM rate this GPU delivers right now, to put a measured SpMV time into perspective. */

@@ -210,6 +210,28 @@ def test_both_preconditioners_solve_the_embankment_system(embankment, mode):
         assert info["iterations"] < 200 and c.precond_info()["coarse_nodes"] > 0
 
 
+def test_dense_spd_inverse_kernels(gpu_ctx):
+    """fcvm_spd_inverse (blocked Cholesky, triangular inverse, X^T X in HIP kernels: the aggregate level's solver) against
+    LAPACK, sizes around the 64-wide tiles."""
+    from fcvm_hip._lib import call
+    c = gpu_ctx
+    rng = np.random.default_rng(11)
+    for n in (5, 64, 130, 700):
+        q = rng.standard_normal((n, n))
+        a = q @ q.T + n * np.diag(rng.uniform(0.5, 2.0, n))
+        d_a, d_i = c.array(a.reshape(-1)), c.empty(n * n)
+        call("fcvm_spd_inverse", c.h, n, d_a.ptr, d_i.ptr)
+        inv = d_i.get().reshape(n, n)
+        assert np.array_equal(inv, inv.T)
+        assert np.abs(inv @ a - np.eye(n)).max() < 1e-11 * np.linalg.cond(a)
+        assert rel(inv, np.linalg.inv(a)) < 1e-10
+    # not positive definite -> error, not garbage
+    bad = np.eye(70)
+    bad[40, 40] = -1.0
+    with pytest.raises(Exception, match="positive definite"):
+        call("fcvm_spd_inverse", c.h, 70, c.array(bad.reshape(-1)).ptr, c.empty(70 * 70).ptr)
+
+
 def test_vector_kernels(gpu_ctx):
     c = make_model(small_case(1)).ctx
     rng = np.random.default_rng(0)

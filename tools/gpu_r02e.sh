@@ -3,7 +3,7 @@
 O=gpurun_out/r02e
 mkdir -p $O
 export TMPDIR=/tmp
-timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py -x -q -k "assemble or tangent or lug_pressure or cube_analysis or embankment_analysis or gnly_updated or buckling_factors or bitwise or pcg_solve or both_precond or refined_embankment" > $O/parity.log 2>&1 || { tail -30 $O/parity.log; exit 1; }
+timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py -x -q -k "dense_spd or assemble or tangent or lug_pressure or cube_analysis or embankment_analysis or gnly_updated or buckling_factors or bitwise or pcg_solve or both_precond or refined_embankment" > $O/parity.log 2>&1 || { tail -30 $O/parity.log; exit 1; }
 tail -3 $O/parity.log
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu --no-plate > $O/bench_trace.log 2>&1 || exit 1
 timeout -k 10 300 python3 bench.py --steps 10 --warmup 3 --no-cpu --no-plate > $O/bench_new.log 2>&1 || exit 1
