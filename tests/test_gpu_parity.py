@@ -228,8 +228,9 @@ def test_dense_spd_inverse_kernels(gpu_ctx):
     # not positive definite -> error, not garbage
     bad = np.eye(70)
     bad[40, 40] = -1.0
+    d_bad, d_out = c.array(bad.reshape(-1)), c.empty(70 * 70)
     with pytest.raises(Exception, match="positive definite"):
-        call("fcvm_spd_inverse", c.h, 70, c.array(bad.reshape(-1)).ptr, c.empty(70 * 70).ptr)
+        call("fcvm_spd_inverse", c.h, 70, d_bad.ptr, d_out.ptr)
 
 
 def test_vector_kernels(gpu_ctx):
