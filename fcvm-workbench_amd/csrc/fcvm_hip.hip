@@ -68,7 +68,6 @@ struct fcvm_ctx {
     double *d_part_vec = nullptr, *d_part_spmv = nullptr, *d_part_misc = nullptr, *d_out8 = nullptr;
     long long *d_pidx = nullptr;
     int64_t nb_vec = 0, nb_spmv = 0, nb_gp = 0;
-    int spmv_split1 = 1;  // level-1 products: a workgroup of four wavefronts per slice (FCVM_SPMV_SPLIT1=0: one wavefront)
     int spmv_spw = 1;  // waves per SpMV workgroup: 1 keeps the tail of the launch short (long and short slices differ 3x): -5 % vs 4
     double last_spmv_ms = 0, last_total_ms = 0;
     double row_spread = 0.0;
@@ -147,30 +146,19 @@ struct MatView {
     const double *vals;
     const int32_t *rownode;
     const float *vals32 = nullptr;  // optional FP32 copy of the values (coarse multigrid level)
-    bool split = false;             // few slices: one workgroup of four wavefronts per slice (k_spmv_split)
 };
 static MatView fine_view(const fcvm_ctx *c) { return {c->pat.nslices, c->nb_spmv, c->d_sptr, c->d_cols, c->d_vals, c->d_rownode}; }
 static MatView coarse_view(const fcvm_ctx *c) {
-    return {c->pat1.nslices, c->nb_spmv1, c->d_sptr1, c->d_cols1, c->d_vals1, c->d_rownode1, c->mg_fp32 ? c->d_vals1f : nullptr,
-            c->spmv_split1 != 0};
+    return {c->pat1.nslices, c->nb_spmv1, c->d_sptr1, c->d_cols1, c->d_vals1, c->d_rownode1, c->mg_fp32 ? c->d_vals1f : nullptr};
 }
 
 #define FCVM_SPMV_LAUNCH(DOT_, NT_, UN_, V2_, EPI_, vals_, epi_)                                                               \
     hipLaunchKernelGGL((k_spmv<DOT_, NT_, UN_, V2_, EPI_>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols, \
                        (const V2_ *)(vals_), m.rownode, x, y, part, done, epi_)
 
-#define FCVM_SPMV_SPLIT_LAUNCH(NT_, V2_, EPI_, vals_, epi_)                                                                   \
-    hipLaunchKernelGGL((k_spmv_split<NT_, V2_, EPI_>), dim3((unsigned)m.nslices), dim3(256), 0, c->stream, m.nslices, m.sptr, m.cols, \
-                       (const V2_ *)(vals_), m.rownode, x, y, done, epi_)
-
 template <bool DOT>
 static void launch_spmv_t(fcvm_ctx *c, const MatView &m, const double *x, double *y, double *part, const double *done) {
     dim3 grid((unsigned)m.nb), block(64 * c->spmv_spw);
-    if (m.split && !DOT) {
-        if (m.vals32) FCVM_SPMV_SPLIT_LAUNCH(false, float2, 0, m.vals32, ChebEpi{});
-        else FCVM_SPMV_SPLIT_LAUNCH(false, double2, 0, m.vals, ChebEpi{});
-        return;
-    }
     if (m.vals32) {  // FP32-stored matrix, FP64 vectors and accumulation
         FCVM_SPMV_LAUNCH(DOT, false, 4, float2, 0, m.vals32, ChebEpi{});
         return;
@@ -182,11 +170,6 @@ static void launch_spmv_t(fcvm_ctx *c, const MatView &m, const double *x, double
 static void launch_spmv_cheb(fcvm_ctx *c, const MatView &m, const double *x, const double *done, const ChebEpi &epi) {
     dim3 grid((unsigned)m.nb), block(64 * c->spmv_spw);
     double *y = nullptr, *part = nullptr;
-    if (m.split) {
-        if (m.vals32) FCVM_SPMV_SPLIT_LAUNCH(false, float2, 1, m.vals32, epi);
-        else FCVM_SPMV_SPLIT_LAUNCH(false, double2, 1, m.vals, epi);
-        return;
-    }
     if (m.vals32) FCVM_SPMV_LAUNCH(false, false, 4, float2, 1, m.vals32, epi);
     else FCVM_SPMV_LAUNCH(false, true, 4, double2, 1, m.vals, epi);
 }
@@ -380,7 +363,6 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_ASSEMBLE_ATOMIC")) c->assemble_atomic = atoi(v);
     if (const char *v = getenv("FCVM_ASSEMBLE_LDS")) c->assemble_lds = atoi(v);
     if (const char *v = getenv("FCVM_QIN_ATOMIC")) c->qin_atomic = atoi(v);
-    if (const char *v = getenv("FCVM_SPMV_SPLIT1")) c->spmv_split1 = atoi(v);
     if (const char *v = getenv("FCVM_SPMV_SPW")) c->spmv_spw = std::min(4, std::max(1, atoi(v)));   // slices (waves) per workgroup
     if (const char *v = getenv("FCVM_MG_ADDITIVE")) c->mg_additive = atoi(v);
     if (const char *v = getenv("FCVM_MG_FP32")) c->mg_fp32 = atoi(v);
@@ -1178,6 +1160,23 @@ int fcvm_mg_l2_prolong(fcvm_ctx *c, const double *e2, double *d1) {
     NEED(c && c->l2, "fcvm_mg_l2_prolong: no aggregate level (fcvm_mg_set_level2)");
     hipLaunchKernelGGL(k_l2_prolong, dim3((unsigned)cdiv(c->nc, 256)), dim3(256), 0, c->stream, c->nc, c->d_agg, c->d_aoff, c->d_Z, e2,
                        d1, (const double *)nullptr);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_pack_nodes(fcvm_ctx *c, int64_t n, const int64_t *idx, int ncomp, const double *v, double *out) {
+    NEED(c && n >= 0 && ncomp > 0, "fcvm_pack_nodes: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_pack_nodes, dim3((unsigned)cdiv(n * ncomp, 256)), dim3(256), 0, c->stream, n, idx, ncomp, v, out);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_unpack_sum(fcvm_ctx *c, int64_t nshared, const int64_t *node, const int64_t *eptr, const int64_t *src, int ncomp, double *v,
+                    const double *recv) {
+    NEED(c && nshared >= 0 && ncomp > 0, "fcvm_unpack_sum: bad arguments");
+    if (nshared == 0) return 0;
+    hipLaunchKernelGGL(k_unpack_sum, dim3((unsigned)cdiv(nshared * ncomp, 256)), dim3(256), 0, c->stream, nshared, node, eptr, src, ncomp, v, recv);
     HCHK(hipGetLastError());
     return 0;
 }

@@ -671,65 +671,6 @@ __global__ __launch_bounds__(256, (sizeof(V2) == 16 ? 4 : 1)) void k_spmv(int64_
     }
 }
 
-// The same product for a matrix with few slices (the tet4 level of the multigrid cycle: 2.7 k slices of 8-14 block pairs
-// at 1 M elements, i.e. fewer than three wavefronts per SIMD, each walking its whole slice through two or three dependent
-// rounds of loads): one WORKGROUP of four wavefronts per slice, wavefront w takes the block pairs p = w, w + 4, ..., all
-// of them in flight at once; the four partial row sums meet in LDS and wavefront 0 adds them in a fixed order and runs
-// the epilogue.  Four times the wavefronts, a quarter of the dependent rounds: 28 -> 12 us per level-1 product.
-template <bool NT, class V2, int EPI>
-__global__ __launch_bounds__(256) void k_spmv_split(int64_t nslices, const int64_t *__restrict__ sptr,
-                                                    const int32_t *__restrict__ cols, const V2 *__restrict__ vals,
-                                                    const int32_t *__restrict__ rownode, const double *__restrict__ x,
-                                                    double *__restrict__ y, const double *__restrict__ done, ChebEpi epi) {
-    __shared__ double part[3][3][64];
-    if (done && *done != 0.0) return;
-    const int64_t b = blockIdx.x, nblocks = gridDim.x;
-    const int64_t q = nblocks >> 3, r = nblocks & 7, xcd = b & 7;
-    const int64_t s = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t jb = sptr[s], je = sptr[s + 1];
-    const int64_t np = (je - jb) >> 1;
-    const int32_t *cp = cols + jb * 64 + lane;
-    const V2 *vp = vals + (jb >> 1) * (9 * 64) + lane;
-    double y0 = 0.0, y1 = 0.0, y2 = 0.0, z0 = 0.0, z1 = 0.0, z2 = 0.0;
-    int64_t p = w;
-    for (; p + 4 < np; p += 8) {   // two pairs of this wavefront per trip, independent accumulators
-        spmv_pair<NT, V2>(cp + p * 128, vp + p * (9 * 64), x, y0, y1, y2);
-        spmv_pair<NT, V2>(cp + (p + 4) * 128, vp + (p + 4) * (9 * 64), x, z0, z1, z2);
-    }
-    if (p < np) spmv_pair<NT, V2>(cp + p * 128, vp + p * (9 * 64), x, y0, y1, y2);
-    y0 += z0; y1 += z1; y2 += z2;
-    if (w > 0) {
-        part[w - 1][0][lane] = y0; part[w - 1][1][lane] = y1; part[w - 1][2][lane] = y2;
-    }
-    __syncthreads();
-    if (w > 0) return;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        y0 += part[k][0][lane]; y1 += part[k][1][lane]; y2 += part[k][2][lane];
-    }
-    const int node = rownode[s * 64 + lane];
-    if (node < 0) return;
-    const int64_t o = 3 * (int64_t)node;
-    if (EPI == 0) {
-        y[o] = y0; y[o + 1] = y1; y[o + 2] = y2;
-    } else {
-        const double d0 = x[o], d1 = x[o + 1], d2 = x[o + 2];
-        const double r0 = epi.r[o] - y0, r1 = epi.r[o + 1] - y1, r2 = epi.r[o + 2] - y2;
-        epi.r[o] = r0; epi.r[o + 1] = r1; epi.r[o + 2] = r2;
-        double a0 = d0, a1 = d1, a2 = d2;
-        if (epi.update_d) {
-            double t0, t1, t2;
-            apply_dinv(epi.dinv + (int64_t)node * 9, r0, r1, r2, t0, t1, t2);
-            const double n0 = epi.cdd * d0 + epi.cdr * t0, n1 = epi.cdd * d1 + epi.cdr * t1, n2 = epi.cdd * d2 + epi.cdr * t2;
-            epi.dout[o] = n0; epi.dout[o + 1] = n1; epi.dout[o + 2] = n2;
-            if (epi.add_dout) { a0 += n0; a1 += n1; a2 += n2; }
-        }
-        epi.x[o] += a0; epi.x[o + 1] += a1; epi.x[o + 2] += a2;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // PCG scalars live on the device: S[0]=rz S[1]=pq S[2]=alpha S[3]=beta S[4]=rr S[5]=thresh
 // S[6]=done S[7]=iterations S[8]=bb

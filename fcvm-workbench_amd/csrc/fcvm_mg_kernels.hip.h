@@ -487,6 +487,34 @@ __global__ __launch_bounds__(256) void k_l2_prolong(int64_t nc, const int32_t *_
     d1[3 * i] = v0; d1[3 * i + 1] = v1; d1[3 * i + 2] = v2;
 }
 
+// ---- shared-node exchange of the element partition (multi-GPU): pack / fixed-order sum ----------------
+// out[k][c] = v[idx[k]][c]: the values a rank sends to its neighbours, all neighbours in one buffer
+__global__ __launch_bounds__(256) void k_pack_nodes(int64_t n, const int64_t *__restrict__ idx, int ncomp, const double *__restrict__ v,
+                                                    double *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * ncomp) return;
+    const int64_t k = t / ncomp, c = t - k * ncomp;
+    out[t] = v[idx[k] * ncomp + c];
+}
+// v[node[t]][c] = sum over the entries of interface node t, in list order, of (src < 0 ? v[node[t]][c] : recv[src][c]).
+// The lists are sorted by the rank a contribution comes from, the own one standing at the place of the own rank, so that
+// every rank holding the node adds the same numbers in the same order: shared values stay bit-identical on all sharers.
+__global__ __launch_bounds__(256) void k_unpack_sum(int64_t nshared, const int64_t *__restrict__ node, const int64_t *__restrict__ eptr,
+                                                    const int64_t *__restrict__ src, int ncomp, double *__restrict__ v,
+                                                    const double *__restrict__ recv) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nshared * ncomp) return;
+    const int64_t k = t / ncomp, c = t - k * ncomp;
+    const int64_t nd = node[k];
+    const double own = v[nd * ncomp + c];
+    double acc = 0.0;
+    for (int64_t e = eptr[k]; e < eptr[k + 1]; e++) {
+        const int64_t sidx = src[e];
+        acc += sidx < 0 ? own : recv[sidx * ncomp + c];
+    }
+    v[nd * ncomp + c] = acc;
+}
+
 __global__ __launch_bounds__(256) void k_add_if(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ o,
                                                 const double *__restrict__ done) {
     if (done && *done != 0.0) return;

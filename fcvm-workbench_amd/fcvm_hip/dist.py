@@ -104,35 +104,85 @@ class Partition:
 
 
 class Exchanger:
-    """Adds the partial sums at shared nodes across ranks (ncomp values per node)."""
+    """Adds the partial sums at shared nodes across ranks (ncomp values per node).
 
-    def __init__(self, part, device, shared=None, nn=None):
+    One send buffer holds the values for all neighbours (neighbours in ascending rank order, nodes in ascending global
+    number); the received rows are added per interface node in ascending order of the rank they come from, the own
+    value standing at the place of the own rank -- every rank that holds a node therefore adds the same numbers in the
+    same order and the consistent vectors stay bit-identical on all sharers.  With `ops` offering pack / unpack_sum
+    (HipLocalOps: fcvm_pack_nodes / fcvm_unpack_sum) both steps are HIP kernels on the rank's stream; otherwise torch
+    (CPU tests)."""
+
+    def __init__(self, part, device, shared=None, nn=None, ops=None):
         self.part, self.device = part, device
         shared = part.shared if shared is None else shared
         self.nn = part.nn if nn is None else nn
-        self.idx = {s: torch.as_tensor(ix, dtype=torch.int64, device=device) for s, ix in shared.items() if len(ix)}
+        self.ops = ops if (ops is not None and hasattr(ops, "pack")) else None
+        self.ranks = sorted(s for s, ix in shared.items() if len(ix))
+        self.offs, rows = {}, 0
+        for s in self.ranks:
+            self.offs[s] = (rows, rows + len(shared[s]))
+            rows += len(shared[s])
+        self.rows = rows
+        if not self.ranks:
+            return
+        idx_all = np.concatenate([np.asarray(shared[s], dtype=np.int64) for s in self.ranks])
+        self.idx_all = torch.as_tensor(idx_all, dtype=torch.int64, device=device)
+        # interface nodes and their entry lists (source rank ascending; -1 = the own value)
+        inodes = np.unique(idx_all)
+        pos = {s: dict(zip(np.asarray(shared[s]).tolist(), range(self.offs[s][0], self.offs[s][1]))) for s in self.ranks}
+        eptr, src = [0], []
+        for nd in inodes.tolist():
+            ent = [(part.rank, -1)] + [(s, pos[s][nd]) for s in self.ranks if nd in pos[s]]
+            ent.sort()
+            src.extend(e[1] for e in ent)
+            eptr.append(len(src))
+        self.inodes = torch.as_tensor(inodes, dtype=torch.int64, device=device)
+        self.eptr = torch.as_tensor(np.asarray(eptr, dtype=np.int64), device=device)
+        self.src = torch.as_tensor(np.asarray(src, dtype=np.int64), device=device)
+        cnt = np.diff(eptr)
+        self.maxmult = int(cnt.max())
+        srcmat = np.full((len(inodes), self.maxmult), -2, dtype=np.int64)     # -2: no entry
+        for k in range(self.maxmult):
+            m = cnt > k
+            srcmat[m, k] = np.asarray(src, dtype=np.int64)[np.asarray(eptr[:-1])[m] + k]
+        self.srcmat = torch.as_tensor(srcmat, device=device)
 
     def interface_sum(self, t, ncomp):
         """t: flat tensor [nn*ncomp]; in place."""
         p = self.part
-        if p.world == 1 or not self.idx:
+        if p.world == 1 or not self.ranks:
             return t
-        v = t.view(self.nn, ncomp)
+        send = torch.empty(self.rows * ncomp, dtype=t.dtype, device=t.device)
+        if self.ops is not None and t.is_cuda:
+            self.ops.pack(self.idx_all, ncomp, t, send)
+        else:
+            send.copy_(t.view(self.nn, ncomp).index_select(0, self.idx_all).reshape(-1))
         # gloo has no GPU point-to-point: stage through the host there (CPU tests / shared-GPU rehearsal);
         # with nccl (= RCCL) the buffers go GPU to GPU over xGMI
         stage = t.is_cuda and dist.get_backend(p.group) == "gloo"
-        sends, recvs, ops = {}, {}, []
-        for s, ix in self.idx.items():
-            b = v.index_select(0, ix).contiguous()
-            sends[s] = b.cpu() if stage else b
-            recvs[s] = torch.empty_like(sends[s])
-        for s in sorted(self.idx):
-            ops.append(dist.P2POp(dist.isend, sends[s], s, group=p.group))
-            ops.append(dist.P2POp(dist.irecv, recvs[s], s, group=p.group))
+        sbuf = send.cpu() if stage else send
+        rbuf = torch.empty_like(sbuf)
+        ops = []
+        for s in self.ranks:
+            a, b = self.offs[s]
+            ops.append(dist.P2POp(dist.isend, sbuf[a * ncomp:b * ncomp], s, group=p.group))
+            ops.append(dist.P2POp(dist.irecv, rbuf[a * ncomp:b * ncomp], s, group=p.group))
         for w in dist.batch_isend_irecv(ops):
             w.wait()
-        for s, ix in self.idx.items():
-            v.index_add_(0, ix, recvs[s].to(t.device) if stage else recvs[s])
+        recv = rbuf.to(t.device) if stage else rbuf
+        if self.ops is not None and t.is_cuda:
+            self.ops.unpack_sum(self.inodes, self.eptr, self.src, ncomp, t, recv)
+        else:
+            v, r = t.view(self.nn, ncomp), recv.view(self.rows, ncomp)
+            own = v.index_select(0, self.inodes)
+            acc = torch.zeros_like(own)
+            for k in range(self.maxmult):       # sequential adds: the same fixed order as the kernel
+                col = self.srcmat[:, k]
+                term = torch.where((col >= 0).unsqueeze(1), r.index_select(0, col.clamp(min=0)),
+                                   torch.where((col == -1).unsqueeze(1), own, torch.zeros_like(own)))
+                acc = acc + term
+            v.index_copy_(0, self.inodes, acc)
         return t
 
 
@@ -141,7 +191,7 @@ class DistBackend:
 
     def __init__(self, part, ops, device, pcg_check_every=25):
         self.part, self.ops, self.device = part, ops, device
-        self.ex = Exchanger(part, device)
+        self.ex = Exchanger(part, device, ops=ops)
         self.nn, self.ne = part.nn, len(part.elNodes)
         w = np.repeat(part.owned.astype(np.float64), 3)
         self.w = torch.as_tensor(w, device=device)
@@ -394,7 +444,7 @@ class DistMG:
         for s, ix in part.shared.items():
             cix = f2c[ix]
             shared1[s] = cix[cix >= 0]  # shared corner nodes, same (global id) order on both sides
-        self.ex1 = Exchanger(part, dev, shared=shared1, nn=self.nc)
+        self.ex1 = Exchanger(part, dev, shared=shared1, nn=self.nc, ops=self.ops)
         ones = torch.ones(part.nn, dtype=torch.float64, device=dev)
         be.ex.interface_sum(ones, 1)
         self.w0 = (1.0 / ones).repeat_interleave(3)           # 1 / (ranks holding the node), per dof
@@ -711,6 +761,15 @@ class HipLocalOps:
 
     def precond(self, r, z):
         self.c.precond(self._p(r), self._p(z))
+
+    def pack(self, idx, ncomp, t, out):
+        from ._lib import call
+        call("fcvm_pack_nodes", self.c.h, idx.numel(), idx.data_ptr(), int(ncomp), t.data_ptr(), out.data_ptr())
+
+    def unpack_sum(self, inodes, eptr, src, ncomp, t, recv):
+        from ._lib import call
+        call("fcvm_unpack_sum", self.c.h, inodes.numel(), inodes.data_ptr(), eptr.data_ptr(), src.data_ptr(), int(ncomp),
+             t.data_ptr(), recv.data_ptr())
 
     def wdot(self, w, x, y, out):
         """out[0] = sum w x y (torch tensors on this rank's device)"""

@@ -163,6 +163,14 @@ int fcvm_solve_timing(fcvm_ctx *c, double out[4]);
  * fcvm_assemble.
  */
 int fcvm_set_precond(fcvm_ctx *c, int mode, int k0, int k1, double alpha0, double alpha1);
+/* Shared-node exchange of the element partition (one process per GPU): values of the nodes a rank shares with its
+ * neighbours go into one send buffer (fcvm_pack_nodes: out[k][c] = v[idx[k]][c]); after the point-to-point transfers
+ * fcvm_unpack_sum replaces v at every interface node by the sum over its entry list, src < 0 standing for the rank's
+ * own value and src >= 0 for row src of the receive buffer.  The host sorts the lists by source rank, so every sharer
+ * adds the same numbers in the same order.  Index arrays are device pointers (int64). */
+int fcvm_pack_nodes(fcvm_ctx *c, int64_t n, const int64_t *idx, int ncomp, const double *v, double *out);
+int fcvm_unpack_sum(fcvm_ctx *c, int64_t nshared, const int64_t *node, const int64_t *eptr, const int64_t *src, int ncomp,
+                    double *v, const double *recv);
 /* level-0 part of the V-cycle: additive != 0 (default): x = weight*c0*Dinv b + P M1^-1 P^T b, i.e. no
  * fine-level SpMV inside the preconditioner; additive == 0: multiplicative Chebyshev pre/post smoothing */
 int fcvm_set_mg_cycle(fcvm_ctx *c, int additive, double weight);
