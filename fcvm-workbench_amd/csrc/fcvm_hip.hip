@@ -153,7 +153,7 @@ static MatView coarse_view(const fcvm_ctx *c) {
 }
 
 #define FCVM_SPMV_LAUNCH(DOT_, NT_, UN_, V2_, EPI_, vals_, epi_)                                                               \
-    hipLaunchKernelGGL((k_spmv<DOT_, NT_, UN_, V2_, EPI_>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols, \
+    hipLaunchKernelGGL((k_spmv<DOT_, NT_, UN_, V2_, EPI_, 0>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols, \
                        (const V2_ *)(vals_), m.rownode, x, y, part, done, epi_)
 
 template <bool DOT>
@@ -164,6 +164,9 @@ static void launch_spmv_t(fcvm_ctx *c, const MatView &m, const double *x, double
         return;
     }
     if (c->spmv_variant == 0) FCVM_SPMV_LAUNCH(DOT, false, 1, double2, 0, m.vals, ChebEpi{});
+    else if (c->spmv_variant == 5)   // experiment: 8 + 16 byte gathers
+        hipLaunchKernelGGL((k_spmv<DOT, true, 4, double2, 0, 1>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols,
+                           (const double2 *)m.vals, m.rownode, x, y, part, done, ChebEpi{});
     else FCVM_SPMV_LAUNCH(DOT, true, 4, double2, 0, m.vals, ChebEpi{});
 }
 // SpMV t = A d fused with a Chebyshev smoother step on the same rows (see ChebEpi); nothing is written but epi's vectors
@@ -858,6 +861,19 @@ int fcvm_vec_dot(fcvm_ctx *c, int64_t n, const double *x, const double *y, doubl
 int fcvm_vec_wdot_dev(fcvm_ctx *c, int64_t n, const double *w, const double *x, const double *y, double *result_dev) {
     return dot_common(c, n, w, x, y, result_dev);
 }
+int fcvm_any_u8(fcvm_ctx *c, int64_t n, const uint8_t *a, int *result_host) {
+    NEED(c && n >= 0 && result_host, "fcvm_any_u8: bad arguments");
+    *result_host = 0;
+    if (n == 0) return 0;
+    int *flag = (int *)(c->d_out8 + 12);
+    HCHK(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_any_u8, dim3((unsigned)std::min<int64_t>(cdiv(n, 256), 2048)), dim3(256), 0, c->stream, n, a, flag);
+    HCHK(hipGetLastError());
+    HCHK(hipMemcpyAsync(result_host, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int fcvm_vec_max_node_norm(fcvm_ctx *c, int64_t nnodes, const double *u, double *result_host) {
     NEED(c && c->d_part_misc, "vector reductions need a mesh (work buffers)");
     int64_t nb = std::min<int64_t>(std::max<int64_t>(cdiv(nnodes, 256), 1), 2048);
@@ -896,7 +912,7 @@ int fcvm_host_pattern_check(int64_t ne, int64_t nn, const int64_t *elNodes, int6
                 int64_t slot = p.slotof[el[e * 10 + a]];
                 int64_t s = slot / SLICE;
                 if (slot % SLICE != l || jglob < p.sptr[s] || jglob >= p.sptr[s + 1]) { bad++; continue; }
-                if (p.cols[jglob * SLICE + l] != el[e * 10 + b]) bad++;
+                if (p.cols[p.col_index(s, l, jglob - p.sptr[s])] != el[e * 10 + b]) bad++;
             }
     for (int64_t i = 0; i < nn; i++) {
         int64_t slot = p.slotof[i];

@@ -559,16 +559,36 @@ __device__ __forceinline__ int32_t ld_col(const int32_t *p) {
     return NT ? __builtin_nontemporal_load(p) : *p;
 }
 
-template <bool NT, class V2>
+// one block pair of a lane: the two column nodes (one 8-byte load), nine 16-byte value loads, two 24-byte x gathers.
+// GATHER = 1: every gathered node is fetched with one 8-byte and one 16-byte load instead of three 8-byte ones (node
+// numbers are 24 bytes apart: even nodes are 16-byte aligned, odd ones 8 bytes off, so the 16-byte load takes
+// (x, y) of an even and (y, z) of an odd node).
+template <bool NT, class V2, int GATHER>
 __device__ __forceinline__ void spmv_pair(const int32_t *cp, const V2 *vp, const double *__restrict__ x,
                                           double &y0, double &y1, double &y2) {
-    const int32_t c0 = ld_col<NT>(cp), c1 = ld_col<NT>(cp + 64);
+    int2 cc;
+    if (NT) {
+        cc.x = __builtin_nontemporal_load(cp);
+        cc.y = __builtin_nontemporal_load(cp + 1);
+    } else {
+        cc = *(const int2 *)cp;
+    }
+    const int32_t c0 = cc.x, c1 = cc.y;
     double2 v[9];
 #pragma unroll
     for (int c = 0; c < 9; c++) v[c] = ld_val<NT>(vp + c * 64);
+    double a0, a1, a2, b0, b1, b2;
     const double *xa = x + 3 * (int64_t)c0, *xb = x + 3 * (int64_t)c1;
-    const double a0 = xa[0], a1 = xa[1], a2 = xa[2];
-    const double b0 = xb[0], b1 = xb[1], b2 = xb[2];
+    if (GATHER == 1) {
+        const int oa = c0 & 1, ob = c1 & 1;
+        const double2 wa = *(const double2 *)(xa + oa), wb = *(const double2 *)(xb + ob);
+        const double sa = xa[oa ? 0 : 2], sb = xb[ob ? 0 : 2];
+        a0 = oa ? sa : wa.x; a1 = oa ? wa.x : wa.y; a2 = oa ? wa.y : sa;
+        b0 = ob ? sb : wb.x; b1 = ob ? wb.x : wb.y; b2 = ob ? wb.y : sb;
+    } else {
+        a0 = xa[0]; a1 = xa[1]; a2 = xa[2];
+        b0 = xb[0]; b1 = xb[1]; b2 = xb[2];
+    }
     y0 += v[0].x * a0 + v[1].x * a1 + v[2].x * a2 + v[0].y * b0 + v[1].y * b1 + v[2].y * b2;
     y1 += v[3].x * a0 + v[4].x * a1 + v[5].x * a2 + v[3].y * b0 + v[4].y * b1 + v[5].y * b2;
     y2 += v[6].x * a0 + v[7].x * a1 + v[8].x * a2 + v[6].y * b0 + v[7].y * b1 + v[8].y * b2;
@@ -586,7 +606,7 @@ struct ChebEpi {
 };
 __device__ __forceinline__ void apply_dinv(const double *d, double r0, double r1, double r2, double &z0, double &z1, double &z2);
 
-template <bool DOT, bool NT, int UNROLL, class V2 = double2, int EPI = 0>
+template <bool DOT, bool NT, int UNROLL, class V2 = double2, int EPI = 0, int GATHER = 0>
 __global__ __launch_bounds__(256, (sizeof(V2) == 16 ? 4 : 1)) void k_spmv(int64_t nslices, int64_t nblocks, const int64_t *__restrict__ sptr,
                                               const int32_t *__restrict__ cols,
                                               const V2 *__restrict__ vals,
@@ -608,16 +628,16 @@ __global__ __launch_bounds__(256, (sizeof(V2) == 16 ? 4 : 1)) void k_spmv(int64_
     int node = -1;
     if (s < nslices) {
         const int64_t jb = sptr[s], je = sptr[s + 1];
-        const int32_t *cp = cols + jb * 64 + lane;
+        const int32_t *cp = cols + jb * 64 + 2 * lane;   // two column nodes per lane and pair, adjacent
         const V2 *vp = vals + (jb >> 1) * (9 * 64) + lane;
         int64_t np = (je - jb) >> 1;
         if (UNROLL == 4) {
             double z0 = 0.0, z1 = 0.0, z2 = 0.0, u0 = 0.0, u1 = 0.0, u2 = 0.0, w0 = 0.0, w1 = 0.0, w2 = 0.0;
             for (; np >= 4; np -= 4) {
-                spmv_pair<NT, V2>(cp, vp, x, y0, y1, y2);
-                spmv_pair<NT, V2>(cp + 128, vp + 9 * 64, x, z0, z1, z2);
-                spmv_pair<NT, V2>(cp + 256, vp + 18 * 64, x, u0, u1, u2);
-                spmv_pair<NT, V2>(cp + 384, vp + 27 * 64, x, w0, w1, w2);
+                spmv_pair<NT, V2, GATHER>(cp, vp, x, y0, y1, y2);
+                spmv_pair<NT, V2, GATHER>(cp + 128, vp + 9 * 64, x, z0, z1, z2);
+                spmv_pair<NT, V2, GATHER>(cp + 256, vp + 18 * 64, x, u0, u1, u2);
+                spmv_pair<NT, V2, GATHER>(cp + 384, vp + 27 * 64, x, w0, w1, w2);
                 cp += 512;
                 vp += 36 * 64;
             }
@@ -626,15 +646,15 @@ __global__ __launch_bounds__(256, (sizeof(V2) == 16 ? 4 : 1)) void k_spmv(int64_
         if (UNROLL >= 2) {
             double z0 = 0.0, z1 = 0.0, z2 = 0.0;
             for (; np >= 2; np -= 2) {
-                spmv_pair<NT, V2>(cp, vp, x, y0, y1, y2);
-                spmv_pair<NT, V2>(cp + 128, vp + 9 * 64, x, z0, z1, z2);
+                spmv_pair<NT, V2, GATHER>(cp, vp, x, y0, y1, y2);
+                spmv_pair<NT, V2, GATHER>(cp + 128, vp + 9 * 64, x, z0, z1, z2);
                 cp += 256;
                 vp += 18 * 64;
             }
             y0 += z0; y1 += z1; y2 += z2;
         }
         for (; np > 0; np--) {
-            spmv_pair<NT, V2>(cp, vp, x, y0, y1, y2);
+            spmv_pair<NT, V2, GATHER>(cp, vp, x, y0, y1, y2);
             cp += 128;
             vp += 9 * 64;
         }
@@ -1037,6 +1057,13 @@ __global__ __launch_bounds__(256) void k_principal(int64_t n, const double *__re
         ps[3 * i + k] = ev;
         for (int c = 0; c < 3; c++) pv[9 * i + 3 * k + c] = ev * V[c][ord[k]];
     }
+}
+
+// flag[0] = 1 if any byte of a is non-zero (flag zeroed by the caller; every writer stores the same value)
+__global__ __launch_bounds__(256) void k_any_u8(int64_t n, const uint8_t *__restrict__ a, int *__restrict__ flag) {
+    bool hit = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) hit |= a[i] != 0;
+    if (__any(hit) && (threadIdx.x & 63) == 0) flag[0] = 1;
 }
 
 __global__ __launch_bounds__(256) void k_to_f32(int64_t n, const double *__restrict__ a, float *__restrict__ o) {

@@ -118,7 +118,7 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
                 for (int64_t j = 0; j < L; j++) {
                     int32_t c = 0;
                     if (nd >= 0) c = (j < len[nd]) ? p.colidx[p.rowptr[nd] + j] : nd;
-                    p.cols[(p.sptr[s] + j) * SLICE + l] = c;
+                    p.cols[p.col_index(s, l, j)] = c;
                 }
             }
         }

@@ -22,7 +22,7 @@ struct Pattern {
     std::vector<int64_t> sptr;      // [nslices+1] cumulative slice lengths (blocks per lane, even)
     std::vector<int32_t> rownode;   // [nslices*64] node of slot, -1 = padding
     std::vector<int32_t> slotof;    // [nn] slot (slice*64+lane) of node
-    std::vector<int32_t> cols;      // [sptr[nslices]*64] column node per (slice, j, lane)
+    std::vector<int32_t> cols;      // [sptr[nslices]*64] column nodes, the two of a block pair adjacent per lane: see col_index
     std::vector<uint32_t> emap;     // [ne*npe*npe] packed location of component 0 of block (a,b), see pack_offset
     std::vector<uint32_t> diagoff;  // [nn] packed location of component 0 of the diagonal block
     std::vector<int64_t> nptr;      // [nn+1] node -> element incidence (CSR)
@@ -33,6 +33,8 @@ struct Pattern {
         int64_t s = slot / SLICE, l = slot % SLICE;
         return (uint64_t)(((sptr[s] / 2 + (j >> 1)) * 9 * SLICE + l) * 2 + (j & 1));
     }
+    // position in `cols` of the column node of block j of lane l of slice s: one 8-byte load per lane and block pair
+    inline int64_t col_index(int64_t s, int64_t l, int64_t j) const { return (((sptr[s] + j) >> 1) * SLICE + l) * 2 + (j & 1); }
     int64_t value_count() const { return sptr[nslices] * SLICE * 9; }
     // 32-bit form of block_offset for the device tables: pair row P = sptr[s]/2 + j/2 (25 bits), lane (6 bits), j & 1;
     // offset in doubles = ((P * 9 * 64) + lane) * 2 + (j & 1)  (unpack_offset in fcvm_kernels.hip.h).  2^25 pair rows

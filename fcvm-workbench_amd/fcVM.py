@@ -150,6 +150,7 @@ def _model_for(elNodes, nocoord, materialbyElement, fix=None):
     elif m._xyz_digest != dx:
         m.ctx.set_coords(xyz)
         m.nocoord = xyz.copy()
+        m._ext = None
         m._xyz_digest = dx
     return m
 
@@ -248,6 +249,8 @@ def run(name, elNodes, nocoord, materialbyElement, fix, loads=None, control_dir=
     res = run_analysis(elNodes, nocoord, np.asarray(materialbyElement)[0], fix, loads or Loads(), ctl,
                        device=settings["device"], log=print, rtol=settings["rtol"])
     _model_cache.clear()
+    res["model"]._el_digest = _digest(res["model"].elNodes, np.int64)
+    res["model"]._xyz_digest = _digest(res["model"].nocoord, np.float64)
     _model_cache["run"] = res["model"]
     inpout.write_out(os.path.join(output_dir, name + ".out"), name, len(elNodes), len(nocoord), ctl["gnl"],
                      ctl["nstep"], res["eigenval"], res["loadsum"], res["crip"], res["x"], res["lout"], res["un"],

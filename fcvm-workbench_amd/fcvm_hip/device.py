@@ -216,6 +216,12 @@ class Context:
         call("fcvm_solve", self.h, f.ptr, u.ptr, float(rtol), int(maxit), info)
         return u, dict(iterations=int(info[0]), rel_residual=info[1], spmv=int(info[2]))
 
+    def any_nonzero(self, a):
+        """any(a != 0) of a uint8 device array, reduced on the device (4 bytes come back)"""
+        out = C.c_int(0)
+        call("fcvm_any_u8", self.h, a.n, a.ptr, C.byref(out))
+        return bool(out.value)
+
     def solve_timing(self):
         t = (C.c_double * 4)()
         call("fcvm_solve_timing", self.h, t)

@@ -199,6 +199,7 @@ class DistBackend:
         self.check_every = pcg_check_every
         self._timing = dict(spmv_ms=0.0, total_ms=0.0)
         self.mg = None  # DistMG once enabled (enable_multigrid)
+        self.local_solver = False
 
     # -- allocation ---------------------------------------------------------------------------
     def _dt(self, dtype):
@@ -237,6 +238,10 @@ class DistBackend:
 
     def norm(self, x):
         return float(np.sqrt(self.dot(x, x)))
+
+    def any_nonzero(self, a):
+        v = (a.t != 0).any().to(torch.float64).reshape(1)
+        return bool(self._allreduce(v, dist.ReduceOp.MAX).item() > 0.0)
 
     def loadsum(self, glv):
         v = (self.w * glv.t).view(-1, 3).sum(0)
@@ -283,7 +288,13 @@ class DistBackend:
         return glv, modf, float(self._allreduce(v).item())
 
     def enable_multigrid(self, nocoord_local, **kw):
-        """p-multigrid V-cycle as PCG preconditioner on all ranks (needs LocalOps with the mg_* methods)."""
+        """p-multigrid V-cycle as PCG preconditioner on all ranks (needs LocalOps with the mg_* methods).  A single
+        rank has nothing to exchange: it runs the library's own V-cycle PCG (fcvm_solve), i.e. exactly the one-GPU
+        solver, instead of the host-sequenced cycle."""
+        if self.part.world == 1 and hasattr(self.ops, "enable_local_multigrid"):
+            self.ops.enable_local_multigrid()
+            self.local_solver = True
+            return
         self.ops.mg_enable()
         self.mg = DistMG(self, nocoord_local, **kw)
         if self.mg.check_every:
@@ -338,6 +349,10 @@ class DistBackend:
         after 1, 1, 2, 4 ... check_every iterations (a Newton step whose start vector is nearly exact converges in one)."""
         if u is None:
             u = self.empty(f.n)
+        if self.local_solver:
+            info = self.ops.solve_local(f, u, rtol, maxit)
+            self._timing = self.ops.c.solve_timing()
+            return u, info
         x, r = u.t, f.t.clone()
         x.zero_()
         z, q = self.empty(f.n), self.empty(f.n)
@@ -721,6 +736,7 @@ class HipLocalOps:
         self.c.set_material(*material)
         self.c.set_fix(fix_local)
         self.element_offset = element_offset
+        self.local_mg = False
 
     def _p(self, v):
         from .device import DArr
@@ -737,7 +753,17 @@ class HipLocalOps:
         call("fcvm_assemble", self.c.h, disp.ptr if disp is not None else None, sig.ptr if sig is not None else None,
              pgp.ptr if pgp is not None else None, float(Et_E), g, glv.ptr, modf.ptr,
              xgp.ptr if xgp is not None else None, C.byref(vol))
+        if self.local_mg and self.c.precond_info()["l2_aggregates"] == 0:
+            self.c.build_level2()   # single rank: the library's own three-level cycle (as device.Context.assemble)
         return vol.value
+
+    def enable_local_multigrid(self):
+        self.c.set_precond("mg")
+        self.local_mg = True
+
+    def solve_local(self, f, u, rtol, maxit):
+        _, info = self.c.solve(self._p(f), self._p(u), rtol=rtol, maxit=maxit)
+        return info
 
     def get_diag_blocks(self, dblk):
         from ._lib import call

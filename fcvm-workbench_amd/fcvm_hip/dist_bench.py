@@ -109,8 +109,10 @@ def run(args, ctl, material, traction, rtol, hbm_peak, cpu_baseline):
                                        "in z-slabs, clamped base, top traction, von Mises plasticity, one Newton/Riks "
                                        "iteration per step" % (world, args.cells, ne_total, model.ne),
                            "pcg_rtol": rtol,
-                           "preconditioner": ("distributed p-multigrid V-cycle (tet10 -> tet4 -> %d aggregates x rigid-body modes, dense inverse "
-                                              "split by rows over the ranks)" % be.mg.nagg) if be.mg is not None else "block-Jacobi 3x3", "parallelism": "element-partition x%d" % world,
+                           "preconditioner": (("distributed p-multigrid V-cycle (tet10 -> tet4 -> %d aggregates x rigid-body modes, dense inverse "
+                                               "split by rows over the ranks)" % be.mg.nagg) if be.mg is not None else
+                                              ("the one-GPU p-multigrid PCG of the library (single rank: nothing to exchange)" if be.local_solver
+                                               else "block-Jacobi 3x3")), "parallelism": "element-partition x%d" % world,
                            "exchange": "point-to-point shared-node sums per SpMV (1 fine + 5 coarse per PCG iteration), 2 scalar and 2 aggregate-level all-reduces (%s)" % backend},
                 "newton_iterations_per_s": args.steps / dt, "pcg_iterations_per_step": pcg / args.steps,
                 "roofline": {"bound": "hbm", "kernel": "k_spmv (rank 0, local matrix)", "achieved": achieved, "peak": hbm_peak,

@@ -44,6 +44,7 @@ class GpuModel:
         self.fixdof = self.ctx.array(fixdof)
         self.movdof = self.ctx.array(movdof)
         self.moving = bool(movdof.max() == 1.0) if len(movdof) else False
+        self._ext = None   # device copy of the external load vector (None: not built yet, False: no such loads)
 
     def calc_gsm(self, grav, disp=None, sig=None, pgp=None, Et_E=0.0, want_x=True):
         """calcGSM (fcVM.py:621-816) / calcTSM material part: assembles K on the GPU, returns
@@ -51,9 +52,18 @@ class GpuModel:
         c = self.ctx
         xgp = c.empty(12 * self.ne) if want_x else None
         glv_g, modf, V = c.assemble(grav, disp=disp, sig=sig, pgp=pgp, Et_E=Et_E, xgp=xgp)
-        ext = external_loads(self.nocoord, self.loads, None if disp is None else disp.get())
-        if np.any(ext != 0.0):
-            c.axpby(1.0, glv_g, 1.0, c.array(ext), out=glv_g)
+        # surface / edge / vertex loads (host, O(surface)): only pressure follows the deformed geometry (fcVM.py:858-883), so
+        # the displacements come back to the host only then; otherwise the load vector is built once and kept on the device
+        follower = disp is not None and self.loads.has_pressure
+        if follower or self._ext is None:
+            ext = external_loads(self.nocoord, self.loads, disp.get() if follower else None)
+            ext_d = c.array(ext) if np.any(ext != 0.0) else False
+            if not follower:
+                self._ext = ext_d
+        else:
+            ext_d = self._ext
+        if ext_d is not False:
+            c.axpby(1.0, glv_g, 1.0, ext_d, out=glv_g)
         return glv_g, modf, V, xgp
 
 
@@ -136,6 +146,7 @@ class RiksDriver:
                 imper = buckling.imperfection(self.eigenvec, float(ctl["ev1"]), float(ctl["ev2"]), maxImp)
                 model.nocoord = model.nocoord + imper.reshape(-1, 3)
                 c.set_coords(model.nocoord)
+                model._ext = None   # load integrals follow the geometry
             # back to the ordinary stiffness matrix (on the imperfect geometry, if any) and its elastic solution
             self._hist, self._gram = [], None
             self.glv, self.modf, self.V, self.xgp = model.calc_gsm(self.grav)
@@ -262,7 +273,7 @@ class RiksDriver:
         self.iterat += 1
         self.iterat_tot += 1
         self.st["newton_iterations"] += 1
-        if self.LD and (self.iterat == 1 or bool(self.pgp.get().any())):  # fcVM.py:1351-1396
+        if self.LD and (self.iterat == 1 or c.any_nonzero(self.pgp)):  # fcVM.py:1351-1396
             self.glv, self.modf, _, _ = self.model.calc_gsm(self.grav, disp=self.disp_new, sig=self.sig_old,
                                                             pgp=self.pgp, Et_E=self.Et_E, want_x=False)
             self._hist, self._gram = [], None   # new tangent matrix: the stored K U products are stale

@@ -147,6 +147,8 @@ int fcvm_vec_dot(fcvm_ctx *c, int64_t n, const double *x, const double *y, doubl
 /* w-weighted dot: sum w_i x_i y_i (owner weights of the multi-GPU partition); result [dev] */
 int fcvm_vec_wdot_dev(fcvm_ctx *c, int64_t n, const double *w, const double *x, const double *y, double *result_dev);
 /* sqrt(max over the first nnodes nodes of |u_node|^2) (fcVM.py:1539-1542) */
+/* *result_host = 1 if any of the n bytes at a (device) is non-zero (the "any plastic Gauss point?" test of fcVM.py:1351) */
+int fcvm_any_u8(fcvm_ctx *c, int64_t n, const uint8_t *a, int *result_host);
 int fcvm_vec_max_node_norm(fcvm_ctx *c, int64_t nnodes, const double *u, double *result_host);
 
 /* timing of the last fcvm_solve (HIP events on the solver's stream): out[0] = milliseconds spent in

@@ -31,6 +31,8 @@ def _worker(rank, world, port, out, use_mg):
         case = small_case(3)
         el, xyz = case["elNodes"], case["nocoord"]
         ne = len(el)
+        if shuffle:   # scattered element ranges: ragged interfaces, nodes held by many ranks
+            el = el[np.random.default_rng(3).permutation(ne)]
         lo, hi = rank * ne // world, (rank + 1) * ne // world
         part = Partition(el[lo:hi])
         xyz_loc = xyz[part.gnodes - 1]
@@ -60,7 +62,7 @@ def _worker(rank, world, port, out, use_mg):
         dist.destroy_process_group()
 
 
-def _solve_worker(rank, world, port, out, n):
+def _solve_worker(rank, world, port, out, n, shuffle=False):
     """one elastic solve K u = f with the distributed multigrid PCG (aggregate level split over 4 ranks)"""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -74,6 +76,8 @@ def _solve_worker(rank, world, port, out, n):
         case = small_case(n, prescribed=False)
         el, xyz = case["elNodes"], case["nocoord"]
         ne = len(el)
+        if shuffle:   # scattered element ranges: ragged interfaces, nodes held by many ranks
+            el = el[np.random.default_rng(3).permutation(ne)]
         lo, hi = rank * ne // world, (rank + 1) * ne // world
         part = Partition(el[lo:hi])
         xyz_loc = xyz[part.gnodes - 1]
@@ -162,3 +166,35 @@ def test_four_rank_multigrid_solve(orc, tmp_path):
     for g in got:
         assert np.abs(g["u"].reshape(-1, 3) - ref[g["gnodes"] - 1]).max() < 1e-8 * np.abs(ref).max()
         assert 20 < g["info"]["iterations"] < 80
+
+
+@pytest.mark.timeout(600)
+def test_eight_rank_multigrid_solve_and_bit_identical_shared_values(orc, tmp_path):
+    """8 ranks (the rank count of the target node) over gloo: element ranges of a randomly permuted element list of a
+    6^3-cell cube (ragged interfaces, nodes held by up to all 8 ranks).  The solution equals the oracle's direct solve on every rank, and -- because the shared-node sums
+    are taken in one fixed order (source rank ascending) on every sharer -- the values a node has on different ranks
+    are BIT-identical, not merely equal to round-off."""
+    out = str(tmp_path / "solve8.pt")
+    mp.spawn(_solve_worker, args=(8, _free_port(), out, 6, True), nprocs=8, join=True)
+    got = torch.load(out, weights_only=False)
+    case = small_case(6, prescribed=False)
+    stm, row, col, glv, modf, *_ = orc.calcGSM(case["elNodes"], case["nocoord"], case["material"], case["fix"], (0.0, 0.0, -9.81),
+                                               orc.Loads(ufaces=case["ufaces"], uloads=case["uloads"]))
+    ndof = 3 * len(case["nocoord"])
+    fixdof = np.ones(ndof)
+    fixdof[list(case["fix"])] = 0.0
+    ref = orc._Direct(stm, row, col, ndof)(fixdof * glv + modf).reshape(-1, 3)
+    nn = len(case["nocoord"])
+    first = np.full((nn, 3), np.nan)
+    holders = np.zeros(nn, int)
+    for g in got:
+        u = g["u"].reshape(-1, 3)
+        idx = g["gnodes"] - 1
+        assert np.abs(u - ref[idx]).max() < 1e-8 * np.abs(ref).max()
+        seen = ~np.isnan(first[idx, 0])
+        assert np.array_equal(u[seen], first[idx[seen]]), "a shared node has different bits on two ranks"
+        first[idx[~seen]] = u[~seen]
+        holders[idx] += 1
+        assert 20 < g["info"]["iterations"] < 90
+    assert holders.min() >= 1 and holders.max() >= 6      # scattered element ranges: nodes held by most of the ranks
+    assert len({g["info"]["iterations"] for g in got}) == 1
