@@ -57,6 +57,10 @@ struct fcvm_ctx {
     int32_t *d_asm_items = nullptr, *d_asm_rlen = nullptr;   // work items; blocks of the longest row of every slice
     int64_t asm_count[ASM_BUCKETS] = {0, 0, 0, 0, 0}, asm_first[ASM_BUCKETS] = {0, 0, 0, 0, 0};
     bool asm_lds_ok = false;
+    // the length classes run side by side on streams of their own (a CU holds one long-row item next to two short-row ones)
+    hipStream_t asm_stream[ASM_BUCKETS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t asm_fork = nullptr, asm_join[ASM_BUCKETS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int asm_overlap = 1;         // FCVM_ASSEMBLE_OVERLAP=0: one stream, class after class
     int qin_atomic = 0;          // FCVM_QIN_ATOMIC=1: internal forces scattered with f64 atomics
     double *d_fe = nullptr;      // [ne][10][3] element nodal forces of the last stress update
     double *d_part_vol = nullptr;  // [nslices] volume partials of the row-owner assembly
@@ -72,7 +76,7 @@ struct fcvm_ctx {
     double last_spmv_ms = 0, last_total_ms = 0;
     double row_spread = 0.0;
     bool row_order_morton = false;
-    int spmv_variant = 4;  // 0 plain loads, one pair per iteration; 4 nontemporal matrix loads, four pairs in flight (shipped)
+    int spmv_variant = 5;  // 5 (shipped): nontemporal matrix loads, four pairs in flight, 8 + 16 byte x gathers; 4: three 8-byte gathers; 0: plain loads, one pair per iteration
     double last_spmv_timed = 0;
     // host copies needed to build the coarse level
     std::vector<int32_t> h_el;
@@ -153,7 +157,7 @@ static MatView coarse_view(const fcvm_ctx *c) {
 }
 
 #define FCVM_SPMV_LAUNCH(DOT_, NT_, UN_, V2_, EPI_, vals_, epi_)                                                               \
-    hipLaunchKernelGGL((k_spmv<DOT_, NT_, UN_, V2_, EPI_, 0>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols, \
+    hipLaunchKernelGGL((k_spmv<DOT_, NT_, UN_, V2_, EPI_, 1>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols, \
                        (const V2_ *)(vals_), m.rownode, x, y, part, done, epi_)
 
 template <bool DOT>
@@ -164,8 +168,8 @@ static void launch_spmv_t(fcvm_ctx *c, const MatView &m, const double *x, double
         return;
     }
     if (c->spmv_variant == 0) FCVM_SPMV_LAUNCH(DOT, false, 1, double2, 0, m.vals, ChebEpi{});
-    else if (c->spmv_variant == 5)   // experiment: 8 + 16 byte gathers
-        hipLaunchKernelGGL((k_spmv<DOT, true, 4, double2, 0, 1>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols,
+    else if (c->spmv_variant == 4)   // for comparison: three 8-byte gathers per node instead of 8 + 16
+        hipLaunchKernelGGL((k_spmv<DOT, true, 4, double2, 0, 0>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols,
                            (const double2 *)m.vals, m.rownode, x, y, part, done, ChebEpi{});
     else FCVM_SPMV_LAUNCH(DOT, true, 4, double2, 0, m.vals, ChebEpi{});
 }
@@ -329,15 +333,36 @@ static int build_asm_items(fcvm_ctx *c) {
 }
 
 template <bool TANGENT>
-static void launch_assemble_lds(fcvm_ctx *c, const double *disp, const double *sig, const uint8_t *pgp, const MatConst &mc,
-                                const double grav[3], double *glv, double *modf, double *xgp, double *vol_part, int penalty_bc) {
-    for (int b = 0; b < fcvm_ctx::ASM_BUCKETS; b++) {
+static int launch_assemble_lds(fcvm_ctx *c, const double *disp, const double *sig, const uint8_t *pgp, const MatConst &mc,
+                               const double grav[3], double *glv, double *modf, double *xgp, double *vol_part, int penalty_bc) {
+    int nb = 0;
+    for (int b = 0; b < fcvm_ctx::ASM_BUCKETS; b++) nb += c->asm_count[b] ? 1 : 0;
+    const bool overlap = c->asm_overlap && nb > 1;
+    if (overlap) {
+        if (!c->asm_fork) {
+            HCHK(hipEventCreateWithFlags(&c->asm_fork, hipEventDisableTiming));
+            for (int b = 0; b < fcvm_ctx::ASM_BUCKETS; b++) {
+                HCHK(hipStreamCreateWithFlags(&c->asm_stream[b], hipStreamNonBlocking));
+                HCHK(hipEventCreateWithFlags(&c->asm_join[b], hipEventDisableTiming));
+            }
+        }
+        HCHK(hipEventRecord(c->asm_fork, c->stream));
+    }
+    for (int b = fcvm_ctx::ASM_BUCKETS - 1; b >= 0; b--) {   // longest rows first: their items run longest
         if (!c->asm_count[b]) continue;
-        hipLaunchKernelGGL(k_assemble_lds<TANGENT>, dim3((unsigned)c->asm_count[b]), dim3(64), (size_t)asm_lds_bytes(ASM_LEN_LIMIT[b]), c->stream,
+        hipStream_t st = overlap ? c->asm_stream[b] : c->stream;
+        if (overlap) HCHK(hipStreamWaitEvent(st, c->asm_fork, 0));
+        hipLaunchKernelGGL(k_assemble_lds<TANGENT>, dim3((unsigned)c->asm_count[b]), dim3(64), (size_t)asm_lds_bytes(ASM_LEN_LIMIT[b]), st,
                            c->d_asm_items + c->asm_first[b], c->d_asm_rlen, c->d_sptr, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord, disp, c->d_fixmask,
                            c->d_fixval, c->d_emap, sig, pgp, mc, grav[0], grav[1], grav[2], c->d_vals, glv, modf, xgp,
                            vol_part ? vol_part + c->asm_first[b] : nullptr, penalty_bc);
+        if (overlap) {
+            HCHK(hipEventRecord(c->asm_join[b], st));
+            HCHK(hipStreamWaitEvent(c->stream, c->asm_join[b], 0));
+        }
     }
+    HCHK(hipGetLastError());
+    return 0;
 }
 
 extern "C" {
@@ -365,6 +390,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_SPMV_VARIANT")) c->spmv_variant = atoi(v);
     if (const char *v = getenv("FCVM_ASSEMBLE_ATOMIC")) c->assemble_atomic = atoi(v);
     if (const char *v = getenv("FCVM_ASSEMBLE_LDS")) c->assemble_lds = atoi(v);
+    if (const char *v = getenv("FCVM_ASSEMBLE_OVERLAP")) c->asm_overlap = atoi(v);
     if (const char *v = getenv("FCVM_QIN_ATOMIC")) c->qin_atomic = atoi(v);
     if (const char *v = getenv("FCVM_SPMV_SPW")) c->spmv_spw = std::min(4, std::max(1, atoi(v)));   // slices (waves) per workgroup
     if (const char *v = getenv("FCVM_MG_ADDITIVE")) c->mg_additive = atoi(v);
@@ -394,6 +420,11 @@ int fcvm_destroy(fcvm_ctx *c) {
     free_mesh(c);
     dfree(c->d_S); dfree(c->d_out8);
     for (auto e : c->evpool) (void)hipEventDestroy(e);
+    if (c->asm_fork) (void)hipEventDestroy(c->asm_fork);
+    for (int b = 0; b < fcvm_ctx::ASM_BUCKETS; b++) {
+        if (c->asm_join[b]) (void)hipEventDestroy(c->asm_join[b]);
+        if (c->asm_stream[b]) (void)hipStreamDestroy(c->asm_stream[b]);
+    }
     if (c->own) (void)hipStreamDestroy(c->own);
     delete c;
     return 0;
@@ -604,8 +635,9 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
     const int64_t nslots = c->pat.nslices * SLICE;
     dim3 rgrid((unsigned)cdiv(nslots, 256));
     if (use_lds) {  // quarter slices accumulated in LDS, written once (fcvm_assemble_lds.hip.h)
-        if (sig) launch_assemble_lds<true>(c, disp, sig, pgp, mc, grav, glv_grav, modf, xgp, c->d_part_vol, 0);
-        else launch_assemble_lds<false>(c, disp, nullptr, nullptr, mc, grav, glv_grav, modf, xgp, c->d_part_vol, 0);
+        if (sig ? launch_assemble_lds<true>(c, disp, sig, pgp, mc, grav, glv_grav, modf, xgp, c->d_part_vol, 0)
+                : launch_assemble_lds<false>(c, disp, nullptr, nullptr, mc, grav, glv_grav, modf, xgp, c->d_part_vol, 0))
+            return 1;
         hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, s, c->d_part_vol, 4 * c->pat.nslices, c->d_out8);
     } else
     if (!c->assemble_atomic) {  // one lane per matrix row, no atomics, bitwise reproducible
@@ -1222,7 +1254,7 @@ int fcvm_assemble_buckling(fcvm_ctx *c, const double *sig, double shift) {
     dim3 grid((unsigned)cdiv(c->ne * 10, 256)), block(256);
     if (use_lds) {
         const double g0[3] = {0.0, 0.0, 0.0};
-        launch_assemble_lds<false>(c, nullptr, nullptr, nullptr, mc, g0, c->d_r, c->d_z, nullptr, nullptr, 1);
+        if (launch_assemble_lds<false>(c, nullptr, nullptr, nullptr, mc, g0, c->d_r, c->d_z, nullptr, nullptr, 1)) return 1;
     } else if (!c->assemble_atomic) {
         const int64_t nslots = c->pat.nslices * SLICE;
         hipLaunchKernelGGL(k_assemble_rows<false>, dim3((unsigned)cdiv(nslots, 256)), block, 0, s, nslots, c->d_rownode, c->d_nptr, c->d_nel,

@@ -599,22 +599,38 @@ class DistMG:
         try:
             # raw rigid-body modes: aggregates with collinear / fully clamped nodes have zero-energy combinations, which
             # the diagonal shift turns into harmless tiny pivots; the shift grows until the factorisation goes through
-            # (identical decisions on every rank: the matrix is replicated and info is a property of the matrix)
-            shift, L = 1e-10 * dmax, None
+            # (identical decisions on every rank: the matrix is replicated and the pivots are a property of the matrix)
+            shift, done = 1e-10 * dmax, False
             for _ in range(4):
                 A2.diagonal().add_(shift)
-                L, info = torch.linalg.cholesky_ex(A2)
-                if int(info.item()) == 0:
+                if hasattr(self.ops, "spd_inverse"):
+                    # the library's own blocked Cholesky / triangular inverse / X^T X kernels (fcvm_spd_inverse): no vendor
+                    # solver library is loaded; the whole inverse is formed, this rank keeps its rows
+                    try:
+                        inv = self.ops.spd_inverse(A2)
+                        rows.copy_(inv[self.row_lo:self.row_hi])
+                        del inv
+                        done = True
+                    except Exception as e:   # not positive definite at this shift
+                        why = repr(e)
+                else:   # CPU tests: LAPACK through torch
+                    L, info = torch.linalg.cholesky_ex(A2)
+                    if int(info.item()) == 0:
+                        for c0 in range(self.row_lo, self.row_hi, 4096):
+                            c1 = min(self.row_hi, c0 + 4096)
+                            E = torch.zeros(n2, c1 - c0, dtype=torch.float64, device=dev)
+                            E[c0:c1] = torch.eye(c1 - c0, dtype=torch.float64, device=dev)
+                            rows[c0 - self.row_lo:c1 - self.row_lo] = torch.cholesky_solve(E, L).T
+                        del L, E
+                        done = True
+                    else:
+                        why = "cholesky_ex info %d" % int(info.item())
+                if done:
                     break
-                L, shift = None, shift * 100.0
-            if L is None:
-                raise RuntimeError("cholesky_ex info %d after the largest diagonal shift" % int(info.item()))
-            for c0 in range(self.row_lo, self.row_hi, 4096):
-                c1 = min(self.row_hi, c0 + 4096)
-                E = torch.zeros(n2, c1 - c0, dtype=torch.float64, device=dev)
-                E[c0:c1] = torch.eye(c1 - c0, dtype=torch.float64, device=dev)
-                rows[c0 - self.row_lo:c1 - self.row_lo] = torch.cholesky_solve(E, L).T
-            del L, E
+                shift *= 100.0
+            if not done:
+                raise RuntimeError("no factorisation after the largest diagonal shift (%s)" % why)
+            why = ""
         except Exception as e:  # keep every rank in step: the failure is agreed on below
             ok.zero_()
             why = repr(e)
@@ -796,6 +812,15 @@ class HipLocalOps:
         from ._lib import call
         call("fcvm_unpack_sum", self.c.h, inodes.numel(), inodes.data_ptr(), eptr.data_ptr(), src.data_ptr(), int(ncomp),
              t.data_ptr(), recv.data_ptr())
+
+    def spd_inverse(self, A):
+        """inverse of the SPD matrix A (torch f64 [n, n] on this rank's device) by the library's dense kernels"""
+        from ._lib import call
+        n = A.shape[0]
+        A = A.contiguous()
+        out = torch.empty_like(A)
+        call("fcvm_spd_inverse", self.c.h, n, A.data_ptr(), out.data_ptr())
+        return out
 
     def wdot(self, w, x, y, out):
         """out[0] = sum w x y (torch tensors on this rank's device)"""

@@ -31,8 +31,6 @@ def _worker(rank, world, port, out, use_mg):
         case = small_case(3)
         el, xyz = case["elNodes"], case["nocoord"]
         ne = len(el)
-        if shuffle:   # scattered element ranges: ragged interfaces, nodes held by many ranks
-            el = el[np.random.default_rng(3).permutation(ne)]
         lo, hi = rank * ne // world, (rank + 1) * ne // world
         part = Partition(el[lo:hi])
         xyz_loc = xyz[part.gnodes - 1]
