@@ -11,10 +11,11 @@
 //     other three (each Jacobian is computed once per visit instead of four times); shape-function derivatives at
 //     the Gauss points come from a 1.3 KB LDS table instead of per-lane switch statements;
 //   * lane h integrates the blocks K_ab of the local columns b = h, h + 4, h + 8 and adds them to the row's LDS image;
-//   * element connectivity, node coordinates, block locations and support flags of visit v + 1 (and the
-//     connectivity of visit v + 2) are in flight while visit v is integrated.
-// What still goes through the scattered-access path are the inputs: 16 distinct elements per wave-instruction instead
-// of 64 distinct matrix lines, 35 instead of 240 instructions per visit.
+//   * lane h also fetches the inputs of "its" nodes only (connectivity entries, coordinates with one 8-byte and one
+//     16-byte load per node, block locations, support flags: 18 vector-memory instructions per visit); the quad
+//     exchanges the coordinates through LDS;
+//   * the inputs of visit v + 1 (and the connectivity of visit v + 2) are in flight while visit v is integrated.
+// What still goes through the scattered-access path are these inputs: 18 instead of 240 instructions per visit.
 #pragma once
 #include "fcvm_kernels.hip.h"
 
@@ -45,12 +46,21 @@ __device__ __forceinline__ T *reload_each_time(T *p) {
     return p;
 }
 
-struct AsmGeom {
-    double cx[10], cy[10], cz[10];
-    uint32_t em[3];   // packed block location of local column b = h + 4 t
-    int ndb[3];       // node of that column
+struct AsmGeom {      // what lane h of a quad fetches for one visit: its local columns b = h + 4 t
+    double c[3][3];   // (updated) coordinates of node b
+    uint32_t em[3];   // packed block location of (row node, b)
+    int ndb[3];       // node b
     int fb[3];        // its support flags
 };
+
+// three doubles at a 24-byte stride: one 8-byte and one 16-byte load (even nodes are 16-byte aligned, odd ones 8 off)
+__device__ __forceinline__ void load3(const double *__restrict__ base, int node, double &x, double &y, double &z) {
+    const double *p = base + 3 * (int64_t)node;
+    const int o = node & 1;
+    const double2 w = *(const double2 *)(p + o);
+    const double s1 = p[o ? 0 : 2];
+    x = o ? s1 : w.x; y = o ? w.x : w.y; z = o ? w.y : s1;
+}
 
 template <bool TANGENT>
 __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__ items, const int32_t *__restrict__ rlens, const int64_t *__restrict__ sptr,
@@ -100,41 +110,29 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
 
     // packed visit: element << 4 | local index of the row node, -1: no visit (lanes of shorter rows)
     auto load_packed = [&](int v) -> int32_t { return v < nvis ? nel[q0 + v] : -1; };
-    int nd[10];       // element nodes of the visit whose coordinates are fetched next
+    // The four lanes of a quad visit the same element: lane h fetches the nodes b = h, h + 4, h + 8 -- the columns whose
+    // blocks it integrates -- and their coordinates; the quad exchanges the coordinates through LDS (the Jacobian needs all
+    // ten).  12 + 6 vector-memory instructions per visit instead of 44 with every lane loading everything.
+    int nd[3];        // nodes b of the visit whose coordinates are fetched next
     auto load_nodes = [&](int32_t packed) {
         const int64_t e = packed >= 0 ? (int64_t)(packed >> 4) : 0;   // idle lanes read element 0 (valid memory), results unused
-        const int2 *p = (const int2 *)(el + e * 10);                  // 40-byte rows: 8-byte aligned
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const int2 t = p[k];
-            nd[2 * k] = t.x;
-            nd[2 * k + 1] = t.y;
-        }
+        for (int t = 0; t < 3; t++) nd[t] = el[e * 10 + min(h + 4 * t, 9)];
     };
     auto load_geom = [&](int32_t packed, AsmGeom &G) {
-#pragma unroll
-        for (int k = 0; k < 10; k++) {
-            const double *c = coord + 3 * (int64_t)nd[k];
-            G.cx[k] = c[0]; G.cy[k] = c[1]; G.cz[k] = c[2];
-        }
-        if (disp) {
-#pragma unroll
-            for (int k = 0; k < 10; k++) {
-                const double *u = disp + 3 * (int64_t)nd[k];
-                G.cx[k] += u[0]; G.cy[k] += u[1]; G.cz[k] += u[2];
-            }
-        }
         const int64_t e = packed >= 0 ? (int64_t)(packed >> 4) : 0;
         const int a = packed >= 0 ? (packed & 15) : 0;
 #pragma unroll
         for (int t = 0; t < 3; t++) {
-            const int b = min(h + 4 * t, 9);
-            // column node of block t = nd[4 t + h]: read again from the (cached) connectivity row -- selecting it from the
-            // registers makes the compiler index the array at run time, which puts it into scratch memory
-            const int nb_ = el[e * 10 + b];
-            G.ndb[t] = nb_;
-            G.em[t] = emap[e * 100 + a * 10 + b];
-            G.fb[t] = fixmask[nb_];
+            load3(coord, nd[t], G.c[t][0], G.c[t][1], G.c[t][2]);
+            if (disp) {
+                double u0, u1, u2;
+                load3(disp, nd[t], u0, u1, u2);
+                G.c[t][0] += u0; G.c[t][1] += u1; G.c[t][2] += u2;
+            }
+            G.ndb[t] = nd[t];
+            G.em[t] = emap[e * 100 + a * 10 + min(h + 4 * t, 9)];
+            G.fb[t] = fixmask[nd[t]];
         }
     };
 
@@ -143,6 +141,19 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
         const bool active = pk >= 0;
         const int64_t e = active ? (int64_t)(pk >> 4) : 0;
         const int a = active ? (pk & 15) : 0;
+        // ---- coordinates of the element's ten nodes: every lane contributes its three, the row's image is [node][3] ----
+        double *crd = jac + rowl * 4 * ASM_JREC;   // the row's Jacobian records double as the exchange area (30 of 40 doubles)
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+            if (h + 4 * t < 10) {
+                double *o = crd + 3 * (h + 4 * t);
+                o[0] = G0.c[t][0]; o[1] = G0.c[t][1]; o[2] = G0.c[t][2];
+            }
+        __syncthreads();
+        double cx[10], cy[10], cz[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) { cx[k] = crd[3 * k]; cy[k] = crd[3 * k + 1]; cz[k] = crd[3 * k + 2]; }
+        __syncthreads();   // all coordinates are in registers before the records overwrite them
         // ---- Jacobian of Gauss point h (fcVM.py:436-453) -> LDS record of (row, h) ----
         {
             double xs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -150,9 +161,9 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
 #pragma unroll
             for (int k = 0; k < 10; k++) {
                 const double d0 = dn[3 * k], d1 = dn[3 * k + 1], d2 = dn[3 * k + 2];
-                xs[0] += G0.cx[k] * d0; xs[1] += G0.cx[k] * d1; xs[2] += G0.cx[k] * d2;
-                xs[3] += G0.cy[k] * d0; xs[4] += G0.cy[k] * d1; xs[5] += G0.cy[k] * d2;
-                xs[6] += G0.cz[k] * d0; xs[7] += G0.cz[k] * d1; xs[8] += G0.cz[k] * d2;
+                xs[0] += cx[k] * d0; xs[1] += cx[k] * d1; xs[2] += cx[k] * d2;
+                xs[3] += cy[k] * d0; xs[4] += cy[k] * d1; xs[5] += cy[k] * d2;
+                xs[6] += cz[k] * d0; xs[7] += cz[k] * d1; xs[8] += cz[k] * d2;
             }
             double mine[9];
             const double xsj = jac_inverse(xs, mine);
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
 #pragma unroll
             for (int k = 0; k < 10; k++) {
                 const double n = nsa[k];
-                px += G0.cx[k] * n; py += G0.cy[k] * n; pz += G0.cz[k] * n;
+                px += cx[k] * n; py += cy[k] * n; pz += cz[k] * n;
             }
             double *o = xgp + 3 * (4 * e + a);
             o[0] = px; o[1] = py; o[2] = pz;
