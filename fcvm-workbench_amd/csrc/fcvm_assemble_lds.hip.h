@@ -23,7 +23,7 @@ namespace fcvm {
 
 constexpr int ASM_ROWS = 16;                       // rows per wavefront (4 lanes each)
 #ifndef ASM_RELOAD_DN
-#define ASM_RELOAD_DN true
+#define ASM_RELOAD_DN false
 #endif
 #ifndef ASM_RELOAD_DB
 #define ASM_RELOAD_DB TANGENT
@@ -45,6 +45,11 @@ __device__ __forceinline__ T *reload_each_time(T *p) {
     if (ON) asm volatile("" : "+v"(p));
     return p;
 }
+
+// dst += v in LDS with one ds_add_f64 (no return value).  Inside one instruction every lane has its own address (the
+// four lanes of a row hold different columns), and the instructions of the single wavefront of a work item execute in
+// program order: the sums are formed in a fixed order, the atomic is only the cheaper encoding of read-add-write.
+__device__ __forceinline__ void lds_add(double *dst, double v) { __hip_atomic_fetch_add(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 struct AsmGeom {      // what lane h of a quad fetches for one visit: its local columns b = h + 4 t
     double c[3][3];   // (updated) coordinates of node b
@@ -151,8 +156,14 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
             }
         __syncthreads();
         double cx[10], cy[10], cz[10];
+        {   // 30 doubles as fifteen 16-byte LDS reads (the row's area is 16-byte aligned)
+            const double2 *c2 = (const double2 *)crd;
+            double f[30];
 #pragma unroll
-        for (int k = 0; k < 10; k++) { cx[k] = crd[3 * k]; cy[k] = crd[3 * k + 1]; cz[k] = crd[3 * k + 2]; }
+            for (int k = 0; k < 15; k++) { const double2 t2 = c2[k]; f[2 * k] = t2.x; f[2 * k + 1] = t2.y; }
+#pragma unroll
+            for (int k = 0; k < 10; k++) { cx[k] = f[3 * k]; cy[k] = f[3 * k + 1]; cz[k] = f[3 * k + 2]; }
+        }
         __syncthreads();   // all coordinates are in registers before the records overwrite them
         // ---- Jacobian of Gauss point h (fcVM.py:436-453) -> LDS record of (row, h) ----
         {
@@ -167,9 +178,9 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
             }
             double mine[9];
             const double xsj = jac_inverse(xs, mine);
-#pragma unroll
-            for (int k = 0; k < 9; k++) myjac[k] = mine[k];
-            myjac[9] = xsj * FCVM_GPW;
+            double2 *j2 = (double2 *)myjac;   // 10 doubles = five 16-byte LDS writes
+            j2[0] = double2{mine[0], mine[1]}; j2[1] = double2{mine[2], mine[3]}; j2[2] = double2{mine[4], mine[5]};
+            j2[3] = double2{mine[6], mine[7]}; j2[4] = double2{mine[8], xsj * FCVM_GPW};
         }
         // Gauss point coordinates (fcVM.py:761): lane 3 of the quad (it integrates one block less)
         if (xgp && active && a < 4 && h == 3) {
@@ -193,12 +204,11 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
         double gam = 0.0, vol = 0.0;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            const double *J = rowjac + g * ASM_JREC;
-            double xsi[9];
-#pragma unroll
-            for (int k = 0; k < 9; k++) xsi[k] = J[k];
-            const double wg_ = fabs(J[9]);
-            vol += J[9];
+            const double2 *J2 = (const double2 *)(rowjac + g * ASM_JREC);
+            const double2 q0_ = J2[0], q1_ = J2[1], q2_ = J2[2], q3_ = J2[3], q4_ = J2[4];
+            const double xsi[9] = {q0_.x, q0_.y, q1_.x, q1_.y, q2_.x, q2_.y, q3_.x, q3_.y, q4_.x};
+            const double wg_ = fabs(q4_.y);
+            vol += q4_.y;
             const double *da = tab + 30 * g + 3 * a;
             double ga[3];
             to_global(xsi, da[0], da[1], da[2], ga[0], ga[1], ga[2]);
@@ -282,10 +292,10 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                     for (int r = 0; r < 3; r++)
 #pragma unroll
                         for (int c = 0; c < 3; c++)
-                            dst[r * 3 + c] += (((fa >> r) & 1) && diag && r == c) ? 100.0 * K[r * 3 + c] : K[r * 3 + c];
+                            lds_add(dst + r * 3 + c, (((fa >> r) & 1) && diag && r == c) ? 100.0 * K[r * 3 + c] : K[r * 3 + c]);
                 } else if ((fa | fb) == 0) {   // no supports at either node: the whole block
 #pragma unroll
-                    for (int k = 0; k < 9; k++) dst[k] += K[k];
+                    for (int k = 0; k < 9; k++) lds_add(dst + k, K[k]);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 3; r++) {
@@ -294,11 +304,11 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                         for (int c = 0; c < 3; c++) {
                             const bool cfix = (fb >> c) & 1;
                             if (!rfix && !cfix) {
-                                dst[r * 3 + c] += K[r * 3 + c];
+                                lds_add(dst + r * 3 + c, K[r * 3 + c]);
                             } else if (!rfix && cfix) {
                                 racc[3 + r] -= K[r * 3 + c] * fixval[3 * (int64_t)G0.ndb[t] + c];
                             } else if (rfix && diag && r == c) {   // fcVM.py:773-778: unit diagonal per element occurrence
-                                dst[r * 3 + c] += 1.0;
+                                lds_add(dst + r * 3 + c, 1.0);
                                 racc[3 + r] += fixval[3 * (int64_t)node + r];
                             }
                         }
