@@ -263,6 +263,8 @@ class Context:
             # aggregates; small meshes (cheap either way) go down to 16
             nc = pi["coarse_nodes"]
             target = max(16, int(round(nc / 1000.0)), int(min(176, nc / 200.0)))
+        if k1s is None and os.environ.get("FCVM_MG_K1S"):
+            k1s = int(os.environ["FCVM_MG_K1S"])
         if k1s is None:
             # level-1 Chebyshev steps before / after the aggregate correction: larger aggregates leave more for the
             # smoother to do (1 M cube with 1400-node aggregates: 95 PCG iterations with 2 steps, 79 with 3; 2800: 113 / 87 with 4)
