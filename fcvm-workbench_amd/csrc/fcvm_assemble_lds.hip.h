@@ -32,10 +32,9 @@ constexpr int ASM_ROWS = 16;                       // rows per wavefront (4 lane
 constexpr int ASM_TAB = 160;                       // doubles: dN/dxi at the 4 Gauss points [4][10][3], then N [4][10]
 constexpr int ASM_JREC = 10;                       // doubles per (row, Gauss point): xsi[9], GPW * det J (signed)
 constexpr int ASM_JAC = ASM_ROWS * 4 * ASM_JREC;   // doubles
-// rlen = blocks of the longest row of the slice (the slice stores rlen rounded up to even: the padding block is written
-// as zeros without passing through LDS); row stride in doubles, odd so that the 16 rows spread over the LDS banks
-__host__ __device__ inline int64_t asm_row_stride(int64_t rlen) { return rlen * 9 + ((rlen & 1) ? 0 : 1); }
-__host__ __device__ inline int64_t asm_lds_bytes(int64_t rlen) { return (ASM_TAB + ASM_JAC + ASM_ROWS * asm_row_stride(rlen)) * 8; }
+// len = blocks of the longest row of the slice; row stride in doubles, odd so that the 16 rows spread over the LDS banks
+__host__ __device__ inline int64_t asm_row_stride(int64_t len) { return len * 9 + ((len & 1) ? 0 : 1); }
+__host__ __device__ inline int64_t asm_lds_bytes(int64_t len) { return (ASM_TAB + ASM_JAC + ASM_ROWS * asm_row_stride(len)) * 8; }
 
 // Hides where a pointer came from, so that loads through it are not hoisted out of the visit loop: every lane always
 // uses the same table entries (its Gauss point, its three local columns: 66 doubles), and keeping all of them in
@@ -68,7 +67,7 @@ __device__ __forceinline__ void load3(const double *__restrict__ base, int node,
 }
 
 template <bool TANGENT>
-__global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__ items, const int32_t *__restrict__ rlens, const int64_t *__restrict__ sptr,
+__global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__ items, const int64_t *__restrict__ sptr,
                                                      const int32_t *__restrict__ rownode, const int64_t *__restrict__ nptr,
                                                      const int32_t *__restrict__ nel, const int32_t *__restrict__ el,
                                                      const double *__restrict__ coord, const double *__restrict__ disp,
@@ -87,9 +86,8 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
     const int64_t s = item >> 2;
     const int qd = item & 3;
     const int lane = threadIdx.x, rowl = lane >> 2, h = lane & 3;
-    const int64_t jb = sptr[s], len = sptr[s + 1] - jb, cbase = jb >> 1;
-    const int64_t rlen = rlens[s];
-    const int64_t S = asm_row_stride(rlen);
+    const int64_t jb = sptr[s], len = sptr[s + 1] - jb;   // blocks of the slice's longest row = half chunks of the slice
+    const int64_t S = asm_row_stride(len);
     for (int64_t i = lane; i < ASM_ROWS * S; i += 64) rowbuf[i] = 0.0;
     if (lane < 40) {   // shape-function tables (fcVM.py:365-424 at the Gauss points of fcVM.py:587-596)
         const int g = lane / 10, k = lane - 10 * g;
@@ -283,7 +281,7 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                 }
                 // boundary conditions folded in (fcVM.py:773-800) and accumulation into the row's LDS image
                 const uint32_t em = G0.em[t];
-                const int64_t jj = 2 * ((int64_t)(em >> 7) - cbase) + (int64_t)(em & 1);
+                const int64_t jj = (int64_t)(em >> 2) - jb + (int64_t)((em >> 1) & 1u);   // block index inside the row
                 double *dst = myrow + jj * 9;
                 const int fb = G0.fb[t];
                 const bool diag = (a == b);
@@ -356,23 +354,29 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
         const double vsum = wave_sum(h == 0 ? racc[6] : 0.0);
         if (lane == 0) volume[wg] = vsum;
     }
-    // ---- the finished quarter slice leaves LDS: (pair p, component c) -> 16 lanes x 16 B, four segments per instruction ----
+    // ---- the finished quarter slice leaves LDS: (pair p, component c) -> 16 lanes x 16 B, four segments per instruction;
+    //      the single last block of an odd-length slice as 16 lanes x 8 B ----
     __syncthreads();
     {
+        typedef double v2d __attribute__((ext_vector_type(2)));
         const int sub = lane >> 4, r16 = lane & 15;
         const double *src = rowbuf + r16 * S;
-        typedef double v2d __attribute__((ext_vector_type(2)));
-        v2d *out = (v2d *)vals + cbase * (9 * 64) + qd * ASM_ROWS + r16;
+        double *base = vals + jb * (9 * 64);
+        v2d *out = (v2d *)base + qd * ASM_ROWS + r16;
         const int64_t npairs = len >> 1;
         int64_t p = 0;
         int c = sub;
         while (p < npairs) {
             v2d d;
             d.x = src[(2 * p) * 9 + c];
-            d.y = (2 * p + 1 < rlen) ? src[(2 * p + 1) * 9 + c] : 0.0;   // the padding block of an odd-length slice
+            d.y = src[(2 * p + 1) * 9 + c];
             __builtin_nontemporal_store(d, out + (p * 9 + c) * 64);
             c += 4;
             if (c >= 9) { c -= 9; p++; }
+        }
+        if (len & 1) {
+            double *o1 = base + 2 * npairs * (9 * 64) + qd * ASM_ROWS + r16;
+            for (int cc = sub; cc < 9; cc += 4) __builtin_nontemporal_store(src[(len - 1) * 9 + cc], o1 + cc * 64);
         }
     }
 }

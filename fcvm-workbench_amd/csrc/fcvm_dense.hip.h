@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_trace(int64_t n, const double *__restri
 // the entries of its slot in list order: no atomics, bitwise reproducible.
 __global__ __launch_bounds__(256) void k_galerkin_rows(const int64_t *__restrict__ sptr_g, const int32_t *__restrict__ slot_agg,
                                                        const int64_t *__restrict__ eptr, const int32_t *__restrict__ ent_i,
-                                                       const int32_t *__restrict__ ent_j, const uint32_t *__restrict__ ent_loc,
+                                                       const int32_t *__restrict__ ent_j, const uint64_t *__restrict__ ent_loc,
                                                        const double *__restrict__ vals1, const double *__restrict__ Z,
                                                        const int64_t *__restrict__ aoff, double *__restrict__ A2, int64_t ld) {
     const int64_t g = blockIdx.x;
@@ -248,11 +248,12 @@ __global__ __launch_bounds__(256) void k_galerkin_rows(const int64_t *__restrict
         double acc = 0.0;
         for (int64_t e = eptr[sl]; e < eptr[sl + 1]; e++) {
             const double *zi = Z + (int64_t)ent_i[e] * 18, *zj = Z + (int64_t)ent_j[e] * 18;
-            const double *v = vals1 + unpack_offset(ent_loc[e]);
+            int st;
+            const double *v = vals1 + unpack_abs(ent_loc[e], st);
             const double z0 = zj[kp], z1 = zj[6 + kp], z2 = zj[12 + kp];
-            const double t0 = v[0] * z0 + v[128] * z1 + v[256] * z2;
-            const double t1 = v[384] * z0 + v[512] * z1 + v[640] * z2;
-            const double t2 = v[768] * z0 + v[896] * z1 + v[1024] * z2;
+            const double t0 = v[0] * z0 + v[st] * z1 + v[2 * st] * z2;
+            const double t1 = v[3 * st] * z0 + v[4 * st] * z1 + v[5 * st] * z2;
+            const double t2 = v[6 * st] * z0 + v[7 * st] * z1 + v[8 * st] * z2;
             acc += zi[k] * t0 + zi[6 + k] * t1 + zi[12 + k] * t2;
         }
         A2[(og + k) * ld + oh + kp] = acc;

@@ -47,14 +47,14 @@ struct fcvm_ctx {
     // device mesh
     int32_t *d_el = nullptr, *d_cols = nullptr, *d_rownode = nullptr, *d_noce = nullptr;
     int64_t *d_sptr = nullptr;
-    uint32_t *d_emap = nullptr, *d_diagoff = nullptr;
+    uint32_t *d_emap = nullptr;
+    uint64_t *d_diagoff = nullptr, *d_diagoff1 = nullptr;
     int64_t *d_nptr = nullptr, *d_nptr1 = nullptr;   // node -> element incidence for the row-owner assembly (fine / tet4 level)
     int32_t *d_nel = nullptr, *d_nel1 = nullptr;
-    int assemble_atomic = 0;     // FCVM_ASSEMBLE_ATOMIC=1: the (element, row) scatter kernel with f64 atomics
     int assemble_lds = 1;        // rows accumulated in LDS, one coalesced write per value (FCVM_ASSEMBLE_LDS=0: global read-modify-writes)
     // work items of k_assemble_lds (slice * 4 + quarter), grouped by the LDS a quarter slice needs
     static constexpr int ASM_BUCKETS = 5;
-    int32_t *d_asm_items = nullptr, *d_asm_rlen = nullptr;   // work items; blocks of the longest row of every slice
+    int32_t *d_asm_items = nullptr;
     int64_t asm_count[ASM_BUCKETS] = {0, 0, 0, 0, 0}, asm_first[ASM_BUCKETS] = {0, 0, 0, 0, 0};
     bool asm_lds_ok = false;
     // the length classes run side by side on streams of their own (a CU holds one long-row item next to two short-row ones)
@@ -92,7 +92,7 @@ struct fcvm_ctx {
     int32_t *d_el4 = nullptr, *d_cols1 = nullptr, *d_rownode1 = nullptr, *d_c2f = nullptr, *d_mids = nullptr, *d_pa = nullptr,
             *d_pb = nullptr;
     int64_t *d_sptr1 = nullptr, *d_mptr = nullptr;
-    uint32_t *d_emap4 = nullptr, *d_diagoff1 = nullptr;
+    uint32_t *d_emap4 = nullptr;
     uint8_t *d_fixmask1 = nullptr;
     double *d_coord1 = nullptr, *d_vals1 = nullptr, *d_dblk1 = nullptr, *d_dinv1 = nullptr;
     double *d_mr = nullptr, *d_md = nullptr, *d_mt = nullptr, *d_r1 = nullptr, *d_x1 = nullptr, *d_d1 = nullptr, *d_t1 = nullptr,
@@ -297,17 +297,11 @@ static int build_asm_items(fcvm_ctx *c) {
     const Pattern &p = c->pat;
     c->asm_lds_ok = false;
     dfree(c->d_asm_items);
-    dfree(c->d_asm_rlen);
     if (p.maxlen > ASM_LEN_LIMIT[fcvm_ctx::ASM_BUCKETS - 1]) return 0;   // a row that does not fit the LDS: global read-modify-write kernel
-    std::vector<int32_t> items[fcvm_ctx::ASM_BUCKETS], rlen(p.nslices, 0);
+    std::vector<int32_t> items[fcvm_ctx::ASM_BUCKETS];
     NEED(p.nslices < (int64_t(1) << 29), "too many slices for 32-bit assembly work items");
     for (int64_t s = 0; s < p.nslices; s++) {
-        int64_t m = 1;
-        for (int l = 0; l < SLICE; l++) {
-            const int32_t nd = p.rownode[s * SLICE + l];
-            if (nd >= 0) m = std::max(m, p.rowptr[nd + 1] - p.rowptr[nd]);
-        }
-        rlen[s] = (int32_t)m;
+        const int64_t m = p.slice_len(s);
         int b = 0;
         while (m > ASM_LEN_LIMIT[b]) b++;
         for (int q = 0; q < 4; q++) items[b].push_back((int32_t)(s * 4 + q));
@@ -318,9 +312,8 @@ static int build_asm_items(fcvm_ctx *c) {
         c->asm_count[b] = (int64_t)items[b].size();
         all.insert(all.end(), items[b].begin(), items[b].end());
     }
-    if (dalloc(&c->d_asm_items, (int64_t)all.size()) || dalloc(&c->d_asm_rlen, p.nslices)) return 1;
+    if (dalloc(&c->d_asm_items, (int64_t)all.size())) return 1;
     HCHK(hipMemcpyAsync(c->d_asm_items, all.data(), sizeof(int32_t) * all.size(), hipMemcpyHostToDevice, c->stream));
-    HCHK(hipMemcpyAsync(c->d_asm_rlen, rlen.data(), sizeof(int32_t) * rlen.size(), hipMemcpyHostToDevice, c->stream));
     HCHK(hipStreamSynchronize(c->stream));
     for (int b = 0; b < fcvm_ctx::ASM_BUCKETS; b++) {   // dynamic LDS beyond 64 KiB has to be requested per kernel
         const int bytes = (int)asm_lds_bytes(ASM_LEN_LIMIT[b]);
@@ -353,7 +346,7 @@ static int launch_assemble_lds(fcvm_ctx *c, const double *disp, const double *si
         hipStream_t st = overlap ? c->asm_stream[b] : c->stream;
         if (overlap) HCHK(hipStreamWaitEvent(st, c->asm_fork, 0));
         hipLaunchKernelGGL(k_assemble_lds<TANGENT>, dim3((unsigned)c->asm_count[b]), dim3(64), (size_t)asm_lds_bytes(ASM_LEN_LIMIT[b]), st,
-                           c->d_asm_items + c->asm_first[b], c->d_asm_rlen, c->d_sptr, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord, disp, c->d_fixmask,
+                           c->d_asm_items + c->asm_first[b], c->d_sptr, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord, disp, c->d_fixmask,
                            c->d_fixval, c->d_emap, sig, pgp, mc, grav[0], grav[1], grav[2], c->d_vals, glv, modf, xgp,
                            vol_part ? vol_part + c->asm_first[b] : nullptr, penalty_bc);
         if (overlap) {
@@ -388,7 +381,6 @@ int fcvm_create(int device, fcvm_ctx **out) {
     fcvm_ctx *c = new fcvm_ctx();
     c->device = device;
     if (const char *v = getenv("FCVM_SPMV_VARIANT")) c->spmv_variant = atoi(v);
-    if (const char *v = getenv("FCVM_ASSEMBLE_ATOMIC")) c->assemble_atomic = atoi(v);
     if (const char *v = getenv("FCVM_ASSEMBLE_LDS")) c->assemble_lds = atoi(v);
     if (const char *v = getenv("FCVM_ASSEMBLE_OVERLAP")) c->asm_overlap = atoi(v);
     if (const char *v = getenv("FCVM_QIN_ATOMIC")) c->qin_atomic = atoi(v);
@@ -406,7 +398,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
 static void free_mesh(fcvm_ctx *c) {
     dfree(c->d_el); dfree(c->d_cols); dfree(c->d_rownode); dfree(c->d_noce); dfree(c->d_sptr);
     dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
-    dfree(c->d_nptr); dfree(c->d_nel); dfree(c->d_fe); dfree(c->d_part_vol); dfree(c->d_asm_items); dfree(c->d_asm_rlen);
+    dfree(c->d_nptr); dfree(c->d_nel); dfree(c->d_fe); dfree(c->d_part_vol); dfree(c->d_asm_items);
     dfree(c->d_vals); dfree(c->d_vals_g); dfree(c->d_dblk); dfree(c->d_dinv); dfree(c->d_r); dfree(c->d_z); dfree(c->d_p);
     dfree(c->d_q); dfree(c->d_part_vec); dfree(c->d_part_spmv); dfree(c->d_part_misc); dfree(c->d_pidx);
     mg_free(c);
@@ -528,7 +520,7 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     HCHK(hipMemcpyAsync(c->d_noce, noce.data(), sizeof(int32_t) * nn, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_sptr, p.sptr.data(), sizeof(int64_t) * (p.nslices + 1), hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_emap, p.emap.data(), sizeof(uint32_t) * ne * 100, hipMemcpyHostToDevice, s));
-    HCHK(hipMemcpyAsync(c->d_diagoff, p.diagoff.data(), sizeof(uint32_t) * nn, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_diagoff, p.diagoff.data(), sizeof(uint64_t) * nn, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_nptr, p.nptr.data(), sizeof(int64_t) * (nn + 1), hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_nel, p.nel.data(), sizeof(int32_t) * ne * 10, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_coord, nocoord, sizeof(double) * nn * 3, hipMemcpyHostToDevice, s));
@@ -600,12 +592,13 @@ int fcvm_matrix_to_coo(fcvm_ctx *c, int64_t *row, int64_t *col, double *val) {
     int64_t k = 0;
     for (int64_t i = 0; i < p.nn; i++)
         for (int64_t q = p.rowptr[i]; q < p.rowptr[i + 1]; q++) {
-            uint64_t off = p.block_offset(p.slotof[i], q - p.rowptr[i]);
+            const uint64_t off = p.block_offset(p.slotof[i], q - p.rowptr[i]);
+            const int64_t cs = p.comp_stride(p.slotof[i], q - p.rowptr[i]);
             for (int r = 0; r < 3; r++)
                 for (int cc = 0; cc < 3; cc++) {
                     row[k] = 3 * i + r;
                     col[k] = 3 * (int64_t)p.colidx[q] + cc;
-                    val[k] = v[off + (r * 3 + cc) * VSTRIDE];
+                    val[k] = v[off + (r * 3 + cc) * cs];
                     k++;
                 }
         }
@@ -625,13 +618,13 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
     NEED(glv_grav && modf, "fcvm_assemble: glv_grav and modf are required");
     NEED((sig == nullptr) == (pgp == nullptr), "fcvm_assemble: sig and pgp go together");
     hipStream_t s = c->stream;
-    const bool use_lds = !c->assemble_atomic && c->assemble_lds && c->asm_lds_ok;
+    const bool use_lds = c->assemble_lds && c->asm_lds_ok;
     if (!use_lds) HCHK(hipMemsetAsync(c->d_vals, 0, sizeof(double) * c->pat.value_count(), s));   // the LDS kernel writes every value once
     HCHK(hipMemsetAsync(glv_grav, 0, sizeof(double) * 3 * c->nn, s));
     HCHK(hipMemsetAsync(modf, 0, sizeof(double) * 3 * c->nn, s));
     HCHK(hipMemsetAsync(c->d_out8, 0, sizeof(double), s));
     MatConst mc = matconst(c, Et_E);
-    dim3 grid((unsigned)cdiv(c->ne * 10, 256)), block(256);
+    dim3 block(256);
     const int64_t nslots = c->pat.nslices * SLICE;
     dim3 rgrid((unsigned)cdiv(nslots, 256));
     if (use_lds) {  // quarter slices accumulated in LDS, written once (fcvm_assemble_lds.hip.h)
@@ -639,8 +632,7 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
                 : launch_assemble_lds<false>(c, disp, nullptr, nullptr, mc, grav, glv_grav, modf, xgp, c->d_part_vol, 0))
             return 1;
         hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, s, c->d_part_vol, 4 * c->pat.nslices, c->d_out8);
-    } else
-    if (!c->assemble_atomic) {  // one lane per matrix row, no atomics, bitwise reproducible
+    } else {  // one lane per matrix row, global read-modify-writes, no atomics, bitwise reproducible
         if (sig)
             hipLaunchKernelGGL(k_assemble_rows<true>, rgrid, block, 0, s, nslots, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord,
                                disp, c->d_fixmask, c->d_fixval, c->d_emap, sig, pgp, mc, grav[0], grav[1], grav[2], c->d_vals, glv_grav,
@@ -650,14 +642,7 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
                                disp, c->d_fixmask, c->d_fixval, c->d_emap, (const double *)nullptr, (const uint8_t *)nullptr, mc,
                                grav[0], grav[1], grav[2], c->d_vals, glv_grav, modf, xgp, c->d_part_vol, 0);
         hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, s, c->d_part_vol, c->pat.nslices, c->d_out8);
-    } else if (sig)
-        hipLaunchKernelGGL(k_assemble<true>, grid, block, 0, s, c->ne, c->d_el, c->d_coord, disp, c->d_fixmask,
-                           c->d_fixval, c->d_emap, sig, pgp, mc, grav[0], grav[1], grav[2], c->d_vals, glv_grav, modf,
-                           xgp, c->d_out8, 0);
-    else
-        hipLaunchKernelGGL(k_assemble<false>, grid, block, 0, s, c->ne, c->d_el, c->d_coord, disp, c->d_fixmask,
-                           c->d_fixval, c->d_emap, (const double *)nullptr, (const uint8_t *)nullptr, mc, grav[0],
-                           grav[1], grav[2], c->d_vals, glv_grav, modf, xgp, c->d_out8, 0);
+    }
     HCHK(hipGetLastError());
     if (refresh_precond(c)) return 1;
     if (c->precond_mode >= 1) {
@@ -933,18 +918,19 @@ int fcvm_host_pattern_check(int64_t ne, int64_t nn, const int64_t *elNodes, int6
         return fail(std::string("fcvm_host_pattern_check: ") + ex.what());
     }
     int64_t bad = 0;
-    // every element block must land on a slot whose column is the block's column node and whose
-    // row slot belongs to the block's row node
+    // every element block must land in its row's slice, on the block whose column entry is the block's column node;
+    // pairs and the single last block of odd-length slices must be flagged consistently
     for (int64_t e = 0; e < ne; e++)
         for (int a = 0; a < 10; a++)
             for (int b = 0; b < 10; b++) {
-                const uint32_t em = p.emap[e * 100 + a * 10 + b];   // packed: pair row << 7 | lane << 1 | (j & 1)
-                const int64_t j0 = em & 1, l = (em >> 1) & 63;
-                const int64_t jglob = (int64_t)(em >> 7) * 2 + j0;  // = sptr[s] + j
-                int64_t slot = p.slotof[el[e * 10 + a]];
-                int64_t s = slot / SLICE;
-                if (slot % SLICE != l || jglob < p.sptr[s] || jglob >= p.sptr[s + 1]) { bad++; continue; }
-                if (p.cols[p.col_index(s, l, jglob - p.sptr[s])] != el[e * 10 + b]) bad++;
+                const uint32_t em = p.emap[e * 100 + a * 10 + b];   // packed: half chunk << 2 | (j & 1) << 1 | single
+                const bool single = em & 1u;
+                const int64_t unit = em >> 2, sub = (em >> 1) & 1u;
+                const int64_t slot = p.slotof[el[e * 10 + a]], s = slot / SLICE, l = slot % SLICE;
+                const int64_t j = unit - p.sptr[s] + sub;
+                if (j < 0 || j >= p.slice_len(s) || single != p.is_single(s, j) || (single && sub) || (!single && ((unit - p.sptr[s]) & 1))) { bad++; continue; }
+                if (p.cols[p.col_index(s, l, j)] != el[e * 10 + b]) bad++;
+                if (p.pack_offset(slot, j) != em) bad++;
             }
     for (int64_t i = 0; i < nn; i++) {
         int64_t slot = p.slotof[i];
@@ -1000,12 +986,13 @@ int fcvm_mg_coarse_to_coo(fcvm_ctx *c, int64_t *row, int64_t *col, double *val) 
     int64_t k = 0;
     for (int64_t i = 0; i < p.nn; i++)
         for (int64_t q = p.rowptr[i]; q < p.rowptr[i + 1]; q++) {
-            uint64_t off = p.block_offset(p.slotof[i], q - p.rowptr[i]);
+            const uint64_t off = p.block_offset(p.slotof[i], q - p.rowptr[i]);
+            const int64_t cs = p.comp_stride(p.slotof[i], q - p.rowptr[i]);
             for (int r = 0; r < 3; r++)
                 for (int cc = 0; cc < 3; cc++) {
                     row[k] = 3 * i + r;
                     col[k] = 3 * (int64_t)p.colidx[q] + cc;
-                    val[k] = v[off + (r * 3 + cc) * VSTRIDE];
+                    val[k] = v[off + (r * 3 + cc) * cs];
                     k++;
                 }
         }
@@ -1247,23 +1234,20 @@ int fcvm_assemble_buckling(fcvm_ctx *c, const double *sig, double shift) {
     hipStream_t s = c->stream;
     const int64_t nv = c->pat.value_count();
     if (!c->d_vals_g && dalloc(&c->d_vals_g, nv)) return 1;
-    const bool use_lds = !c->assemble_atomic && c->assemble_lds && c->asm_lds_ok;
+    const bool use_lds = c->assemble_lds && c->asm_lds_ok;
     if (!use_lds) HCHK(hipMemsetAsync(c->d_vals, 0, sizeof(double) * nv, s));
     HCHK(hipMemsetAsync(c->d_vals_g, 0, sizeof(double) * nv, s));
     MatConst mc = matconst(c, 0.0);
-    dim3 grid((unsigned)cdiv(c->ne * 10, 256)), block(256);
+    dim3 block(256);
     if (use_lds) {
         const double g0[3] = {0.0, 0.0, 0.0};
         if (launch_assemble_lds<false>(c, nullptr, nullptr, nullptr, mc, g0, c->d_r, c->d_z, nullptr, nullptr, 1)) return 1;
-    } else if (!c->assemble_atomic) {
+    } else {
         const int64_t nslots = c->pat.nslices * SLICE;
         hipLaunchKernelGGL(k_assemble_rows<false>, dim3((unsigned)cdiv(nslots, 256)), block, 0, s, nslots, c->d_rownode, c->d_nptr, c->d_nel,
                            c->d_el, c->d_coord, (const double *)nullptr, c->d_fixmask, c->d_fixval, c->d_emap, (const double *)nullptr,
                            (const uint8_t *)nullptr, mc, 0.0, 0.0, 0.0, c->d_vals, c->d_r, c->d_z, (double *)nullptr, (double *)nullptr, 1);
-    } else
-        hipLaunchKernelGGL(k_assemble<false>, grid, block, 0, s, c->ne, c->d_el, c->d_coord, (const double *)nullptr, c->d_fixmask,
-                           c->d_fixval, c->d_emap, (const double *)nullptr, (const uint8_t *)nullptr, mc, 0.0, 0.0, 0.0, c->d_vals,
-                           c->d_r, c->d_z, (double *)nullptr, (double *)nullptr, 1);
+    }
     {
         const int64_t nslots = c->pat.nslices * SLICE;
         hipLaunchKernelGGL(k_assemble_geometric, dim3((unsigned)cdiv(nslots, 256)), block, 0, s, nslots, c->d_rownode, c->d_nptr, c->d_nel,

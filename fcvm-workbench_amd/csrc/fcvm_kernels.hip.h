@@ -97,9 +97,18 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
 
 __device__ __forceinline__ void atomic_add_f64(double *p, double v) { unsafeAtomicAdd(p, v); }
 
-// packed block location (Pattern::pack_offset) -> offset in doubles of component 0 of the 3x3 block
-__device__ __forceinline__ int64_t unpack_offset(uint32_t em) {
-    return (((int64_t)(em >> 7) * 576 + (int64_t)((em >> 1) & 63)) << 1) + (int64_t)(em & 1);
+// packed block location (Pattern::pack_offset: half chunk << 2 | (j & 1) << 1 | single) of a block of the row in `lane`
+// -> offset in doubles of component 0 of the 3x3 block; its components are `stride` doubles apart (128 in a block pair,
+// 64 in the single last block of an odd-length slice)
+__device__ __forceinline__ int64_t unpack_offset(uint32_t em, int lane, int &stride) {
+    const bool single = em & 1u;
+    stride = single ? 64 : 128;
+    return (int64_t)(em >> 2) * 576 + (single ? lane : 2 * lane + (int)((em >> 1) & 1u));
+}
+// the 64-bit form (Pattern::abs_offset: offset << 1 | single) of tables that are read without knowing the lane
+__device__ __forceinline__ int64_t unpack_abs(uint64_t loc, int &stride) {
+    stride = (loc & 1ull) ? 64 : 128;
+    return (int64_t)(loc >> 1);
 }
 
 __device__ __forceinline__ void atomic_fmax_f64(double *addr, double v) {
@@ -275,11 +284,11 @@ __global__ __launch_bounds__(256) void k_gather_qin(int64_t nn, const int64_t *_
 // (element, row node a); it integrates the ten 3x3 blocks K_ab over the four Gauss points and
 // scatters them into the sliced-ELL matrix with the boundary conditions folded in.
 // ---------------------------------------------------------------------------------------------
-// OWNER = false: scatter with f64 atomics (any thread may hold any row).  OWNER = true: the calling lane is the only one
-// that ever touches row nd[a] (k_assemble_rows), so the matrix blocks are plain read-modify-writes in a fixed element
-// order (bitwise reproducible) and the row's gravity / modf / volume sums stay in the caller's registers.
-template <bool TANGENT, bool OWNER>
-__device__ __forceinline__ void assemble_element_row(int64_t e, const int a, const bool valid, const int32_t *__restrict__ el,
+// The calling lane is the only one that ever touches row nd[a] (k_assemble_rows), so the matrix blocks are plain
+// read-modify-writes in a fixed element order (bitwise reproducible) and the row's gravity / modf / volume sums stay in
+// the caller's registers.  lane = the row's lane in its slice (slot & 63).
+template <bool TANGENT>
+__device__ __forceinline__ void assemble_element_row(int64_t e, const int a, const int lane, const int32_t *__restrict__ el,
                                                   const double *__restrict__ coord,
                                                   const double *__restrict__ disp,
                                                   const uint8_t *__restrict__ fixmask,
@@ -288,8 +297,7 @@ __device__ __forceinline__ void assemble_element_row(int64_t e, const int a, con
                                                   const double *__restrict__ sig,
                                                   const uint8_t *__restrict__ pgp, MatConst mc, double gx,
                                                   double gy, double gz, double *__restrict__ vals,
-                                                  double *__restrict__ glv, double *__restrict__ modf,
-                                                  double *__restrict__ xgp, double *__restrict__ volume, int penalty_bc,
+                                                  double *__restrict__ xgp, int penalty_bc,
                                                   double *racc) {
     int nd[10];
     double cx[10], cy[10], cz[10];
@@ -347,36 +355,21 @@ __device__ __forceinline__ void assemble_element_row(int64_t e, const int a, con
             ta[g][2] = ga[g][2] * S[g][2] + ga[g][0] * S[g][4] + ga[g][1] * S[g][5];
         }
     }
-    if (valid) {
-        // gravity load (fcVM.py:757-767) and Gauss point coordinates (fcVM.py:761)
-        if (OWNER) {
-            racc[0] += gx * mc.rho * gam; racc[1] += gy * mc.rho * gam; racc[2] += gz * mc.rho * gam;
-        } else {
-            if (gx != 0.0) atomic_add_f64(glv + 3 * (int64_t)nd[a], gx * mc.rho * gam);
-            if (gy != 0.0) atomic_add_f64(glv + 3 * (int64_t)nd[a] + 1, gy * mc.rho * gam);
-            if (gz != 0.0) atomic_add_f64(glv + 3 * (int64_t)nd[a] + 2, gz * mc.rho * gam);
-        }
-        if (xgp && a < 4) {
-            double xi, et, ze;
-            gp_point(a, xi, et, ze);
-            double px = 0, py = 0, pz = 0;
+    // gravity load (fcVM.py:757-767) and Gauss point coordinates (fcVM.py:761)
+    racc[0] += gx * mc.rho * gam; racc[1] += gy * mc.rho * gam; racc[2] += gz * mc.rho * gam;
+    if (xgp && a < 4) {
+        double xi, et, ze;
+        gp_point(a, xi, et, ze);
+        double px = 0, py = 0, pz = 0;
 #pragma unroll
-            for (int k = 0; k < 10; k++) {
-                const double n = shp_k(k, xi, et, ze);
-                px += cx[k] * n; py += cy[k] * n; pz += cz[k] * n;
-            }
-            double *o = xgp + 3 * (4 * e + a);
-            o[0] = px; o[1] = py; o[2] = pz;
+        for (int k = 0; k < 10; k++) {
+            const double n = shp_k(k, xi, et, ze);
+            px += cx[k] * n; py += cy[k] * n; pz += cz[k] * n;
         }
+        double *o = xgp + 3 * (4 * e + a);
+        o[0] = px; o[1] = py; o[2] = pz;
     }
-    if (OWNER) {
-        if (valid && a == 0) racc[6] += vol;
-    } else if (volume) {
-        double v = (valid && a == 0) ? vol : 0.0;
-        v = wave_sum(v);
-        if ((threadIdx.x & 63) == 0 && v != 0.0) atomic_add_f64(volume, v);
-    }
-    if (!valid) return;
+    if (a == 0) racc[6] += vol;
     const int fa = fixmask[nd[a]];
     double macc[3] = {0, 0, 0};
     const uint32_t *em = emap + e * 100 + a * 10;
@@ -408,7 +401,8 @@ __device__ __forceinline__ void assemble_element_row(int64_t e, const int a, con
                 }
         }
         const int fb = fixmask[nd[b]];
-        double *dst = vals + unpack_offset(em[b]);
+        int st;
+        double *dst = vals + unpack_offset(em[b], lane, st);
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const bool rfix = (fa >> r) & 1;
@@ -430,40 +424,12 @@ __device__ __forceinline__ void assemble_element_row(int64_t e, const int a, con
                     has = true;
                     macc[r] += fixval[3 * (int64_t)nd[a] + r];
                 }
-                if (has) {
-                    if (OWNER) dst[(r * 3 + c) * 128] += add;
-                    else atomic_add_f64(dst + (r * 3 + c) * 128, add);
-                }
+                if (has) dst[(r * 3 + c) * st] += add;
             }
         }
     }
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-        if (OWNER) racc[3 + r] += macc[r];
-        else if (macc[r] != 0.0) atomic_add_f64(modf + 3 * (int64_t)nd[a] + r, macc[r]);
-    }
-}
-
-
-template <bool TANGENT>
-__global__ __launch_bounds__(256) void k_assemble(int64_t ne, const int32_t *__restrict__ el,
-                                                  const double *__restrict__ coord,
-                                                  const double *__restrict__ disp,
-                                                  const uint8_t *__restrict__ fixmask,
-                                                  const double *__restrict__ fixval,
-                                                  const uint32_t *__restrict__ emap,
-                                                  const double *__restrict__ sig,
-                                                  const uint8_t *__restrict__ pgp, MatConst mc, double gx,
-                                                  double gy, double gz, double *__restrict__ vals,
-                                                  double *__restrict__ glv, double *__restrict__ modf,
-                                                  double *__restrict__ xgp, double *__restrict__ volume, int penalty_bc) {
-    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    int64_t e = t / 10;
-    const int a = (int)(t - e * 10);
-    const bool valid = e < ne;
-    if (!valid) e = ne - 1;
-    assemble_element_row<TANGENT, false>(e, a, valid, el, coord, disp, fixmask, fixval, emap, sig, pgp, mc, gx, gy, gz, vals, glv, modf,
-                                         xgp, volume, penalty_bc, nullptr);
+    for (int r = 0; r < 3; r++) racc[3 + r] += macc[r];
 }
 
 // Atomic-free assembly: one lane per matrix row (slot of the sliced-ELL layout, i.e. one node), walking the elements
@@ -486,8 +452,8 @@ __global__ __launch_bounds__(256) void k_assemble_rows(int64_t nslots, const int
     if (node >= 0) {
         for (int64_t q = nptr[node]; q < nptr[node + 1]; q++) {
             const int32_t packed = nel[q];
-            assemble_element_row<TANGENT, true>((int64_t)(packed >> 4), packed & 15, true, el, coord, disp, fixmask, fixval, emap, sig, pgp,
-                                                mc, gx, gy, gz, vals, glv, modf, xgp, volume, penalty_bc, racc);
+            assemble_element_row<TANGENT>((int64_t)(packed >> 4), packed & 15, (int)(slot & 63), el, coord, disp, fixmask, fixval, emap, sig, pgp,
+                                          mc, gx, gy, gz, vals, xgp, penalty_bc, racc);
         }
         glv[3 * (int64_t)node] = racc[0]; glv[3 * (int64_t)node + 1] = racc[1]; glv[3 * (int64_t)node + 2] = racc[2];
         modf[3 * (int64_t)node] = racc[3]; modf[3 * (int64_t)node + 1] = racc[4]; modf[3 * (int64_t)node + 2] = racc[5];
@@ -499,13 +465,14 @@ __global__ __launch_bounds__(256) void k_assemble_rows(int64_t nslots, const int
 }
 
 // inverse of the 3x3 diagonal blocks -> dinv[node*9]
-__global__ __launch_bounds__(256) void k_diag_get(int64_t nn, const uint32_t *__restrict__ diagoff,
+__global__ __launch_bounds__(256) void k_diag_get(int64_t nn, const uint64_t *__restrict__ diagoff,
                                                   const double *__restrict__ vals, double *__restrict__ dblk) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nn) return;
-    const double *v = vals + unpack_offset(diagoff[i]);
+    int st;
+    const double *v = vals + unpack_abs(diagoff[i], st);
 #pragma unroll
-    for (int c = 0; c < 9; c++) dblk[i * 9 + c] = v[c * 128];
+    for (int c = 0; c < 9; c++) dblk[i * 9 + c] = v[c * st];
 }
 
 __global__ __launch_bounds__(256) void k_diag_invert(int64_t nn, const double *__restrict__ dblk, double *__restrict__ dinv) {
@@ -594,6 +561,31 @@ __device__ __forceinline__ void spmv_pair(const int32_t *cp, const V2 *vp, const
     y2 += v[6].x * a0 + v[7].x * a1 + v[8].x * a2 + v[6].y * b0 + v[7].y * b1 + v[8].y * b2;
 }
 
+// the single last block of an odd-length slice: nine 8-byte (4-byte) value loads, one column node, one gather
+template <bool NT, class V2, int GATHER>
+__device__ __forceinline__ void spmv_single(const int32_t *cp, const V2 *vp2, const double *__restrict__ x,
+                                            double &y0, double &y1, double &y2) {
+    typedef decltype(V2().x) T;                    // double or float
+    const T *vp = (const T *)vp2;
+    const int32_t c0 = ld_col<NT>(cp);
+    double v[9];
+#pragma unroll
+    for (int c = 0; c < 9; c++) v[c] = (double)(NT ? __builtin_nontemporal_load(vp + c * 64) : vp[c * 64]);
+    const double *xa = x + 3 * (int64_t)c0;
+    double a0, a1, a2;
+    if (GATHER == 1) {
+        const int oa = c0 & 1;
+        const double2 wa = *(const double2 *)(xa + oa);
+        const double sa = xa[oa ? 0 : 2];
+        a0 = oa ? sa : wa.x; a1 = oa ? wa.x : wa.y; a2 = oa ? wa.y : sa;
+    } else {
+        a0 = xa[0]; a1 = xa[1]; a2 = xa[2];
+    }
+    y0 += v[0] * a0 + v[1] * a1 + v[2] * a2;
+    y1 += v[3] * a0 + v[4] * a1 + v[5] * a2;
+    y2 += v[6] * a0 + v[7] * a1 + v[8] * a2;
+}
+
 // Optional epilogue of the SpMV (EPI = 1): one Chebyshev step of the multigrid smoother on the row's own node,
 // with t = (A d)_node still in registers (no t vector, no second kernel):
 //   x += d ; r -= t ; if (update_d) { dout = cdd * d + cdr * Dinv r ; if (add_dout) x += dout }
@@ -627,10 +619,13 @@ __global__ __launch_bounds__(256, (sizeof(V2) == 16 ? 4 : 1)) void k_spmv(int64_
     double y0 = 0.0, y1 = 0.0, y2 = 0.0;
     int node = -1;
     if (s < nslices) {
+        // a slice of len blocks = len half chunks of 9 x 64 scalars, starting at half chunk sptr[s]: len / 2 block pairs
+        // (two half chunks each: nine double2 components) and, when len is odd, one single block
         const int64_t jb = sptr[s], je = sptr[s + 1];
         const int32_t *cp = cols + jb * 64 + 2 * lane;   // two column nodes per lane and pair, adjacent
-        const V2 *vp = vals + (jb >> 1) * (9 * 64) + lane;
+        const V2 *vp = (const V2 *)((const decltype(V2().x) *)vals + jb * (9 * 64)) + lane;
         int64_t np = (je - jb) >> 1;
+        const bool odd = (je - jb) & 1;
         if (UNROLL == 4) {
             double z0 = 0.0, z1 = 0.0, z2 = 0.0, u0 = 0.0, u1 = 0.0, u2 = 0.0, w0 = 0.0, w1 = 0.0, w2 = 0.0;
             for (; np >= 4; np -= 4) {
@@ -658,6 +653,8 @@ __global__ __launch_bounds__(256, (sizeof(V2) == 16 ? 4 : 1)) void k_spmv(int64_
             cp += 128;
             vp += 9 * 64;
         }
+        if (odd)   // cp, vp point at the first lane of the single block: step back to this lane's scalar slot
+            spmv_single<NT, V2, GATHER>(cp - lane, (const V2 *)((const decltype(V2().x) *)(vp - lane) + lane), x, y0, y1, y2);
         node = rownode[s * 64 + lane];
         if (EPI == 0) {
             if (node >= 0) {
@@ -1084,7 +1081,7 @@ __global__ __launch_bounds__(256) void k_stream_read(int64_t n2, const double2 *
 // geometric stiffness of calcTSM(nstep = 1), fcVM.py:1002-1006: Kg_ab = (sum_gp w ga . sigma . gb) I3, scattered into a
 // second value array that shares the pattern of the stiffness matrix.  One lane per matrix row walking its elements
 // (as k_assemble_rows: plain read-modify-writes in a fixed order, no atomics).
-__device__ __forceinline__ void geometric_element_row(const int64_t e, const int a, const int32_t *__restrict__ el,
+__device__ __forceinline__ void geometric_element_row(const int64_t e, const int a, const int lane, const int32_t *__restrict__ el,
                                                       const double *__restrict__ coord, const uint32_t *__restrict__ emap,
                                                       const double *__restrict__ sig, double *__restrict__ vals_g) {
     int nd[10];
@@ -1131,10 +1128,11 @@ __device__ __forceinline__ void geometric_element_row(const int64_t e, const int
             to_global(xsi[g], d0, d1, d2, g0, g1, g2);
             v += w[g] * (sa[g][0] * g0 + sa[g][1] * g1 + sa[g][2] * g2);
         }
-        double *dst = vals_g + unpack_offset(em[b]);
+        int st;
+        double *dst = vals_g + unpack_offset(em[b], lane, st);
         dst[0] += v;
-        dst[4 * 128] += v;
-        dst[8 * 128] += v;
+        dst[4 * st] += v;
+        dst[8 * st] += v;
     }
 }
 
@@ -1149,7 +1147,7 @@ __global__ __launch_bounds__(256) void k_assemble_geometric(int64_t nslots, cons
     if (node < 0) return;
     for (int64_t q = nptr[node]; q < nptr[node + 1]; q++) {
         const int32_t packed = nel[q];
-        geometric_element_row((int64_t)(packed >> 4), packed & 15, el, coord, emap, sig, vals_g);
+        geometric_element_row((int64_t)(packed >> 4), packed & 15, (int)(slot & 63), el, coord, emap, sig, vals_g);
     }
 }
 

@@ -11,7 +11,7 @@ namespace fcvm {
 // k_assemble<true>, fcVM.py:983-998) and the displaced corner coordinates -- for straight-sided elements this is the
 // Galerkin operator P^T K_t P of the tangent matrix, so the coarse correction stays consistent with a softened fine level.
 template <bool TANGENT, bool OWNER>
-__device__ __forceinline__ void tet4_element_row(const int64_t e, const int a, const int32_t *__restrict__ el4,
+__device__ __forceinline__ void tet4_element_row(const int64_t e, const int a, const int lane, const int32_t *__restrict__ el4,
                                                        const double *__restrict__ coord1,
                                                        const uint8_t *__restrict__ fixmask1,
                                                        const uint32_t *__restrict__ emap4, MatConst mc,
@@ -96,7 +96,8 @@ __device__ __forceinline__ void tet4_element_row(const int64_t e, const int a, c
             }
         }
         const int fb = fixmask1[nd[b]];
-        double *dst = vals + unpack_offset(emap4[(e * 4 + a) * 4 + b]);
+        int st;
+        double *dst = vals + unpack_offset(emap4[(e * 4 + a) * 4 + b], lane, st);
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const bool rfix = (fa >> r) & 1;
@@ -111,8 +112,7 @@ __device__ __forceinline__ void tet4_element_row(const int64_t e, const int a, c
                 if (!rfix && !cfix) add = vol * v;
                 else if (rfix && a == b && r == c) add = 1.0;
                 else continue;
-                if (OWNER) dst[(r * 3 + c) * 128] += add;
-                else atomic_add_f64(dst + (r * 3 + c) * 128, add);
+                dst[(r * 3 + c) * st] += add;
             }
         }
     }
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_assemble_tet4_rows(int64_t nslots, cons
     if (node < 0) return;
     for (int64_t q = nptr1[node]; q < nptr1[node + 1]; q++) {
         const int32_t packed = nel1[q];
-        tet4_element_row<TANGENT, true>((int64_t)(packed >> 4), packed & 15, el4, coord1, fixmask1, emap4, mc, vals, c2f, disp, sig, pgp);
+        tet4_element_row<TANGENT, true>((int64_t)(packed >> 4), packed & 15, (int)(slot & 63), el4, coord1, fixmask1, emap4, mc, vals, c2f, disp, sig, pgp);
     }
 }
 

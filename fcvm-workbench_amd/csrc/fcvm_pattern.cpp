@@ -103,12 +103,11 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
             if (nd >= 0) m = std::max(m, len[nd]);
         }
         p.maxlen = std::max(p.maxlen, m);
-        m = (m + 1) & ~(int64_t)1;  // even: blocks are stored in pairs (one 16-byte load per lane)
-        p.sptr[s + 1] = p.sptr[s] + m;
+        p.sptr[s + 1] = p.sptr[s] + std::max<int64_t>(m, 1);   // pairs of blocks + a single last block when m is odd
     }
     p.nslots = p.sptr[p.nslices] * SLICE;
-    if ((uint64_t)(p.sptr[p.nslices] / 2) >= (1ull << 25))
-        throw std::runtime_error("matrix too large for the packed 32-bit block locations (2^25 pair rows)");
+    if ((uint64_t)p.sptr[p.nslices] >= (1ull << 30))
+        throw std::runtime_error("matrix too large for the packed 32-bit block locations (2^30 half chunks)");
     p.cols.assign(p.nslots, 0);
     parallel_for(p.nslices, nt, [&](int64_t b, int64_t e, int) {
         for (int64_t s = b; s < e; s++) {
@@ -144,7 +143,7 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
         const int32_t *rb = p.colidx.data() + p.rowptr[i];
         const int32_t *re = p.colidx.data() + p.rowptr[i + 1];
         int64_t j = std::lower_bound(rb, re, (int32_t)i) - rb;
-        p.diagoff[i] = p.pack_offset(p.slotof[i], j);
+        p.diagoff[i] = p.abs_offset(p.slotof[i], j);
     }
 }
 

@@ -8,41 +8,57 @@ namespace fcvm {
 
 constexpr int SLICE = 64;           // rows (nodes) per slice = one wavefront, one row per lane
 constexpr int SORT_WINDOW = 64;     // slices per length-sorting window (4096 rows); measured: 8 -> 64 = -4% bytes
-constexpr int64_t VSTRIDE = 2 * SLICE;  // doubles between two components of one 3x3 block
+constexpr int64_t HALF = 9 * SLICE;   // doubles of one block of all 64 lanes of a slice ("half chunk": 4.5 KiB)
 
+// Storage of a slice of `len` blocks per lane (len = blocks of its longest row): the blocks 2p, 2p+1 of a lane form a
+// pair whose nine components are stored as double2's, 64 lanes contiguous (one 1 KiB line per component: a 16-byte
+// load per lane); if len is odd the last block stands alone, its components stored as 64 contiguous doubles each.
+// A slice occupies exactly len half chunks (HALF doubles each), starting at half chunk sptr[s]: no rounding of odd
+// lengths to pairs (round 2; 3.3 % of the matrix bytes on the cube meshes, whose row lengths 19 / 27 / 65 are all odd).
 struct Pattern {
     int64_t ne = 0, nn = 0;
     int npe = 10;           // nodes per element (10: tet10 fine level, 4: tet4 coarse level)
     int64_t nslices = 0;
     int64_t nnzb = 0;       // true 3x3 blocks
-    int64_t nslots = 0;     // padded block slots (sum over slices of 64 * slice length)
+    int64_t nslots = 0;     // stored block slots (sum over slices of 64 * slice length)
     int64_t maxlen = 0;
     std::vector<int64_t> rowptr;    // [nn+1] CSR over nodes (sorted columns, diagonal included)
     std::vector<int32_t> colidx;    // [nnzb]
-    std::vector<int64_t> sptr;      // [nslices+1] cumulative slice lengths (blocks per lane, even)
+    std::vector<int64_t> sptr;      // [nslices+1] cumulative slice lengths (blocks per lane) = first half chunk of a slice
     std::vector<int32_t> rownode;   // [nslices*64] node of slot, -1 = padding
     std::vector<int32_t> slotof;    // [nn] slot (slice*64+lane) of node
-    std::vector<int32_t> cols;      // [sptr[nslices]*64] column nodes, the two of a block pair adjacent per lane: see col_index
-    std::vector<uint32_t> emap;     // [ne*npe*npe] packed location of component 0 of block (a,b), see pack_offset
-    std::vector<uint32_t> diagoff;  // [nn] packed location of component 0 of the diagonal block
+    std::vector<int32_t> cols;      // [sptr[nslices]*64] column nodes: see col_index
+    std::vector<uint32_t> emap;     // [ne*npe*npe] packed location of element block (a,b), see pack_offset
+    std::vector<uint64_t> diagoff;  // [nn] location of the diagonal block of a node, see abs_offset
     std::vector<int64_t> nptr;      // [nn+1] node -> element incidence (CSR)
     std::vector<int32_t> nel;       // [ne*npe] element << 4 | local node index, ascending elements per node
 
-    // offset in doubles of component 0 of block j of the row living in `slot`
+    inline int64_t slice_len(int64_t s) const { return sptr[s + 1] - sptr[s]; }
+    inline bool is_single(int64_t s, int64_t j) const { const int64_t len = slice_len(s); return (len & 1) && j == len - 1; }
+    // first half chunk of the storage unit (pair or single) that holds block j of slice s
+    inline int64_t unit(int64_t s, int64_t j) const { return sptr[s] + (is_single(s, j) ? j : (j & ~(int64_t)1)); }
+    // offset in doubles of component 0 of block j of the row living in `slot`; the components are comp_stride apart
     inline uint64_t block_offset(int64_t slot, int64_t j) const {
-        int64_t s = slot / SLICE, l = slot % SLICE;
-        return (uint64_t)(((sptr[s] / 2 + (j >> 1)) * 9 * SLICE + l) * 2 + (j & 1));
+        const int64_t s = slot / SLICE, l = slot % SLICE;
+        return (uint64_t)(unit(s, j) * HALF + (is_single(s, j) ? l : 2 * l + (j & 1)));
     }
-    // position in `cols` of the column node of block j of lane l of slice s: one 8-byte load per lane and block pair
-    inline int64_t col_index(int64_t s, int64_t l, int64_t j) const { return (((sptr[s] + j) >> 1) * SLICE + l) * 2 + (j & 1); }
-    int64_t value_count() const { return sptr[nslices] * SLICE * 9; }
-    // 32-bit form of block_offset for the device tables: pair row P = sptr[s]/2 + j/2 (25 bits), lane (6 bits), j & 1;
-    // offset in doubles = ((P * 9 * 64) + lane) * 2 + (j & 1)  (unpack_offset in fcvm_kernels.hip.h).  2^25 pair rows
-    // = 309 GB of values: beyond the HBM of one GPU.
+    inline int64_t comp_stride(int64_t slot, int64_t j) const { return is_single(slot / SLICE, j) ? SLICE : 2 * SLICE; }
+    // position in `cols` of the column node of block j of lane l of slice s: the two nodes of a pair adjacent per lane
+    // (one 8-byte load), the node of a single block alone
+    inline int64_t col_index(int64_t s, int64_t l, int64_t j) const {
+        return is_single(s, j) ? (sptr[s] + j) * SLICE + l : (sptr[s] + (j & ~(int64_t)1)) * SLICE + 2 * l + (j & 1);
+    }
+    int64_t value_count() const { return sptr[nslices] * HALF; }
+    // 32-bit form for the element maps: half chunk << 2 | (j & 1) << 1 | single.  The lane is not stored: every kernel
+    // that places element blocks owns the row and knows its lane (unpack_offset in fcvm_kernels.hip.h).  2^30 half
+    // chunks = 4.9 TB of values.
     inline uint32_t pack_offset(int64_t slot, int64_t j) const {
-        int64_t s = slot / SLICE, l = slot % SLICE;
-        return (uint32_t)((((uint64_t)(sptr[s] / 2 + (j >> 1))) << 7) | ((uint64_t)l << 1) | (uint64_t)(j & 1));
+        const int64_t s = slot / SLICE;
+        const bool single = is_single(s, j);
+        return (uint32_t)(((uint64_t)unit(s, j) << 2) | (single ? 1u : (uint64_t)((j & 1) << 1)));
     }
+    // 64-bit form for tables that are read without knowing the lane: offset of component 0 << 1 | single
+    inline uint64_t abs_offset(int64_t slot, int64_t j) const { return (block_offset(slot, j) << 1) | (is_single(slot / SLICE, j) ? 1u : 0u); }
 };
 
 // elnodes0: 0-based int32 [ne*10].  Throws std::runtime_error on bad input.
