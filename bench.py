@@ -206,6 +206,18 @@ def run_single(args):
         drv.iteration()
     c.sync()
     dt = time.perf_counter() - t0
+    # the same SpMV launched back to back on its own (no V-cycle in between, no p.Ap partials): what the kernel does when the
+    # caches hold nothing but its own data -- context for the in-solver average below, not the roofline figure
+    xs, ys = c.array(np.random.default_rng(0).standard_normal(info["ndof"])), c.empty(info["ndof"])
+    for _ in range(3):
+        c.spmv(xs, ys)
+    c.sync()
+    t1 = time.perf_counter()
+    for _ in range(20):
+        c.spmv(xs, ys)
+    c.sync()
+    standalone_ms = (time.perf_counter() - t1) / 20 * 1e3
+    del xs, ys
     stream_gbs = c.membench(3 << 30)
     spmv_launches = stats["spmv_launches"] - s0["spmv_launches"]
     spmv_ms = stats["spmv_ms"] - s0["spmv_ms"]
@@ -236,7 +248,7 @@ def run_single(args):
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
-                     "launches_timed": spmv_launches, "padded_matrix_bytes": info["matrix_bytes"],
+                     "launches_timed": spmv_launches, "back_to_back_launch_ms": standalone_ms, "padded_matrix_bytes": info["matrix_bytes"],
                      # what this box's HBM delivers for a plain 16 B/lane streaming read of a fresh 3 GB buffer, measured right
                      # after the timed region (boxes of the pool differ: 5.1 .. 6.3 TB/s): context for `frac`
                      "stream_read_GBs_this_box": stream_gbs,

@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256, (sizeof(V2) == 16 ? 4 : 1)) void k_spmv(int64_
         if (EPI == 0) {
             if (node >= 0) {
                 double *yo = y + 3 * (int64_t)node;
-                yo[0] = y0; yo[1] = y1; yo[2] = y2;
+                yo[0] = y0; yo[1] = y1; yo[2] = y2;   // (nontemporal y stores: 0.641 against 0.617 ms, profiles/r02m_spmv_nt_y_ab.txt)
             }
         } else if (node >= 0) {
             const int64_t o = 3 * (int64_t)node;

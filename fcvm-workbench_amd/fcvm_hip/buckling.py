@@ -14,8 +14,6 @@ sees the m x m Ritz problem.
 import numpy as np
 import scipy.linalg as sla
 
-from ._lib import call
-
 
 def buckling_factors(model, grav, k=2, sigma=0.1, block=6, tol=1e-10, maxit=80, rtol_solve=1e-11, log=None):
     """Returns (eigenvalues [k], eigenvectors host array [ndof, k], ue device vector of the elastic solution).
@@ -37,15 +35,20 @@ def buckling_factors(model, grav, k=2, sigma=0.1, block=6, tol=1e-10, maxit=80, 
     sig, sig_t = c.empty(24 * ne), c.empty(24 * ne)
     c.update_stress_load(c.array(np.full(4 * ne, 1.0e30)), None, ue, c.zeros(24 * ne), sig, sig_t, c.empty(ndof), 0.0, False,
                          c.empty(4 * ne, np.uint8))
-    call("fcvm_assemble_buckling", c.h, sig.ptr, float(sigma))
+    c.assemble_buckling(sig, sigma)
     m = max(block, k + 2)
-    rng = np.random.default_rng(12345)
-    X = [c.array(rng.standard_normal(ndof)) for _ in range(m)]
+    nstart = [0]
+
+    def start_vector():   # the same on one GPU and on any partition: a fixed function of the global dof number
+        nstart[0] += 1
+        return c.start_vector(nstart[0])
+
+    X = [start_vector() for _ in range(m)]
     Y = [c.empty(ndof) for _ in range(m)]
     tmp = c.empty(ndof)
 
     def G(x, y):  # y = G x = -K_g x
-        call("fcvm_spmv_geometric", c.h, x.ptr, tmp.ptr)
+        c.spmv_geometric(x, tmp)
         c.axpby(-1.0, tmp, 0.0, None, out=y)
 
     theta_old = None
@@ -78,7 +81,7 @@ def buckling_factors(model, grav, k=2, sigma=0.1, block=6, tol=1e-10, maxit=80, 
             if np.all(th[:k] > 0.0) or m >= 4 * block:
                 break
             # converged onto a block without k positive factors: widen it and go on
-            extra = [c.array(rng.standard_normal(ndof)) for _ in range(block)]
+            extra = [start_vector() for _ in range(block)]
             X, Y, m = X + extra, Y + [c.empty(ndof) for _ in range(block)], m + block
             say("buckling subspace: block widened to %d (negative factors nearer to the shift than the wanted ones)" % m)
             theta_old = None
@@ -91,13 +94,18 @@ def buckling_factors(model, grav, k=2, sigma=0.1, block=6, tol=1e-10, maxit=80, 
     return lam, vec, ue
 
 
-def imperfection(eigenvec, ev1, ev2, maxImp):
-    """fcVM.py:1226-1236: imperfection shape from the two buckling modes, scaled to maxImp."""
+def imperfection(eigenvec, ev1, ev2, maxImp, global_extreme=None):
+    """fcVM.py:1226-1236: imperfection shape from the two buckling modes, scaled to maxImp.
+    global_extreme(v) -> (max |v|, sign of that entry) over all ranks of a partitioned model (None: this process holds
+    the whole vector)."""
+    def extreme(v):
+        if global_extreme is not None:
+            return global_extreme(v)
+        i = np.argmax(np.abs(v))
+        return float(np.abs(v[i])), float(np.sign(v[i]))
     ua = ev1 / (ev1 + ev2) * eigenvec[:, 0] + ev2 / (ev1 + ev2) * eigenvec[:, 1]
     ub = ev1 / (ev1 + ev2) * eigenvec[:, 0] - ev2 / (ev1 + ev2) * eigenvec[:, 1]
-    ma, mb = np.max(np.abs(ua)), np.max(np.abs(ub))
+    (ma, sa), (mb, sb) = extreme(ua), extreme(ub)
     if ma > mb:
-        imax = np.argmax(np.abs(ua))
-        return maxImp / ma * np.sign(ua[imax]) * ua
-    imax = np.argmax(np.abs(ub))
-    return maxImp / mb * np.sign(ub[imax]) * ub
+        return maxImp / ma * sa * ua
+    return maxImp / mb * sb * ub

@@ -216,6 +216,21 @@ class Context:
         call("fcvm_solve", self.h, f.ptr, u.ptr, float(rtol), int(maxit), info)
         return u, dict(iterations=int(info[0]), rel_residual=info[1], spmv=int(info[2]))
 
+    # -- linear-buckling pre-analysis (fcvm_hip/buckling.py) ------------------------------------
+    def assemble_buckling(self, sig, sigma):
+        call("fcvm_assemble_buckling", self.h, sig.ptr, float(sigma))
+
+    def spmv_geometric(self, x, y):
+        call("fcvm_spmv_geometric", self.h, x.ptr, y.ptr)
+        return y
+
+    def start_vector(self, k, global_dofs=None):
+        """start vector number k of the subspace iteration: a fixed pseudo-random function of the GLOBAL dof number, so that
+        a partitioned model starts from the same vectors as the whole one"""
+        g = np.arange(3 * self.nn, dtype=np.float64) if global_dofs is None else np.asarray(global_dofs, dtype=np.float64)
+        v = np.sin(g * (12.9898 + 0.37 * k) + 78.233 * k) * 43758.5453
+        return self.array(v - np.floor(v) - 0.5)
+
     def any_nonzero(self, a):
         """any(a != 0) of a uint8 device array, reduced on the device (4 bytes come back)"""
         out = C.c_int(0)

@@ -239,6 +239,44 @@ class DistBackend:
     def norm(self, x):
         return float(np.sqrt(self.dot(x, x)))
 
+    # -- linear-buckling pre-analysis (fcvm_hip/buckling.py) ------------------------------------
+    def assemble_buckling(self, sig, sigma):
+        """K_b + sigma K_g of calcTSM(nstep = 1) on every rank (fcvm_assemble_buckling on the local elements), consistent
+        diagonal blocks, multigrid levels refreshed for the shifted operator"""
+        self.ops.assemble_buckling(sig, sigma)
+        if self.local_solver:
+            return
+        dblk = self.empty(9 * self.nn)
+        self.ops.get_diag_blocks(dblk)
+        self.ex.interface_sum(dblk.t, 9)
+        self.ops.set_diag_blocks(dblk)
+        if self.mg is not None:
+            self.mg.setup()
+
+    def spmv_geometric(self, x, y):
+        self.ops.spmv_geometric(x, y)
+        self.ex.interface_sum(y.t, 3)
+        return y
+
+    def start_vector(self, k):
+        g = (3 * (self.part.gnodes.astype(np.float64) - 1.0))[:, None] + np.arange(3.0)[None, :]
+        v = np.sin(g.reshape(-1) * (12.9898 + 0.37 * k) + 78.233 * k) * 43758.5453
+        return self.array(v - np.floor(v) - 0.5)
+
+    def set_coords(self, nocoord_local):
+        self.ops.set_coords(nocoord_local)
+        if self.mg is not None:
+            self.mg.xyz = np.ascontiguousarray(nocoord_local, dtype=np.float64)
+
+    def global_extreme(self, v):
+        """(max |v|, sign of that entry) over all ranks; ties go to the lowest global dof like numpy's argmax"""
+        i = int(np.argmax(np.abs(v)))
+        mine = (float(np.abs(v[i])), -(3 * int(self.part.gnodes[i // 3] - 1) + i % 3), float(np.sign(v[i])))
+        allv = [None] * self.part.world
+        dist.all_gather_object(allv, mine, group=self.group)
+        best = max(allv)
+        return best[0], best[2]
+
     def any_nonzero(self, a):
         v = (a.t != 0).any().to(torch.float64).reshape(1)
         return bool(self._allreduce(v, dist.ReduceOp.MAX).item() > 0.0)
@@ -712,7 +750,8 @@ class DistModel:
         self.material = tuple(float(v) for v in material)
         self.fix = dict(fix_local)
         self.loads = loads_local
-        self._ext = external_loads_fn
+        self._ext_fn = external_loads_fn
+        self._ext = None   # (solver.GpuModel keeps a cached load vector under this name; not cached here)
         self.ne, self.nn = len(part.elNodes), part.nn
         self.ndof = 3 * self.nn
         fixdof, movdof = np.ones(self.ndof), np.zeros(self.ndof)
@@ -729,7 +768,7 @@ class DistModel:
     def calc_gsm(self, grav, disp=None, sig=None, pgp=None, Et_E=0.0, want_x=True):
         c = self.ctx
         xgp = c.empty(12 * self.ne) if want_x else None
-        ext = self._ext(self.nocoord, self.loads, None if disp is None else disp.get())
+        ext = self._ext_fn(self.nocoord, self.loads, None if disp is None else disp.get())
         glv, modf, V = c.assemble(grav, disp=disp, sig=sig, pgp=pgp, Et_E=Et_E, xgp=xgp)
         # every rank takes part in the exchange, loaded or not (a rank-local "any load?" test would
         # leave the neighbours waiting)
@@ -737,6 +776,66 @@ class DistModel:
         c.ex.interface_sum(e.t, 3)
         glv.t.add_(e.t)
         return glv, modf, V, xgp
+
+
+def _local_loads(part, loads):
+    """The rank's share of the load entities of the global model: every face / edge / vertex load goes to the LOWEST rank that
+    holds all of its nodes (a face belongs to one element, so at least one rank does), renumbered to local nodes."""
+    from .loads import Loads
+    lut = np.zeros(int(part.gnodes.max()) + 2 if part.nn else 2, dtype=np.int64)
+    lut[part.gnodes] = np.arange(1, part.nn + 1)
+
+    def mine(nodes):
+        if not len(nodes):
+            held = np.zeros(0, dtype=bool)
+        else:
+            nodes = np.asarray(nodes, dtype=np.int64).reshape(len(nodes), -1)
+            inr = nodes < len(lut)
+            held = (inr & (lut[np.where(inr, nodes, 0)] > 0)).all(axis=1)
+        every = [None] * part.world
+        if part.world > 1:
+            dist.all_gather_object(every, held, group=part.group)
+        else:
+            every = [held]
+        first = np.full(len(held), -1)
+        for r in range(part.world - 1, -1, -1):
+            first[every[r]] = r
+        if (first < 0).any():
+            raise ValueError("a load entity whose nodes no rank holds together")
+        return first == part.rank
+
+    out = {}
+    for nodes_name, vals_name in (("pfaces", "pvals"), ("vnodes", "vloads"), ("ufaces", "uloads"), ("edges", "eloads")):
+        nodes, vals = getattr(loads, nodes_name), getattr(loads, vals_name)
+        keep = mine(nodes)
+        out[nodes_name], out[vals_name] = lut[nodes[keep]], vals[keep]
+    return Loads(**out)
+
+
+def partition_model(elNodes, nocoord, material, fix, loads, device_index, device=None, group=None, precond="mg", order=None):
+    """One rank's DistModel of the element-range partition of a global model (the 1 -> N split of north_star): elements
+    [rank * ne / world, (rank + 1) * ne / world) of the global list (or of `order`, a permutation of it), the nodes they
+    touch, the supports and load entities that fall on them.  Collective: every rank of `group` calls it."""
+    from .loads import Loads, external_loads
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    el = np.asarray(elNodes)
+    ne = len(el)
+    lo, hi = rank * ne // world, (rank + 1) * ne // world
+    sel = np.arange(lo, hi) if order is None else np.asarray(order)[lo:hi]
+    part = Partition(el[sel], group=group)
+    xyz_loc = np.ascontiguousarray(np.asarray(nocoord, dtype=np.float64)[part.gnodes - 1])
+    gd = np.array(sorted(fix), dtype=np.int64)
+    here, ld = part.local_dofs_of(gd)
+    fix_loc = {int(d): float(fix[int(g)]) for d, g in zip(ld, gd[here])}
+    ops = HipLocalOps(part, xyz_loc, material, fix_loc, device_index, element_offset=lo)
+    be = DistBackend(part, ops, device if device is not None else torch.device("cuda", device_index))
+    if precond == "mg":
+        be.enable_multigrid(xyz_loc)
+    model = DistModel(part, be, xyz_loc, material, fix_loc, _local_loads(part, loads if loads is not None else Loads()),
+                      external_loads)
+    model.elements = sel
+    return model
 
 
 class HipLocalOps:
@@ -812,6 +911,17 @@ class HipLocalOps:
         from ._lib import call
         call("fcvm_unpack_sum", self.c.h, inodes.numel(), inodes.data_ptr(), eptr.data_ptr(), src.data_ptr(), int(ncomp),
              t.data_ptr(), recv.data_ptr())
+
+    def assemble_buckling(self, sig, sigma):
+        from ._lib import call
+        call("fcvm_assemble_buckling", self.c.h, sig.ptr, float(sigma))
+
+    def spmv_geometric(self, x, y):
+        from ._lib import call
+        call("fcvm_spmv_geometric", self.c.h, x.ptr, y.ptr)
+
+    def set_coords(self, nocoord_local):
+        self.c.set_coords(np.ascontiguousarray(nocoord_local, dtype=np.float64))
 
     def spd_inverse(self, A):
         """inverse of the SPD matrix A (torch f64 [n, n] on this rank's device) by the library's dense kernels"""

@@ -138,12 +138,11 @@ class RiksDriver:
         maxImp = float(ctl.get("maxImp", 0.0)) if self.LD else 0.0
         if self.LD and ctl.get("buckling", True) and not (float(self.nstep) > 1.0 and maxImp == 0.0):
             from . import buckling
-            if not hasattr(c, "h"):
-                raise NotImplementedError("the buckling pre-analysis runs on one GPU only")
             self.eigenval, self.eigenvec, _ = buckling.buckling_factors(model, self.grav, log=self.say)
             self.say("buckling load factors: {}".format(self.eigenval))
             if not self.elastic_only and maxImp != 0.0:
-                imper = buckling.imperfection(self.eigenvec, float(ctl["ev1"]), float(ctl["ev2"]), maxImp)
+                imper = buckling.imperfection(self.eigenvec, float(ctl["ev1"]), float(ctl["ev2"]), maxImp,
+                                              global_extreme=getattr(c, "global_extreme", None))
                 model.nocoord = model.nocoord + imper.reshape(-1, 3)
                 c.set_coords(model.nocoord)
                 model._ext = None   # load integrals follow the geometry

@@ -63,6 +63,22 @@ class OracleLocalOps:
     def spmv(self, x, y):
         y.set(self.K @ x.get())
 
+    # -- buckling pre-analysis: K_b + sigma K_g and K_g of the rank's elements (oracle element matrices) --------------
+    def assemble_buckling(self, sig, sigma):
+        ne, n = len(self.el), 3 * len(self.xyz)
+        isfix, _ = orc.fix_arrays(self.fix, n)
+        r, c = np.zeros(900 * ne, np.int64), np.zeros(900 * ne, np.int64)
+        ks, kg = np.zeros(900 * ne), np.zeros(900 * ne)
+        orc.lib().orc_buckling_matrices(ne, self.el, self.xyz, self.mat[0], self.mat[1], isfix, sig.get(), r, c, ks, kg)
+        self.Kg = sp.csr_matrix((kg, (r, c)), shape=(n, n))
+        self.K = (sp.csr_matrix((ks, (r, c)), shape=(n, n)) + sigma * self.Kg).tocsr()
+
+    def spmv_geometric(self, x, y):
+        y.set(self.Kg @ x.get())
+
+    def set_coords(self, nocoord_local):
+        self.xyz = np.ascontiguousarray(nocoord_local, dtype=np.float64)
+
     # -- multigrid building blocks, numpy / scipy restatement for the CPU tests -----------------
     def mg_enable(self):
         self.mg = True

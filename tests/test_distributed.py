@@ -196,3 +196,69 @@ def test_eight_rank_multigrid_solve_and_bit_identical_shared_values(orc, tmp_pat
         assert 20 < g["info"]["iterations"] < 90
     assert holders.min() >= 1 and holders.max() >= 6      # scattered element ranges: nodes held by most of the ranks
     assert len({g["info"]["iterations"] for g in got}) == 1
+
+
+BUCKLING_CTL = dict(sig_yield=1.0e5, grav_x=0.0, grav_y=0.0, grav_z=0.0, nstep=2, iterat_max=20, error_max=1e-4, relax=1.2,
+                    scale_re=2.0, scale_up=1.2, scale_dn=1.2, disp_output="total", ultimate_strain=0.25, Et_E=0.0, target_LF=10.0,
+                    csr_option="PEEQ", averaged_option="unaveraged", gnl="GNLY", maxImp="0.5", ev1="1.0", ev2="0.3")
+
+
+def _column_case():
+    from fcvm_hip import meshgen
+    el, xyz = meshgen.cube_tet10(4, 1, 1, 40.0, 6.0, 10.0)
+    fix = {3 * int(n) + k: 0.0 for n in meshgen.nodes_on_plane(xyz, 0, 0.0) for k in range(3)}
+    faces = meshgen.boundary_faces_on_plane(el, xyz, 0, 40.0)
+    return el, xyz, np.array([210000.0, 0.3, 7.8e-6]), fix, faces, np.tile([-5000.0, 0.0, 0.0], (len(faces), 1))
+
+
+def _buckling_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dist_helpers import OracleLocalOps
+        from fcvm_hip.dist import DistBackend, DistModel, Partition, _local_loads
+        from fcvm_hip.loads import Loads, external_loads
+        from fcvm_hip.solver import calc_disp
+        el, xyz, mat, fix, faces, ul = _column_case()
+        order = np.random.default_rng(3).permutation(len(el))
+        lo, hi = rank * len(el) // world, (rank + 1) * len(el) // world
+        part = Partition(el[order[lo:hi]])
+        xyz_loc = xyz[part.gnodes - 1]
+        gd = np.array(sorted(fix), dtype=np.int64)
+        here, ld = part.local_dofs_of(gd)
+        fix_loc = {int(d): fix[int(g)] for d, g in zip(ld, gd[here])}
+        loads = _local_loads(part, Loads(ufaces=faces, uloads=ul))
+        ops = OracleLocalOps(part, xyz_loc, mat, fix_loc, element_offset=lo)
+        be = DistBackend(part, ops, torch.device("cpu"), pcg_check_every=10)   # block-Jacobi PCG: the ~100 solves of the
+        model = DistModel(part, be, xyz_loc, mat, fix_loc, loads, external_loads)  # subspace iteration stay cheap on the CPU
+        res = calc_disp(model, BUCKLING_CTL, rtol=1e-11)
+        payload = dict(gnodes=part.gnodes, nfaces=len(loads.ufaces), eigenval=res["eigenval"], nocoord=res["nocoord"],
+                       lout=res["lout"], un=res["un"], disp=res["displacements"])
+        gathered = [None] * world
+        dist.all_gather_object(gathered, payload)
+        if rank == 0:
+            torch.save(gathered, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gnly_buckling_preanalysis_matches_oracle(orc, tmp_path):
+    """fcVM.py:1199-1296 on two ranks (shuffled element partition): buckling factors from the distributed subspace iteration,
+    the imperfection scaled with the global extreme of the mixed shape, and the first GNLY steps on the imperfect geometry,
+    against the single-process oracle (ARPACK eigsh in buckling mode)."""
+    out = str(tmp_path / "b.pt")
+    world = 2
+    mp.spawn(_buckling_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = torch.load(out, weights_only=False)
+    el, xyz, mat, fix, faces, ul = _column_case()
+    o = orc.run_analysis(el, xyz, mat, fix, orc.Loads(ufaces=faces, uloads=ul), BUCKLING_CTL, use_imperfection=True)
+    rel = lambda a, b: np.abs(np.asarray(a) - b).max() / np.abs(b).max()  # noqa: E731
+    assert sum(g["nfaces"] for g in got) == len(faces)            # every loaded face on exactly one rank
+    assert np.abs(o["nocoord"] - xyz).max() == pytest.approx(0.5, rel=1e-9)
+    for g in got:
+        assert np.allclose(np.sort(g["eigenval"]), np.sort(o["eigenval"]), rtol=1e-7)
+        assert rel(g["nocoord"], o["nocoord"][g["gnodes"] - 1]) < 1e-6
+        assert len(g["lout"]) == len(o["lout"])
+        assert rel(g["lout"], o["lout"]) < 1e-5 and rel(g["un"], o["un"]) < 1e-5
+        assert rel(g["disp"], o["displacements"].reshape(-1, 3)[g["gnodes"] - 1].reshape(-1)) < 1e-5

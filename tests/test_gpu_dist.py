@@ -132,3 +132,60 @@ def test_three_ranks_unstructured_partition(tmp_path):
         d = ref["displacements"].reshape(-1, 3)[g["gnodes"] - 1].reshape(-1)
         assert rel(g["disp"], d) < 1e-6
     assert got[0]["pcg"] / got[0]["solves"] < 400
+
+
+COLUMN_CTL = dict(sig_yield=240.0, grav_x=0.0, grav_y=0.0, grav_z=0.0, nstep=5, iterat_max=20, error_max=1e-4, relax=1.2,
+                  scale_re=2.0, scale_up=1.2, scale_dn=1.2, disp_output="total", ultimate_strain=0.25, Et_E=0.0, target_LF=10.0,
+                  csr_option="PEEQ", averaged_option="unaveraged", gnl="GNLY", maxImp="0.5", ev1="1.0", ev2="0.3")
+
+
+def _column():
+    from fcvm_hip import meshgen
+    from fcvm_hip.loads import Loads
+    el, xyz = meshgen.cube_tet10(10, 2, 3, 40.0, 6.0, 10.0)
+    fix = {3 * int(n) + k: 0.0 for n in meshgen.nodes_on_plane(xyz, 0, 0.0) for k in range(3)}
+    faces = meshgen.boundary_faces_on_plane(el, xyz, 0, 40.0)
+    return el, xyz, (210000.0, 0.3, 7.8e-6), fix, Loads(ufaces=faces, uloads=np.tile([-5000.0, 0.0, 0.0], (len(faces), 1)))
+
+
+def _worker_buckling(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fcvm_hip.dist import partition_model
+        from fcvm_hip.solver import calc_disp
+        torch.cuda.set_device(0)
+        el, xyz, mat, fix, loads = _column()
+        order = np.random.default_rng(5).permutation(len(el))   # ragged interfaces, the loaded face split over the ranks
+        model = partition_model(el, xyz, mat, fix, loads, 0, order=order)
+        res = calc_disp(model, COLUMN_CTL, rtol=1e-11, maxit=4000)
+        payload = dict(gnodes=model.part.gnodes, disp=res["displacements"], lout=res["lout"], un=res["un"],
+                       eigenval=res["eigenval"], nocoord=res["nocoord"], eigenvec=res["eigenvec"])
+        got = [None] * world
+        dist.all_gather_object(got, payload)
+        if rank == 0:
+            torch.save(got, out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gnly_buckling_preanalysis_on_a_partitioned_model(tmp_path):
+    """The GNLY flow of fcVM.py:1199-1296 on an element partition: elastic solution, buckling factors by subspace iteration
+    with distributed multigrid-PCG solves on K_b + sigma K_g, imperfection scaled by the GLOBAL extreme of the mixed buckling
+    shape, restart on the imperfect geometry -- three ranks on GPU 0 against the single-GPU run of the same column."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "r.pt")
+    mp.spawn(_worker_buckling, args=(3, port, out), nprocs=3, join=True)
+    got = torch.load(out, weights_only=False)
+    from fcvm_hip.solver import run_analysis
+    el, xyz, mat, fix, loads = _column()
+    ref = run_analysis(el, xyz, mat, fix, loads, COLUMN_CTL, rtol=1e-11)
+    rel = lambda a, b: np.abs(np.asarray(a) - b).max() / np.abs(b).max()  # noqa: E731
+    assert np.abs(ref["nocoord"] - xyz).max() == pytest.approx(0.5, rel=1e-9)
+    for g in got:
+        assert np.allclose(g["eigenval"], ref["eigenval"], rtol=1e-8)
+        assert rel(g["nocoord"], ref["nocoord"][g["gnodes"] - 1]) < 1e-8          # the same imperfection on every rank
+        assert len(g["lout"]) == len(ref["lout"])
+        assert rel(g["lout"], ref["lout"]) < 1e-6 and rel(g["un"], ref["un"]) < 1e-6
+        assert rel(g["disp"], ref["displacements"].reshape(-1, 3)[g["gnodes"] - 1].reshape(-1)) < 1e-6
