@@ -230,7 +230,9 @@ def run_single(args):
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     plastic = int(drv.pgp.get().sum())
     ne = model.ne
-    traffic, traffic_src = spmv_traffic(n, info["spmv_variant"])
+    winfo = c.spmv_info()
+    layout = ("window-%dx64-split%d" % (winfo["waves_per_group"], winfo["split"])) if winfo["window_format"] else "sliced-ell-v%d" % info["spmv_variant"]
+    traffic, traffic_src = spmv_traffic(n, layout)
     out = {
         "metric": "elements*GP/s over Newton iterations (Newton iterations/s x elements x 4 GP), 1M tet10",
         "value": ne * 4 * args.steps / dt, "unit": "elements*GP/s", "n_gpus": 1, "steps": args.steps,
@@ -244,7 +246,10 @@ def run_single(args):
         "fine_spmv_per_step": (stats.get("spmv_total", 0) - s0.get("spmv_total", 0)) / args.steps,
         "assembly": {"ms": t_asm * 1e3, "elements_gp_per_s": ne * 4 / t_asm},
         "setup_s": {"mesh": t_mesh, "pattern_host": model.t_pattern, "assembly_plus_preconditioner_hierarchy": t_setup},
-        "roofline": {"bound": "hbm", "kernel": "k_spmv<true> (sliced-ELL 3x3-block SpMV + p.Ap partials)",
+        "roofline": {"bound": "hbm",
+                     "kernel": ("k_spmv_win<true> (window-format 3x3-block SpMV, x staged in LDS, + p.Ap partials)" if winfo["window_format"]
+                                else "k_spmv<true> (sliced-ELL 3x3-block SpMV + p.Ap partials)"),
+                     "storage": layout, "spmv_storage_bytes": winfo["bytes"] if winfo["window_format"] else info["matrix_bytes"],
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "fcvm_kernels.hip.h"
+#include "fcvm_spmv_win.hip.h"
 #include "fcvm_mg_kernels.hip.h"
 #include "fcvm_assemble_lds.hip.h"
 #include "fcvm_dense.hip.h"
@@ -76,6 +77,16 @@ struct fcvm_ctx {
     double last_spmv_ms = 0, last_total_ms = 0;
     double row_spread = 0.0;
     bool row_order_morton = false;
+    // window-format copy of the fine matrix for the SpMV (fcvm_spmv_win.hip.h); 0: the sliced-ELL kernel does it
+    int spmv_win = 1, win_v2 = 1;   // win_v2: value components in 16-byte pairs (FCVM_WIN_V2=0: nine 8-byte runs)
+    bool win_on = false;
+    WinPattern win;
+    int64_t *d_w_gptr = nullptr, *d_w_woff = nullptr;
+    int32_t *d_w_wlist = nullptr, *d_w_rownode = nullptr, *d_w_srcslot = nullptr, *d_w_gextra = nullptr;
+    uint32_t *d_w_seg = nullptr;
+    uint16_t *d_w_rowlen = nullptr, *d_w_own = nullptr, *d_w_cols = nullptr, *d_w_jstart = nullptr;
+    double *d_w_vals = nullptr;
+    size_t win_lds = 0;
     int spmv_variant = 5;  // 5 (shipped): nontemporal matrix loads, four pairs in flight, 8 + 16 byte x gathers; 4: three 8-byte gathers; 0: plain loads, one pair per iteration
     double last_spmv_timed = 0;
     // host copies needed to build the coarse level
@@ -184,7 +195,29 @@ static void launch_gemv_f32(fcvm_ctx *c, const double *r2, double *e2, const dou
     hipLaunchKernelGGL(k_gemv_f32x4, dim3((unsigned)cdiv(c->n2, 16)), dim3(256), 0, c->stream, c->n2, c->n2, (c->n2 + 3) / 4 * 4,
                        c->d_A2invf, r2, e2, done);
 }
+template <bool DOT, int WAVES, bool V2>
+static void launch_spmv_win_t(fcvm_ctx *c, const double *x, double *y, const double *done) {
+    hipLaunchKernelGGL((k_spmv_win<DOT, WAVES, V2>), dim3((unsigned)c->win.ngroups), dim3(64 * WAVES), c->win_lds, c->stream,
+                       c->win.ngroups, c->win.wmax, c->d_w_gptr, c->d_w_gextra, c->d_w_wlist, c->d_w_woff, c->d_w_rowlen, c->d_w_rownode,
+                       c->d_w_seg, c->d_w_own, c->d_w_cols, c->d_w_vals, x, y, DOT ? c->d_part_spmv : (double *)nullptr, done);
+}
+static void launch_spmv_win(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done) {
+    if (c->win.waves == 4) {   // meshes whose 512-row windows do not fit the LDS: groups of 256 rows
+        if (dot) launch_spmv_win_t<true, 4, true>(c, x, y, done);
+        else launch_spmv_win_t<false, 4, true>(c, x, y, done);
+    } else if (c->win_v2) {
+        if (dot) launch_spmv_win_t<true, WIN_WAVES, true>(c, x, y, done);
+        else launch_spmv_win_t<false, WIN_WAVES, true>(c, x, y, done);
+    } else {
+        if (dot) launch_spmv_win_t<true, WIN_WAVES, false>(c, x, y, done);
+        else launch_spmv_win_t<false, WIN_WAVES, false>(c, x, y, done);
+    }
+}
 static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done) {
+    if (c->win_on) {   // window format: x through LDS (the p.Ap partials beyond the group count stay zero)
+        launch_spmv_win(c, dot, x, y, done);
+        return;
+    }
     if (dot) launch_spmv_t<true>(c, fine_view(c), x, y, c->d_part_spmv, done);
     else launch_spmv_t<false>(c, fine_view(c), x, y, nullptr, done);
 }
@@ -198,6 +231,71 @@ static int dot_common(fcvm_ctx *c, int64_t n, const double *w, const double *x, 
     return 0;
 }
 #include "fcvm_mg.inc"
+
+// Second storage of the fine matrix for the SpMV (WinPattern): built when every group's window fits the LDS twice per CU
+static int setup_window_format(fcvm_ctx *c, const double *nocoord) {
+    c->win_on = false;
+    if (!c->spmv_win || c->nn < 2048) return 0;
+    int nt = (int)std::thread::hardware_concurrency();
+    nt = std::min(std::max(nt, 1), 32);
+    int64_t max_window = 3200;   // 2 x 24 B x (3200 + partial-result slots) < 160 KB: two workgroups per CU
+    if (const char *v = getenv("FCVM_WIN_MAX")) max_window = std::max(64, atoi(v));   // (tests: force the smaller groups)
+    try {
+        bool built = build_window_format(c->pat, nocoord, nt, max_window, c->win, WIN_WAVES);
+        if (!built) {   // smaller groups have smaller windows (at the price of more x traffic from the L2)
+            const long long w8 = (long long)c->win.wmax;
+            c->win = WinPattern();
+            built = build_window_format(c->pat, nocoord, nt, max_window, c->win, 4);
+            if (getenv("FCVM_VERBOSE"))
+                fprintf(stderr, "fcvm: window format: largest window of 512-row groups %lld nodes, of 256-row groups %lld\n", w8, (long long)c->win.wmax);
+            if (built) c->win_v2 = 1;
+        }
+        if (!built) {
+            if (getenv("FCVM_VERBOSE")) fprintf(stderr, "fcvm: window format not used (largest window %lld nodes)\n", (long long)c->win.wmax);
+            c->win = WinPattern();
+            return 0;
+        }
+    } catch (const std::exception &ex) {
+        return fail(std::string("fcvm_set_mesh (window format): ") + ex.what());
+    }
+    const WinPattern &w = c->win;
+    const int64_t nrows = w.nwaves * SLICE;
+    if (dalloc(&c->d_w_gptr, w.ngroups + 1) || dalloc(&c->d_w_woff, w.nwaves + 1) || dalloc(&c->d_w_wlist, (int64_t)w.wlist.size()) ||
+        dalloc(&c->d_w_rownode, nrows) || dalloc(&c->d_w_srcslot, nrows) || dalloc(&c->d_w_rowlen, nrows) || dalloc(&c->d_w_own, nrows) ||
+        dalloc(&c->d_w_cols, w.nblocks) || dalloc(&c->d_w_vals, 9 * w.nblocks) || dalloc(&c->d_w_gextra, w.ngroups) ||
+        dalloc(&c->d_w_seg, nrows) || dalloc(&c->d_w_jstart, nrows))
+        return 1;
+    hipStream_t s = c->stream;
+    HCHK(hipMemcpyAsync(c->d_w_gptr, w.gptr.data(), sizeof(int64_t) * (w.ngroups + 1), hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_w_woff, w.woff.data(), sizeof(int64_t) * (w.nwaves + 1), hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_w_wlist, w.wlist.data(), sizeof(int32_t) * w.wlist.size(), hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_w_rownode, w.rownode.data(), sizeof(int32_t) * nrows, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_w_srcslot, w.srcslot.data(), sizeof(int32_t) * nrows, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_w_rowlen, w.rowlen.data(), sizeof(uint16_t) * nrows, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_w_own, w.own.data(), sizeof(uint16_t) * nrows, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_w_jstart, w.jstart.data(), sizeof(uint16_t) * nrows, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_w_seg, w.seg.data(), sizeof(uint32_t) * nrows, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_w_gextra, w.gextra.data(), sizeof(int32_t) * w.ngroups, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(c->d_w_cols, w.cols.data(), sizeof(uint16_t) * w.nblocks, hipMemcpyHostToDevice, s));
+    HCHK(hipMemsetAsync(c->d_w_vals, 0, sizeof(double) * 9 * w.nblocks, s));
+    HCHK(hipMemsetAsync(c->d_part_spmv, 0, sizeof(double) * c->nb_spmv, s));
+    HCHK(hipStreamSynchronize(s));
+    c->win_lds = sizeof(double) * 3 * (size_t)(w.wmax + w.xmax);
+    HCHK(hipFuncSetAttribute((const void *)k_spmv_win<true, WIN_WAVES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->win_lds));
+    HCHK(hipFuncSetAttribute((const void *)k_spmv_win<false, WIN_WAVES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->win_lds));
+    HCHK(hipFuncSetAttribute((const void *)k_spmv_win<true, WIN_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->win_lds));
+    HCHK(hipFuncSetAttribute((const void *)k_spmv_win<false, WIN_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->win_lds));
+    HCHK(hipFuncSetAttribute((const void *)k_spmv_win<true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->win_lds));
+    HCHK(hipFuncSetAttribute((const void *)k_spmv_win<false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->win_lds));
+    // the host copies are not needed again
+    c->win.wlist.clear(); c->win.wlist.shrink_to_fit();
+    c->win.cols.clear(); c->win.cols.shrink_to_fit();
+    c->win_on = true;
+    if (getenv("FCVM_VERBOSE"))
+        fprintf(stderr, "fcvm: window format: %lld groups, windows mean %.0f / max %lld nodes (%zu B LDS), %lld blocks\n", (long long)w.ngroups,
+                w.wmean, (long long)w.wmax, c->win_lds, (long long)w.nblocks);
+    return 0;
+}
 
 // The same SpMV on the same GPU runs at 0.51 or at 0.59 ms depending on which physical pages hipMalloc handed out for the
 // value array (measured: several model instances in one process, tools/alloc_probe.py; the x / y vectors do not matter).
@@ -381,6 +479,8 @@ int fcvm_create(int device, fcvm_ctx **out) {
     fcvm_ctx *c = new fcvm_ctx();
     c->device = device;
     if (const char *v = getenv("FCVM_SPMV_VARIANT")) c->spmv_variant = atoi(v);
+    if (const char *v = getenv("FCVM_SPMV_WIN")) c->spmv_win = atoi(v);
+    if (const char *v = getenv("FCVM_WIN_V2")) c->win_v2 = atoi(v) != 0;
     if (const char *v = getenv("FCVM_ASSEMBLE_LDS")) c->assemble_lds = atoi(v);
     if (const char *v = getenv("FCVM_ASSEMBLE_OVERLAP")) c->asm_overlap = atoi(v);
     if (const char *v = getenv("FCVM_QIN_ATOMIC")) c->qin_atomic = atoi(v);
@@ -399,6 +499,10 @@ static void free_mesh(fcvm_ctx *c) {
     dfree(c->d_el); dfree(c->d_cols); dfree(c->d_rownode); dfree(c->d_noce); dfree(c->d_sptr);
     dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
     dfree(c->d_nptr); dfree(c->d_nel); dfree(c->d_fe); dfree(c->d_part_vol); dfree(c->d_asm_items);
+    dfree(c->d_w_gptr); dfree(c->d_w_woff); dfree(c->d_w_wlist); dfree(c->d_w_rownode); dfree(c->d_w_srcslot); dfree(c->d_w_rowlen);
+    dfree(c->d_w_own); dfree(c->d_w_cols); dfree(c->d_w_vals); dfree(c->d_w_gextra); dfree(c->d_w_seg); dfree(c->d_w_jstart);
+    c->win_on = false;
+    c->win = WinPattern();
     dfree(c->d_vals); dfree(c->d_vals_g); dfree(c->d_dblk); dfree(c->d_dinv); dfree(c->d_r); dfree(c->d_z); dfree(c->d_p);
     dfree(c->d_q); dfree(c->d_part_vec); dfree(c->d_part_spmv); dfree(c->d_part_misc); dfree(c->d_pidx);
     mg_free(c);
@@ -484,7 +588,9 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
         int mode = -1;  // auto
         if (const char *v = getenv("FCVM_ROW_ORDER")) mode = atoi(v);
         c->row_spread = numbering_spread(ne, nn, el.data(), 10);
-        const bool use_morton = mode == 1 || (mode < 0 && nn > 4096 && c->row_spread > 0.05);
+        // with the window format the sliced-ELL rows follow the same Morton curve: k_repack_win then copies between two
+        // layouts whose neighbourhoods coincide (its scattered 8-byte reads are absorbed by the L2 instead of going to HBM)
+        const bool use_morton = mode == 1 || (mode < 0 && nn > 4096 && (c->row_spread > 0.05 || c->spmv_win));
         std::vector<int32_t> order;
         if (use_morton) order = morton_order(nn, nocoord);
         c->row_order_morton = use_morton;
@@ -531,7 +637,8 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     c->ne = ne;
     c->nn = nn;
     if (build_asm_items(c)) return 1;
-    if (tune_matrix_placement(c)) return 1;
+    if (setup_window_format(c, nocoord)) return 1;
+    if (!c->win_on && tune_matrix_placement(c)) return 1;
     // the element->slot map is only needed on the device from here on
     c->pat.emap.clear();
     c->pat.emap.shrink_to_fit();
@@ -583,6 +690,19 @@ int fcvm_pattern_info(fcvm_ctx *c, int64_t out[8]) {
     return 0;
 }
 
+int fcvm_spmv_info(fcvm_ctx *c, int64_t out[8]) {
+    NEED(c && c->have_mesh, "fcvm_spmv_info: no mesh");
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    out[0] = c->win_on ? c->win.waves : 0;
+    if (!c->win_on) return 0;
+    const WinPattern &w = c->win;
+    out[1] = w.ngroups; out[2] = w.wmax; out[3] = (int64_t)(w.wmean + 0.5); out[4] = w.nblocks;
+    // bytes one launch streams from this format: values, 16-bit columns, window lists, per-vrow tables
+    out[5] = w.nblocks * 74 + w.gptr[w.ngroups] * 4 + w.nwaves * SLICE * 16 + (w.nwaves + w.ngroups) * 8;
+    out[6] = (int64_t)c->win_lds; out[7] = WIN_SPLIT;
+    return 0;
+}
+
 int fcvm_matrix_to_coo(fcvm_ctx *c, int64_t *row, int64_t *col, double *val) {
     NEED(c && c->have_mesh, "fcvm_matrix_to_coo: no mesh");
     const Pattern &p = c->pat;
@@ -605,7 +725,12 @@ int fcvm_matrix_to_coo(fcvm_ctx *c, int64_t *row, int64_t *col, double *val) {
     return 0;
 }
 
-static int refresh_precond(fcvm_ctx *c) {
+static int refresh_precond(fcvm_ctx *c) {   // after every assembly into d_vals
+    if (c->win_on) {
+        const int64_t nrows = c->win.nwaves * SLICE;
+        hipLaunchKernelGGL(k_repack_win, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, c->stream, nrows, c->d_w_srcslot, c->d_w_rowlen,
+                           c->d_w_jstart, c->d_w_woff, c->d_sptr, c->d_vals, c->d_w_vals, c->win_v2);
+    }
     hipLaunchKernelGGL(k_diag_get, dim3(cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_diagoff, c->d_vals, c->d_dblk);
     hipLaunchKernelGGL(k_diag_invert, dim3(cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_dblk, c->d_dinv);
     HCHK(hipGetLastError());
@@ -902,6 +1027,78 @@ int fcvm_vec_max_node_norm(fcvm_ctx *c, int64_t nnodes, const double *u, double 
     return 0;
 }
 
+int fcvm_host_window_check(int64_t ne, int64_t nn, const int64_t *elNodes, const double *nocoord, int64_t max_window, int64_t out[8]) {
+    // host-only (no GPU needed): sliced-ELL pattern + window format of the same matrix, and the invariants the kernels rely on
+    NEED(ne > 0 && nn > 0 && elNodes && nocoord, "fcvm_host_window_check: empty mesh");
+    std::vector<int32_t> el(ne * 10);
+    for (int64_t i = 0; i < ne * 10; i++) {
+        int64_t v = elNodes[i] - 1;
+        NEED(v >= 0 && v < nn, "fcvm_host_window_check: element node number out of range");
+        el[i] = (int32_t)v;
+    }
+    Pattern p;
+    WinPattern w;
+    bool built = false;
+    try {
+        build_pattern(ne, nn, el.data(), p, 4, SORT_WINDOW);
+        built = build_window_format(p, nocoord, 4, max_window > 0 ? max_window : 65535, w);
+    } catch (const std::exception &ex) {
+        return fail(std::string("fcvm_host_window_check: ") + ex.what());
+    }
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    out[0] = built ? 1 : 0; out[2] = w.wmax;
+    if (!built) return 0;
+    int64_t bad = 0, rows = 0, blocks = 0;
+    std::vector<int64_t> covered(nn, 0);     // blocks of a node's row covered by its segments
+    std::vector<uint8_t> firsts(nn, 0);
+    for (int64_t wave = 0; wave < w.nwaves; wave++) {
+        const int64_t g = wave / w.waves;
+        const int32_t *wl = &w.wlist[w.gptr[g]];
+        const int64_t W = w.gptr[g + 1] - w.gptr[g];
+        const uint16_t *len = &w.rowlen[wave * SLICE];
+        for (int l = 0; l < SLICE; l++) {
+            const int64_t at = wave * SLICE + l;
+            const int32_t nd = w.rownode[at];
+            if (l > 0 && len[l] > len[l - 1]) bad++;                         // lanes sorted by length: prefixes
+            if (nd < 0) { if (len[l]) bad++; continue; }
+            rows++;
+            const int nseg = (int)(w.seg[at] & 255u);
+            const int64_t rl = p.rowptr[nd + 1] - p.rowptr[nd];
+            if (len[l] > WIN_SPLIT || w.jstart[at] + len[l] > rl) bad++;
+            if (nseg > 0) {                                                   // first segment: exactly one per node
+                if (firsts[nd]++) bad++;
+                if (w.jstart[at] != 0 || nseg != std::max<int64_t>(1, (rl + WIN_SPLIT - 1) / WIN_SPLIT)) bad++;
+                if ((int64_t)(w.seg[at] >> 8) + nseg - 1 > w.gextra[g]) bad++;
+            } else if ((int64_t)(w.seg[at] >> 8) >= w.gextra[g]) bad++;
+            covered[nd] += len[l];
+            if (w.srcslot[at] != p.slotof[nd]) bad++;
+            if (w.own[at] >= W || wl[w.own[at]] != nd) bad++;
+        }
+        int64_t off = w.woff[wave];
+        for (int64_t j = 0; j < len[0]; j++) {
+            int64_t n = 0;
+            while (n < SLICE && len[n] > j) n++;
+            for (int64_t l = 0; l < n; l++) {
+                const int64_t at = wave * SLICE + l;
+                const int32_t nd = w.rownode[at];
+                const uint16_t cidx = w.cols[off + l];
+                if (cidx >= W || wl[cidx] != p.colidx[p.rowptr[nd] + w.jstart[at] + j]) bad++;   // its column through the window
+            }
+            off += n;
+            blocks += n;
+        }
+        if (off > w.woff[wave + 1] || w.woff[wave + 1] - off >= 16 || w.woff[wave] % 16) bad++;   // waves start on 128-byte lines
+    }
+    for (int64_t i = 0; i < nn; i++)
+        if (firsts[i] != 1 || covered[i] != p.rowptr[i + 1] - p.rowptr[i]) bad++;   // every block of every row exactly once
+    for (int64_t g = 0; g < w.ngroups; g++)
+        for (int64_t i = w.gptr[g] + 1; i < w.gptr[g + 1]; i++)
+            if (w.wlist[i] <= w.wlist[i - 1]) bad++;                          // ascending, unique
+    if (rows < nn || blocks != p.nnzb || w.nblocks < p.nnzb || w.nblocks >= p.nnzb + 16 * w.nwaves) bad++;
+    out[1] = w.ngroups; out[3] = (int64_t)(w.wmean + 0.5); out[4] = bad; out[5] = w.nblocks; out[6] = p.nnzb; out[7] = p.nslots;
+    return 0;
+}
+
 int fcvm_host_pattern_check(int64_t ne, int64_t nn, const int64_t *elNodes, int64_t out[8]) {
     // host-only (no GPU needed): builds the sliced-ELL pattern and verifies its invariants
     NEED(ne > 0 && nn > 0 && elNodes, "fcvm_host_pattern_check: empty mesh");
@@ -962,6 +1159,9 @@ int fcvm_membench(fcvm_ctx *c, int64_t nbytes, double out[2]) {
     HCHK(hipEventElapsedTime(&ms, e0, e1));
     out[0] = (double)n2 * 16.0 / (ms / 10.0 * 1e-3) / 1e9;   // GB/s read
     out[1] = ms / 10.0;
+    // the same bytes with 8 B per lane (not timed into out[]: a known byte count for counter calibration, tools/pmc_summary.py)
+    for (int k = 0; k < 3; k++) hipLaunchKernelGGL(k_stream_read8, dim3(grid), dim3(256), 0, s, 2 * n2, (const double *)buf, sink);
+    HCHK(hipStreamSynchronize(s));
     HCHK(hipEventDestroy(e0));
     HCHK(hipEventDestroy(e1));
     dfree(buf);

@@ -1078,6 +1078,13 @@ __global__ __launch_bounds__(256) void k_stream_read(int64_t n2, const double2 *
     if (s == 1.2345e300) out[0] = s;   // never true: keeps the loads alive
 }
 
+// the same with 8 B per lane (the load width of the window-format SpMV): calibrates the FETCH_SIZE counter for that width
+__global__ __launch_bounds__(256) void k_stream_read8(int64_t n, const double *__restrict__ a, double *__restrict__ out) {
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += __builtin_nontemporal_load(a + i);
+    if (s == 1.2345e300) out[0] = s;
+}
+
 // geometric stiffness of calcTSM(nstep = 1), fcVM.py:1002-1006: Kg_ab = (sum_gp w ga . sigma . gb) I3, scattered into a
 // second value array that shares the pattern of the stiffness matrix.  One lane per matrix row walking its elements
 // (as k_assemble_rows: plain read-modify-writes in a fixed order, no atomics).

@@ -191,4 +191,117 @@ double numbering_spread(int64_t ne, int64_t nn, const int32_t *el, int npe) {
     return ne > 0 && nn > 0 ? s / (double)ne / (double)nn : 0.0;
 }
 
+bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int64_t max_window, WinPattern &w, int waves) {
+    const int64_t nn = p.nn, WV = waves, R = WV * SLICE;
+    w.waves = waves;
+    if (p.maxlen > 65535) return false;
+    std::vector<int32_t> order = morton_order(nn, xyz);
+    auto nseg_of = [&](int32_t nd) { return (int)((p.rowptr[nd + 1] - p.rowptr[nd] + WIN_SPLIT - 1) / WIN_SPLIT); };
+    // groups: consecutive nodes of the Morton order while their vrows fit
+    std::vector<int64_t> gfirst{0};
+    {
+        int64_t used = 0;
+        for (int64_t i = 0; i < nn; i++) {
+            const int k = std::max(1, nseg_of(order[i]));
+            if (used + k > R) { gfirst.push_back(i); used = 0; }
+            used += k;
+        }
+        gfirst.push_back(nn);
+    }
+    const int64_t ng = (int64_t)gfirst.size() - 1;
+    w.ngroups = ng;
+    w.nwaves = ng * WV;
+    w.rownode.assign(w.nwaves * SLICE, -1);
+    w.srcslot.assign(w.nwaves * SLICE, 0);
+    w.rowlen.assign(w.nwaves * SLICE, 0);
+    w.jstart.assign(w.nwaves * SLICE, 0);
+    w.seg.assign(w.nwaves * SLICE, 1);
+    w.own.assign(w.nwaves * SLICE, 0);
+    w.woff.assign(w.nwaves + 1, 0);
+    w.gptr.assign(ng + 1, 0);
+    w.gextra.assign(ng, 0);
+    struct VRow { int64_t len; int32_t nd; int32_t j0; uint32_t seg; };
+    // pass 1: vrows of every group sorted by length, dealt round-robin to the waves; window sizes; entries per wave
+    std::vector<std::vector<int32_t>> win(ng);
+    parallel_for(ng, nthreads, [&](int64_t b, int64_t e, int) {
+        std::vector<VRow> rows;
+        for (int64_t g = b; g < e; g++) {
+            rows.clear();
+            auto &wl = win[g];
+            int32_t extra = 0;
+            for (int64_t i = gfirst[g]; i < gfirst[g + 1]; i++) {
+                const int32_t nd = order[i];
+                const int64_t len = p.rowptr[nd + 1] - p.rowptr[nd];
+                const int k = std::max(1, nseg_of(nd));
+                int64_t j0 = 0;
+                for (int t = 0; t < k; t++) {       // equal segments: len = q * k + rem, the first rem segments one longer
+                    const int64_t l = len / k + (t < len % k ? 1 : 0);
+                    const uint32_t code = t == 0 ? ((uint32_t)extra << 8) | (uint32_t)k : ((uint32_t)(extra + t - 1) << 8);
+                    rows.push_back({l, nd, (int32_t)j0, code});
+                    j0 += l;
+                }
+                extra += k - 1;
+                wl.insert(wl.end(), p.colidx.begin() + p.rowptr[nd], p.colidx.begin() + p.rowptr[nd + 1]);
+            }
+            w.gextra[g] = extra;
+            std::stable_sort(rows.begin(), rows.end(), [](const VRow &x, const VRow &y) { return x.len > y.len; });
+            for (size_t k = 0; k < rows.size(); k++) {
+                const int64_t wave = g * WV + (int64_t)k % WV, lane = (int64_t)k / WV;
+                const int64_t at = wave * SLICE + lane;
+                w.rownode[at] = rows[k].nd;
+                w.srcslot[at] = p.slotof[rows[k].nd];
+                w.rowlen[at] = (uint16_t)rows[k].len;
+                w.jstart[at] = (uint16_t)rows[k].j0;
+                w.seg[at] = rows[k].seg;
+                w.woff[wave + 1] += rows[k].len;
+            }
+            std::sort(wl.begin(), wl.end());
+            wl.erase(std::unique(wl.begin(), wl.end()), wl.end());
+            wl.shrink_to_fit();
+            w.gptr[g + 1] = (int64_t)wl.size();
+        }
+    });
+    w.wmax = 0;
+    w.xmax = 0;
+    for (int64_t g = 0; g < ng; g++) {
+        w.wmax = std::max(w.wmax, w.gptr[g + 1]);
+        w.xmax = std::max<int64_t>(w.xmax, w.gextra[g]);
+        w.gptr[g + 1] += w.gptr[g];
+    }
+    w.wmean = (double)w.gptr[ng] / (double)ng;
+    if (w.wmax > max_window || w.wmax > 65535 || w.xmax >= (1 << 24)) return false;
+    // every wave starts on a 128-byte line of the value array (9 * 16 entries * 8 B = 9 lines): its full block rows
+    // (64 lanes: 36 lines) stay aligned; costs < 16 entries per wave
+    for (int64_t i = 0; i < w.nwaves; i++) w.woff[i + 1] = (w.woff[i + 1] + 15) / 16 * 16 + w.woff[i];
+    w.nblocks = w.woff[w.nwaves];
+    w.wlist.resize(w.gptr[ng]);
+    w.cols.assign(w.nblocks, 0);
+    // pass 2: window lists, 16-bit columns in the prefix layout
+    parallel_for(ng, nthreads, [&](int64_t b, int64_t e, int) {
+        for (int64_t g = b; g < e; g++) {
+            const auto &wl = win[g];
+            std::copy(wl.begin(), wl.end(), w.wlist.begin() + w.gptr[g]);
+            for (int64_t wave = g * WV; wave < (g + 1) * WV; wave++) {
+                const uint16_t *len = &w.rowlen[wave * SLICE];
+                int64_t off = w.woff[wave];
+                for (int64_t j = 0; j < len[0]; j++) {     // lane 0 holds the longest vrow of the wave
+                    int64_t n = 0;
+                    while (n < SLICE && len[n] > j) n++;   // lanes sorted by length: a prefix
+                    for (int64_t l = 0; l < n; l++) {
+                        const int32_t nd = w.rownode[wave * SLICE + l];
+                        const int32_t col = p.colidx[p.rowptr[nd] + w.jstart[wave * SLICE + l] + j];
+                        w.cols[off + l] = (uint16_t)(std::lower_bound(wl.begin(), wl.end(), col) - wl.begin());
+                    }
+                    off += n;
+                }
+                for (int64_t l = 0; l < SLICE; l++) {
+                    const int32_t nd = w.rownode[wave * SLICE + l];
+                    if (nd >= 0) w.own[wave * SLICE + l] = (uint16_t)(std::lower_bound(wl.begin(), wl.end(), nd) - wl.begin());
+                }
+            }
+        }
+    });
+    return true;
+}
+
 }  // namespace fcvm

@@ -65,6 +65,50 @@ struct Pattern {
 void build_pattern(int64_t ne, int64_t nn, const int32_t *elnodes0, Pattern &p, int nthreads,
                    int sort_window = SORT_WINDOW, int npe = 10, const int32_t *row_order = nullptr);
 
+// ---------------------------------------------------------------------------------------------------------------
+// Second storage of the same matrix for the SpMV alone ("window format", round 2).  The sliced-ELL layout above is what
+// the assembly kernels write; its SpMV gathers x from global memory, 64 scattered addresses per instruction, and those
+// gathers keep the address pipeline busy (DESIGN.md "SpMV").  Here
+//   * rows are taken along a Morton curve; a row longer than WIN_SPLIT blocks is cut into equal SEGMENTS of at most
+//     WIN_SPLIT blocks (the corner nodes of tet10 meshes couple to 65 nodes, the others to 19-27: without the cut a wave
+//     would spend most of its time on a few long rows); rows and segments -- "vrows" -- are collected into GROUPS of at
+//     most WIN_WAVES * 64 vrows (one workgroup; the segments of a row stay in one group);
+//   * the union of the column nodes of a group -- its WINDOW, a compact patch of the mesh -- is listed once; the workgroup
+//     copies x of the window into LDS with near-coalesced loads and every block's x comes from LDS;
+//   * column entries are 16-bit positions in the window;
+//   * the vrows of a group are sorted by length (longest first) and dealt to the waves round-robin, so every wave holds
+//     vrows of all lengths, longest in lane 0: for block number j the lanes that still have a block are a PREFIX of the
+//     wave, n_j of them, and only those are stored (no padding at all): entry (j, lane) of wave w is number
+//     woff[w] + sum_{i<j} n_i + lane, its nine values are vals[9 * (woff[w] + sum_{i<j} n_i) + c * n_j + lane];
+//   * the partial results of the second, third .. segment of a row go through LDS to the lane of its first segment, which
+//     adds them in segment order (fixed order: bitwise reproducible) and writes y.
+// The values are copied from the sliced-ELL array by k_repack_win after every assembly (src: SELL slot of the row; both
+// layouts keep a row's blocks in ascending column order, so block j of a segment is block jstart + j of the row).
+constexpr int WIN_WAVES = 8;      // waves per group (default; WinPattern::waves holds the value a pattern was built with)
+constexpr int WIN_SPLIT = 32;
+struct WinPattern {
+    int64_t ngroups = 0, nwaves = 0, nblocks = 0;
+    int waves = WIN_WAVES;            // waves (of 64 vrows) per group
+    int64_t wmax = 0;                 // largest window (nodes)
+    int64_t xmax = 0;                 // most second-and-later segments in one group (LDS slots for their partial results)
+    double wmean = 0.0;
+    std::vector<int32_t> rownode;     // [nwaves*64] node of (wave, lane), -1 = no vrow
+    std::vector<int32_t> srcslot;     // [nwaves*64] SELL slot (slice*64+lane) of that node
+    std::vector<uint16_t> rowlen;     // [nwaves*64] blocks of the vrow (0 for empty lanes)
+    std::vector<uint16_t> jstart;     // [nwaves*64] first block of the segment within its row
+    std::vector<uint32_t> seg;        // [nwaves*64] LDS slot << 8 | segments: segments = 1 ordinary row; > 1: first segment of a
+                                      // split row, adds the partials in slots slot .. slot + segments - 2; 0: later segment,
+                                      // writes its partial to slot
+    std::vector<uint16_t> own;        // [nwaves*64] window position of the row's own node
+    std::vector<int64_t> woff;        // [nwaves+1] first entry of a wave
+    std::vector<int64_t> gptr;        // [ngroups+1] first window entry of a group
+    std::vector<int32_t> gextra;      // [ngroups] later segments in the group
+    std::vector<int32_t> wlist;       // [gptr[ngroups]] window nodes, ascending per group
+    std::vector<uint16_t> cols;       // [nblocks] window position of the column node of an entry
+};
+// false: the mesh does not suit the format (a window larger than max_window nodes)
+bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int64_t max_window, WinPattern &w, int waves = WIN_WAVES);
+
 // nodes sorted along a Morton (Z-order) curve through their coordinates: a locality-preserving order in which
 // the SpMV walks the rows when the caller's node numbering has none (unstructured meshes)
 std::vector<int32_t> morton_order(int64_t nn, const double *xyz);

@@ -163,6 +163,12 @@ class Context:
         return dict(nnz_blocks=out[0], padded_slots=out[1], slices=out[2], matrix_bytes=out[3],
                     max_row_blocks=out[4], ndof=out[5], spmv_variant=out[7])
 
+    def spmv_info(self):
+        out = (C.c_int64 * 8)()
+        call("fcvm_spmv_info", self.h, out)
+        return dict(window_format=bool(out[0]), waves_per_group=out[0], groups=out[1], max_window=out[2], mean_window=out[3], blocks=out[4],
+                    bytes=out[5], lds_bytes=out[6], split=out[7])
+
     def matrix_coo(self):
         nnz = 9 * self.pattern_info()["nnz_blocks"]
         r, c, v = np.empty(nnz, np.int64), np.empty(nnz, np.int64), np.empty(nnz, np.float64)

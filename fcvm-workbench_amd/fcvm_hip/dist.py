@@ -265,8 +265,9 @@ class DistBackend:
 
     def set_coords(self, nocoord_local):
         self.ops.set_coords(nocoord_local)
-        if self.mg is not None:
+        if self.mg is not None:   # the library rebuilds its hierarchy for the new geometry: so does the distributed cycle
             self.mg.xyz = np.ascontiguousarray(nocoord_local, dtype=np.float64)
+            self.mg.topo, self.mg.nagg, self.mg.ready = False, 0, False
 
     def global_extreme(self, v):
         """(max |v|, sign of that entry) over all ranks; ties go to the lowest global dof like numpy's argmax"""

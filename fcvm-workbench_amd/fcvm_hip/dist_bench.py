@@ -53,6 +53,8 @@ def run(args, ctl, material, traction, rtol, hbm_peak, cpu_baseline):
         faulthandler.dump_traceback_later(float(os.environ["FCVM_DIST_DEBUG"]), repeat=True)
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     share_gpu = os.environ.get("FCVM_DIST_SHARE_GPU") == "1"  # rehearsal: all ranks on GPU 0 over gloo
+    if share_gpu:   # several processes on one GPU: one hardware queue each, or the scheduler time-slices them (see tests/conftest.py)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "1")
     dev_index = 0 if share_gpu else local
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)

@@ -62,6 +62,12 @@ int fcvm_set_coords(fcvm_ctx *c, const double *nocoord);
  * out[3]=matrix bytes (values+cols), out[4]=max row length, out[5]=ndof, out[6]=1 (reserved),
  * out[7]=SpMV kernel variant */
 int fcvm_pattern_info(fcvm_ctx *c, int64_t out[8]);
+/* which kernel fcvm_spmv / the PCG iteration use for the fine matrix: out[0]=8 or 4: the window format with groups of that
+ * many 64-row waves (second storage of the
+ * matrix for the SpMV, csrc/fcvm_spmv_win.hip.h; FCVM_SPMV_WIN=0 or a mesh whose windows do not fit the LDS: 0 = the
+ * sliced-ELL kernel), out[1]=groups (workgroups), out[2]=largest window in nodes, out[3]=mean window, out[4]=stored blocks,
+ * out[5]=bytes streamed per launch from that storage, out[6]=LDS bytes per workgroup, out[7]=row split length */
+int fcvm_spmv_info(fcvm_ctx *c, int64_t out[8]);
 /* host copy of the assembled matrix as scalar COO (row, col, val) of the FULL symmetric matrix,
  * nnz = 9 * nnz blocks; for tests.  Arrays must hold 9*out[0] entries. */
 int fcvm_matrix_to_coo(fcvm_ctx *c, int64_t *row, int64_t *col, double *val);
@@ -214,6 +220,13 @@ int fcvm_membench(fcvm_ctx *c, int64_t nbytes, double out[2]);
  * out[1]=padded slots, out[2]=slices, out[3]=max row length, out[4]=number of violated invariants
  * (must be 0), out[5]=value count, out[6]=sum of slice lengths */
 int fcvm_host_pattern_check(int64_t ne, int64_t nn, const int64_t *elNodes, int64_t out[8]);
+
+/* host-only self check of the SpMV's window format (second storage of the fine matrix: groups of 512 rows along a Morton
+ * curve, x of a group's column nodes staged in LDS, 16-bit window columns, padding-free prefix storage; csrc/fcvm_pattern.h).
+ * nocoord [nn*3]; max_window: largest admissible window in nodes (0: 65535).  out[0]=1 if the format was built (0: some
+ * window is too large, the sliced-ELL kernel would be used), out[1]=groups, out[2]=largest window, out[3]=mean window,
+ * out[4]=number of violated invariants (must be 0), out[5]=stored blocks, out[6]=nnz blocks, out[7]=sliced-ELL slots */
+int fcvm_host_window_check(int64_t ne, int64_t nn, const int64_t *elNodes, const double *nocoord, int64_t max_window, int64_t out[8]);
 
 /*
  * Fine-grained multigrid building blocks (levels 0 = tet10 matrix, 1 = tet4 matrix) for a V-cycle

@@ -54,3 +54,21 @@ def small_case(n=3, prescribed=True):
             case["fix"][3 * int(nd)] = -0.002
     case["material"] = np.array([210000.0, 0.3, 7.8e-6])
     return case
+
+
+def spawn_sharing_gpu(fn, args, nprocs):
+    """mp.spawn of `nprocs` ranks that all use GPU 0 (gloo control plane).  Every HIP process opens up to four hardware
+    queues by default; from three processes on the hardware scheduler time-slices them and every host<->device
+    synchronisation of the host-staged exchange costs milliseconds (measured: a 136-iteration solve on three ranks 9.1 s,
+    1.5 s with one queue per process; profiles/r02q_three_ranks_hw_queues.txt).  One queue per rank for the rehearsal."""
+    import os
+    import torch.multiprocessing as mp
+    old = os.environ.get("GPU_MAX_HW_QUEUES")
+    os.environ["GPU_MAX_HW_QUEUES"] = "1"
+    try:
+        mp.spawn(fn, args=args, nprocs=nprocs, join=True)
+    finally:
+        if old is None:
+            del os.environ["GPU_MAX_HW_QUEUES"]
+        else:
+            os.environ["GPU_MAX_HW_QUEUES"] = old

@@ -14,6 +14,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import spawn_sharing_gpu  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -150,7 +152,7 @@ def test_config3_embankment_337k_element_partition_matches_one_rank(tmp_path, wo
     nstep = 3
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "r.pt")
-    mp.spawn(_worker_emb337, args=(world, port, out, nstep), nprocs=world, join=True)
+    spawn_sharing_gpu(_worker_emb337, (world, port, out, nstep), world)
     got = torch.load(out, weights_only=False)
     _, m, ref, _, _ = _embankment_run(3, nstep=nstep)
     m.ctx.close()

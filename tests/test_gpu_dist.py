@@ -9,6 +9,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from conftest import spawn_sharing_gpu  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 CELLS = 4
@@ -45,7 +47,7 @@ def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, precond):
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "r.pt")
-    mp.spawn(_worker, args=(2, port, out, precond), nprocs=2, join=True)
+    spawn_sharing_gpu(_worker, (2, port, out, precond), 2)
     got = torch.load(out, weights_only=False)
     from fcvm_hip import meshgen
     from fcvm_hip.loads import Loads
@@ -115,7 +117,7 @@ def test_three_ranks_unstructured_partition(tmp_path):
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "r.pt")
-    mp.spawn(_worker_emb, args=(3, port, out), nprocs=3, join=True)
+    spawn_sharing_gpu(_worker_emb, (3, port, out), 3)
     got = torch.load(out, weights_only=False)
     from fcvm_hip import examples
     from fcvm_hip.loads import Loads
@@ -176,7 +178,7 @@ def test_gnly_buckling_preanalysis_on_a_partitioned_model(tmp_path):
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "r.pt")
-    mp.spawn(_worker_buckling, args=(3, port, out), nprocs=3, join=True)
+    spawn_sharing_gpu(_worker_buckling, (3, port, out), 3)
     got = torch.load(out, weights_only=False)
     from fcvm_hip.solver import run_analysis
     el, xyz, mat, fix, loads = _column()

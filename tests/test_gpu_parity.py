@@ -210,6 +210,54 @@ def test_both_preconditioners_solve_the_embankment_system(embankment, mode):
         assert info["iterations"] < 200 and c.precond_info()["coarse_nodes"] > 0
 
 
+def test_window_format_spmv_and_pcg_match_sliced_ell(monkeypatch):
+    """The SpMV's second storage of the fine matrix (window format: Morton groups, x of a group's column nodes in LDS,
+    16-bit window columns, prefix storage without padding, long rows cut into segments) against the sliced-ELL kernel and
+    against scipy on the matrix read back from the device -- unstructured mesh (Embankment refined twice) and a cube whose
+    corner-node rows (65 blocks) are split in three; then the PCG solve, whose p.Ap comes from the kernel's own partials."""
+    from fcvm_hip import examples, meshgen
+    from fcvm_hip.device import Context
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import GpuModel
+    emb = examples.embankment(refine=2)
+    cube = meshgen.cube_case(12, l=10.0, traction=(0.0, 0.0, 1.0))
+    cube["material"] = (210000.0, 0.3, 7.8e-6)
+    for case, grav in ((emb, (0.0, 0.0, -10.0)), (cube, (0.0, 0.0, 0.0))):
+        models = {}
+        for win in ("1", "0", "small"):     # "small": a window limit that only groups of 4 waves (256 rows) meet
+            monkeypatch.setenv("FCVM_SPMV_WIN", "0" if win == "0" else "1")
+            if win == "small":
+                monkeypatch.setenv("FCVM_WIN_MAX", str(models["1"].ctx.spmv_info()["max_window"] - 1))
+            m = GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"], Loads(), ctx=Context(0))
+            assert m.ctx.spmv_info()["waves_per_group"] == {"1": 8, "0": 0, "small": 4}[win]
+            models[win] = m
+        monkeypatch.delenv("FCVM_SPMV_WIN")
+        monkeypatch.delenv("FCVM_WIN_MAX")
+        mw, ms = models["1"], models["0"]
+        info = mw.ctx.spmv_info()
+        assert mw.ctx.pattern_info()["nnz_blocks"] <= info["blocks"] < mw.ctx.pattern_info()["padded_slots"] and 0 < info["max_window"] <= 3200
+        x = np.random.default_rng(3).standard_normal(mw.ndof)
+        out = {}
+        for k, m in models.items():
+            glv, modf, _, _ = m.calc_gsm(grav, want_x=False)
+            out[k] = (m.ctx.spmv(m.ctx.array(x), m.ctx.empty(m.ndof)).get(), glv, modf)
+        K = gpu_matrix(ms)
+        assert rel(out["0"][0], K @ x) < 1e-13 and rel(out["1"][0], K @ x) < 1e-13
+        assert rel(out["1"][0], out["0"][0]) < 1e-14 and rel(out["small"][0], out["0"][0]) < 1e-14
+        sols = {}
+        for k, m in models.items():
+            c = m.ctx
+            f = c.mul(m.fixdof, out[k][1]) if np.abs(out[k][1].get()).max() > 0 else c.array(m.fixdof_h * x)
+            u, it = c.solve(f, rtol=1e-12)
+            r = c.axpby(1.0, f, -1.0, c.spmv(u, c.empty(m.ndof)))
+            assert c.norm(r) <= 5e-12 * c.norm(f)
+            sols[k] = (u.get(), it["iterations"])
+        assert rel(sols["1"][0], sols["0"][0]) < 1e-9 and rel(sols["small"][0], sols["0"][0]) < 1e-9
+        assert abs(sols["1"][1] - sols["0"][1]) <= 2          # same Krylov iteration, different summation order
+        for m in models.values():
+            m.ctx.close()
+
+
 def test_dense_spd_inverse_kernels(gpu_ctx):
     """fcvm_spd_inverse (blocked Cholesky, triangular inverse, X^T X in HIP kernels: the aggregate level's solver) against
     LAPACK, sizes around the 64-wide tiles."""

@@ -40,6 +40,25 @@ def test_pattern_builder_invariants():
         assert out[3] == np.diff(A.indptr).max()
 
 
+def test_window_format_invariants():
+    """the SpMV's second storage (groups of 512 rows along a Morton curve, LDS windows, prefix storage without padding)
+    on a structured and an unstructured mesh: every block once, columns reachable through the window, lanes sorted by length"""
+    from fcvm_hip import _lib, examples, meshgen
+    el, xyz = meshgen.cube_tet10(9, 8, 10)
+    emb = examples.embankment(refine=1)
+    for e, x in ((el, xyz), (emb["elNodes"], emb["nocoord"])):
+        e, x = np.ascontiguousarray(e, np.int64), np.ascontiguousarray(x, np.float64)
+        out = (C.c_int64 * 8)()
+        _lib.call("fcvm_host_window_check", len(e), len(x), e.ctypes.data, x.ctypes.data, 0, out)
+        assert out[0] == 1 and out[4] == 0, list(out)
+        assert out[6] <= out[5] < out[7]                 # stored entries: the blocks + < 16 per wave of alignment, fewer than sliced-ELL slots
+        assert out[1] >= -(-len(x) // 512) and 0 < out[3] <= out[2] < 3400
+        # a window limit below the largest window: the format is declined (the sliced-ELL kernel stays in charge)
+        small = (C.c_int64 * 8)()
+        _lib.call("fcvm_host_window_check", len(e), len(x), e.ctypes.data, x.ctypes.data, int(out[2]) - 1, small)
+        assert small[0] == 0 and small[2] == out[2]
+
+
 def test_bad_mesh_is_rejected():
     from fcvm_hip import _lib
     import pytest

@@ -46,8 +46,16 @@ def worker(rank, world, port, a):
             print("solve: %s  %.3f s  l2 %s" % (out[1], time.perf_counter() - t, getattr(be.mg, "l2_info", None)), file=log)
             return out
         be.solve = solve
+        import cProfile
+        import pstats
+        pr = cProfile.Profile() if a.profile else None
+        if pr:
+            pr.enable()
         res = calc_disp(model, dict(case["ctl"], nstep=a.nstep), rtol=1e-11, maxit=a.maxit,
                         log=lambda *m: print(*m, file=log))
+        if pr:
+            pr.disable()
+            pstats.Stats(pr, stream=log).sort_stats("tottime").print_stats(30)
         print("done: lout", res["lout"], "pcg", res["stats"]["pcg_iterations"], "solves", res["stats"]["solves"],
               "%.1f s" % (time.perf_counter() - t0), file=log)
     finally:
@@ -63,6 +71,7 @@ if __name__ == "__main__":
     ap.add_argument("--maxit", type=int, default=1500)
     ap.add_argument("--dump", type=float, default=60.0)
     ap.add_argument("--tag", default="dist_debug")
+    ap.add_argument("--profile", action="store_true")
     a = ap.parse_args()
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()

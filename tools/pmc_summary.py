@@ -23,7 +23,7 @@ for grp in sorted(os.listdir(root)):
             acc[(short(k), grid)][row["Counter_Name"]].append(float(row["Counter_Value"]))
     print("\n== %s ==" % grp)
     for (k, grid), cs in sorted(acc.items(), key=lambda kv: -kv[0][1]):
-        if not any(s in k for s in ("k_spmv", "k_stream_read", "k_assemble", "k_update_stress", "k_gather_qin")):
+        if not any(s in k for s in ("k_spmv", "k_stream_read", "k_assemble", "k_update_stress", "k_gather_qin", "k_repack")):
             continue
         if "k_spmv" in k and grid < 500000:
             continue

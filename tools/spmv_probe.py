@@ -41,6 +41,9 @@ alg = info["nnz_blocks"] * 76 + 2 * info["ndof"] * 8
 print("elements %d ndof %d nnzb %d padded_slots %d  spmv %.4f ms  %.1f GB/s algorithmic (%.1f GB/s incl. padding)" %
       (m.ne, m.ndof, info["nnz_blocks"], info["padded_slots"], ms, alg / ms / 1e6,
        (info["matrix_bytes"] + 2 * info["ndof"] * 8) / ms / 1e6))
+w = c.spmv_info()
+print("spmv kernel:", ("window format, %d groups, windows mean %d / max %d nodes, %d B LDS, %.4f GB streamed per launch" %
+                       (w["groups"], w["mean_window"], w["max_window"], w["lds_bytes"], w["bytes"] / 1e9)) if w["window_format"] else "sliced-ELL")
 if a.membench:
     print("stream read %.0f GB/s" % c.membench(3 << 30))
 if a.pcg:
