@@ -38,6 +38,18 @@ static int fail(const std::string &m) {
         if (!(cond)) return fail(msg); \
     } while (0)
 
+// device side of a WinPattern (window-format copy of one matrix)
+struct WinDev {
+    bool on = false;
+    WinPattern pat;
+    int64_t *gptr = nullptr, *woff = nullptr;
+    int32_t *wlist = nullptr, *rownode = nullptr, *srcslot = nullptr, *gextra = nullptr;
+    uint32_t *seg = nullptr;
+    uint16_t *rowlen = nullptr, *own = nullptr, *cols = nullptr, *jstart = nullptr;
+    void *vals = nullptr;   // 9 * nblocks doubles
+    size_t lds = 0;
+};
+
 struct fcvm_ctx {
     int device = 0;
     hipStream_t own = nullptr, stream = nullptr;
@@ -70,23 +82,18 @@ struct fcvm_ctx {
     double *d_vals_g = nullptr;  // geometric stiffness (linear buckling), same pattern as d_vals
     // pcg work
     double *d_r = nullptr, *d_z = nullptr, *d_p = nullptr, *d_q = nullptr, *d_S = nullptr;
-    double *d_part_vec = nullptr, *d_part_spmv = nullptr, *d_part_misc = nullptr, *d_out8 = nullptr;
+    double *d_part_vec = nullptr, *d_part_spmv = nullptr, *d_part_misc = nullptr, *d_out8 = nullptr, *d_part_mdot = nullptr;
     long long *d_pidx = nullptr;
     int64_t nb_vec = 0, nb_spmv = 0, nb_gp = 0;
     int spmv_spw = 1;  // waves per SpMV workgroup: 1 keeps the tail of the launch short (long and short slices differ 3x): -5 % vs 4
     double last_spmv_ms = 0, last_total_ms = 0;
     double row_spread = 0.0;
     bool row_order_morton = false;
-    // window-format copy of the fine matrix for the SpMV (fcvm_spmv_win.hip.h); 0: the sliced-ELL kernel does it
+    // window-format copies of the matrices for the SpMV (fcvm_spmv_win.hip.h); 0: the sliced-ELL kernel does it
     int spmv_win = 1, win_v2 = 1;   // win_v2: value components in 16-byte pairs (FCVM_WIN_V2=0: nine 8-byte runs)
-    bool win_on = false;
-    WinPattern win;
-    int64_t *d_w_gptr = nullptr, *d_w_woff = nullptr;
-    int32_t *d_w_wlist = nullptr, *d_w_rownode = nullptr, *d_w_srcslot = nullptr, *d_w_gextra = nullptr;
-    uint32_t *d_w_seg = nullptr;
-    uint16_t *d_w_rowlen = nullptr, *d_w_own = nullptr, *d_w_cols = nullptr, *d_w_jstart = nullptr;
-    double *d_w_vals = nullptr;
-    size_t win_lds = 0;
+    WinDev win;                     // the fine matrix.  (The level-1 matrix of the multigrid cycle was tried on the same format with
+                                    // FP32 values and the smoother epilogue: 31.0 against 28.3 us per launch -- 686 workgroups are too
+                                    // few and the staging barrier adds latency; it stays on the sliced-ELL kernel, profiles/r02v_*.)
     int spmv_variant = 5;  // 5 (shipped): nontemporal matrix loads, four pairs in flight, 8 + 16 byte x gathers; 4: three 8-byte gathers; 0: plain loads, one pair per iteration
     double last_spmv_timed = 0;
     // host copies needed to build the coarse level
@@ -167,6 +174,13 @@ static MatView coarse_view(const fcvm_ctx *c) {
     return {c->pat1.nslices, c->nb_spmv1, c->d_sptr1, c->d_cols1, c->d_vals1, c->d_rownode1, c->mg_fp32 ? c->d_vals1f : nullptr};
 }
 
+template <bool DOT, int WAVES, bool V2>
+static void launch_spmv_win_t(fcvm_ctx *c, const WinDev &w, const double *x, double *y, const double *done) {
+    hipLaunchKernelGGL((k_spmv_win<DOT, WAVES, V2>), dim3((unsigned)w.pat.ngroups), dim3(64 * WAVES), w.lds, c->stream, w.pat.ngroups,
+                       w.pat.wmax, w.gptr, w.gextra, w.wlist, w.woff, w.rowlen, w.rownode, w.seg, w.own, w.cols, (const double *)w.vals, x,
+                       y, DOT ? c->d_part_spmv : (double *)nullptr, done);
+}
+
 #define FCVM_SPMV_LAUNCH(DOT_, NT_, UN_, V2_, EPI_, vals_, epi_)                                                               \
     hipLaunchKernelGGL((k_spmv<DOT_, NT_, UN_, V2_, EPI_, 1>), grid, block, 0, c->stream, m.nslices, m.nb, m.sptr, m.cols, \
                        (const V2_ *)(vals_), m.rownode, x, y, part, done, epi_)
@@ -195,26 +209,21 @@ static void launch_gemv_f32(fcvm_ctx *c, const double *r2, double *e2, const dou
     hipLaunchKernelGGL(k_gemv_f32x4, dim3((unsigned)cdiv(c->n2, 16)), dim3(256), 0, c->stream, c->n2, c->n2, (c->n2 + 3) / 4 * 4,
                        c->d_A2invf, r2, e2, done);
 }
-template <bool DOT, int WAVES, bool V2>
-static void launch_spmv_win_t(fcvm_ctx *c, const double *x, double *y, const double *done) {
-    hipLaunchKernelGGL((k_spmv_win<DOT, WAVES, V2>), dim3((unsigned)c->win.ngroups), dim3(64 * WAVES), c->win_lds, c->stream,
-                       c->win.ngroups, c->win.wmax, c->d_w_gptr, c->d_w_gextra, c->d_w_wlist, c->d_w_woff, c->d_w_rowlen, c->d_w_rownode,
-                       c->d_w_seg, c->d_w_own, c->d_w_cols, c->d_w_vals, x, y, DOT ? c->d_part_spmv : (double *)nullptr, done);
-}
 static void launch_spmv_win(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done) {
-    if (c->win.waves == 4) {   // meshes whose 512-row windows do not fit the LDS: groups of 256 rows
-        if (dot) launch_spmv_win_t<true, 4, true>(c, x, y, done);
-        else launch_spmv_win_t<false, 4, true>(c, x, y, done);
+    const WinDev &w = c->win;
+    if (w.pat.waves == 4) {   // meshes whose 512-row windows do not fit the LDS: groups of 256 rows
+        if (dot) launch_spmv_win_t<true, 4, true>(c, w, x, y, done);
+        else launch_spmv_win_t<false, 4, true>(c, w, x, y, done);
     } else if (c->win_v2) {
-        if (dot) launch_spmv_win_t<true, WIN_WAVES, true>(c, x, y, done);
-        else launch_spmv_win_t<false, WIN_WAVES, true>(c, x, y, done);
+        if (dot) launch_spmv_win_t<true, WIN_WAVES, true>(c, w, x, y, done);
+        else launch_spmv_win_t<false, WIN_WAVES, true>(c, w, x, y, done);
     } else {
-        if (dot) launch_spmv_win_t<true, WIN_WAVES, false>(c, x, y, done);
-        else launch_spmv_win_t<false, WIN_WAVES, false>(c, x, y, done);
+        if (dot) launch_spmv_win_t<true, WIN_WAVES, false>(c, w, x, y, done);
+        else launch_spmv_win_t<false, WIN_WAVES, false>(c, w, x, y, done);
     }
 }
 static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done) {
-    if (c->win_on) {   // window format: x through LDS (the p.Ap partials beyond the group count stay zero)
+    if (c->win.on) {   // window format: x through LDS (the p.Ap partials beyond the group count stay zero)
         launch_spmv_win(c, dot, x, y, done);
         return;
     }
@@ -232,68 +241,91 @@ static int dot_common(fcvm_ctx *c, int64_t n, const double *w, const double *x, 
 }
 #include "fcvm_mg.inc"
 
+static void win_free(WinDev &w) {
+    dfree(w.gptr); dfree(w.woff); dfree(w.wlist); dfree(w.rownode); dfree(w.srcslot); dfree(w.gextra); dfree(w.seg); dfree(w.rowlen);
+    dfree(w.own); dfree(w.cols); dfree(w.jstart);
+    if (w.vals) { (void)hipFree(w.vals); w.vals = nullptr; }
+    w.on = false;
+    w.pat = WinPattern();
+    w.lds = 0;
+}
+
+// device copy of a built WinPattern
+static int win_upload(fcvm_ctx *c, WinDev &d) {
+    const int value_bytes = 8;
+    const WinPattern &w = d.pat;
+    const int64_t nrows = w.nwaves * SLICE;
+    if (dalloc(&d.gptr, w.ngroups + 1) || dalloc(&d.woff, w.nwaves + 1) || dalloc(&d.wlist, (int64_t)w.wlist.size()) ||
+        dalloc(&d.rownode, nrows) || dalloc(&d.srcslot, nrows) || dalloc(&d.rowlen, nrows) || dalloc(&d.own, nrows) ||
+        dalloc(&d.cols, w.nblocks) || dalloc(&d.gextra, w.ngroups) || dalloc(&d.seg, nrows) || dalloc(&d.jstart, nrows))
+        return 1;
+    if (hipMalloc(&d.vals, (size_t)value_bytes * 9 * (size_t)w.nblocks) != hipSuccess) return fail("out of device memory (window format values)");
+    hipStream_t s = c->stream;
+    HCHK(hipMemcpyAsync(d.gptr, w.gptr.data(), sizeof(int64_t) * (w.ngroups + 1), hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.woff, w.woff.data(), sizeof(int64_t) * (w.nwaves + 1), hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.wlist, w.wlist.data(), sizeof(int32_t) * w.wlist.size(), hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.rownode, w.rownode.data(), sizeof(int32_t) * nrows, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.srcslot, w.srcslot.data(), sizeof(int32_t) * nrows, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.rowlen, w.rowlen.data(), sizeof(uint16_t) * nrows, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.own, w.own.data(), sizeof(uint16_t) * nrows, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.jstart, w.jstart.data(), sizeof(uint16_t) * nrows, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.seg, w.seg.data(), sizeof(uint32_t) * nrows, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.gextra, w.gextra.data(), sizeof(int32_t) * w.ngroups, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.cols, w.cols.data(), sizeof(uint16_t) * w.nblocks, hipMemcpyHostToDevice, s));
+    HCHK(hipMemsetAsync(d.vals, 0, (size_t)value_bytes * 9 * (size_t)w.nblocks, s));
+    HCHK(hipStreamSynchronize(s));
+    d.lds = sizeof(double) * 3 * (size_t)(w.wmax + w.xmax);
+    // the host copies are not needed again
+    d.pat.wlist.clear(); d.pat.wlist.shrink_to_fit();
+    d.pat.cols.clear(); d.pat.cols.shrink_to_fit();
+    d.on = true;
+    return 0;
+}
+
+template <class K>
+static int win_allow_lds(K kernel, size_t bytes) {
+    HCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
 // Second storage of the fine matrix for the SpMV (WinPattern): built when every group's window fits the LDS twice per CU
 static int setup_window_format(fcvm_ctx *c, const double *nocoord) {
-    c->win_on = false;
+    win_free(c->win);
     if (!c->spmv_win || c->nn < 2048) return 0;
     int nt = (int)std::thread::hardware_concurrency();
     nt = std::min(std::max(nt, 1), 32);
     int64_t max_window = 3200;   // 2 x 24 B x (3200 + partial-result slots) < 160 KB: two workgroups per CU
     if (const char *v = getenv("FCVM_WIN_MAX")) max_window = std::max(64, atoi(v));   // (tests: force the smaller groups)
+    WinPattern &w = c->win.pat;
     try {
-        bool built = build_window_format(c->pat, nocoord, nt, max_window, c->win, WIN_WAVES);
+        bool built = build_window_format(c->pat, nocoord, nt, max_window, w, WIN_WAVES);
         if (!built) {   // smaller groups have smaller windows (at the price of more x traffic from the L2)
-            const long long w8 = (long long)c->win.wmax;
-            c->win = WinPattern();
-            built = build_window_format(c->pat, nocoord, nt, max_window, c->win, 4);
+            const long long w8 = (long long)w.wmax;
+            w = WinPattern();
+            built = build_window_format(c->pat, nocoord, nt, max_window, w, 4);
             if (getenv("FCVM_VERBOSE"))
-                fprintf(stderr, "fcvm: window format: largest window of 512-row groups %lld nodes, of 256-row groups %lld\n", w8, (long long)c->win.wmax);
+                fprintf(stderr, "fcvm: window format: largest window of 512-row groups %lld nodes, of 256-row groups %lld\n", w8, (long long)w.wmax);
             if (built) c->win_v2 = 1;
         }
         if (!built) {
-            if (getenv("FCVM_VERBOSE")) fprintf(stderr, "fcvm: window format not used (largest window %lld nodes)\n", (long long)c->win.wmax);
-            c->win = WinPattern();
+            if (getenv("FCVM_VERBOSE")) fprintf(stderr, "fcvm: window format not used (largest window %lld nodes)\n", (long long)w.wmax);
+            w = WinPattern();
             return 0;
         }
     } catch (const std::exception &ex) {
         return fail(std::string("fcvm_set_mesh (window format): ") + ex.what());
     }
-    const WinPattern &w = c->win;
-    const int64_t nrows = w.nwaves * SLICE;
-    if (dalloc(&c->d_w_gptr, w.ngroups + 1) || dalloc(&c->d_w_woff, w.nwaves + 1) || dalloc(&c->d_w_wlist, (int64_t)w.wlist.size()) ||
-        dalloc(&c->d_w_rownode, nrows) || dalloc(&c->d_w_srcslot, nrows) || dalloc(&c->d_w_rowlen, nrows) || dalloc(&c->d_w_own, nrows) ||
-        dalloc(&c->d_w_cols, w.nblocks) || dalloc(&c->d_w_vals, 9 * w.nblocks) || dalloc(&c->d_w_gextra, w.ngroups) ||
-        dalloc(&c->d_w_seg, nrows) || dalloc(&c->d_w_jstart, nrows))
+    if (win_upload(c, c->win)) return 1;
+    HCHK(hipMemsetAsync(c->d_part_spmv, 0, sizeof(double) * c->nb_spmv, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+    const size_t lds = c->win.lds;
+    if (win_allow_lds(k_spmv_win<true, WIN_WAVES, true>, lds) || win_allow_lds(k_spmv_win<false, WIN_WAVES, true>, lds) ||
+        win_allow_lds(k_spmv_win<true, WIN_WAVES, false>, lds) || win_allow_lds(k_spmv_win<false, WIN_WAVES, false>, lds) ||
+        win_allow_lds(k_spmv_win<true, 4, true>, lds) || win_allow_lds(k_spmv_win<false, 4, true>, lds))
         return 1;
-    hipStream_t s = c->stream;
-    HCHK(hipMemcpyAsync(c->d_w_gptr, w.gptr.data(), sizeof(int64_t) * (w.ngroups + 1), hipMemcpyHostToDevice, s));
-    HCHK(hipMemcpyAsync(c->d_w_woff, w.woff.data(), sizeof(int64_t) * (w.nwaves + 1), hipMemcpyHostToDevice, s));
-    HCHK(hipMemcpyAsync(c->d_w_wlist, w.wlist.data(), sizeof(int32_t) * w.wlist.size(), hipMemcpyHostToDevice, s));
-    HCHK(hipMemcpyAsync(c->d_w_rownode, w.rownode.data(), sizeof(int32_t) * nrows, hipMemcpyHostToDevice, s));
-    HCHK(hipMemcpyAsync(c->d_w_srcslot, w.srcslot.data(), sizeof(int32_t) * nrows, hipMemcpyHostToDevice, s));
-    HCHK(hipMemcpyAsync(c->d_w_rowlen, w.rowlen.data(), sizeof(uint16_t) * nrows, hipMemcpyHostToDevice, s));
-    HCHK(hipMemcpyAsync(c->d_w_own, w.own.data(), sizeof(uint16_t) * nrows, hipMemcpyHostToDevice, s));
-    HCHK(hipMemcpyAsync(c->d_w_jstart, w.jstart.data(), sizeof(uint16_t) * nrows, hipMemcpyHostToDevice, s));
-    HCHK(hipMemcpyAsync(c->d_w_seg, w.seg.data(), sizeof(uint32_t) * nrows, hipMemcpyHostToDevice, s));
-    HCHK(hipMemcpyAsync(c->d_w_gextra, w.gextra.data(), sizeof(int32_t) * w.ngroups, hipMemcpyHostToDevice, s));
-    HCHK(hipMemcpyAsync(c->d_w_cols, w.cols.data(), sizeof(uint16_t) * w.nblocks, hipMemcpyHostToDevice, s));
-    HCHK(hipMemsetAsync(c->d_w_vals, 0, sizeof(double) * 9 * w.nblocks, s));
-    HCHK(hipMemsetAsync(c->d_part_spmv, 0, sizeof(double) * c->nb_spmv, s));
-    HCHK(hipStreamSynchronize(s));
-    c->win_lds = sizeof(double) * 3 * (size_t)(w.wmax + w.xmax);
-    HCHK(hipFuncSetAttribute((const void *)k_spmv_win<true, WIN_WAVES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->win_lds));
-    HCHK(hipFuncSetAttribute((const void *)k_spmv_win<false, WIN_WAVES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->win_lds));
-    HCHK(hipFuncSetAttribute((const void *)k_spmv_win<true, WIN_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->win_lds));
-    HCHK(hipFuncSetAttribute((const void *)k_spmv_win<false, WIN_WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->win_lds));
-    HCHK(hipFuncSetAttribute((const void *)k_spmv_win<true, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->win_lds));
-    HCHK(hipFuncSetAttribute((const void *)k_spmv_win<false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->win_lds));
-    // the host copies are not needed again
-    c->win.wlist.clear(); c->win.wlist.shrink_to_fit();
-    c->win.cols.clear(); c->win.cols.shrink_to_fit();
-    c->win_on = true;
     if (getenv("FCVM_VERBOSE"))
-        fprintf(stderr, "fcvm: window format: %lld groups, windows mean %.0f / max %lld nodes (%zu B LDS), %lld blocks\n", (long long)w.ngroups,
-                w.wmean, (long long)w.wmax, c->win_lds, (long long)w.nblocks);
+        fprintf(stderr, "fcvm: window format: %lld groups of %d waves, windows mean %.0f / max %lld nodes (%zu B LDS), %lld entries\n",
+                (long long)w.ngroups, w.waves, w.wmean, (long long)w.wmax, lds, (long long)w.nblocks);
     return 0;
 }
 
@@ -499,10 +531,7 @@ static void free_mesh(fcvm_ctx *c) {
     dfree(c->d_el); dfree(c->d_cols); dfree(c->d_rownode); dfree(c->d_noce); dfree(c->d_sptr);
     dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
     dfree(c->d_nptr); dfree(c->d_nel); dfree(c->d_fe); dfree(c->d_part_vol); dfree(c->d_asm_items);
-    dfree(c->d_w_gptr); dfree(c->d_w_woff); dfree(c->d_w_wlist); dfree(c->d_w_rownode); dfree(c->d_w_srcslot); dfree(c->d_w_rowlen);
-    dfree(c->d_w_own); dfree(c->d_w_cols); dfree(c->d_w_vals); dfree(c->d_w_gextra); dfree(c->d_w_seg); dfree(c->d_w_jstart);
-    c->win_on = false;
-    c->win = WinPattern();
+    win_free(c->win);
     dfree(c->d_vals); dfree(c->d_vals_g); dfree(c->d_dblk); dfree(c->d_dinv); dfree(c->d_r); dfree(c->d_z); dfree(c->d_p);
     dfree(c->d_q); dfree(c->d_part_vec); dfree(c->d_part_spmv); dfree(c->d_part_misc); dfree(c->d_pidx);
     mg_free(c);
@@ -514,7 +543,7 @@ int fcvm_destroy(fcvm_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_mesh(c);
-    dfree(c->d_S); dfree(c->d_out8);
+    dfree(c->d_S); dfree(c->d_out8); dfree(c->d_part_mdot);
     for (auto e : c->evpool) (void)hipEventDestroy(e);
     if (c->asm_fork) (void)hipEventDestroy(c->asm_fork);
     for (int b = 0; b < fcvm_ctx::ASM_BUCKETS; b++) {
@@ -638,7 +667,7 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     c->nn = nn;
     if (build_asm_items(c)) return 1;
     if (setup_window_format(c, nocoord)) return 1;
-    if (!c->win_on && tune_matrix_placement(c)) return 1;
+    if (!c->win.on && tune_matrix_placement(c)) return 1;
     // the element->slot map is only needed on the device from here on
     c->pat.emap.clear();
     c->pat.emap.shrink_to_fit();
@@ -693,13 +722,13 @@ int fcvm_pattern_info(fcvm_ctx *c, int64_t out[8]) {
 int fcvm_spmv_info(fcvm_ctx *c, int64_t out[8]) {
     NEED(c && c->have_mesh, "fcvm_spmv_info: no mesh");
     for (int k = 0; k < 8; k++) out[k] = 0;
-    out[0] = c->win_on ? c->win.waves : 0;
-    if (!c->win_on) return 0;
-    const WinPattern &w = c->win;
+    out[0] = c->win.on ? c->win.pat.waves : 0;
+    if (!c->win.on) return 0;
+    const WinPattern &w = c->win.pat;
     out[1] = w.ngroups; out[2] = w.wmax; out[3] = (int64_t)(w.wmean + 0.5); out[4] = w.nblocks;
     // bytes one launch streams from this format: values, 16-bit columns, window lists, per-vrow tables
     out[5] = w.nblocks * 74 + w.gptr[w.ngroups] * 4 + w.nwaves * SLICE * 16 + (w.nwaves + w.ngroups) * 8;
-    out[6] = (int64_t)c->win_lds; out[7] = WIN_SPLIT;
+    out[6] = (int64_t)c->win.lds; out[7] = w.split;
     return 0;
 }
 
@@ -726,10 +755,11 @@ int fcvm_matrix_to_coo(fcvm_ctx *c, int64_t *row, int64_t *col, double *val) {
 }
 
 static int refresh_precond(fcvm_ctx *c) {   // after every assembly into d_vals
-    if (c->win_on) {
-        const int64_t nrows = c->win.nwaves * SLICE;
-        hipLaunchKernelGGL(k_repack_win, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, c->stream, nrows, c->d_w_srcslot, c->d_w_rowlen,
-                           c->d_w_jstart, c->d_w_woff, c->d_sptr, c->d_vals, c->d_w_vals, c->win_v2);
+    if (c->win.on) {
+        const WinDev &w = c->win;
+        const int64_t nrows = w.pat.nwaves * SLICE;
+        hipLaunchKernelGGL(k_repack_win, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, c->stream, nrows, w.srcslot, w.rowlen,
+                           w.jstart, w.woff, c->d_sptr, c->d_vals, (double *)w.vals, c->win_v2);
     }
     hipLaunchKernelGGL(k_diag_get, dim3(cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_diagoff, c->d_vals, c->d_dblk);
     hipLaunchKernelGGL(k_diag_invert, dim3(cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_dblk, c->d_dinv);
@@ -1000,6 +1030,20 @@ int fcvm_vec_dot(fcvm_ctx *c, int64_t n, const double *x, const double *y, doubl
     HCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
+int fcvm_vec_mdot(fcvm_ctx *c, int64_t n, int k, const double *const *xs, const double *y, double *result_host) {
+    NEED(c && n > 0 && k >= 1 && k <= 16 && xs && y && result_host, "fcvm_vec_mdot: 1..16 vectors");
+    const int64_t nb = std::min<int64_t>(std::max<int64_t>(cdiv(n, 256), 1), 2048);   // as dot_common
+    if (!c->d_part_mdot && dalloc(&c->d_part_mdot, 16 * 2048 + 16)) return 1;
+    MdotPtrs p;
+    for (int j = 0; j < 16; j++) p.x[j] = j < k ? xs[j] : nullptr;
+    double *out = c->d_part_mdot + 16 * 2048;
+    hipLaunchKernelGGL(k_mdot_partial, dim3((unsigned)nb), dim3(256), 0, c->stream, n, k, p, y, c->d_part_mdot, nb);
+    hipLaunchKernelGGL(k_msum_final, dim3((unsigned)k), dim3(256), 0, c->stream, c->d_part_mdot, nb, out);
+    HCHK(hipGetLastError());
+    HCHK(hipMemcpyAsync(result_host, out, sizeof(double) * k, hipMemcpyDeviceToHost, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
 int fcvm_vec_wdot_dev(fcvm_ctx *c, int64_t n, const double *w, const double *x, const double *y, double *result_dev) {
     return dot_common(c, n, w, x, y, result_dev);
 }
@@ -1064,10 +1108,10 @@ int fcvm_host_window_check(int64_t ne, int64_t nn, const int64_t *elNodes, const
             rows++;
             const int nseg = (int)(w.seg[at] & 255u);
             const int64_t rl = p.rowptr[nd + 1] - p.rowptr[nd];
-            if (len[l] > WIN_SPLIT || w.jstart[at] + len[l] > rl) bad++;
+            if (len[l] > w.split || w.jstart[at] + len[l] > rl) bad++;
             if (nseg > 0) {                                                   // first segment: exactly one per node
                 if (firsts[nd]++) bad++;
-                if (w.jstart[at] != 0 || nseg != std::max<int64_t>(1, (rl + WIN_SPLIT - 1) / WIN_SPLIT)) bad++;
+                if (w.jstart[at] != 0 || nseg != std::max<int64_t>(1, (rl + w.split - 1) / w.split)) bad++;
                 if ((int64_t)(w.seg[at] >> 8) + nseg - 1 > w.gextra[g]) bad++;
             } else if ((int64_t)(w.seg[at] >> 8) >= w.gextra[g]) bad++;
             covered[nd] += len[l];

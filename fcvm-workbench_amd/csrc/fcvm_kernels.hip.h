@@ -832,6 +832,34 @@ __global__ __launch_bounds__(256) void k_sum_final(const double *__restrict__ pa
     double v = sum_partials(part, n, sh);
     if (threadIdx.x == 0) *out = v;
 }
+// k <= 16 inner products x_j . y in one pass over y (the Newton driver's projection / Gram / Riks scalars: one launch and one
+// host synchronisation instead of k).  Same grid, same per-thread order and the same two-stage sums as k_dot_partial /
+// k_sum_final, so every result is bitwise what fcvm_vec_dot returns for that pair.
+struct MdotPtrs { const double *x[16]; };
+__global__ __launch_bounds__(256) void k_mdot_partial(int64_t n, int k, MdotPtrs xs, const double *__restrict__ y, double *__restrict__ part,
+                                                      int64_t nb) {
+    __shared__ double sh[4];
+    double v[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) v[j] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double yi = y[i];
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (j < k) v[j] += 1.0 * xs.x[j][i] * yi;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+        if (j < k) {
+            const double t = block_sum(v[j], sh);
+            if (threadIdx.x == 0) part[j * nb + blockIdx.x] = t;
+        }
+}
+__global__ __launch_bounds__(256) void k_msum_final(const double *__restrict__ part, int64_t nb, double *__restrict__ out) {
+    __shared__ double sh[4];
+    double v = sum_partials(part + blockIdx.x * nb, nb, sh);
+    if (threadIdx.x == 0) out[blockIdx.x] = v;
+}
 __global__ __launch_bounds__(256) void k_max_node_norm_partial(int64_t nnodes, const double *__restrict__ u, double *__restrict__ part) {
     __shared__ double sh[4];
     double v = 0.0;

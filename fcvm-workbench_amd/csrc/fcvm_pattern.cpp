@@ -7,6 +7,9 @@
 #include <functional>
 #include <stdexcept>
 #include <thread>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace fcvm {
 
@@ -28,6 +31,14 @@ static void parallel_for(int64_t n, int nthreads, const std::function<void(int64
 
 void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nthreads, int sort_window, int npe,
                    const int32_t *row_order) {
+    const bool timing = getenv("FCVM_PATTERN_TIMING") != nullptr;
+    auto tprev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "fcvm pattern: %-28s %.3f s\n", what, std::chrono::duration<double>(t - tprev).count());
+        tprev = t;
+    };
     if (ne <= 0 || nn <= 0) throw std::runtime_error("empty mesh");
     for (int64_t i = 0; i < ne * npe; i++)
         if (el[i] < 0 || el[i] >= nn) throw std::runtime_error("element node index out of range");
@@ -47,6 +58,7 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
         for (int64_t e = 0; e < ne; e++)
             for (int k = 0; k < npe; k++) nel[fill[el[e * npe + k]]++] = (int32_t)((e << 4) | k);
     }
+    lap("node -> elements");
     // node -> sorted unique neighbour nodes (diagonal included)
     int nt = std::max(1, nthreads);
     std::vector<std::vector<int32_t>> chunks(nt);
@@ -70,6 +82,7 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
             out.insert(out.end(), tmp.begin(), tmp.end());
         }
     });
+    lap("node adjacency");
     p.rowptr.assign(nn + 1, 0);
     for (int64_t i = 0; i < nn; i++) p.rowptr[i + 1] = p.rowptr[i] + len[i];
     p.nnzb = p.rowptr[nn];
@@ -79,21 +92,40 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
             std::copy(chunks[t].begin(), chunks[t].end(), p.colidx.begin() + p.rowptr[cbeg[t]]);
     chunks.clear();
     chunks.shrink_to_fit();
+    lap("CSR copy");
     // slices: rows sorted by descending length inside windows of SORT_WINDOW slices
     p.nslices = (nn + SLICE - 1) / SLICE;
     p.rownode.assign(p.nslices * SLICE, -1);
     p.slotof.assign(nn, -1);
     const int64_t win = (int64_t)SLICE * sort_window;
-    for (int64_t w0 = 0; w0 < nn; w0 += win) {
-        int64_t w1 = std::min(nn, w0 + win);
-        std::vector<int32_t> ids(w1 - w0);
-        for (int64_t i = w0; i < w1; i++) ids[i - w0] = row_order ? row_order[i] : (int32_t)i;
-        std::stable_sort(ids.begin(), ids.end(), [&](int32_t a, int32_t b) { return len[a] > len[b]; });
-        for (int64_t k = 0; k < (int64_t)ids.size(); k++) {
-            p.rownode[w0 + k] = ids[k];
-            p.slotof[ids[k]] = (int32_t)(w0 + k);
+    {
+        const int64_t nwin = (nn + win - 1) / win;
+        auto sort_windows = [&](int64_t b, int64_t e, int) {
+            std::vector<int32_t> ids;
+            for (int64_t wi = b; wi < e; wi++) {
+                const int64_t w0 = wi * win, w1 = std::min(nn, w0 + win);
+                ids.resize(w1 - w0);
+                for (int64_t i = w0; i < w1; i++) ids[i - w0] = row_order ? row_order[i] : (int32_t)i;
+                std::stable_sort(ids.begin(), ids.end(), [&](int32_t a, int32_t b2) { return len[a] > len[b2]; });
+                for (int64_t k = 0; k < (int64_t)ids.size(); k++) {
+                    p.rownode[w0 + k] = ids[k];
+                    p.slotof[ids[k]] = (int32_t)(w0 + k);
+                }
+            }
+        };
+        if (nwin >= 64) {     // (parallel_for runs serially below 4096 items: split the windows by hand)
+            std::vector<std::thread> th;
+            const int64_t chunk = (nwin + nt - 1) / nt;
+            for (int t = 0; t < nt; t++) {
+                const int64_t b = t * chunk, e = std::min(nwin, b + chunk);
+                if (b < e) th.emplace_back(sort_windows, b, e, t);
+            }
+            for (auto &x : th) x.join();
+        } else {
+            sort_windows(0, nwin, 0);
         }
     }
+    lap("length sort");
     p.sptr.assign(p.nslices + 1, 0);
     p.maxlen = 0;
     for (int64_t s = 0; s < p.nslices; s++) {
@@ -108,6 +140,7 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
     p.nslots = p.sptr[p.nslices] * SLICE;
     if ((uint64_t)p.sptr[p.nslices] >= (1ull << 30))
         throw std::runtime_error("matrix too large for the packed 32-bit block locations (2^30 half chunks)");
+    lap("slice lengths");
     p.cols.assign(p.nslots, 0);
     parallel_for(p.nslices, nt, [&](int64_t b, int64_t e, int) {
         for (int64_t s = b; s < e; s++) {
@@ -122,6 +155,7 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
             }
         }
     });
+    lap("columns");
     // element block (a,b) -> offset of its component 0
     p.emap.resize(ne * npe * npe);
     parallel_for(ne, nt, [&](int64_t b, int64_t e, int) {
@@ -138,13 +172,16 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
             }
         }
     });
+    lap("element map");
     p.diagoff.resize(nn);
-    for (int64_t i = 0; i < nn; i++) {
-        const int32_t *rb = p.colidx.data() + p.rowptr[i];
-        const int32_t *re = p.colidx.data() + p.rowptr[i + 1];
-        int64_t j = std::lower_bound(rb, re, (int32_t)i) - rb;
-        p.diagoff[i] = p.abs_offset(p.slotof[i], j);
-    }
+    parallel_for(nn, nt, [&](int64_t b, int64_t e, int) {
+        for (int64_t i = b; i < e; i++) {
+            const int32_t *rb = p.colidx.data() + p.rowptr[i];
+            const int32_t *re = p.colidx.data() + p.rowptr[i + 1];
+            int64_t j = std::lower_bound(rb, re, (int32_t)i) - rb;
+            p.diagoff[i] = p.abs_offset(p.slotof[i], j);
+        }
+    });
 }
 
 std::vector<int32_t> morton_order(int64_t nn, const double *xyz) {
@@ -191,12 +228,13 @@ double numbering_spread(int64_t ne, int64_t nn, const int32_t *el, int npe) {
     return ne > 0 && nn > 0 ? s / (double)ne / (double)nn : 0.0;
 }
 
-bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int64_t max_window, WinPattern &w, int waves) {
+bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int64_t max_window, WinPattern &w, int waves, int split) {
     const int64_t nn = p.nn, WV = waves, R = WV * SLICE;
     w.waves = waves;
+    w.split = split;
     if (p.maxlen > 65535) return false;
     std::vector<int32_t> order = morton_order(nn, xyz);
-    auto nseg_of = [&](int32_t nd) { return (int)((p.rowptr[nd + 1] - p.rowptr[nd] + WIN_SPLIT - 1) / WIN_SPLIT); };
+    auto nseg_of = [&](int32_t nd) { return (int)((p.rowptr[nd + 1] - p.rowptr[nd] + split - 1) / split); };
     // groups: consecutive nodes of the Morton order while their vrows fit
     std::vector<int64_t> gfirst{0};
     {
@@ -225,6 +263,7 @@ bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int6
     std::vector<std::vector<int32_t>> win(ng);
     parallel_for(ng, nthreads, [&](int64_t b, int64_t e, int) {
         std::vector<VRow> rows;
+        std::vector<int32_t> stamp(nn, -1);     // group that last listed the node: unique window entries without a big sort
         for (int64_t g = b; g < e; g++) {
             rows.clear();
             auto &wl = win[g];
@@ -241,7 +280,10 @@ bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int6
                     j0 += l;
                 }
                 extra += k - 1;
-                wl.insert(wl.end(), p.colidx.begin() + p.rowptr[nd], p.colidx.begin() + p.rowptr[nd + 1]);
+                for (int64_t q = p.rowptr[nd]; q < p.rowptr[nd + 1]; q++) {
+                    const int32_t col = p.colidx[q];
+                    if (stamp[col] != (int32_t)g) { stamp[col] = (int32_t)g; wl.push_back(col); }
+                }
             }
             w.gextra[g] = extra;
             std::stable_sort(rows.begin(), rows.end(), [](const VRow &x, const VRow &y) { return x.len > y.len; });
@@ -256,7 +298,6 @@ bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int6
                 w.woff[wave + 1] += rows[k].len;
             }
             std::sort(wl.begin(), wl.end());
-            wl.erase(std::unique(wl.begin(), wl.end()), wl.end());
             wl.shrink_to_fit();
             w.gptr[g + 1] = (int64_t)wl.size();
         }
@@ -278,9 +319,11 @@ bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int6
     w.cols.assign(w.nblocks, 0);
     // pass 2: window lists, 16-bit columns in the prefix layout
     parallel_for(ng, nthreads, [&](int64_t b, int64_t e, int) {
+        std::vector<uint16_t> pos(nn, 0);       // window position of a node (valid for the nodes of the current window only)
         for (int64_t g = b; g < e; g++) {
             const auto &wl = win[g];
             std::copy(wl.begin(), wl.end(), w.wlist.begin() + w.gptr[g]);
+            for (size_t i = 0; i < wl.size(); i++) pos[wl[i]] = (uint16_t)i;
             for (int64_t wave = g * WV; wave < (g + 1) * WV; wave++) {
                 const uint16_t *len = &w.rowlen[wave * SLICE];
                 int64_t off = w.woff[wave];
@@ -290,13 +333,13 @@ bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int6
                     for (int64_t l = 0; l < n; l++) {
                         const int32_t nd = w.rownode[wave * SLICE + l];
                         const int32_t col = p.colidx[p.rowptr[nd] + w.jstart[wave * SLICE + l] + j];
-                        w.cols[off + l] = (uint16_t)(std::lower_bound(wl.begin(), wl.end(), col) - wl.begin());
+                        w.cols[off + l] = pos[col];
                     }
                     off += n;
                 }
                 for (int64_t l = 0; l < SLICE; l++) {
                     const int32_t nd = w.rownode[wave * SLICE + l];
-                    if (nd >= 0) w.own[wave * SLICE + l] = (uint16_t)(std::lower_bound(wl.begin(), wl.end(), nd) - wl.begin());
+                    if (nd >= 0) w.own[wave * SLICE + l] = pos[nd];
                 }
             }
         }

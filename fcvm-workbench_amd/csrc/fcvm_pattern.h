@@ -85,10 +85,11 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *elnodes0, Pattern &p, 
 // The values are copied from the sliced-ELL array by k_repack_win after every assembly (src: SELL slot of the row; both
 // layouts keep a row's blocks in ascending column order, so block j of a segment is block jstart + j of the row).
 constexpr int WIN_WAVES = 8;      // waves per group (default; WinPattern::waves holds the value a pattern was built with)
-constexpr int WIN_SPLIT = 32;
+constexpr int WIN_SPLIT = 32;     // longest row segment (default; WinPattern::split)
 struct WinPattern {
     int64_t ngroups = 0, nwaves = 0, nblocks = 0;
     int waves = WIN_WAVES;            // waves (of 64 vrows) per group
+    int split = WIN_SPLIT;            // longest row segment
     int64_t wmax = 0;                 // largest window (nodes)
     int64_t xmax = 0;                 // most second-and-later segments in one group (LDS slots for their partial results)
     double wmean = 0.0;
@@ -107,7 +108,8 @@ struct WinPattern {
     std::vector<uint16_t> cols;       // [nblocks] window position of the column node of an entry
 };
 // false: the mesh does not suit the format (a window larger than max_window nodes)
-bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int64_t max_window, WinPattern &w, int waves = WIN_WAVES);
+bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int64_t max_window, WinPattern &w, int waves = WIN_WAVES,
+                         int split = WIN_SPLIT);
 
 // nodes sorted along a Morton (Z-order) curve through their coordinates: a locality-preserving order in which
 // the SpMV walks the rows when the caller's node numbering has none (unstructured meshes)

@@ -50,6 +50,7 @@ SIGNATURES = {
     "fcvm_vec_axpby": [_vp, _i64, _f64, _vp, _f64, _vp, _vp],
     "fcvm_vec_mul": [_vp, _i64, _vp, _vp, _vp],
     "fcvm_vec_dot": [_vp, _i64, _vp, _vp, _pf64],
+    "fcvm_vec_mdot": [_vp, _i64, C.c_int, _vp, _vp, _vp],
     "fcvm_vec_wdot_dev": [_vp, _i64, _vp, _vp, _vp, _vp],
     "fcvm_vec_max_node_norm": [_vp, _i64, _vp, _pf64],
     "fcvm_solve_timing": [_vp, _pf64],

@@ -277,6 +277,8 @@ class Context:
         pi = self.precond_info()
         if pi["mode"] != "mg" or pi["coarse_nodes"] < self.l2_min_coarse_nodes:
             return None
+        if target is None and os.environ.get("FCVM_MG_TARGET"):
+            target = int(os.environ["FCVM_MG_TARGET"])
         if target is None:
             # nodes per aggregate: at most ~1000 aggregates (the dense inverse costs n^3 at set-up and n^2 per cycle);
             # the iteration count follows the aggregate SIZE (57 / 66 / 80 PCG iterations for 176 / 350 / 700 nodes on
@@ -319,6 +321,17 @@ class Context:
         r = C.c_double(0.0)
         call("fcvm_vec_dot", self.h, x.n, x.ptr, y.ptr, C.byref(r))
         return r.value
+
+    def mdot(self, xs, y):
+        """[x . y for x in xs] in one pass over y and one host synchronisation (bitwise the values of dot())"""
+        out = []
+        for k0 in range(0, len(xs), 16):
+            part = xs[k0:k0 + 16]
+            ptrs = (C.c_void_p * len(part))(*[x.ptr for x in part])
+            res = (C.c_double * len(part))()
+            call("fcvm_vec_mdot", self.h, y.n, len(part), ptrs, y.ptr, res)
+            out += list(res)
+        return out
 
     def norm(self, x):
         return float(np.sqrt(self.dot(x, x)))

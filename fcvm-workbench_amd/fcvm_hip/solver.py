@@ -168,6 +168,11 @@ class RiksDriver:
         self.pgp.zero()
 
     # -- building blocks ----------------------------------------------------------------------
+    def dots(self, xs, y):
+        """[x . y for x in xs]: one launch and one host synchronisation where the backend has a fused form"""
+        c = self.c
+        return c.mdot(xs, y) if hasattr(c, "mdot") else [c.dot(x, y) for x in xs]
+
     def solve(self, rhs):
         """K u = rhs to ||rhs - K u|| <= rtol ||rhs||.  The Newton loop solves with the same matrix over and over
         (the reference back-substitutes with one factorisation); successive right-hand sides are far from
@@ -182,7 +187,8 @@ class RiksDriver:
         nf = n0 = 1.0
         if hist and self.proj_depth > 0:
             U = [h[0] for h in hist]
-            b = np.array([c.dot(ui, rhs) for ui in U])
+            bn = self.dots(U + [rhs], rhs)          # projections and ||rhs||^2 in one pass over rhs
+            b, nf2 = np.array(bn[:-1]), bn[-1]
             # least squares with a cut-off: a start vector that is (nearly) a combination of older ones makes the
             # Gram matrix (nearly) singular; np.linalg.solve would answer with huge coefficients instead of failing
             a = np.linalg.lstsq(self._gram, b, rcond=1e-12)[0]
@@ -193,7 +199,7 @@ class RiksDriver:
                 r0 = c.spmv(x0, c.empty(rhs.n))             # true residual of the start vector
                 c.axpby(1.0, rhs, -1.0, r0, out=r0)
                 st["projection_spmv"] = st.get("projection_spmv", 0) + 1
-                nf, n0 = c.norm(rhs), c.norm(r0)
+                nf, n0 = float(np.sqrt(nf2)), c.norm(r0)
                 if not np.isfinite(n0) or n0 >= nf:         # projection did not help: plain solve
                     x0, r0, n0 = None, rhs, nf
         if x0 is not None and n0 <= self.rtol * nf:
@@ -213,8 +219,9 @@ class RiksDriver:
             if old is not None and old.shape[0] >= m - 1 and m > 1:
                 keep = old[-(m - 1):, -(m - 1):]
                 g[:m - 1, :m - 1] = keep
-            for i in range(m):      # new row / column: U_i . F_new  (symmetric: U^T K U)
-                g[i, m - 1] = g[m - 1, i] = c.dot(hist[i][0], hist[m - 1][1])
+            col = self.dots([h[0] for h in hist], hist[m - 1][1])      # new row / column: U_i . F_new  (symmetric: U^T K U)
+            for i in range(m):
+                g[i, m - 1] = g[m - 1, i] = col[i]
             self._gram = g
         st["solve_s"] += time.perf_counter() - t0
         st["pcg_iterations"] += info["iterations"]
@@ -283,9 +290,10 @@ class RiksDriver:
             c.axpby(c.norm(self.du) / c.norm(self.a), self.a, 0.0, None, out=self.a)
         c.axpby(self.relax, self.r, 0.0, None, out=self.f)
         due = self.solve(self.f)
-        self.dl = -c.dot(self.a, due) / c.dot(self.a, self.ue)  # fcVM.py:1414-1417 Riks correction
+        a_due, a_ue, a_a = self.dots([due, self.ue, self.a], self.a)
+        self.dl = -a_due / a_ue  # fcVM.py:1414-1417 Riks correction
         lbd[step + 1] += self.dl
-        self.aa = c.norm(self.a)
+        self.aa = float(np.sqrt(a_a))
         c.axpby(1.0, self.du, 1.0, due, out=self.du)
         c.axpby(1.0, self.du, self.dl, self.ue, out=self.du)
         uu = c.norm(self.du)

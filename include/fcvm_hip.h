@@ -150,6 +150,9 @@ int fcvm_set_diag_blocks(fcvm_ctx *c, const double *dblk);
 int fcvm_vec_axpby(fcvm_ctx *c, int64_t n, double a, const double *x, double b, const double *y, double *out);
 int fcvm_vec_mul(fcvm_ctx *c, int64_t n, const double *x, const double *y, double *out);
 int fcvm_vec_dot(fcvm_ctx *c, int64_t n, const double *x, const double *y, double *result_host);
+/* k (1..16) inner products xs[j] . y in one pass over y and one host synchronisation; every result is bitwise what
+ * fcvm_vec_dot returns for that pair.  xs: host array of k device pointers; result_host[k]. */
+int fcvm_vec_mdot(fcvm_ctx *c, int64_t n, int k, const double *const *xs, const double *y, double *result_host);
 /* w-weighted dot: sum w_i x_i y_i (owner weights of the multi-GPU partition); result [dev] */
 int fcvm_vec_wdot_dev(fcvm_ctx *c, int64_t n, const double *w, const double *x, const double *y, double *result_dev);
 /* sqrt(max over the first nnodes nodes of |u_node|^2) (fcVM.py:1539-1542) */
