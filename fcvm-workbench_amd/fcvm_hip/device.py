@@ -280,12 +280,15 @@ class Context:
         if target is None and os.environ.get("FCVM_MG_TARGET"):
             target = int(os.environ["FCVM_MG_TARGET"])
         if target is None:
-            # nodes per aggregate: at most ~1000 aggregates (the dense inverse costs n^3 at set-up and n^2 per cycle);
-            # the iteration count follows the aggregate SIZE (57 / 66 / 80 PCG iterations for 176 / 350 / 700 nodes on
-            # the 1 M cube), so mid-size meshes keep the 176 of the 1 M case instead of paying for 1000 small
-            # aggregates; small meshes (cheap either way) go down to 16
+            # nodes per aggregate.  The iteration count follows the aggregate SIZE (57 / 66 / 80 PCG iterations for 176 / 350 /
+            # 700 nodes on the 1 M cube), the cost of the dense inverse the aggregate COUNT (n^3 at set-up, n^2 per cycle):
+            # 176 nodes while that needs no more than 3000 aggregates (18,000 unknowns: 1.3 GB of FP32 inverse, 0.4 s more
+            # set-up at 8 M elements, where it brings 70 -> 60 iterations and 496 -> 408 ms per Newton iteration against the
+            # 1000 aggregates of round 1; 4900 aggregates: 54 iterations, 397 ms, 3 s of set-up -- profiles/r02x_*); small
+            # meshes (cheap either way) go down to 16
             nc = pi["coarse_nodes"]
-            target = max(16, int(round(nc / 1000.0)), int(min(176, nc / 200.0)))
+            max_aggr = int(os.environ.get("FCVM_MG_MAX_AGGREGATES", "3000"))
+            target = max(16, -(-nc // max_aggr), int(min(176, nc / 200.0)))
         if k1s is None and os.environ.get("FCVM_MG_K1S"):
             k1s = int(os.environ["FCVM_MG_K1S"])
         if k1s is None:
