@@ -17,6 +17,7 @@
 #include "fcvm_mg_kernels.hip.h"
 #include "fcvm_assemble_lds.hip.h"
 #include "fcvm_dense.hip.h"
+#include "fcvm_l2s_kernels.hip.h"
 #include "fcvm_pattern.h"
 
 using namespace fcvm;
@@ -48,6 +49,18 @@ struct WinDev {
     uint16_t *rowlen = nullptr, *own = nullptr, *cols = nullptr, *jstart = nullptr;
     void *vals = nullptr;   // 9 * nblocks doubles
     size_t lds = 0;
+};
+
+struct L2sDev {   // device state of the sparse aggregate level (owned by fcvm_ctx)
+    bool on = false;
+    int64_t nagg = 0, nslots = 0, nsuper = 0, n3 = 0, lda3 = 0;
+    int k2 = 2;
+    double lmax2 = 0.0, alpha2 = 8.0;
+    int64_t *sptr_g = nullptr, *soff = nullptr, *sptr_s = nullptr;
+    int32_t *slot_agg = nullptr, *sagg = nullptr, *smem = nullptr;
+    float *blocks = nullptr, *A3invf = nullptr;
+    double *dinv = nullptr, *C = nullptr;
+    double *x = nullptr, *r = nullptr, *d = nullptr, *t = nullptr, *r3 = nullptr, *e3 = nullptr;
 };
 
 struct fcvm_ctx {
@@ -126,6 +139,9 @@ struct fcvm_ctx {
     const double *mg_done = nullptr;  // device flag that turns the V-cycle kernels into no-ops once PCG has converged
     // level 2: aggregates + dense inverse (set from the host binding)
     bool l2 = false;
+    L2sDev l2s;                    // sparse aggregate level + dense super-aggregate level (fcvm_l2s.inc), large meshes
+    int64_t mg_max_dense = 3000;   // most aggregates a dense inverse is built for (FCVM_MG_MAX_AGGREGATES)
+    int64_t mg_spmv2 = 0;
     int64_t nagg = 0, n2 = 0;
     int mg_k1s = 2;
     double mg_alpha1s = 8.0;
@@ -518,6 +534,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_QIN_ATOMIC")) c->qin_atomic = atoi(v);
     if (const char *v = getenv("FCVM_SPMV_SPW")) c->spmv_spw = std::min(4, std::max(1, atoi(v)));   // slices (waves) per workgroup
     if (const char *v = getenv("FCVM_MG_ADDITIVE")) c->mg_additive = atoi(v);
+    if (const char *v = getenv("FCVM_MG_MAX_AGGREGATES")) c->mg_max_dense = std::max(8, atoi(v));
     if (const char *v = getenv("FCVM_MG_FP32")) c->mg_fp32 = atoi(v);
     if (const char *v = getenv("FCVM_MG_ADD_W")) c->mg_add_w = atof(v);
     HCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
@@ -1291,6 +1308,7 @@ int fcvm_mg_set_level2(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg
 }
 
 }  // extern "C"
+#include "fcvm_l2s.inc"
 #include "fcvm_level2.inc"
 extern "C" {
 
@@ -1302,6 +1320,14 @@ int fcvm_mg_build_level2(fcvm_ctx *c, int64_t target, int k1s, double alpha1s, i
     HCHK(hipSetDevice(c->device));
     if (mg_build_level2(c, target, k1s, alpha1s, 1e-6)) return 1;
     if (out) { out[0] = c->nagg; out[1] = c->n2; }
+    return 0;
+}
+
+/* sparse aggregate level (meshes with more aggregates than a dense inverse carries): out[0] = 1 if in use, out[1] = 6 x 6 blocks of
+ * A2, out[2] = super-aggregates, out[3] = unknowns of the dense top level */
+int fcvm_mg_sparse_info(fcvm_ctx *c, int64_t out[4]) {
+    NEED(c && out, "fcvm_mg_sparse_info: bad arguments");
+    out[0] = c->l2 && c->l2s.on ? 1 : 0; out[1] = c->l2s.nslots; out[2] = c->l2s.nsuper; out[3] = c->l2s.n3;
     return 0;
 }
 

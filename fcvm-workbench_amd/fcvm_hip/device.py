@@ -263,8 +263,15 @@ class Context:
         call("fcvm_precond_info", self.h, o)
         d = dict(mode="mg" if o[0] == 1 else "bj", coarse_nodes=int(o[1]), lmax0=o[2], lmax1=o[3],
                  coarse_nnz_blocks=int(o[4]), vcycle_fine_spmv=int(o[5]), l2_aggregates=int(o[6]), l2_unknowns=int(o[7]))
-        d["level2"] = (" -> %d aggregates x rigid-body modes (%d unknowns, dense inverse)" % (d["l2_aggregates"], d["l2_unknowns"])
-                       if d["l2_aggregates"] else "")
+        sp = (C.c_int64 * 4)()
+        call("fcvm_mg_sparse_info", self.h, sp)
+        d["l2_sparse"], d["l3_super_aggregates"], d["l3_unknowns"] = bool(sp[0]), int(sp[2]), int(sp[3])
+        if sp[0]:
+            d["level2"] = (" -> %d aggregates x rigid-body modes (sparse, %d blocks of 6 x 6, block-Jacobi Chebyshev) -> %d super-aggregates "
+                           "(%d unknowns, dense inverse)" % (d["l2_aggregates"], sp[1], sp[2], sp[3]))
+        else:
+            d["level2"] = (" -> %d aggregates x rigid-body modes (%d unknowns, dense inverse)" % (d["l2_aggregates"], d["l2_unknowns"])
+                           if d["l2_aggregates"] else "")
         return d
 
     def set_mg_cycle(self, additive=True, weight=1.0):
@@ -288,7 +295,11 @@ class Context:
             # meshes (cheap either way) go down to 16
             nc = pi["coarse_nodes"]
             max_aggr = int(os.environ.get("FCVM_MG_MAX_AGGREGATES", "3000"))
-            target = max(16, -(-nc // max_aggr), int(min(176, nc / 200.0)))
+            if os.environ.get("FCVM_MG_SPARSE", "1") != "0":
+                # beyond max_aggr aggregates of 176 nodes the library keeps the aggregate level sparse (fcvm_l2s.inc)
+                target = max(16, int(min(176, nc / 200.0)))
+            else:
+                target = max(16, -(-nc // max_aggr), int(min(176, nc / 200.0)))
         if k1s is None and os.environ.get("FCVM_MG_K1S"):
             k1s = int(os.environ["FCVM_MG_K1S"])
         if k1s is None:

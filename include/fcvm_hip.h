@@ -212,6 +212,11 @@ int fcvm_mg_set_level2(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg
  * kernels): aggregates = uniform bins of about `target` level-1 nodes, six orthonormalised rigid-body modes each,
  * A2 = Z^T A1 Z, explicit inverse kept in FP32.  out[0] = aggregates, out[1] = unknowns.  Call after fcvm_assemble. */
 int fcvm_mg_build_level2(fcvm_ctx *c, int64_t target, int k1s, double alpha1s, int64_t out[2]);
+/* When the aggregates outnumber what a dense inverse is built for (FCVM_MG_MAX_AGGREGATES, default 3000: meshes beyond
+ * ~3 M tet10), fcvm_mg_build_level2 keeps A2 sparse (6 x 6 blocks, block-Jacobi Chebyshev smoothing) and closes the cycle with a
+ * dense level of super-aggregates (bins of 2 x 2 x 2 aggregates x rigid-body modes).  out[0] = 1 if that path is in use,
+ * out[1] = blocks of A2, out[2] = super-aggregates, out[3] = unknowns of the dense top level. */
+int fcvm_mg_sparse_info(fcvm_ctx *c, int64_t out[4]);
 /* dst = inverse of the SPD n x n matrix src (row-major, device pointers, no aliasing) */
 int fcvm_spd_inverse(fcvm_ctx *c, int64_t n, const double *src, double *dst);
 

@@ -258,6 +258,39 @@ def test_window_format_spmv_and_pcg_match_sliced_ell(monkeypatch):
             m.ctx.close()
 
 
+def test_sparse_aggregate_level_solves_like_the_dense_one(monkeypatch):
+    """Meshes with more aggregates than a dense inverse carries keep A2 = Z^T A1 Z sparse (6 x 6 blocks, block-Jacobi Chebyshev
+    smoothing) under a dense level of super-aggregates.  Forced here on the Embankment model refined twice with a limit of 40
+    aggregates: the same solution as with the dense aggregate level and a comparable iteration count."""
+    from fcvm_hip import examples
+    from fcvm_hip.device import Context
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import GpuModel
+    case = examples.embankment(refine=2)
+    res = {}
+    for name, env in (("dense", {}), ("sparse", {"FCVM_MG_MAX_AGGREGATES": "40"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"], Loads(), ctx=Context(0))
+        c = m.ctx
+        glv, modf, _, _ = m.calc_gsm((0.0, 0.0, -10.0), want_x=False)
+        pi = c.precond_info()
+        f = c.mul(m.fixdof, glv)
+        u, info = c.solve(f, rtol=1e-11)
+        r = c.axpby(1.0, f, -1.0, c.spmv(u, c.empty(m.ndof)))
+        assert c.norm(r) <= 5e-11 * c.norm(f)
+        res[name] = (u.get(), info["iterations"], pi)
+        c.close()
+        for k in env:
+            monkeypatch.delenv(k)
+    assert not res["dense"][2]["l2_sparse"] and res["dense"][2]["l2_aggregates"] > 40
+    sp = res["sparse"][2]
+    assert sp["l2_sparse"] and sp["l2_aggregates"] == res["dense"][2]["l2_aggregates"] and 0 < sp["l3_super_aggregates"] <= 40
+    assert 0 < sp["l3_unknowns"] <= 6 * sp["l3_super_aggregates"]
+    assert rel(res["sparse"][0], res["dense"][0]) < 1e-8
+    assert res["sparse"][1] <= 1.15 * res["dense"][1] + 5, (res["sparse"][1], res["dense"][1])
+
+
 def test_dense_spd_inverse_kernels(gpu_ctx):
     """fcvm_spd_inverse (blocked Cholesky, triangular inverse, X^T X in HIP kernels: the aggregate level's solver) against
     LAPACK, sizes around the 64-wide tiles."""

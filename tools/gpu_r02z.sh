@@ -1,0 +1,13 @@
+#!/bin/bash
+# round-2 GPU session Z: sparse aggregate level (forced on a mid-size mesh; 8 M cube against the dense level of 2744 aggregates)
+O=gpurun_out/r02z
+mkdir -p $O
+export TMPDIR=/tmp
+timeout -k 10 300 python3 -m pytest tests/test_gpu_parity.py -x -q -k "sparse_aggregate or pcg or precond" > $O/parity.log 2>&1; tail -15 $O/parity.log | cut -c1-220
+( while sleep 45; do date +%T >> $O/heartbeat.txt; done ) &
+HB=$!
+trap "kill $HB" EXIT
+for sp in 1 0; do
+  FCVM_MG_SPARSE=$sp timeout -k 10 420 python3 bench.py --cells 110 --steps 4 --warmup 2 --no-cpu --no-plate > $O/bench8m_sparse$sp.log 2> $O/bench8m_sparse$sp.err || { tail -5 $O/bench8m_sparse$sp.err; exit 1; }
+  echo "sparse $sp"; grep -o '"ms_per_step": [0-9.]*\|"avg_launch_ms": [0-9.]*\|"pcg_iterations_per_step": [0-9.]*\|"assembly_plus_preconditioner_hierarchy": [0-9.]*\|aggregates x[^"]*' $O/bench8m_sparse$sp.log
+done
