@@ -54,7 +54,7 @@ struct WinDev {
 struct L2sDev {   // device state of the sparse aggregate level (owned by fcvm_ctx)
     bool on = false;
     int64_t nagg = 0, nslots = 0, nsuper = 0, n3 = 0, lda3 = 0;
-    int k2 = 2;
+    int k2 = 2, ncoarse = 1;   // smoothing steps per sweep; super-aggregate corrections per cycle (2: smooth, coarse, smooth, coarse, smooth)
     double lmax2 = 0.0, alpha2 = 8.0;
     int64_t *sptr_g = nullptr, *soff = nullptr, *sptr_s = nullptr;
     int32_t *slot_agg = nullptr, *sagg = nullptr, *smem = nullptr;

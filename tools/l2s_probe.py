@@ -63,9 +63,8 @@ def run(tag, env):
 run("dense aggregate level", {})
 M = str(a.max_aggr)
 run("dense, 8x larger aggregates", {"FCVM_MG_TARGET": str(8 * 176)})
-run("sparse, k2 = 2", {"FCVM_MG_MAX_AGGREGATES": M})
-run("sparse, k2 = 1", {"FCVM_MG_MAX_AGGREGATES": M, "FCVM_L2S_K": "1"})
-run("sparse, k2 = 4", {"FCVM_MG_MAX_AGGREGATES": M, "FCVM_L2S_K": "4"})
-run("sparse, k2 = 4, alpha 30", {"FCVM_MG_MAX_AGGREGATES": M, "FCVM_L2S_K": "4", "FCVM_L2S_ALPHA": "30"})
-run("sparse, k2 = 8, alpha 100", {"FCVM_MG_MAX_AGGREGATES": M, "FCVM_L2S_K": "8", "FCVM_L2S_ALPHA": "100"})
-run("sparse, k2 = 30, alpha 1000", {"FCVM_MG_MAX_AGGREGATES": M, "FCVM_L2S_K": "30", "FCVM_L2S_ALPHA": "1000"})
+run("sparse, 8 steps", {"FCVM_MG_MAX_AGGREGATES": M})
+run("sparse, 8 steps, 2 coarse corrections", {"FCVM_MG_MAX_AGGREGATES": M, "FCVM_L2S_COARSE": "2"})
+run("sparse, 4 steps, 2 coarse corrections", {"FCVM_MG_MAX_AGGREGATES": M, "FCVM_L2S_COARSE": "2", "FCVM_L2S_K": "4", "FCVM_L2S_ALPHA": "30"})
+run("sparse, 4 steps, 3 coarse corrections", {"FCVM_MG_MAX_AGGREGATES": M, "FCVM_L2S_COARSE": "3", "FCVM_L2S_K": "4", "FCVM_L2S_ALPHA": "30"})
+run("sparse, 16 steps, alpha 300", {"FCVM_MG_MAX_AGGREGATES": M, "FCVM_L2S_K": "16", "FCVM_L2S_ALPHA": "300"})
