@@ -83,33 +83,6 @@ __global__ __launch_bounds__(256) void k_l2s_init(int64_t nagg, const double *__
     }
 }
 
-// x += d ; r -= t (t = A d) ; if (update_d) { d = cdd * d + cdr * Dinv r ; if (add_d) x += d }      (thread = aggregate)
-__global__ __launch_bounds__(256) void k_l2s_step(int64_t nagg, const double *__restrict__ dinv, const double *__restrict__ t,
-                                                  double *__restrict__ x, double *__restrict__ r, double *__restrict__ d, double cdd,
-                                                  double cdr, int update_d, int add_d, const double *__restrict__ done) {
-    if (done && *done != 0.0) return;
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= nagg) return;
-    double dd[6], rr[6], z[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        dd[k] = d[6 * g + k];
-        rr[k] = r[6 * g + k] - t[6 * g + k];
-        r[6 * g + k] = rr[k];
-    }
-    if (update_d) apply_dinv6(dinv + g * 36, rr, z);
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        double a = dd[k];
-        if (update_d) {
-            const double dn = cdd * dd[k] + cdr * z[k];
-            d[6 * g + k] = dn;
-            if (add_d) a += dn;
-        }
-        x[6 * g + k] += a;
-    }
-}
-
 // one smoother step with its SpMV: t = A2 din ; x += din ; r -= t ; if (update_d) { dout = cdd * din + cdr * Dinv r ; if (add_d)
 // x += dout }.  Eight lanes per aggregate (six active: one per mode) exchange the residual with shuffles; din is read by the
 // neighbours while this launch runs, so the new direction goes to dout (the caller ping-pongs).
