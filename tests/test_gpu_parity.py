@@ -835,6 +835,22 @@ def test_reruns_are_bitwise_identical():
     assert a["stats"]["pcg_iterations"] == b["stats"]["pcg_iterations"]
 
 
+def test_fused_inner_products_are_bitwise_the_single_ones():
+    """fcvm_vec_mdot (the Newton driver's projection / Gram / Riks scalars in one pass) returns, for every pair, exactly the value
+    of fcvm_vec_dot: same grid, same per-thread order, same two-stage sums -- sizes around the block and grid-stride limits,
+    1 to 17 vectors (more than 16 go in batches)."""
+    c = make_model(small_case(2)).ctx       # (the reductions use the work buffers of a context with a mesh)
+    rng = np.random.default_rng(11)
+    for n in (1, 255, 256, 257, 70001, 256 * 2048 + 3):
+        y = c.array(rng.standard_normal(n))
+        for k in (1, 3, 16, 17):
+            xs = [c.array(rng.standard_normal(n) * 10.0 ** rng.integers(-3, 4)) for _ in range(k)]
+            fused = c.mdot(xs, y)
+            single = [c.dot(x, y) for x in xs]
+            assert fused == single, (n, k)
+            assert np.allclose(fused, [float(x.get() @ y.get()) for x in xs], rtol=1e-12, atol=1e-12 * n)
+
+
 def test_error_paths_and_mirror_kernels(orc, gpu_ctx):
     """Loud failures (no silent fallback) and the array-level mirrors fcVM.update_stress_load /
     update_PEEQ_CSR / calculate_principal_stress."""
