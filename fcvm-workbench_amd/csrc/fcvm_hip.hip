@@ -1064,6 +1064,12 @@ int fcvm_vec_mdot(fcvm_ctx *c, int64_t n, int k, const double *const *xs, const 
 int fcvm_vec_wdot_dev(fcvm_ctx *c, int64_t n, const double *w, const double *x, const double *y, double *result_dev) {
     return dot_common(c, n, w, x, y, result_dev);
 }
+int fcvm_dist_pcg_scalars(fcvm_ctx *c, int phase, double *S, const double *in) {
+    NEED(c && S && in && (phase == 0 || phase == 1), "fcvm_dist_pcg_scalars: bad arguments");
+    hipLaunchKernelGGL(k_dist_pcg_scalars, dim3(1), dim3(1), 0, c->stream, phase, S, in);
+    HCHK(hipGetLastError());
+    return 0;
+}
 int fcvm_any_u8(fcvm_ctx *c, int64_t n, const uint8_t *a, int *result_host) {
     NEED(c && n >= 0 && result_host, "fcvm_any_u8: bad arguments");
     *result_host = 0;

@@ -522,4 +522,25 @@ __global__ __launch_bounds__(256) void k_add_if(int64_t n, const double *__restr
     if (i < n) o[i] = a[i] + b[i];
 }
 
+// Scalars of the multi-GPU PCG (fcvm_hip/dist.py), kept on the device so that the host never waits for them:
+// S = {rz, rr, thresh, done, iterations, alpha, beta}.  phase 0: in[0] = p.q (all-reduced) -> alpha; phase 1: in = {r.z, r.r}
+// (all-reduced) -> beta, rz, rr, iterations, done.  After convergence (done != 0) alpha = beta = 0: queued iterations change
+// nothing.  One thread: this replaces a dozen one-element tensor operations per iteration.
+__global__ void k_dist_pcg_scalars(int phase, double *__restrict__ S, const double *__restrict__ in) {
+    const bool live = S[3] == 0.0;
+    if (phase == 0) {
+        const double pq = in[0];
+        S[5] = (live && pq != 0.0) ? S[0] / pq : 0.0;
+        return;
+    }
+    const double rz_new = in[0], rr_new = in[1];
+    S[6] = (live && S[0] != 0.0) ? rz_new / S[0] : 0.0;
+    if (live) {
+        S[0] = rz_new;
+        S[1] = rr_new;
+        S[4] += 1.0;
+    }
+    if (S[1] <= S[2] || !isfinite(S[1])) S[3] = 1.0;
+}
+
 }  // namespace fcvm

@@ -406,39 +406,64 @@ class DistBackend:
         if not np.isfinite(bb_h):
             raise RuntimeError("distributed PCG: non-finite right-hand side")
         dev = self.device
-        thresh = torch.full((1,), rtol * rtol * bb_h, dtype=torch.float64, device=dev)
-        zero, one = torch.zeros(1, dtype=torch.float64, device=dev), torch.ones(1, dtype=torch.float64, device=dev)
-        done = torch.zeros(1, dtype=torch.bool, device=dev)
-        it_t = torch.zeros(1, dtype=torch.float64, device=dev)
-        rr = bb.clone()
         fused = self.mg is not None and self.mg.ready and self.mg.additive
         queued, chunk, spmvs = 0, 1, 0
         finished = False
-        while queued < maxit and not finished:
-            n = min(chunk, maxit - queued)
-            for _ in range(n):
-                self.spmv(p, q)
-                spmvs += 1
-                pq = self.dot_t(p.t, q.t)
-                live = ~done
-                alpha = torch.where(live & (pq != 0.0), rz / torch.where(pq != 0.0, pq, one), zero)
-                if fused:
-                    self.mg.update_and_vcycle(alpha, p, q, TVec(x), TVec(r), z)
-                else:
-                    x.addcmul_(p.t, alpha)                  # x += alpha p
-                    r.addcmul_(q.t, -alpha)                 # r -= alpha q
-                    self.precond(TVec(r), z)
-                both = self.dot2_t(r, z.t)
-                rz_new, rr_new = both[0:1], both[1:2]
-                beta = torch.where(live & (rz != 0.0), rz_new / torch.where(rz != 0.0, rz, one), zero)
-                torch.addcmul(z.t, p.t, beta, out=p.t)     # p = z + beta p
-                rz = torch.where(live, rz_new, rz)
-                rr = torch.where(live, rr_new, rr)
-                it_t += live
-                done = done | (rr <= thresh) | ~torch.isfinite(rr)
-            queued += n
-            chunk = min(self.check_every, 2 * chunk) if queued >= 2 else 1
-            finished = bool(done.item())
+        if hasattr(self.ops, "pcg_scalars"):
+            # scalars on the device in one small array, updated by one single-thread kernel per phase (fcvm_dist_pcg_scalars)
+            S = torch.zeros(7, dtype=torch.float64, device=dev)       # rz, rr, thresh, done, iterations, alpha, beta
+            S[0:1].copy_(rz); S[1:2].copy_(bb); S[2] = rtol * rtol * bb_h
+            alpha, beta = S[5:6], S[6:7]
+            while queued < maxit and not finished:
+                n = min(chunk, maxit - queued)
+                for _ in range(n):
+                    self.spmv(p, q)
+                    spmvs += 1
+                    self.ops.pcg_scalars(0, S, self.dot_t(p.t, q.t))
+                    if fused:
+                        self.mg.update_and_vcycle(alpha, p, q, TVec(x), TVec(r), z)
+                    else:
+                        x.addcmul_(p.t, alpha)                  # x += alpha p
+                        r.addcmul_(q.t, -alpha)                 # r -= alpha q
+                        self.precond(TVec(r), z)
+                    self.ops.pcg_scalars(1, S, self.dot2_t(r, z.t))
+                    torch.addcmul(z.t, p.t, beta, out=p.t)     # p = z + beta p
+                queued += n
+                chunk = min(self.check_every, 2 * chunk) if queued >= 2 else 1
+                finished = bool(S[3].item() != 0.0)
+            Sh = S.cpu()
+            rr, it_t, thresh = Sh[1:2], Sh[4:5], Sh[2:3]
+        else:
+            thresh = torch.full((1,), rtol * rtol * bb_h, dtype=torch.float64, device=dev)
+            zero, one = torch.zeros(1, dtype=torch.float64, device=dev), torch.ones(1, dtype=torch.float64, device=dev)
+            done = torch.zeros(1, dtype=torch.bool, device=dev)
+            it_t = torch.zeros(1, dtype=torch.float64, device=dev)
+            rr = bb.clone()
+            while queued < maxit and not finished:
+                n = min(chunk, maxit - queued)
+                for _ in range(n):
+                    self.spmv(p, q)
+                    spmvs += 1
+                    pq = self.dot_t(p.t, q.t)
+                    live = ~done
+                    alpha = torch.where(live & (pq != 0.0), rz / torch.where(pq != 0.0, pq, one), zero)
+                    if fused:
+                        self.mg.update_and_vcycle(alpha, p, q, TVec(x), TVec(r), z)
+                    else:
+                        x.addcmul_(p.t, alpha)                  # x += alpha p
+                        r.addcmul_(q.t, -alpha)                 # r -= alpha q
+                        self.precond(TVec(r), z)
+                    both = self.dot2_t(r, z.t)
+                    rz_new, rr_new = both[0:1], both[1:2]
+                    beta = torch.where(live & (rz != 0.0), rz_new / torch.where(rz != 0.0, rz, one), zero)
+                    torch.addcmul(z.t, p.t, beta, out=p.t)     # p = z + beta p
+                    rz = torch.where(live, rz_new, rz)
+                    rr = torch.where(live, rr_new, rr)
+                    it_t += live
+                    done = done | (rr <= thresh) | ~torch.isfinite(rr)
+                queued += n
+                chunk = min(self.check_every, 2 * chunk) if queued >= 2 else 1
+                finished = bool(done.item())
         it = int(it_t.item())
         rr_h = float(rr.item())
         info.update(iterations=it, rel_residual=float(np.sqrt(rr_h / bb_h)) if np.isfinite(rr_h) else float("nan"), spmv=spmvs)
@@ -923,6 +948,10 @@ class HipLocalOps:
 
     def set_coords(self, nocoord_local):
         self.c.set_coords(np.ascontiguousarray(nocoord_local, dtype=np.float64))
+
+    def pcg_scalars(self, phase, S, t_in):
+        from ._lib import call
+        call("fcvm_dist_pcg_scalars", self.c.h, int(phase), S.data_ptr(), t_in.data_ptr())
 
     def spd_inverse(self, A):
         """inverse of the SPD matrix A (torch f64 [n, n] on this rank's device) by the library's dense kernels"""

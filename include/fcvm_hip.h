@@ -156,6 +156,10 @@ int fcvm_vec_mdot(fcvm_ctx *c, int64_t n, int k, const double *const *xs, const 
 /* w-weighted dot: sum w_i x_i y_i (owner weights of the multi-GPU partition); result [dev] */
 int fcvm_vec_wdot_dev(fcvm_ctx *c, int64_t n, const double *w, const double *x, const double *y, double *result_dev);
 /* sqrt(max over the first nnodes nodes of |u_node|^2) (fcVM.py:1539-1542) */
+/* scalars of the multi-GPU PCG on the device (fcvm_hip/dist.py): S [dev, 7] = {rz, rr, thresh, done, iterations, alpha, beta};
+ * phase 0: in [dev, 1] = p.q -> alpha; phase 1: in [dev, 2] = {r.z, r.r} -> beta, rz, rr, iterations, done (alpha = beta = 0 once
+ * done): one launch instead of a dozen one-element tensor operations per iteration */
+int fcvm_dist_pcg_scalars(fcvm_ctx *c, int phase, double *S, const double *in);
 /* *result_host = 1 if any of the n bytes at a (device) is non-zero (the "any plastic Gauss point?" test of fcVM.py:1351) */
 int fcvm_any_u8(fcvm_ctx *c, int64_t n, const uint8_t *a, int *result_host);
 int fcvm_vec_max_node_norm(fcvm_ctx *c, int64_t nnodes, const double *u, double *result_host);
