@@ -76,10 +76,9 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *elnodes0, Pattern &p, 
 //   * the union of the column nodes of a group -- its WINDOW, a compact patch of the mesh -- is listed once; the workgroup
 //     copies x of the window into LDS with near-coalesced loads and every block's x comes from LDS;
 //   * column entries are 16-bit positions in the window;
-//   * the vrows of a group are sorted by length (longest first) and dealt to the waves round-robin, so every wave holds
-//     vrows of all lengths, longest in lane 0: for block number j the lanes that still have a block are a PREFIX of the
-//     wave, n_j of them, and only those are stored (no padding at all): entry (j, lane) of wave w is number
-//     woff[w] + sum_{i<j} n_i + lane, its nine values are vals[9 * (woff[w] + sum_{i<j} n_i) + c * n_j + lane];
+//   * the vrows of a group are sorted by length (longest first) and cut into waves of 64, longest in lane 0: for block
+//     number j the lanes that still have a block are a PREFIX of the wave, n_j of them, and only those are stored (no
+//     padding at all): entry (j, lane) of wave w is number woff[w] + sum_{i<j} n_i + lane, its nine values are vals[9 * (woff[w] + sum_{i<j} n_i) + c * n_j + lane];
 //   * the partial results of the second, third .. segment of a row go through LDS to the lane of its first segment, which
 //     adds them in segment order (fixed order: bitwise reproducible) and writes y.
 // The values are copied from the sliced-ELL array by k_repack_win after every assembly (src: SELL slot of the row; both
