@@ -314,11 +314,13 @@ static int setup_window_format(fcvm_ctx *c, const double *nocoord) {
     if (const char *v = getenv("FCVM_WIN_MAX")) max_window = std::max(64, atoi(v));   // (tests: force the smaller groups)
     WinPattern &w = c->win.pat;
     try {
-        bool built = build_window_format(c->pat, nocoord, nt, max_window, w, WIN_WAVES);
+        int split = WIN_SPLIT;
+        if (const char *v = getenv("FCVM_WIN_SPLIT")) split = std::min(512, std::max(4, atoi(v)));
+        bool built = build_window_format(c->pat, nocoord, nt, max_window, w, WIN_WAVES, split);
         if (!built) {   // smaller groups have smaller windows (at the price of more x traffic from the L2)
             const long long w8 = (long long)w.wmax;
             w = WinPattern();
-            built = build_window_format(c->pat, nocoord, nt, max_window, w, 4);
+            built = build_window_format(c->pat, nocoord, nt, max_window, w, 4, split);
             if (getenv("FCVM_VERBOSE"))
                 fprintf(stderr, "fcvm: window format: largest window of 512-row groups %lld nodes, of 256-row groups %lld\n", w8, (long long)w.wmax);
             if (built) c->win_v2 = 1;
@@ -334,7 +336,10 @@ static int setup_window_format(fcvm_ctx *c, const double *nocoord) {
     if (win_upload(c, c->win)) return 1;
     HCHK(hipMemsetAsync(c->d_part_spmv, 0, sizeof(double) * c->nb_spmv, c->stream));
     HCHK(hipStreamSynchronize(c->stream));
-    const size_t lds = c->win.lds;
+    // the limit is a property of the kernel, not of this context: never lower what another context of the process asked for
+    static size_t lds_allowed = 0;
+    lds_allowed = std::max(lds_allowed, c->win.lds);
+    const size_t lds = lds_allowed;
     if (win_allow_lds(k_spmv_win<true, WIN_WAVES, true>, lds) || win_allow_lds(k_spmv_win<false, WIN_WAVES, true>, lds) ||
         win_allow_lds(k_spmv_win<true, WIN_WAVES, false>, lds) || win_allow_lds(k_spmv_win<false, WIN_WAVES, false>, lds) ||
         win_allow_lds(k_spmv_win<true, 4, true>, lds) || win_allow_lds(k_spmv_win<false, 4, true>, lds))
@@ -461,11 +466,14 @@ static int build_asm_items(fcvm_ctx *c) {
     if (dalloc(&c->d_asm_items, (int64_t)all.size())) return 1;
     HCHK(hipMemcpyAsync(c->d_asm_items, all.data(), sizeof(int32_t) * all.size(), hipMemcpyHostToDevice, c->stream));
     HCHK(hipStreamSynchronize(c->stream));
-    for (int b = 0; b < fcvm_ctx::ASM_BUCKETS; b++) {   // dynamic LDS beyond 64 KiB has to be requested per kernel
+    // dynamic LDS beyond 64 KiB has to be requested per kernel; the limit belongs to the kernel, not to this context: only raise it
+    static int asm_lds_allowed = 64 * 1024;
+    for (int b = 0; b < fcvm_ctx::ASM_BUCKETS; b++) {
         const int bytes = (int)asm_lds_bytes(ASM_LEN_LIMIT[b]);
-        if (bytes <= 64 * 1024 || !c->asm_count[b]) continue;
+        if (bytes <= asm_lds_allowed || !c->asm_count[b]) continue;
         HCHK(hipFuncSetAttribute((const void *)k_assemble_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HCHK(hipFuncSetAttribute((const void *)k_assemble_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        asm_lds_allowed = bytes;
     }
     c->asm_lds_ok = true;
     return 0;
