@@ -149,6 +149,8 @@ struct fcvm_ctx {
     int64_t *d_aoff = nullptr, *d_aptr = nullptr;
     double *d_Z = nullptr, *d_A2inv = nullptr, *d_r2 = nullptr, *d_e2 = nullptr;
     std::vector<hipEvent_t> evpool;
+    double *h_pcgS = nullptr;      // pinned copies of the PCG scalars, one per queued chunk (fcvm_mg.inc)
+    int64_t mg_last_iters = 0;     // iterations of the previous multigrid-PCG solve: size of the first chunk of the next one
 };
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -570,6 +572,7 @@ int fcvm_destroy(fcvm_ctx *c) {
     free_mesh(c);
     dfree(c->d_S); dfree(c->d_out8); dfree(c->d_part_mdot);
     for (auto e : c->evpool) (void)hipEventDestroy(e);
+    if (c->h_pcgS) (void)hipHostFree(c->h_pcgS);
     if (c->asm_fork) (void)hipEventDestroy(c->asm_fork);
     for (int b = 0; b < fcvm_ctx::ASM_BUCKETS; b++) {
         if (c->asm_join[b]) (void)hipEventDestroy(c->asm_join[b]);
