@@ -134,6 +134,7 @@ struct fcvm_ctx {
     int mg_additive = 1;
     int mg_fp32 = 1;           // coarse levels: level-1 matrix and aggregate inverse stored in FP32 (FP64 vectors / accumulation)
     float *d_vals1f = nullptr, *d_A2invf = nullptr;
+    float *d_dinv6f = nullptr;     // FP32 copy of the six distinct entries of every fine inverse diagonal block (PCG update kernel)
     bool l2_has_inverse = false;
     double mg_add_w = 1.0;
     const double *mg_done = nullptr;  // device flag that turns the V-cycle kernels into no-ops once PCG has converged
@@ -240,6 +241,8 @@ static void launch_spmv_win(fcvm_ctx *c, bool dot, const double *x, double *y, c
         else launch_spmv_win_t<false, WIN_WAVES, false>(c, w, x, y, done);
     }
 }
+// p.Ap partials the fine SpMV leaves: one per group of the window format, one per workgroup of the sliced-ELL kernel
+static inline int64_t spmv_partials(const fcvm_ctx *c) { return c->win.on ? c->win.pat.ngroups : c->nb_spmv; }
 static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done) {
     if (c->win.on) {   // window format: x through LDS (the p.Ap partials beyond the group count stay zero)
         launch_spmv_win(c, dot, x, y, done);
@@ -559,7 +562,7 @@ static void free_mesh(fcvm_ctx *c) {
     dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
     dfree(c->d_nptr); dfree(c->d_nel); dfree(c->d_fe); dfree(c->d_part_vol); dfree(c->d_asm_items);
     win_free(c->win);
-    dfree(c->d_vals); dfree(c->d_vals_g); dfree(c->d_dblk); dfree(c->d_dinv); dfree(c->d_r); dfree(c->d_z); dfree(c->d_p);
+    dfree(c->d_vals); dfree(c->d_vals_g); dfree(c->d_dblk); dfree(c->d_dinv); dfree(c->d_dinv6f); dfree(c->d_r); dfree(c->d_z); dfree(c->d_p);
     dfree(c->d_q); dfree(c->d_part_vec); dfree(c->d_part_spmv); dfree(c->d_part_misc); dfree(c->d_pidx);
     mg_free(c);
     c->have_mesh = c->assembled = false;
@@ -667,7 +670,7 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
         dalloc(&c->d_noce, nn) || dalloc(&c->d_sptr, p.nslices + 1) || dalloc(&c->d_emap, ne * 100) ||
         dalloc(&c->d_diagoff, nn) || dalloc(&c->d_fixmask, nn) || dalloc(&c->d_coord, nn * 3) ||
         dalloc(&c->d_fixval, nn * 3) || dalloc(&c->d_vals, p.value_count()) || dalloc(&c->d_dblk, nn * 9) ||
-        dalloc(&c->d_dinv, nn * 9) || dalloc(&c->d_r, nn * 3) || dalloc(&c->d_z, nn * 3) || dalloc(&c->d_p, nn * 3) ||
+        dalloc(&c->d_dinv, nn * 9) || dalloc(&c->d_dinv6f, nn * 6) || dalloc(&c->d_r, nn * 3) || dalloc(&c->d_z, nn * 3) || dalloc(&c->d_p, nn * 3) ||
         dalloc(&c->d_q, nn * 3) || dalloc(&c->d_nptr, nn + 1) || dalloc(&c->d_nel, ne * 10) || dalloc(&c->d_part_vol, 4 * p.nslices))
         return 1;
     c->nb_vec = cdiv(nn, 256);
@@ -791,6 +794,7 @@ static int refresh_precond(fcvm_ctx *c) {   // after every assembly into d_vals
     }
     hipLaunchKernelGGL(k_diag_get, dim3(cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_diagoff, c->d_vals, c->d_dblk);
     hipLaunchKernelGGL(k_diag_invert, dim3(cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_dblk, c->d_dinv);
+    hipLaunchKernelGGL(k_dinv_pack6f, dim3(cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_dinv, c->d_dinv6f);
     HCHK(hipGetLastError());
     return 0;
 }
@@ -942,6 +946,7 @@ int fcvm_get_diag_blocks(fcvm_ctx *c, double *dblk) {
 int fcvm_set_diag_blocks(fcvm_ctx *c, const double *dblk) {
     NEED(c && c->have_mesh, "fcvm_set_diag_blocks: no mesh");
     hipLaunchKernelGGL(k_diag_invert, dim3((unsigned)c->nb_vec), dim3(256), 0, c->stream, c->nn, dblk, c->d_dinv);
+    hipLaunchKernelGGL(k_dinv_pack6f, dim3((unsigned)c->nb_vec), dim3(256), 0, c->stream, c->nn, c->d_dinv, c->d_dinv6f);
     HCHK(hipGetLastError());
     return 0;
 }
@@ -976,7 +981,7 @@ int fcvm_solve(fcvm_ctx *c, const double *f, double *u, double rtol, int64_t max
             HCHK(hipEventRecord(c->evpool[2 * j], s));
             launch_spmv(c, true, c->d_p, c->d_q, c->d_S + S_DONE);
             HCHK(hipEventRecord(c->evpool[2 * j + 1], s));
-            hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(1024), 0, s, 1, c->d_part_spmv, nbv, c->nb_spmv, c->d_S, rtol);
+            hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(1024), 0, s, 1, c->d_part_spmv, nbv, spmv_partials(c), c->d_S, rtol);
             hipLaunchKernelGGL(k_pcg_update_xr, dim3((unsigned)nbv), dim3(256), 0, s, nn, c->d_dinv, c->d_p, c->d_q, u,
                                c->d_r, c->d_z, c->d_part_vec, nbv, c->d_S);
             hipLaunchKernelGGL(k_pcg_scalars, dim3(1), dim3(1024), 0, s, 2, c->d_part_vec, nbv, c->nb_spmv, c->d_S, rtol);

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void k_pcg_update_xr_plain(int64_t nn, const d
 __global__ __launch_bounds__(256) void k_pcg_update_xr_z0(int64_t nn, const double *__restrict__ p, const double *__restrict__ q,
                                                           double *__restrict__ x, double *__restrict__ r,
                                                           const double *__restrict__ dinv, double *__restrict__ z0, double w,
-                                                          const double *__restrict__ S) {
+                                                          const double *__restrict__ S, const float *__restrict__ dinv6 = nullptr) {
     if (S[S_DONE] != 0.0) return;
     const double alpha = S[S_ALPHA];
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -325,8 +325,26 @@ __global__ __launch_bounds__(256) void k_pcg_update_xr_z0(int64_t nn, const doub
         r[3 * i + c] = rn[c];
     }
     double a0, a1, a2;
-    apply_dinv(dinv + i * 9, rn[0], rn[1], rn[2], a0, a1, a2);
+    if (dinv6) {   // the six distinct entries of the (symmetric) inverse diagonal block in FP32: 24 instead of 72 bytes per node
+        const float2 *d2 = (const float2 *)(dinv6 + 6 * i);
+        const float2 u0 = d2[0], u1 = d2[1], u2 = d2[2];   // xx xy | xz yy | yz zz
+        a0 = (double)u0.x * rn[0] + (double)u0.y * rn[1] + (double)u1.x * rn[2];
+        a1 = (double)u0.y * rn[0] + (double)u1.y * rn[1] + (double)u2.x * rn[2];
+        a2 = (double)u1.x * rn[0] + (double)u2.x * rn[1] + (double)u2.y * rn[2];
+    } else {
+        apply_dinv(dinv + i * 9, rn[0], rn[1], rn[2], a0, a1, a2);
+    }
     z0[3 * i] = w * a0; z0[3 * i + 1] = w * a1; z0[3 * i + 2] = w * a2;
+}
+
+// six distinct entries of every inverse diagonal block, FP32 (for k_pcg_update_xr_z0)
+__global__ __launch_bounds__(256) void k_dinv_pack6f(int64_t nn, const double *__restrict__ dinv, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nn) return;
+    const double *d = dinv + 9 * i;
+    float *o = out + 6 * i;
+    o[0] = (float)d[0]; o[1] = (float)(0.5 * (d[1] + d[3])); o[2] = (float)(0.5 * (d[2] + d[6]));
+    o[3] = (float)d[4]; o[4] = (float)(0.5 * (d[5] + d[7])); o[5] = (float)d[8];
 }
 
 // additive cycle, second half: z = z0 + M0 P M1 e1 and the partials of r.z (slot 0) and r.r (slot 1)
