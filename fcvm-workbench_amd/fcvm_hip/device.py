@@ -306,6 +306,8 @@ class Context:
             # level-1 Chebyshev steps before / after the aggregate correction: larger aggregates leave more for the
             # smoother to do (1 M cube with 1400-node aggregates: 95 PCG iterations with 2 steps, 79 with 3; 2800: 113 / 87 with 4)
             k1s = 2 if target <= 250 else (3 if target <= 1000 else 4)
+        if alpha1s is None and os.environ.get("FCVM_MG_ALPHA1S"):
+            alpha1s = float(os.environ["FCVM_MG_ALPHA1S"])
         if alpha1s is None:
             alpha1s = 4.0 * k1s
         out = (C.c_int64 * 2)()
