@@ -134,6 +134,7 @@ struct fcvm_ctx {
     int mg_additive = 1;
     int mg_fp32 = 1;           // coarse levels: level-1 matrix and aggregate inverse stored in FP32 (FP64 vectors / accumulation)
     float *d_vals1f = nullptr, *d_A2invf = nullptr;
+    float *d_dinv1_6f = nullptr;   // the same for level 1 (SpMV epilogue of the Chebyshev smoother)
     float *d_dinv6f = nullptr;     // FP32 copy of the six distinct entries of every fine inverse diagonal block (PCG update kernel)
     bool l2_has_inverse = false;
     double mg_add_w = 1.0;
@@ -1396,6 +1397,7 @@ int fcvm_mg_set_diag_blocks(fcvm_ctx *c, int level, const double *dblk) {
     if (level == 0) return fcvm_set_diag_blocks(c, dblk);
     NEED(c && c->mg_topo, "fcvm_mg_set_diag_blocks: no multigrid hierarchy");
     hipLaunchKernelGGL(k_diag_invert, dim3((unsigned)cdiv(c->nc, 256)), dim3(256), 0, c->stream, c->nc, dblk, c->d_dinv1);
+    hipLaunchKernelGGL(k_dinv_pack6f, dim3((unsigned)cdiv(c->nc, 256)), dim3(256), 0, c->stream, c->nc, c->d_dinv1, c->d_dinv1_6f);
     HCHK(hipGetLastError());
     return 0;
 }
