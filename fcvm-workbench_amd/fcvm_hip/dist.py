@@ -838,10 +838,13 @@ def _local_loads(part, loads):
     return Loads(**out)
 
 
-def partition_model(elNodes, nocoord, material, fix, loads, device_index, device=None, group=None, precond="mg", order=None):
+def partition_model(elNodes, nocoord, material, fix, loads, device_index=0, device=None, group=None, precond="mg", order=None,
+                    ops_factory=None, pcg_check_every=25, mg_options=None):
     """One rank's DistModel of the element-range partition of a global model (the 1 -> N split of north_star): elements
     [rank * ne / world, (rank + 1) * ne / world) of the global list (or of `order`, a permutation of it), the nodes they
-    touch, the supports and load entities that fall on them.  Collective: every rank of `group` calls it."""
+    touch, the supports and load entities that fall on them.  Collective: every rank of `group` calls it.
+    ops_factory(part, nocoord_local, material, fix_local, element_offset) -> LocalOps: the rank's kernels (default: HipLocalOps on
+    GPU `device_index`; the CPU tests pass their oracle-backed LocalOps and device = torch.device("cpu"))."""
     from .loads import Loads, external_loads
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -854,10 +857,14 @@ def partition_model(elNodes, nocoord, material, fix, loads, device_index, device
     gd = np.array(sorted(fix), dtype=np.int64)
     here, ld = part.local_dofs_of(gd)
     fix_loc = {int(d): float(fix[int(g)]) for d, g in zip(ld, gd[here])}
-    ops = HipLocalOps(part, xyz_loc, material, fix_loc, device_index, element_offset=lo)
-    be = DistBackend(part, ops, device if device is not None else torch.device("cuda", device_index))
+    if ops_factory is None:
+        ops = HipLocalOps(part, xyz_loc, material, fix_loc, device_index, element_offset=lo)
+        device = device if device is not None else torch.device("cuda", device_index)
+    else:
+        ops = ops_factory(part, xyz_loc, material, fix_loc, lo)
+    be = DistBackend(part, ops, device, pcg_check_every=pcg_check_every)
     if precond == "mg":
-        be.enable_multigrid(xyz_loc)
+        be.enable_multigrid(xyz_loc, **(mg_options or {}))
     model = DistModel(part, be, xyz_loc, material, fix_loc, _local_loads(part, loads if loads is not None else Loads()),
                       external_loads)
     model.elements = sel

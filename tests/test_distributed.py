@@ -217,21 +217,17 @@ def _buckling_worker(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from dist_helpers import OracleLocalOps
-        from fcvm_hip.dist import DistBackend, DistModel, Partition, _local_loads
-        from fcvm_hip.loads import Loads, external_loads
+        from fcvm_hip.dist import partition_model
+        from fcvm_hip.loads import Loads
         from fcvm_hip.solver import calc_disp
         el, xyz, mat, fix, faces, ul = _column_case()
         order = np.random.default_rng(3).permutation(len(el))
-        lo, hi = rank * len(el) // world, (rank + 1) * len(el) // world
-        part = Partition(el[order[lo:hi]])
-        xyz_loc = xyz[part.gnodes - 1]
-        gd = np.array(sorted(fix), dtype=np.int64)
-        here, ld = part.local_dofs_of(gd)
-        fix_loc = {int(d): fix[int(g)] for d, g in zip(ld, gd[here])}
-        loads = _local_loads(part, Loads(ufaces=faces, uloads=ul))
-        ops = OracleLocalOps(part, xyz_loc, mat, fix_loc, element_offset=lo)
-        be = DistBackend(part, ops, torch.device("cpu"), pcg_check_every=10)   # block-Jacobi PCG: the ~100 solves of the
-        model = DistModel(part, be, xyz_loc, mat, fix_loc, loads, external_loads)  # subspace iteration stay cheap on the CPU
+        # the helper a caller of the multi-GPU layer uses, with the oracle's element kernels in place of the HIP ones;
+        # block-Jacobi PCG: the ~100 solves of the subspace iteration stay cheap on the CPU
+        model = partition_model(el, xyz, mat, fix, Loads(ufaces=faces, uloads=ul), device=torch.device("cpu"), precond="bj", order=order,
+                                pcg_check_every=10,
+                                ops_factory=lambda part, x, m, f, lo: OracleLocalOps(part, x, m, f, element_offset=lo))
+        part, loads = model.part, model.loads
         res = calc_disp(model, BUCKLING_CTL, rtol=1e-11)
         payload = dict(gnodes=part.gnodes, nfaces=len(loads.ufaces), eigenval=res["eigenval"], nocoord=res["nocoord"],
                        lout=res["lout"], un=res["un"], disp=res["displacements"])
