@@ -587,6 +587,16 @@ int fcvm_destroy(fcvm_ctx *c) {
     return 0;
 }
 
+/* free and total device memory in bytes (hipMemGetInfo) */
+int fcvm_mem_info(fcvm_ctx *c, int64_t out[2]) {
+    NEED(c && out, "fcvm_mem_info: bad arguments");
+    size_t fr = 0, tot = 0;
+    HCHK(hipSetDevice(c->device));
+    HCHK(hipMemGetInfo(&fr, &tot));
+    out[0] = (int64_t)fr; out[1] = (int64_t)tot;
+    return 0;
+}
+
 int fcvm_synchronize(fcvm_ctx *c) {
     HCHK(hipStreamSynchronize(c->stream));
     return 0;

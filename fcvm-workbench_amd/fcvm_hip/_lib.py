@@ -56,6 +56,7 @@ SIGNATURES = {
     "fcvm_solve_timing": [_vp, _pf64],
     "fcvm_host_pattern_check": [_i64, _i64, _vp, _pi64],
     "fcvm_spmv_info": [_vp, _pi64],
+    "fcvm_mem_info": [_vp, _pi64],
     "fcvm_mg_sparse_info": [_vp, _pi64],
     "fcvm_host_window_check": [_i64, _i64, _vp, _vp, _i64, _pi64],
     "fcvm_set_precond": [_vp, _int, _int, _int, _f64, _f64],

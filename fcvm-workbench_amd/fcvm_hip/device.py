@@ -69,6 +69,7 @@ class Context:
         self.device = device
         self.ne = self.nn = 0
         self._pool, self._pooled = {}, 0
+        self._live = set()      # device buffers handed out to DArr objects and not yet released: freed at close()
         # preconditioner of the linear solve: p-multigrid by default, FCVM_PRECOND=bj for block-Jacobi
         self.set_precond(os.environ.get("FCVM_PRECOND", "mg"))
         self.l2_min_coarse_nodes = int(os.environ.get("FCVM_L2_MIN_COARSE", "50"))
@@ -83,13 +84,17 @@ class Context:
         lst = self._pool.get(nbytes)
         if lst:
             self._pooled -= nbytes
-            return lst.pop()
-        p = C.c_void_p()
-        call("fcvm_malloc", self.h, nbytes, C.byref(p))
-        return p.value
+            ptr = lst.pop()
+        else:
+            p = C.c_void_p()
+            call("fcvm_malloc", self.h, nbytes, C.byref(p))
+            ptr = p.value
+        self._live.add(ptr)
+        return ptr
 
     def _release(self, ptr, nbytes):
         nbytes = max(int(nbytes), 8)
+        self._live.discard(ptr)
         if self._pooled + nbytes <= self._POOL_LIMIT:
             self._pool.setdefault(nbytes, []).append(ptr)
             self._pooled += nbytes
@@ -106,6 +111,9 @@ class Context:
         if self.h:
             try:
                 self.trim_pool()
+                for ptr in self._live:      # arrays still referenced somewhere: their memory goes with the context
+                    call("fcvm_free", self.h, ptr)
+                self._live = set()
             except Exception:
                 pass
             _lib.load().fcvm_destroy(self.h)
@@ -162,6 +170,12 @@ class Context:
         call("fcvm_pattern_info", self.h, out)
         return dict(nnz_blocks=out[0], padded_slots=out[1], slices=out[2], matrix_bytes=out[3],
                     max_row_blocks=out[4], ndof=out[5], spmv_variant=out[7])
+
+    def mem_info(self):
+        """(free, total) device memory in bytes"""
+        out = (C.c_int64 * 2)()
+        call("fcvm_mem_info", self.h, out)
+        return int(out[0]), int(out[1])
 
     def spmv_info(self):
         out = (C.c_int64 * 8)()

@@ -30,6 +30,8 @@ int fcvm_device_count(int *count);
 /* one context = one GPU + one HIP stream + one mesh partition */
 int fcvm_create(int device, fcvm_ctx **out);
 int fcvm_destroy(fcvm_ctx *c);
+/* out[0] = free, out[1] = total device memory in bytes */
+int fcvm_mem_info(fcvm_ctx *c, int64_t out[2]);
 int fcvm_synchronize(fcvm_ctx *c);
 /* external != 0: run the context's kernels on the caller's hipStream_t (e.g. torch's current
  * stream, so that torch ops and RCCL collectives issued by the host order correctly with them;
