@@ -173,8 +173,9 @@ class RiksDriver:
         c = self.c
         return c.mdot(xs, y) if hasattr(c, "mdot") else [c.dot(x, y) for x in xs]
 
-    def solve(self, rhs):
-        """K u = rhs to ||rhs - K u|| <= rtol ||rhs||.  The Newton loop solves with the same matrix over and over
+    def solve(self, rhs, guess=None):
+        """K u = rhs to ||rhs - K u|| <= rtol ||rhs||.  guess: a start vector for a matrix that has no history yet (GNLY: the
+        solution of the same right-hand side with the previous tangent).  The Newton loop solves with the same matrix over and over
         (the reference back-substitutes with one factorisation); successive right-hand sides are far from
         independent, so the solve starts from the Galerkin projection of rhs onto the last few solutions
         (x0 = U a with (U^T K U) a = U^T rhs).  The stored products K U_i only choose the coefficients a: the residual
@@ -202,6 +203,14 @@ class RiksDriver:
                 nf, n0 = float(np.sqrt(nf2)), c.norm(r0)
                 if not np.isfinite(n0) or n0 >= nf:         # projection did not help: plain solve
                     x0, r0, n0 = None, rhs, nf
+        elif guess is not None and self.proj_depth > 0:
+            x0 = guess.clone()
+            r0 = c.spmv(x0, c.empty(rhs.n))                 # true residual of the start vector
+            c.axpby(1.0, rhs, -1.0, r0, out=r0)
+            st["projection_spmv"] = st.get("projection_spmv", 0) + 1
+            nf, n0 = c.norm(rhs), c.norm(r0)
+            if not np.isfinite(n0) or n0 >= nf:
+                x0, r0, n0 = None, rhs, nf
         if x0 is not None and n0 <= self.rtol * nf:
             u, info = x0, dict(iterations=0, rel_residual=n0 / nf, spmv=0)
         else:
@@ -285,7 +294,7 @@ class RiksDriver:
             self._hist, self._gram = [], None   # new tangent matrix: the stored K U products are stale
             c.mul(self.model.fixdof, self.glv, out=self.f)
             c.axpby(1.0, self.f, 1.0, self.modf, out=self.f)
-            self.ue = self.solve(self.f)
+            self.ue = self.solve(self.f, guess=self.ue)   # the previous tangent's answer to (nearly) the same load
             self.a = self.ue.clone()
             c.axpby(c.norm(self.du) / c.norm(self.a), self.a, 0.0, None, out=self.a)
         c.axpby(self.relax, self.r, 0.0, None, out=self.f)
