@@ -98,6 +98,7 @@ struct fcvm_ctx {
     double *d_part_vec = nullptr, *d_part_spmv = nullptr, *d_part_misc = nullptr, *d_out8 = nullptr, *d_part_mdot = nullptr;
     long long *d_pidx = nullptr;
     int64_t nb_vec = 0, nb_spmv = 0, nb_gp = 0;
+    int64_t nb_part_spmv = 0;   // entries of d_part_spmv: max(workgroups of the sliced-ELL kernel, groups of the window format)
     int spmv_spw = 1;  // waves per SpMV workgroup: 1 keeps the tail of the launch short (long and short slices differ 3x): -5 % vs 4
     double last_spmv_ms = 0, last_total_ms = 0;
     double row_spread = 0.0;
@@ -152,10 +153,22 @@ struct fcvm_ctx {
     double *d_Z = nullptr, *d_A2inv = nullptr, *d_r2 = nullptr, *d_e2 = nullptr;
     std::vector<hipEvent_t> evpool;
     double *h_pcgS = nullptr;      // pinned copies of the PCG scalars, one per queued chunk (fcvm_mg.inc)
-    int64_t mg_last_iters = 0;     // iterations of the previous multigrid-PCG solve: size of the first chunk of the next one
+    int64_t mg_last_iters = 0, mg_prev_iters = 0;   // iterations of the two previous multigrid-PCG solves: they size the first chunk of the next one
 };
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// the x gathers / LDS staging read a node's three values as 8 + 16 bytes: vector bases must sit on 16-byte boundaries
+static inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+// LDS a workgroup can get on this device with the per-kernel opt-in (160 KiB on gfx950); the runtime reports it under
+// different attributes depending on its version, so the largest answer counts, and never less than the 64 KiB every CDNA part has
+static int device_lds_cap(int device) {
+    int cap = 64 * 1024, v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, device) == hipSuccess) cap = std::max(cap, v);
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess) cap = std::max(cap, v);
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) == hipSuccess) cap = std::max(cap, v);
+    (void)hipGetLastError();
+    return cap;
+}
 template <class T>
 static int dalloc(T **p, int64_t n) {
     HCHK(hipMalloc((void **)p, (size_t)std::max<int64_t>(n, 1) * sizeof(T)));
@@ -340,10 +353,23 @@ static int setup_window_format(fcvm_ctx *c, const double *nocoord) {
         return fail(std::string("fcvm_set_mesh (window format): ") + ex.what());
     }
     if (win_upload(c, c->win)) return 1;
-    HCHK(hipMemsetAsync(c->d_part_spmv, 0, sizeof(double) * c->nb_spmv, c->stream));
+    // the window kernel leaves one p.Ap partial per GROUP: more than the sliced-ELL kernel's one per workgroup when several
+    // slices share a workgroup (FCVM_SPMV_SPW > 1) or when cut rows add virtual rows
+    c->nb_part_spmv = std::max<int64_t>(c->nb_spmv, w.ngroups);
+    dfree(c->d_part_spmv);
+    if (dalloc(&c->d_part_spmv, c->nb_part_spmv)) return 1;
+    HCHK(hipMemsetAsync(c->d_part_spmv, 0, sizeof(double) * c->nb_part_spmv, c->stream));
     HCHK(hipStreamSynchronize(c->stream));
-    // the limit is a property of the kernel, not of this context: never lower what another context of the process asked for
-    static size_t lds_allowed = 0;
+    // the limit is a property of the kernel (per device), not of this context: never lower what another context of the
+    // process asked for on the same device, and refuse windows the device's LDS cannot hold (-> sliced-ELL kernel)
+    static size_t lds_allowed_dev[64] = {0};
+    const int lds_cap = device_lds_cap(c->device);
+    if (c->win.lds > (size_t)lds_cap) {
+        if (getenv("FCVM_VERBOSE")) fprintf(stderr, "fcvm: window format not used (%zu B of LDS needed, device offers %d)\n", c->win.lds, lds_cap);
+        win_free(c->win);
+        return 0;
+    }
+    size_t &lds_allowed = lds_allowed_dev[c->device & 63];
     lds_allowed = std::max(lds_allowed, c->win.lds);
     const size_t lds = lds_allowed;
     if (win_allow_lds(k_spmv_win<true, WIN_WAVES, true>, lds) || win_allow_lds(k_spmv_win<false, WIN_WAVES, true>, lds) ||
@@ -351,8 +377,8 @@ static int setup_window_format(fcvm_ctx *c, const double *nocoord) {
         win_allow_lds(k_spmv_win<true, 4, true>, lds) || win_allow_lds(k_spmv_win<false, 4, true>, lds))
         return 1;
     if (getenv("FCVM_VERBOSE"))
-        fprintf(stderr, "fcvm: window format: %lld groups of %d waves, windows mean %.0f / max %lld nodes (%zu B LDS), %lld entries\n",
-                (long long)w.ngroups, w.waves, w.wmean, (long long)w.wmax, lds, (long long)w.nblocks);
+        fprintf(stderr, "fcvm: window format: %lld groups of %d waves, windows mean %.0f / max %lld nodes (%zu B LDS of %d), %lld entries\n",
+                (long long)w.ngroups, w.waves, w.wmean, (long long)w.wmax, lds, lds_cap, (long long)w.nblocks);
     return 0;
 }
 
@@ -472,8 +498,14 @@ static int build_asm_items(fcvm_ctx *c) {
     if (dalloc(&c->d_asm_items, (int64_t)all.size())) return 1;
     HCHK(hipMemcpyAsync(c->d_asm_items, all.data(), sizeof(int32_t) * all.size(), hipMemcpyHostToDevice, c->stream));
     HCHK(hipStreamSynchronize(c->stream));
-    // dynamic LDS beyond 64 KiB has to be requested per kernel; the limit belongs to the kernel, not to this context: only raise it
-    static int asm_lds_allowed = 64 * 1024;
+    // dynamic LDS beyond 64 KiB has to be requested per kernel; the limit belongs to the kernel on a device, not to this
+    // context: only raise it.  A length class the device's LDS cannot hold sends the mesh to k_assemble_rows.
+    static int asm_lds_allowed_dev[64] = {0};
+    int &asm_lds_allowed = asm_lds_allowed_dev[c->device & 63];
+    if (asm_lds_allowed == 0) asm_lds_allowed = 64 * 1024;
+    const int lds_cap = device_lds_cap(c->device);
+    for (int b = 0; b < fcvm_ctx::ASM_BUCKETS; b++)
+        if (c->asm_count[b] && (int64_t)asm_lds_bytes(ASM_LEN_LIMIT[b]) > lds_cap) return 0;   // asm_lds_ok stays false
     for (int b = 0; b < fcvm_ctx::ASM_BUCKETS; b++) {
         const int bytes = (int)asm_lds_bytes(ASM_LEN_LIMIT[b]);
         if (bytes <= asm_lds_allowed || !c->asm_count[b]) continue;
@@ -687,6 +719,7 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     c->nb_vec = cdiv(nn, 256);
     c->nb_spmv = cdiv(p.nslices, c->spmv_spw);
     c->nb_gp = cdiv(4 * ne, 256);
+    c->nb_part_spmv = c->nb_spmv;
     if (dalloc(&c->d_part_vec, 2 * c->nb_vec) || dalloc(&c->d_part_spmv, c->nb_spmv) ||
         dalloc(&c->d_part_misc, 2 * std::max<int64_t>(c->nb_gp, 4096)) || dalloc(&c->d_pidx, c->nb_gp))
         return 1;
@@ -935,6 +968,7 @@ int fcvm_principal_stress(fcvm_ctx *c, int64_t n, const double *t10s, double *ps
 int fcvm_spmv(fcvm_ctx *c, const double *x, double *y) {
     NEED(c && c->have_mesh, "fcvm_spmv: no mesh");
     NEED(x != y, "fcvm_spmv: x and y must not alias");
+    NEED(aligned16(x) && aligned16(y), "fcvm_spmv: device vectors must be 16-byte aligned");
     launch_spmv(c, false, x, y, nullptr);
     HCHK(hipGetLastError());
     return 0;
@@ -965,6 +999,7 @@ int fcvm_set_diag_blocks(fcvm_ctx *c, const double *dblk) {
 int fcvm_solve(fcvm_ctx *c, const double *f, double *u, double rtol, int64_t maxit, double info[3]) {
     NEED(c && c->have_mesh && c->assembled, "fcvm_solve: assemble the matrix first");
     NEED(f && u && f != u, "fcvm_solve: f and u must be distinct device arrays");
+    NEED(aligned16(f) && aligned16(u), "fcvm_solve: device vectors must be 16-byte aligned");
     if (c->precond_mode == 1) return mg_pcg(c, f, u, rtol, maxit, info);
     NEED(c->precond_mode == 0, "fcvm_solve: in hierarchy-only mode the solve is driven by the host (multi-GPU)");
     hipStream_t s = c->stream;
@@ -1029,6 +1064,14 @@ int fcvm_solve(fcvm_ctx *c, const double *f, double *u, double rtol, int64_t max
     if (!done) return fail("fcvm_solve: PCG did not converge in " + std::to_string(maxit) + " iterations (rel. residual " +
                            std::to_string(info ? info[1] : -1.0) + ")");
     return 0;
+}
+
+/* z = M^-1 r : one application of the multigrid preconditioner of fcvm_solve (r, z: device vectors, r != z) */
+int fcvm_mg_apply(fcvm_ctx *c, const double *r, double *z) {
+    NEED(c && c->have_mesh && c->assembled && c->precond_mode == 1, "fcvm_mg_apply: assemble with the multigrid preconditioner first");
+    NEED(r && z && r != z && aligned16(r) && aligned16(z), "fcvm_mg_apply: r and z must be distinct 16-byte aligned device vectors");
+    c->mg_done = nullptr;
+    return mg_vcycle(c, r, z);
 }
 
 int fcvm_solve_timing(fcvm_ctx *c, double out_ms[4]) {

@@ -236,6 +236,9 @@ bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int6
     if (p.maxlen > 65535) return false;
     std::vector<int32_t> order = morton_order(nn, xyz);
     auto nseg_of = [&](int32_t nd) { return (int)((p.rowptr[nd + 1] - p.rowptr[nd] + split - 1) / split); };
+    // the segment count of a row is packed into 8 bits of `seg`, and a row's segments must all lie in ONE group: refuse
+    // (the caller falls back to the sliced-ELL kernel) instead of corrupting the tables
+    if ((p.maxlen + split - 1) / split > std::min<int64_t>(255, R)) return false;
     // groups: consecutive nodes of the Morton order while their vrows fit
     std::vector<int64_t> gfirst{0};
     {

@@ -54,6 +54,7 @@ SIGNATURES = {
     "fcvm_vec_wdot_dev": [_vp, _i64, _vp, _vp, _vp, _vp],
     "fcvm_vec_max_node_norm": [_vp, _i64, _vp, _pf64],
     "fcvm_solve_timing": [_vp, _pf64],
+    "fcvm_mg_apply": [_vp, _vp, _vp],
     "fcvm_host_pattern_check": [_i64, _i64, _vp, _pi64],
     "fcvm_spmv_info": [_vp, _pi64],
     "fcvm_mem_info": [_vp, _pi64],

@@ -332,6 +332,11 @@ class Context:
         call("fcvm_spmv", self.h, x.ptr, y.ptr)
         return y
 
+    def mg_apply(self, r, z):
+        """z = M^-1 r with the multigrid preconditioner of solve()"""
+        call("fcvm_mg_apply", self.h, r.ptr, z.ptr)
+        return z
+
     def precond(self, r, z):
         call("fcvm_precond", self.h, r.ptr, z.ptr)
         return z

@@ -166,6 +166,10 @@ int fcvm_dist_pcg_scalars(fcvm_ctx *c, int phase, double *S, const double *in);
 int fcvm_any_u8(fcvm_ctx *c, int64_t n, const uint8_t *a, int *result_host);
 int fcvm_vec_max_node_norm(fcvm_ctx *c, int64_t nnodes, const double *u, double *result_host);
 
+/* z = M^-1 r: one application of the multigrid preconditioner fcvm_solve uses (mode 1), r != z [dev, 16-byte aligned].
+ * No reference counterpart (CHOLMOD's factor(f), fcVM.py:1130, is replaced by PCG); used by the solver-space tools and tests. */
+int fcvm_mg_apply(fcvm_ctx *c, const double *r, double *z);
+
 /* timing of the last fcvm_solve (HIP events on the solver's stream): out[0] = milliseconds spent in
  * the timed fine-level SpMV launches, out[1] = total milliseconds, out[2] = number of timed SpMV
  * launches, out[3] = coarse-level SpMV launches (multigrid) */

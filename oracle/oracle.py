@@ -19,9 +19,14 @@ Parity status: PINNED by tests/test_oracle_golden.py against the reference's own
     calcTSM(nstep = 1) + ARPACK buckling mode, fcVM.py:1199-1214) and the geometrically non-linear
     elastic-plastic post-buckling run (calcTSM tangent re-assembly, stress convection, Riks control,
     face-force loads), .out table and f64 nodal fields (2e-9 relative);
+  * tests/golden/lug.npz -- Lug_Pressure_Example: pressure load integrals with the element normals (fcVM.py:649-672),
+    incremental displacement output and the continuation pass, all 61 rows of the .out and the .vtk fields;
+  * tests/golden/u100.npz -- buckling_U100_3D: buckling factors / shapes, imperfection, the three passes of the .out
+    (22 rows), the final nodal fields of the .vtk through calcSum over the selection of the shipped .avr;
+  * tests/golden/buckling.npz, plate_with_hole.json, vm_uniaxial: see tests/test_oracle_golden.py;
   * principal stresses of four .vtk files.
-Not pinned by a reference fixture: pressure / edge / vertex load integrals (fcVM.py:649-727), hardening
-(Et_E > 0) and prescribed non-zero displacements (no shipped result file with recoverable inputs uses them).
+Not pinned by a reference fixture: edge / vertex load integrals (fcVM.py:673-727), hardening (Et_E > 0) and prescribed
+non-zero displacements (no shipped result file with recoverable inputs uses them).
 """
 import ctypes as C
 import os

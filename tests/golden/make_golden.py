@@ -290,14 +290,26 @@ def u100():
     tf = tf[on[tf - 1].all(1)]
     area = b.face(10).area
     nrow = int(np.argmax(np.isclose(table[:, 4], float(inp[14])))) + 1   # rows up to the target load factor
+    # the selection of the shipped .avr summary (fcVM_sum.FCMacro: Edge7 and Face2 of the Extrude): the 3-node line elements /
+    # 6-node triangles of the mesh on those CAD entities, as FemMesh.getEdgesByEdge / getFacesByFace hand them to calcSum
+    avr = open(os.path.join(REF, "output files", name + ".avr")).read().splitlines()
+    assert avr[6].split()[-1] == "Extrude(Extrude).Edge7" and avr[11].split()[-1] == "Extrude(Extrude).Face2"
+    on_e, on_f = b.edge(7).nodes(x0, 1e-6), b.face(2).nodes(x0, 1e-6)
+    te = np.concatenate([el[:, [p_, q_, 4 + k]] for k, (p_, q_) in enumerate(meshgen.MID_PAIRS)])
+    te = te[on_e[te - 1].all(1)]
+    te = te[np.unique(np.sort(te[:, :2], axis=1), axis=0, return_index=True)[1]]
+    tf2 = np.concatenate([el[:, list(f)] for f in meshgen.TET_FACES])
+    tf2 = tf2[on_f[tf2 - 1].all(1)]
     np.savez_compressed(
         os.path.join(HERE, "u100.npz"),
         nocoord0=x0, nocoord=pts, elNodes=el, fixed_dofs=fd, fixed_vals=np.zeros(len(fd)), ufaces=tf,
         uloads=np.tile([2000.0 / area, 0.0, -50000.0 / area], (len(tf), 1)), material=np.array([E, nu, rho]),
         out_table=table[:nrow], out_table_full=table, out_loadsum=np.array(head["loadsum"]), buckling_factors=np.array(ev),
         shape1=data["Buckling_shape_for_lambda1_=_3.895"], shape2=data["Buckling_shape_for_lambda2_=_8.394"],
-        elastic_displacement=data["Elastic_Displacement"])
-    json.dump({"name": name, "inp": inp}, open(os.path.join(HERE, "u100.json"), "w"), indent=1)
+        elastic_displacement=data["Elastic_Displacement"],
+        avr_edge7=te, avr_face2=tf2, vtk_csr=data["Critical_Strain_Ratio\n"], vtk_peeq=data["Equivalent_Plastic_Strain\n"],
+        vtk_svm=data["von_Mises_Stress\n"])
+    json.dump({"name": name, "inp": inp, "avr": avr}, open(os.path.join(HERE, "u100.json"), "w"), indent=1)
     print(name, "ne", len(cells), "nn", len(pts), "factors", ev, "rows kept", nrow, "loaded faces", len(tf))
 
 

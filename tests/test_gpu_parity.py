@@ -736,6 +736,14 @@ def test_u100_column_full_gnly_flow_matches_reference_files():
     for col, val in ((4, res["lout"]), (5, res["un"]), (6, res["peeqplot"]), (7, res["pplot"]), (8, res["svmplot"]),
                      (9, res["triaxplot"]), (10, res["ecrplot"]), (11, res["csrplot"])):
         assert sig3(val, tab[:, col]), "column %d" % col
+    # calcSum (fcVM.py:2830-2900) over the selection of the shipped .avr (Edge7 / Face2): the GPU's final nodal fields average
+    # to what the nodal fields of the reference's .vtk do (see test_calcSum_on_the_reference_avr_selection for the file itself)
+    import fcVM as ft
+    sel = ([g["avr_edge7"].tolist()], [g["avr_face2"].tolist()], g["nocoord0"])
+    want = ft.calcSum(*sel, g["vtk_csr"], g["vtk_peeq"], g["vtk_svm"])
+    got = ft.calcSum(*sel, res["tet10csr"], res["tet10peeq"], res["tet10svm"])
+    for w, v in zip(want, got):
+        assert abs(v[0] - w[0]) <= 1e-6 * max(abs(w[0]), 1e-3), (w, v)
 
 
 def test_plate_with_hole_configs1_and_north_star_sizes():
