@@ -45,17 +45,18 @@ SPMV_TRAFFIC_FILE = os.path.join(REPO, "profiles", "spmv_traffic.json")
 
 
 def spmv_traffic(cells, variant):
+    """cells: the workload key of the measurement (mesh name; cube edge cells in the entries of rounds 1-2)"""
     try:
         t = json.load(open(SPMV_TRAFFIC_FILE))
     except (OSError, ValueError):
         return None, None
     for e in t.get("measurements", []):
-        if e.get("cells") == cells and e.get("variant") == variant:
+        if e.get("workload", e.get("cells")) == cells and e.get("variant") == variant:
             return float(e["traffic_bytes_per_launch"]), "%s (commit %s, %s)" % (e.get("source", SPMV_TRAFFIC_FILE), e.get("commit", "?"), e.get("method", ""))
     return None, None
 
 
-def _cpu_newton_iterations(orc, el, xyz, mat, fix, loads, iters):
+def _cpu_newton_iterations(orc, el, xyz, mat, fix, loads, iters, sig_yield):
     """The oracle (C restatement + SuperLU in place of CHOLMOD) on this host: one Newton iteration = back substitution +
     update_stress_load, factorisation outside (the reference factorises once, fcVM.py:1121).  Returns
     (seconds per iteration, calcGSM seconds, factorisation seconds)."""
@@ -71,7 +72,7 @@ def _cpu_newton_iterations(orc, el, xyz, mat, fix, loads, iters):
     ue = factor(fixdof * glv + modf)
     du = 0.5 * ue
     sig_old, sig_new, sig_test = np.zeros(24 * ne), np.zeros(24 * ne), np.zeros(24 * ne)
-    sy = np.full(4 * ne, CTL["sig_yield"])
+    sy = np.full(4 * ne, sig_yield)
     pgp = np.zeros(4 * ne, np.uint8)
     disp = np.zeros(3 * nn)
     qin = np.zeros(3 * nn)
@@ -79,7 +80,7 @@ def _cpu_newton_iterations(orc, el, xyz, mat, fix, loads, iters):
     r = fixdof * (0.5 * glv - qin)
     t0 = time.perf_counter()
     for _ in range(iters):
-        due = factor(CTL["relax"] * r)
+        due = factor(1.2 * r)
         du = du + due
         qin = np.zeros(3 * nn)
         orc.update_stress_load(el, xyz, mat, sy, disp, du, sig_old, sig_new, sig_test, qin, 0.0, False, pgp)
@@ -88,99 +89,180 @@ def _cpu_newton_iterations(orc, el, xyz, mat, fix, loads, iters):
     return (time.perf_counter() - t0) / iters, t_asm, t_fac
 
 
-def cpu_baseline(cells=12, iters=5, plate_h=6.0):
-    """cpu_baseline leg (rank 0, N = 1): the oracle port timed on this host's cores on two bounded samples --
-    (1) the benchmark's own cube geometry at 12^3 cells (the 1 M-element cube would take SuperLU hours), in the
-    headline unit; (2) `same_mesh`: the reference's Plate_with_hole_Example (BASELINE configs[1] / north-star geometry,
-    shipped control file) on ONE mesh for both sides: CPU Newton iterations/s from the oracle, GPU Newton iterations/s from
-    the whole collapse analysis through the C-ABI, so that the north_star's ">= 10x CPU Newton iterations/s" reads off
-    one object.  plate_h = 6.0 gives 16,830 tet10 (17 s of factorisation); bench.py --cpu-plate-h 4.0 runs the
-    configs[1] size (48,600 tet10: 160 s of factorisation, profiles/r02_same_mesh_48k.json holds such a run)."""
-    from fcvm_hip import examples, meshgen
+def cpu_baseline(plate_h=6.0, iters=5):
+    """cpu_baseline leg (rank 0, N = 1): the oracle port timed on this host's cores on a bounded sample of the headline workload --
+    the reference's Plate_with_hole_Example (shipped control file) on a mesh of the same generator at plate_h (6.0: 16,830
+    tet10, ~7 s of factorisation; 4.0: 48,600 = BASELINE configs[1], ~160 s; profiles/r03_cpu_gpu_table.json holds three
+    sizes).  The 1 M-element mesh itself is out of reach of a sparse direct solver on one core (hours, > 100 GB of fill).  One
+    Newton iteration = back substitution + update_stress_load, as in the reference's loop; the GPU side of `same_mesh` is
+    the whole collapse analysis on the SAME mesh through the C-ABI.  SuperLU (symmetric mode) stands in for the reference's
+    CHOLMOD (fcVM.py:1121-1135; sksparse is not installed): CHOLMOD's supernodal back substitution is probably faster than
+    SuperLU's, so the CPU figure here is likely lower than the reference's own would be."""
+    from fcvm_hip import examples
     from oracle import oracle as orc
-    case = meshgen.cube_case(cells, l=100.0, traction=TRACTION)
-    el, xyz = case["elNodes"], case["nocoord"]
-    ne, nn = len(el), len(xyz)
-    dt, t_asm, t_fac = _cpu_newton_iterations(orc, el, xyz, np.array(MATERIAL), case["fix"],
-                                              orc.Loads(ufaces=case["ufaces"], uloads=case["uloads"]), iters)
-    out = {"value": ne * 4 / dt, "unit": "elements*GP/s", "cores": 1, "kind": "port",
-           "newton_iterations_per_s": 1.0 / dt,
-           "sample": "%d^3-cell cube = %d tet10 / %d dof, %d Newton iterations (SuperLU back-substitution + "
-                     "update_stress_load); one-time calcGSM %.1fs and factorisation %.1fs excluded" %
-                     (cells, ne, 3 * nn, iters, t_asm, t_fac)}
-    if plate_h:
-        pc = examples.plate_with_hole(plate_h)
-        pdt, p_asm, p_fac = _cpu_newton_iterations(orc, pc["elNodes"], pc["nocoord"], pc["material"], pc["fix"],
-                                                   orc.Loads(ufaces=pc["ufaces"], uloads=pc["uloads"]), iters)
-        gpu = plate_with_hole_run(plate_h)
-        out["same_mesh"] = {
-            "workload": "%s: %d tet10 / %d dof" % (pc["name"], len(pc["elNodes"]), 3 * len(pc["nocoord"])),
-            "cpu_newton_iterations_per_s": 1.0 / pdt, "cpu_cores": 1, "cpu_kind": "port",
-            "cpu_sample": "%d Newton iterations (SuperLU back-substitution + update_stress_load)" % iters,
-            "cpu_one_time_s": {"calcGSM": p_asm, "factorisation": p_fac},
-            "gpu_newton_iterations_per_s": gpu["newton_iterations_per_s"],
-            "gpu_sample": "whole analysis (%d steps, %d Newton iterations, %d linear solves, %.1f PCG iterations per solve) incl. "
-                          "assembly and multigrid set-up: %.2f s" % (gpu["steps"], gpu["newton_iterations"], gpu["linear_solves"],
-                                                                   gpu["pcg_iterations_per_solve"], gpu["analysis_s"]),
-            "gpu_over_cpu_newton_iterations_per_s": gpu["newton_iterations_per_s"] * pdt,
-            "gpu_whole_analysis_s": gpu["analysis_s"],
-            "cpu_whole_analysis_estimate_s": p_asm + p_fac + gpu["newton_iterations"] * pdt,
-            "collapse_load_factor_gpu": gpu["collapse_load_factor"]}
-    return out
+    pc = examples.plate_with_hole(plate_h)
+    ne, nn = len(pc["elNodes"]), len(pc["nocoord"])
+    pdt, p_asm, p_fac = _cpu_newton_iterations(orc, pc["elNodes"], pc["nocoord"], pc["material"], pc["fix"],
+                                               orc.Loads(ufaces=pc["ufaces"], uloads=pc["uloads"]), iters, float(pc["ctl"]["sig_yield"]))
+    gpu = collapse_run(pc, 0, 10 ** 9)["analysis"]
+    return {"value": ne * 4 / pdt, "unit": "elements*GP/s", "cores": 1, "kind": "port",
+            "newton_iterations_per_s": 1.0 / pdt,
+            "sample": "%s: %d tet10 / %d dof, %d Newton iterations (SuperLU back-substitution + update_stress_load); one-time "
+                      "calcGSM %.1fs and factorisation %.1fs excluded" % (pc["name"], ne, 3 * nn, iters, p_asm, p_fac),
+            "solver_note": "scipy SuperLU (symmetric mode, 1 core) stands in for the reference's CHOLMOD (sksparse not installed); "
+                           "CHOLMOD's back substitution is probably faster, so this CPU figure is likely lower than the reference's own",
+            "same_mesh": {
+                "workload": "%s: %d tet10 / %d dof" % (pc["name"], ne, 3 * nn),
+                "cpu_newton_iterations_per_s": 1.0 / pdt, "cpu_cores": 1, "cpu_kind": "port",
+                "cpu_one_time_s": {"calcGSM": p_asm, "factorisation": p_fac},
+                "gpu_newton_iterations_per_s": gpu["newton_iterations_per_s"],
+                "gpu_sample": "whole analysis (%d steps, %d Newton iterations, %d linear solves, %.1f PCG iterations per solve) incl. "
+                              "assembly and multigrid set-up: %.2f s" % (gpu["steps"], gpu["newton_iterations"], gpu["linear_solves"],
+                                                                       gpu["pcg_iterations_per_solve"], gpu["analysis_s"]),
+                "gpu_over_cpu_newton_iterations_per_s": gpu["newton_iterations_per_s"] * pdt,
+                "gpu_whole_analysis_s": gpu["analysis_s"],
+                "cpu_whole_analysis_estimate_s": p_asm + p_fac + gpu["newton_iterations"] * pdt,
+                "collapse_load_factor_gpu": gpu["collapse_load_factor"]}}
 
 
 def precond_label(c):
     pi = c.precond_info()
     if pi["mode"] != "mg":
         return "block-Jacobi 3x3"
-    return ("p-multigrid V-cycle: tet10 (Chebyshev/block-Jacobi smoothing) -> tet4 on %d corner nodes%s" %
-            (pi["coarse_nodes"], pi.get("level2", "")))
+    form = {0: "multiplicative V-cycle (FP64 smoother SpMVs)", 1: "additive level-0 correction",
+            2: "multiplicative V(1,1), smoother SpMVs on a 16-bit fixed-point copy of the matrix"}.get(pi.get("cycle_form", 1), "")
+    return ("p-multigrid, %s: tet10 (block-Jacobi smoothing) -> tet4 on %d corner nodes%s" % (form, pi["coarse_nodes"], pi.get("level2", "")))
 
 
-def plate_with_hole_run(h):
-    """The north-star workload as a whole job: the reference's Plate_with_hole_Example (its shipped control file: 10
-    arc-length steps to collapse, error_max 5e-3) on the mapped mesh of ~1M tet10, mesh arrays in -> load history out.
-    Reported next to the headline line, not part of `value`."""
-    from fcvm_hip import examples
+class _Stop(Exception):
+    pass
+
+
+def collapse_run(case, warmup, steps):
+    """The headline workload as the reference runs it (fcVM.py:1304-1559): calcGSM, elastic solve, then the arc-length steps of
+    the control file with its own error_max -- predictor (start_step), Newton iterations, step bookkeeping (end_step).
+    The timed region covers Newton iterations warmup+1 .. warmup+steps of that analysis, with whatever start_step / end_step
+    calls fall between them.  If the control file's steps are used up before the region ends, the analysis is continued the
+    way the reference's plot window does ("add": another pass of nstep steps).  Returns the region's measurements and the
+    whole first pass (= the analysis the reference's .out file documents)."""
     from fcvm_hip.loads import Loads
-    from fcvm_hip.solver import GpuModel, calc_disp
+    from fcvm_hip.solver import GpuModel, RiksDriver
     t0 = time.perf_counter()
-    case = examples.plate_with_hole(h)
-    t_mesh = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    m = GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"], Loads(ufaces=case["ufaces"], uloads=case["uloads"]))
+    model = GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"],
+                     Loads(ufaces=case["ufaces"], uloads=case["uloads"]))
     t_model = time.perf_counter() - t0
+    c = model.ctx
     st = {}
+    t_begin = time.perf_counter()
+    d = RiksDriver(model, case["ctl"], rtol=RTOL, stats=st)     # calcGSM + multigrid hierarchy + elastic solve
+    c.sync()
+    t_setup = time.perf_counter() - t_begin
+    reg = {"n": 0}
+
+    def mark(key):
+        c.sync()
+        reg[key] = (time.perf_counter(), dict(st))
+
+    def after_iteration(first_pass_done):
+        reg["n"] += 1
+        if reg["n"] == warmup:
+            mark("start")
+        if reg["n"] == warmup + steps:
+            mark("end")
+            if first_pass_done:
+                raise _Stop
+    if warmup == 0:
+        mark("start")
+    analysis, passes = None, 0
+    try:
+        while True:
+            pstep = 0
+            while pstep < d.nstep and not d.mrr:
+                pstep += 1
+                error = d.start_step()
+                while error > d.error_max and not d.mrr:
+                    error = d.iteration()
+                    after_iteration(passes > 0)
+                    if d.iterat > d.iterat_max:
+                        d.restart()
+                        error = d.error
+                if d.end_step():
+                    break
+            passes += 1
+            if passes == 1:
+                c.sync()
+                dt = time.perf_counter() - t_begin
+                analysis = {"analysis_s": dt, "steps": len(d.lbd) - 1, "newton_iterations": st["newton_iterations"],
+                            "newton_iterations_per_s": st["newton_iterations"] / dt,
+                            "elements_gp_per_s": st["newton_iterations"] * model.ne * 4 / dt, "linear_solves": st["solves"],
+                            "pcg_iterations_per_solve": st["pcg_iterations"] / max(st["solves"], 1),
+                            "collapse_load_factor": float(d.lbd[-1]), "setup_s_inside": t_setup}
+            if "end" in reg or d.mrr or d.elastic_only:
+                break
+            d.next_pass()
+    except _Stop:
+        pass
+    out = {"model": model, "driver": d, "analysis": analysis, "pattern_and_upload_s": t_model, "passes": passes}
+    if "start" in reg and "end" in reg:
+        (ta, sa), (tb, sb) = reg["start"], reg["end"]
+        out["region"] = {"s": tb - ta, "stats0": sa, "stats1": sb}
+    return out
+
+
+def cube_run(cells, warmup, steps):
+    """BASELINE configs[2] geometry (synthetic cube, 1 M tet10) with the plasticity of the real analysis, iterating on one load
+    step without a convergence test (error_max = 0): the headline of rounds 1-2, kept as a secondary object for continuity.  Its
+    PCG count depends on how long the loop has run (start vectors from the solution history), which is why it is no longer `value`."""
+    from fcvm_hip import meshgen
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import GpuModel, RiksDriver
+    case = meshgen.cube_case(cells, l=100.0, traction=TRACTION)
+    model = GpuModel(case["elNodes"], case["nocoord"], MATERIAL, case["fix"], Loads(ufaces=case["ufaces"], uloads=case["uloads"]))
+    c = model.ctx
+    st = {}
+    drv = RiksDriver(model, CTL, rtol=RTOL, stats=st)
+    drv.start_step()
+    for _ in range(warmup):
+        drv.iteration()
+    c.sync()
+    s0 = dict(st)
     t0 = time.perf_counter()
-    res = calc_disp(m, case["ctl"], rtol=RTOL, stats=st)
-    m.ctx.sync()
+    for _ in range(steps):
+        drv.iteration()
+    c.sync()
     dt = time.perf_counter() - t0
-    out = {"workload": "%s: %d tet10, %d dof, control file of the reference example (10 Riks steps to collapse)" % (case["name"], m.ne, m.ndof),
-           "analysis_s": dt, "mesh_s": t_mesh, "pattern_and_upload_s": t_model, "steps": len(res["lout"]) - 1,
-           "newton_iterations": st["newton_iterations"], "newton_iterations_per_s": st["newton_iterations"] / dt,
-           "elements_gp_per_s": st["newton_iterations"] * m.ne * 4 / dt,
-           "linear_solves": st["solves"], "pcg_iterations_per_solve": st["pcg_iterations"] / max(st["solves"], 1),
-           "collapse_load_factor": float(res["lout"][-1]), "reference_out_load_factor_395_elements": 0.232}
-    m.ctx.close()
+    n_spmv = st["spmv_launches"] - s0["spmv_launches"]
+    out = {"workload": "synthetic cube %d^3 cells = %d tet10, %d dof, one load step iterated %d + %d times (error_max = 0)" %
+                       (cells, model.ne, model.ndof, warmup, steps),
+           "ms_per_newton_iteration": dt / steps * 1e3, "pcg_iterations_per_newton_iteration": (st["pcg_iterations"] - s0["pcg_iterations"]) / steps,
+           "spmv_avg_launch_ms": (st["spmv_ms"] - s0["spmv_ms"]) / max(n_spmv, 1), "pattern_host_s": model.t_pattern}
+    c.close()
     return out
 
 
 def run_single(args):
-    from fcvm_hip import _lib, meshgen
-    from fcvm_hip.loads import Loads
-    from fcvm_hip.solver import GpuModel, RiksDriver
+    from fcvm_hip import _lib, examples
     if _lib.device_count() < 1:
         raise SystemExit("bench.py: no HIP device / libfcvm_hip.so -- there is no CPU fallback")
-    n = args.cells
     t0 = time.perf_counter()
-    case = meshgen.cube_case(n, l=100.0, traction=TRACTION)
+    case = examples.plate_with_hole(args.plate_h)
     t_mesh = time.perf_counter() - t0
-    model = GpuModel(case["elNodes"], case["nocoord"], MATERIAL, case["fix"],
-                     Loads(ufaces=case["ufaces"], uloads=case["uloads"]))
-    c = model.ctx
+    run = collapse_run(case, args.warmup, args.steps)
+    model, drv, c = run["model"], run["driver"], run["model"].ctx
+    if "region" not in run:
+        raise SystemExit("bench.py: the analysis ended (maximum restarts) before %d + %d Newton iterations" % (args.warmup, args.steps))
+    reg = run["region"]
+    s0, s1, dt = reg["stats0"], reg["stats1"], reg["s"]
     info = c.pattern_info()
-    # calcGSM on the GPU, timed on its own (one-time work of an analysis): first the bare assembly
-    # (block-Jacobi mode builds nothing else), then assembly + multigrid hierarchy set-up
+    ndof, ne = info["ndof"], model.ne
+    # one-time work of an analysis, timed on its own after the run: the bare assembly (calcGSM on the GPU), and assembly + hierarchy
+    t_pat = model.t_pattern
+    model.calc_gsm((0.0, 0.0, 0.0), want_x=False)
+    c.sync()
+    t0 = time.perf_counter()
+    model.calc_gsm((0.0, 0.0, 0.0), want_x=False)
+    c.sync()
+    t_asm_setup = time.perf_counter() - t0
     mode = c.precond_info()["mode"]
     c.set_precond("bj")
     model.calc_gsm((0.0, 0.0, 0.0), want_x=False)
@@ -190,25 +272,8 @@ def run_single(args):
     c.sync()
     t_asm = time.perf_counter() - t0
     c.set_precond(mode)
-    t0 = time.perf_counter()
-    model.calc_gsm((0.0, 0.0, 0.0), want_x=False)
-    c.sync()
-    t_setup = time.perf_counter() - t0
-    stats = {}
-    drv = RiksDriver(model, CTL, rtol=RTOL, stats=stats)  # assembly + elastic solve
-    drv.start_step()
-    for _ in range(args.warmup):
-        drv.iteration()
-    c.sync()
-    s0 = dict(stats)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        drv.iteration()
-    c.sync()
-    dt = time.perf_counter() - t0
-    # the same SpMV launched back to back on its own (no V-cycle in between, no p.Ap partials): what the kernel does when the
-    # caches hold nothing but its own data -- context for the in-solver average below, not the roofline figure
-    xs, ys = c.array(np.random.default_rng(0).standard_normal(info["ndof"])), c.empty(info["ndof"])
+    # the same SpMV launched back to back on its own (no V-cycle in between, no p.Ap partials): context for the in-solver average
+    xs, ys = c.array(np.random.default_rng(0).standard_normal(ndof)), c.empty(ndof)
     for _ in range(3):
         c.spmv(xs, ys)
     c.sync()
@@ -219,33 +284,37 @@ def run_single(args):
     standalone_ms = (time.perf_counter() - t1) / 20 * 1e3
     del xs, ys
     stream_gbs = c.membench(3 << 30)
-    spmv_launches = stats["spmv_launches"] - s0["spmv_launches"]
-    spmv_ms = stats["spmv_ms"] - s0["spmv_ms"]
-    pcg_its = stats["pcg_iterations"] - s0["pcg_iterations"]
-    # algorithmic bytes of one SpMV launch: every 3x3 block once (72 B values + 4 B column), x read
-    # once, y written once (DESIGN.md "Roofline accounting")
-    ndof = info["ndof"]
+    spmv_launches = s1["spmv_launches"] - s0["spmv_launches"]
+    spmv_ms = s1["spmv_ms"] - s0["spmv_ms"]
+    pcg_its = s1["pcg_iterations"] - s0["pcg_iterations"]
+    solves = s1["solves"] - s0["solves"]
+    # algorithmic bytes of one SpMV launch: every 3x3 block once (72 B values + 4 B column), x read once, y written once
     alg_bytes = info["nnz_blocks"] * 76 + 2 * ndof * 8
     avg_ms = spmv_ms / max(spmv_launches, 1)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     plastic = int(drv.pgp.get().sum())
-    ne = model.ne
     winfo = c.spmv_info()
     layout = ("window-%dx64-split%d" % (winfo["waves_per_group"], winfo["split"])) if winfo["window_format"] else "sliced-ell-v%d" % info["spmv_variant"]
-    traffic, traffic_src = spmv_traffic(n, layout)
+    traffic, traffic_src = spmv_traffic(case["name"], layout)
+    an = run["analysis"]
     out = {
         "metric": "elements*GP/s over Newton iterations (Newton iterations/s x elements x 4 GP), 1M tet10",
         "value": ne * 4 * args.steps / dt, "unit": "elements*GP/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "synthetic cube %d^3 cells = %d tet10, %d dof, clamped base, top traction, von Mises "
-                               "plasticity (%d of %d Gauss points plastic), one Newton/Riks iteration per step" %
-                               (n, ne, ndof, plastic, 4 * ne), "pcg_rtol": RTOL, "preconditioner": precond_label(c)},
+        "config": {"workload": "%s: %d tet10, %d dof -- the reference's Plate_with_hole_Example (geometry, supports, pressure load, von Mises "
+                               "sig_yield 100, control file: 10 arc-length steps, error_max 5e-3) on a mapped mesh of %d tet10; a step = one "
+                               "Newton/Riks iteration of that collapse analysis (iterations %d..%d of it, start_step / end_step between them "
+                               "included; %d of %d Gauss points plastic at the end of the region)" %
+                               (case["name"], ne, ndof, ne, args.warmup + 1, args.warmup + args.steps, plastic, 4 * ne),
+                   "pcg_rtol": RTOL, "preconditioner": precond_label(c)},
         "newton_iterations_per_s": args.steps / dt,
         "pcg_iterations_per_step": pcg_its / args.steps,
-        "fine_spmv_per_step": (stats.get("spmv_total", 0) - s0.get("spmv_total", 0)) / args.steps,
+        "pcg_iterations_per_solve": pcg_its / max(solves, 1),
+        "fine_spmv_per_step": (s1.get("spmv_total", 0) - s0.get("spmv_total", 0)) / args.steps,
         "assembly": {"ms": t_asm * 1e3, "elements_gp_per_s": ne * 4 / t_asm},
-        "setup_s": {"mesh": t_mesh, "pattern_host": model.t_pattern, "assembly_plus_preconditioner_hierarchy": t_setup},
+        "setup_s": {"mesh": t_mesh, "pattern_and_upload": run["pattern_and_upload_s"], "pattern_host": t_pat,
+                    "assembly_plus_preconditioner_hierarchy": t_asm_setup},
         "roofline": {"bound": "hbm",
                      "kernel": ("k_spmv_win<true> (window-format 3x3-block SpMV, x staged in LDS, + p.Ap partials)" if winfo["window_format"]
                                 else "k_spmv<true> (sliced-ELL 3x3-block SpMV + p.Ap partials)"),
@@ -255,15 +324,22 @@ def run_single(args):
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": avg_ms,
                      "launches_timed": spmv_launches, "back_to_back_launch_ms": standalone_ms, "padded_matrix_bytes": info["matrix_bytes"],
                      # what this box's HBM delivers for a plain 16 B/lane streaming read of a fresh 3 GB buffer, measured right
-                     # after the timed region (boxes of the pool differ: 5.1 .. 6.3 TB/s): context for `frac`
+                     # after the timed region (boxes of the pool differ: 5.1 .. 6.8 TB/s): context for `frac`
                      "stream_read_GBs_this_box": stream_gbs,
                      "csr_equivalent_GBs": (info["nnz_blocks"] * 9 * 12 + 2 * ndof * 8) / (avg_ms * 1e-3) / 1e9},
+        # the whole analysis the timed region is cut from (first pass = what the reference's .out documents), wall clock from
+        # calcGSM to the last step, set-up (assembly, hierarchy, elastic solve) included
+        "north_star_workload": dict(an, workload="%s: %d tet10, %d dof, control file of the reference example (10 Riks steps to collapse)"
+                                                 % (case["name"], ne, ndof),
+                                    mesh_s=t_mesh, pattern_and_upload_s=run["pattern_and_upload_s"],
+                                    reference_out_load_factor_395_elements=0.232),
     }
+    del drv, model, run
+    c.close()
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(plate_h=args.cpu_plate_h)
-    if not args.no_plate:
-        del drv, model
-        out["north_star_workload"] = plate_with_hole_run(args.plate_h)
+    if not args.no_cube:
+        out["configs2_cube"] = cube_run(args.cells, 5, 20)
     print(json.dumps(out))
 
 
@@ -275,9 +351,9 @@ def main():
     ap.add_argument("--cells", type=int, default=55, help="cells per cube edge (55 -> 998,250 tet10)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-plate-h", type=float, default=6.0,
-                    help="mesh size of the same-mesh CPU / GPU comparison on Plate_with_hole (6.0 -> 16,830 tet10; 4.0 -> 48,600 = configs[1]; 0 = skip)")
-    ap.add_argument("--no-plate", action="store_true", help="skip the Plate_with_hole whole-analysis leg (N = 1 only)")
-    ap.add_argument("--plate-h", type=float, default=1.45, help="mesh size of the Plate_with_hole leg (1.45 -> 1,006,434 tet10)")
+                    help="mesh size of the CPU sample / same-mesh comparison on Plate_with_hole (6.0 -> 16,830 tet10; 4.0 -> 48,600 = configs[1])")
+    ap.add_argument("--no-cube", action="store_true", help="skip the secondary cube object (N = 1 only)")
+    ap.add_argument("--plate-h", type=float, default=1.45, help="mesh size of the headline workload (1.45 -> 1,006,434 tet10)")
     args = ap.parse_args()
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and world_env is None:
@@ -303,7 +379,7 @@ def main():
                          % (args.gpus, world, args.gpus, args.gpus, args.gpus))
     if world > 1:
         from fcvm_hip import dist_bench
-        dist_bench.run(args, CTL, MATERIAL, TRACTION, RTOL, HBM_PEAK_GBS, cpu_baseline)
+        dist_bench.run(args, CTL, MATERIAL, TRACTION, RTOL, HBM_PEAK_GBS)
     else:
         run_single(args)
 

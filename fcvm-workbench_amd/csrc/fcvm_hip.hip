@@ -49,6 +49,12 @@ struct WinDev {
     uint16_t *rowlen = nullptr, *own = nullptr, *cols = nullptr, *jstart = nullptr;
     void *vals = nullptr;   // 9 * nblocks doubles
     size_t lds = 0;
+    // 16-bit block-scaled copy of the matrix for the smoother of the multiplicative cycle (mg_additive == 2): 24 bytes per block
+    short8 *lo8 = nullptr;
+    WinLoTail *lo2 = nullptr;
+    double *lo_scale = nullptr;   // [2] on the device: global exponent e0, value of one unit at block exponent 0 (2^(e0 - 15))
+    double *part_lo = nullptr;    // [2 * ngroups] partials of r.z and r.r left by the post-smoothing pass
+    bool lo_valid = false;
 };
 
 struct L2sDev {   // device state of the sparse aggregate level (owned by fcvm_ctx)
@@ -132,7 +138,7 @@ struct fcvm_ctx {
     int64_t mg_spmv0 = 0, mg_spmv1 = 0;
     // level-0 correction: additive (x = w Dinv b + P M1^-1 P^T b: no fine SpMV inside the preconditioner; measured
     // fastest on the benchmark cube) or multiplicative (Chebyshev pre/post smoothing, FCVM_MG_ADDITIVE=0)
-    int mg_additive = 1;
+    int mg_additive = 2;   // 1: additive; 0: multiplicative, FP64 smoother SpMVs; 2: multiplicative V(1,1), smoother SpMVs on a 16-bit fixed-point copy
     int mg_fp32 = 1;           // coarse levels: level-1 matrix and aggregate inverse stored in FP32 (FP64 vectors / accumulation)
     float *d_vals1f = nullptr, *d_A2invf = nullptr;
     float *d_dinv1_6f = nullptr;   // the same for level 1 (SpMV epilogue of the Chebyshev smoother)
@@ -266,6 +272,22 @@ static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const
     else launch_spmv_t<false>(c, fine_view(c), x, y, nullptr, done);
 }
 
+// smoother passes of the multiplicative cycle on the 16-bit copy (EPI 1: out = r - K~ x; EPI 2: out = x + c0 Dinv (r - K~ x) + partials)
+template <int EPI>
+static void launch_spmv_win_lo(fcvm_ctx *c, const double *x, const double *r, double *out, double c0, const double *done) {
+    const WinDev &w = c->win;
+    if (w.pat.waves == 4)
+        hipLaunchKernelGGL((k_spmv_win_lo<EPI, 4>), dim3((unsigned)w.pat.ngroups), dim3(256), w.lds / 2, c->stream, w.pat.ngroups, w.pat.wmax, w.gptr,
+                           w.gextra, w.wlist, w.woff, w.rowlen, w.rownode, w.seg, w.lo8, w.lo2, w.lo_scale, x, r, out, c0,
+                           (const float *)c->d_dinv6f, w.part_lo, done);
+    else
+        hipLaunchKernelGGL((k_spmv_win_lo<EPI, WIN_WAVES>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), w.lds / 2, c->stream, w.pat.ngroups,
+                           w.pat.wmax, w.gptr, w.gextra, w.wlist, w.woff, w.rowlen, w.rownode, w.seg, w.lo8, w.lo2, w.lo_scale, x,
+                           r, out, c0, (const float *)c->d_dinv6f, w.part_lo, done);
+}
+// the multiplicative cycle with the 16-bit smoother matrix needs the window format and its 16-bit copy
+static inline bool mg_use_lo(const fcvm_ctx *c) { return c->mg_additive == 2 && c->win.on && c->win.lo_valid; }
+
 static int dot_common(fcvm_ctx *c, int64_t n, const double *w, const double *x, const double *y, double *result_dev) {
     NEED(c && c->d_part_misc, "vector reductions need a mesh (work buffers)");
     int64_t nb = std::min<int64_t>(std::max<int64_t>(cdiv(n, 256), 1), 2048);
@@ -280,6 +302,8 @@ static void win_free(WinDev &w) {
     dfree(w.gptr); dfree(w.woff); dfree(w.wlist); dfree(w.rownode); dfree(w.srcslot); dfree(w.gextra); dfree(w.seg); dfree(w.rowlen);
     dfree(w.own); dfree(w.cols); dfree(w.jstart);
     if (w.vals) { (void)hipFree(w.vals); w.vals = nullptr; }
+    dfree(w.lo8); dfree(w.lo2); dfree(w.lo_scale); dfree(w.part_lo);
+    w.lo_valid = false;
     w.on = false;
     w.pat = WinPattern();
     w.lds = 0;
@@ -374,7 +398,9 @@ static int setup_window_format(fcvm_ctx *c, const double *nocoord) {
     const size_t lds = lds_allowed;
     if (win_allow_lds(k_spmv_win<true, WIN_WAVES, true>, lds) || win_allow_lds(k_spmv_win<false, WIN_WAVES, true>, lds) ||
         win_allow_lds(k_spmv_win<true, WIN_WAVES, false>, lds) || win_allow_lds(k_spmv_win<false, WIN_WAVES, false>, lds) ||
-        win_allow_lds(k_spmv_win<true, 4, true>, lds) || win_allow_lds(k_spmv_win<false, 4, true>, lds))
+        win_allow_lds(k_spmv_win<true, 4, true>, lds) || win_allow_lds(k_spmv_win<false, 4, true>, lds) ||
+        win_allow_lds(k_spmv_win_lo<1, WIN_WAVES>, lds) || win_allow_lds(k_spmv_win_lo<2, WIN_WAVES>, lds) ||
+        win_allow_lds(k_spmv_win_lo<1, 4>, lds) || win_allow_lds(k_spmv_win_lo<2, 4>, lds))
         return 1;
     if (getenv("FCVM_VERBOSE"))
         fprintf(stderr, "fcvm: window format: %lld groups of %d waves, windows mean %.0f / max %lld nodes (%zu B LDS of %d), %lld entries\n",
@@ -579,7 +605,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_ASSEMBLE_OVERLAP")) c->asm_overlap = atoi(v);
     if (const char *v = getenv("FCVM_QIN_ATOMIC")) c->qin_atomic = atoi(v);
     if (const char *v = getenv("FCVM_SPMV_SPW")) c->spmv_spw = std::min(4, std::max(1, atoi(v)));   // slices (waves) per workgroup
-    if (const char *v = getenv("FCVM_MG_ADDITIVE")) c->mg_additive = atoi(v);
+    if (const char *v = getenv("FCVM_MG_ADDITIVE")) c->mg_additive = std::min(2, std::max(0, atoi(v)));
     if (const char *v = getenv("FCVM_MG_MAX_AGGREGATES")) c->mg_max_dense = std::max(8, atoi(v));
     if (const char *v = getenv("FCVM_MG_FP32")) c->mg_fp32 = atoi(v);
     if (const char *v = getenv("FCVM_MG_ADD_W")) c->mg_add_w = atof(v);
@@ -830,13 +856,24 @@ int fcvm_matrix_to_coo(fcvm_ctx *c, int64_t *row, int64_t *col, double *val) {
 }
 
 static int refresh_precond(fcvm_ctx *c) {   // after every assembly into d_vals
-    if (c->win.on) {
-        const WinDev &w = c->win;
-        const int64_t nrows = w.pat.nwaves * SLICE;
-        hipLaunchKernelGGL(k_repack_win, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, c->stream, nrows, w.srcslot, w.rowlen,
-                           w.jstart, w.woff, c->d_sptr, c->d_vals, (double *)w.vals, c->win_v2);
-    }
     hipLaunchKernelGGL(k_diag_get, dim3(cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_diagoff, c->d_vals, c->d_dblk);
+    if (c->win.on) {
+        WinDev &w = c->win;
+        const int64_t nrows = w.pat.nwaves * SLICE;
+        const bool lo = c->precond_mode == 1 && c->mg_additive == 2;   // the multiplicative cycle smooths with a 16-bit fixed-point copy
+        w.lo_valid = false;
+        if (lo) {
+            if (!w.lo8 && (dalloc(&w.lo8, w.pat.nblocks) || dalloc(&w.lo2, w.pat.nblocks) || dalloc(&w.lo_scale, 2) ||
+                           dalloc(&w.part_lo, 2 * w.pat.ngroups)))
+                return 1;
+            hipLaunchKernelGGL(k_absmax_partial, dim3(1024), dim3(256), 0, c->stream, 9 * c->nn, c->d_dblk, c->d_part_misc);
+            hipLaunchKernelGGL(k_lo_scale, dim3(1), dim3(256), 0, c->stream, c->d_part_misc, (int64_t)1024, w.lo_scale);
+        }
+        hipLaunchKernelGGL(k_repack_win, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, c->stream, nrows, w.srcslot, w.rowlen,
+                           w.jstart, w.woff, c->d_sptr, c->d_vals, (double *)w.vals, c->win_v2, lo ? w.lo_scale : (const double *)nullptr,
+                           lo ? w.lo8 : (short8 *)nullptr, lo ? w.lo2 : (WinLoTail *)nullptr, (const uint16_t *)w.cols);
+        w.lo_valid = lo;
+    }
     hipLaunchKernelGGL(k_diag_invert, dim3(cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_dblk, c->d_dinv);
     hipLaunchKernelGGL(k_dinv_pack6f, dim3(cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_dinv, c->d_dinv6f);
     HCHK(hipGetLastError());
@@ -1564,9 +1601,18 @@ int fcvm_unpack_sum(fcvm_ctx *c, int64_t nshared, const int64_t *node, const int
 }
 
 int fcvm_set_mg_cycle(fcvm_ctx *c, int additive, double weight) {
-    NEED(c && weight > 0.0, "fcvm_set_mg_cycle: weight must be positive");
-    c->mg_additive = additive ? 1 : 0;
+    NEED(c && weight > 0.0 && additive >= 0 && additive <= 2, "fcvm_set_mg_cycle: form 0, 1 or 2; weight must be positive");
+    if ((additive == 2) != (c->mg_additive == 2)) c->assembled = false;   // the 16-bit copy is written by the next fcvm_assemble
+    c->mg_additive = additive;
     c->mg_add_w = weight;
+    return 0;
+}
+
+int fcvm_get_mg_cycle(fcvm_ctx *c, int *form, double *weight, int *fp16_copy_in_use) {
+    NEED(c && form && weight && fp16_copy_in_use, "fcvm_get_mg_cycle: bad arguments");
+    *form = c->mg_additive;
+    *weight = c->mg_add_w;
+    *fp16_copy_in_use = mg_use_lo(c) ? 1 : 0;
     return 0;
 }
 

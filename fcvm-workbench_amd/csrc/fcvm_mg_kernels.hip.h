@@ -227,7 +227,9 @@ __global__ __launch_bounds__(256) void k_prolong(int64_t nn, const int32_t *__re
 // z = z0 + M0 P M1 e1 (the additive cycle's second half without the inner products: multi-GPU host code)
 __global__ __launch_bounds__(256) void k_prolong_add(int64_t nn, const int32_t *__restrict__ pa, const int32_t *__restrict__ pb,
                                                      const uint8_t *__restrict__ fixmask0, const double *__restrict__ e1,
-                                                     const double *__restrict__ z0, double *__restrict__ z) {
+                                                     const double *__restrict__ z0, double *__restrict__ z,
+                                                     const double *__restrict__ done = nullptr) {
+    if (done && *done != 0.0) return;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nn) return;
     const int64_t a = pa[i], b = pb[i];
@@ -335,6 +337,20 @@ __global__ __launch_bounds__(256) void k_pcg_update_xr_z0(int64_t nn, const doub
         apply_dinv(dinv + i * 9, rn[0], rn[1], rn[2], a0, a1, a2);
     }
     z0[3 * i] = w * a0; z0[3 * i + 1] = w * a1; z0[3 * i + 2] = w * a2;
+}
+
+// z = w * Dinv r with the FP32 six-entry form of Dinv: the smoother of the multiplicative cycle outside the PCG loop (the
+// same operator as in k_pcg_update_xr_z0 and the epilogue of k_spmv_win_lo<2>: pre- and post-smoothing must be one S)
+__global__ __launch_bounds__(256) void k_jacobi6f(int64_t nn, const float *__restrict__ dinv6, const double *__restrict__ r, double w,
+                                                  double *__restrict__ z) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nn) return;
+    const float2 *d2 = (const float2 *)(dinv6 + 6 * i);
+    const float2 u0 = d2[0], u1 = d2[1], u2 = d2[2];   // xx xy | xz yy | yz zz
+    const double r0 = r[3 * i], r1 = r[3 * i + 1], r2 = r[3 * i + 2];
+    z[3 * i] = w * ((double)u0.x * r0 + (double)u0.y * r1 + (double)u1.x * r2);
+    z[3 * i + 1] = w * ((double)u0.y * r0 + (double)u1.y * r1 + (double)u2.x * r2);
+    z[3 * i + 2] = w * ((double)u1.x * r0 + (double)u2.x * r1 + (double)u2.y * r2);
 }
 
 // six distinct entries of every inverse diagonal block, FP32 (for k_pcg_update_xr_z0)

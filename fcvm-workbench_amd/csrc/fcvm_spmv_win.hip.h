@@ -25,10 +25,59 @@ __device__ __forceinline__ int win_value_at(int c, int n, int lane, int v2) {
 
 // values of the sliced-ELL array -> window format; thread = (wave, lane) vrow, walks its blocks.  Writes are coalesced over
 // the lanes of a wave, reads follow the row's slice in the source layout.
+// ---- 16-bit copy of the matrix for the smoother of the multiplicative cycle (k_spmv_win_lo) ---------------------------------
+// A 3x3 block is stored as nine 16-bit integers with one power-of-two scale per block: value = q * 2^(e0 + e - 14), e0 the
+// exponent of the largest diagonal entry of the matrix (global), e <= 0 the block's own (int8).  Why not FP16: the smoother
+// applies K~ to smooth vectors (the coarse correction), where K x cancels to a small residual but the rounding errors of K~ do
+// not; FP16's 2^-12 relative error per entry cost 14 % more PCG iterations on the 1 M-element plate than the FP64 smoother
+// (53.6 -> 61.1, gpurun_out/r03d), fixed point on the block maximum is 2^-16 of it.  K_ji = K_ij^T have the same maximum, so the
+// copy is exactly symmetric whenever the FP64 values are.  Entry off + lane of a block row: lo8 = components 0..7 (16 bytes),
+// lo2 = {component 8, window column, block exponent, 0} (8 bytes): two loads, 24 bytes per block instead of 74.
+typedef short short8 __attribute__((ext_vector_type(8)));
+struct __attribute__((aligned(8))) WinLoTail {
+    short q8;
+    unsigned short col;
+    signed char e;
+    signed char pad[3];
+};
+static_assert(sizeof(WinLoTail) == 8, "WinLoTail must be 8 bytes");
+
+// out[0] = e0 (as a double): frexp exponent of max |dblk| -- every entry of an SPD matrix is bounded by its largest diagonal
+// entry, so block exponents relative to e0 are <= 0.  part: block maxima of |dblk| (k_absmax_partial).
+__global__ __launch_bounds__(256) void k_absmax_partial(int64_t n, const double *__restrict__ a, double *__restrict__ part) {
+    __shared__ double sh[4];
+    double v = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) v = fmax(v, fabs(a[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+__global__ __launch_bounds__(256) void k_lo_scale(const double *__restrict__ part, int64_t n, double *__restrict__ out) {
+    __shared__ double sh[4];
+    double v = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) v = fmax(v, part[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double m = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+        int e = 0;
+        if (m > 0.0 && isfinite(m)) (void)frexp(m, &e);      // m = f * 2^e, f in [0.5, 1)
+        out[0] = (double)e;
+        out[1] = ldexp(1.0, e - 15);                          // value of one unit of a block with e = 0 ... see k_spmv_win_lo
+    }
+}
+
+// lo8 / lo2 != NULL: also writes the 16-bit copy (above); cols: the window columns of the format (copied into lo2)
 __global__ __launch_bounds__(256) void k_repack_win(int64_t nrows, const int32_t *__restrict__ srcslot,
                                                     const uint16_t *__restrict__ rowlen, const uint16_t *__restrict__ jstart,
                                                     const int64_t *__restrict__ woff, const int64_t *__restrict__ sptr,
-                                                    const double *__restrict__ src, double *__restrict__ dst, int v2) {
+                                                    const double *__restrict__ src, double *__restrict__ dst, int v2,
+                                                    const double *__restrict__ lo_scale = nullptr, short8 *__restrict__ lo8 = nullptr,
+                                                    WinLoTail *__restrict__ lo2 = nullptr, const uint16_t *__restrict__ cols = nullptr) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= nrows) return;
     const int lane = threadIdx.x & 63;
@@ -46,8 +95,42 @@ __global__ __launch_bounds__(256) void k_repack_win(int64_t nrows, const int32_t
             const double *sp = src + unit * 576 + (single ? ls : 2 * ls + (js & 1));
             const int cs = single ? 64 : 128;
             double *dp = dst + 9 * off;
+            double v[9];
 #pragma unroll
-            for (int c = 0; c < 9; c++) dp[win_value_at(c, n, lane, v2)] = sp[c * cs];
+            for (int c = 0; c < 9; c++) v[c] = sp[c * cs];
+#pragma unroll
+            for (int c = 0; c < 9; c++) dp[win_value_at(c, n, lane, v2)] = v[c];
+            if (lo8) {
+                const int e0 = (int)lo_scale[0];
+                double m = 0.0;
+#pragma unroll
+                for (int c = 0; c < 9; c++) m = fmax(m, fabs(v[c]));
+                int e = -127;                              // m = f * 2^eb, f in [0.5, 1): |v| * 2^(15 - eb) < 2^15
+                if (m > 0.0) {
+                    int eb;
+                    (void)frexp(m, &eb);
+                    e = eb - e0;
+                    e = e < -127 ? -127 : (e > 127 ? 127 : e);   // (> 0 only for matrices that are not SPD, e.g. a shifted buckling operator)
+                }
+                const int sh = 15 - (e0 + e);
+                short8 h;
+                int q[9];
+#pragma unroll
+                for (int c = 0; c < 9; c++) {
+                    double t = rint(ldexp(v[c], sh));
+                    t = t > 32767.0 ? 32767.0 : (t < -32767.0 ? -32767.0 : t);
+                    q[c] = (int)t;
+                }
+#pragma unroll
+                for (int c = 0; c < 8; c++) h[c] = (short)q[c];
+                lo8[off + lane] = h;
+                WinLoTail tl;
+                tl.q8 = (short)q[8];
+                tl.col = cols[off + lane];
+                tl.e = (signed char)e;
+                tl.pad[0] = tl.pad[1] = tl.pad[2] = 0;
+                lo2[off + lane] = tl;
+            }
         }
         off += n;
     }
@@ -184,6 +267,164 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_spmv_win(int64_t ngroups, int
 #pragma unroll
             for (int i = 0; i < WAVES; i++) t += sh[i];
             partial[g] = t;
+        }
+    }
+}
+
+// ---- the same SpMV on the 16-bit copy of the values, for the smoother of the multiplicative cycle ---------------------------
+// 24 instead of 74 bytes per block; x, the accumulation and everything written are FP64.  The SpMV result never leaves the
+// registers: the epilogue is the cycle's step that needs it (no reference counterpart, see the header of this file).
+//   EPI 1 (after pre-smoothing):  out = r - K~ x                                           (residual for the coarse correction)
+//   EPI 2 (post-smoothing):       out = x + c0 * Dinv (r - K~ x) ; partials of r.out and r.r (the PCG's z, r.z, r.r)
+struct WinSlotLo {
+    short8 a;
+    WinLoTail t;
+};
+__device__ __forceinline__ void win_load_lo(WinSlotLo &t, const short8 *__restrict__ lo8, const WinLoTail *__restrict__ lo2,
+                                            int64_t off, int n, int lane) {
+    const int l = lane < n ? lane : n - 1;
+    t.a = __builtin_nontemporal_load(lo8 + off + l);
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 w = __builtin_nontemporal_load((const u32x2 *)(lo2 + off + l));
+    t.t = __builtin_bit_cast(WinLoTail, w);
+}
+// FP32 inside the block products: q (16-bit integer) and x rounded to FP32 carry 2^-24 relative error against 2^-16 of the
+// quantisation; the conversions and products run at the full VALU rate and x of the window takes half the LDS
+__device__ __forceinline__ void win_fma_lo(const WinSlotLo &t, bool active, const float *xs, float &y0, float &y1, float &y2) {
+    const float *xa = xs + 3 * (int)t.t.col;
+    const int e = (int)t.t.e;
+    const float sc = active ? __builtin_bit_cast(float, (127 + (e < -126 ? -126 : e)) << 23) : 0.0f;   // 2^e on x (exact)
+    const float a0 = xa[0] * sc, a1 = xa[1] * sc, a2 = xa[2] * sc;
+    y0 += (float)(int)t.a[0] * a0 + (float)(int)t.a[1] * a1 + (float)(int)t.a[2] * a2;
+    y1 += (float)(int)t.a[3] * a0 + (float)(int)t.a[4] * a1 + (float)(int)t.a[5] * a2;
+    y2 += (float)(int)t.a[6] * a0 + (float)(int)t.a[7] * a1 + (float)(int)t.t.q8 * a2;
+}
+
+template <int EPI, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 4) void k_spmv_win_lo(int64_t ngroups, int64_t wmax, const int64_t *__restrict__ gptr,
+                                                                const int32_t *__restrict__ gextra, const int32_t *__restrict__ wlist,
+                                                                const int64_t *__restrict__ woff, const uint16_t *__restrict__ rowlen,
+                                                                const int32_t *__restrict__ rownode, const uint32_t *__restrict__ seg,
+                                                                const short8 *__restrict__ lo8, const WinLoTail *__restrict__ lo2,
+                                                                const double *__restrict__ lo_scale, const double *__restrict__ x,
+                                                                const double *__restrict__ r, double *__restrict__ out, double c0,
+                                                                const float *__restrict__ dinv6, double *__restrict__ partial,
+                                                                const double *__restrict__ done) {
+    extern __shared__ float xsf[];      // x of the window in FP32 (3 per window node), then the partial results of later segments
+    __shared__ double sh[2 * WAVES];
+    constexpr int WIN_THREADS = 64 * WAVES;
+    if (done && *done != 0.0) return;
+    const int64_t b = blockIdx.x;
+    const int64_t q = ngroups >> 3, rr8 = ngroups & 7, xcd = b & 7;
+    const int64_t g = (xcd < rr8 ? xcd * (q + 1) : rr8 * (q + 1) + (xcd - rr8) * q) + (b >> 3);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wig = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t wave = g * WAVES + wig, row = wave * 64 + lane;
+    const int len = rowlen[row];
+    const int L = __builtin_amdgcn_readfirstlane(len);
+    int64_t off = woff[wave];
+    int j = 0;
+    {
+        const int64_t w0 = gptr[g];
+        const int W = (int)(gptr[g + 1] - w0);
+        for (int i = tid; i < W; i += WIN_THREADS) {
+            const int32_t nd = wlist[w0 + i];
+            const double *xa = x + 3 * (int64_t)nd;
+            const int o = nd & 1;
+            const double2 wv = *(const double2 *)(xa + o);
+            const double sv = xa[o ? 0 : 2];
+            xsf[3 * i] = (float)(o ? sv : wv.x);
+            xsf[3 * i + 1] = (float)(o ? wv.x : wv.y);
+            xsf[3 * i + 2] = (float)(o ? wv.y : sv);
+        }
+    }
+    __syncthreads();
+    float y0 = 0.f, y1 = 0.f, y2 = 0.f;
+    {   // eight blocks in flight (24 bytes each)
+        WinSlotLo s[8];
+        float z0 = 0.f, z1 = 0.f, z2 = 0.f, u0 = 0.f, u1 = 0.f, u2 = 0.f, w0 = 0.f, w1 = 0.f, w2 = 0.f;
+        for (; j + 8 <= L; j += 8) {
+            bool p[8];
+            int n[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                p[k] = len > j + k;
+                n[k] = __popcll(__builtin_amdgcn_ballot_w64(p[k]));
+            }
+            int64_t o = off;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                win_load_lo(s[k], lo8, lo2, o, n[k], lane);
+                o += n[k];
+            }
+            win_fma_lo(s[0], p[0], xsf, y0, y1, y2);
+            win_fma_lo(s[1], p[1], xsf, z0, z1, z2);
+            win_fma_lo(s[2], p[2], xsf, u0, u1, u2);
+            win_fma_lo(s[3], p[3], xsf, w0, w1, w2);
+            win_fma_lo(s[4], p[4], xsf, y0, y1, y2);
+            win_fma_lo(s[5], p[5], xsf, z0, z1, z2);
+            win_fma_lo(s[6], p[6], xsf, u0, u1, u2);
+            win_fma_lo(s[7], p[7], xsf, w0, w1, w2);
+            off = o;
+        }
+        for (; j + 2 <= L; j += 2) {
+            const bool p0 = len > j, p1 = len > j + 1;
+            const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0)), n1 = __popcll(__builtin_amdgcn_ballot_w64(p1));
+            win_load_lo(s[0], lo8, lo2, off, n0, lane);
+            win_load_lo(s[1], lo8, lo2, off + n0, n1, lane);
+            win_fma_lo(s[0], p0, xsf, y0, y1, y2);
+            win_fma_lo(s[1], p1, xsf, z0, z1, z2);
+            off += n0 + n1;
+        }
+        for (; j < L; j++) {
+            const bool p0 = len > j;
+            const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0));
+            win_load_lo(s[0], lo8, lo2, off, n0, lane);
+            win_fma_lo(s[0], p0, xsf, y0, y1, y2);
+            off += n0;
+        }
+        y0 += z0 + u0 + w0; y1 += z1 + u1 + w1; y2 += z2 + u2 + w2;
+    }
+    const int32_t node = rownode[row];
+    const uint32_t sc = seg[row];
+    const int nseg = (int)(sc & 255u);
+    if (gextra[g] > 0) {
+        float *yp = xsf + 3 * wmax + 3 * (int)(sc >> 8);
+        if (node >= 0 && nseg == 0) { yp[0] = y0; yp[1] = y1; yp[2] = y2; }
+        __syncthreads();
+        for (int k = 0; k + 1 < nseg; k++) { y0 += yp[3 * k]; y1 += yp[3 * k + 1]; y2 += yp[3 * k + 2]; }
+    }
+    double rz = 0.0, rr = 0.0;
+    if (node >= 0 && nseg > 0) {
+        const double is = lo_scale[1];
+        const int64_t o = 3 * (int64_t)node;
+        const double r0 = r[o], r1 = r[o + 1], r2 = r[o + 2];
+        const double t0 = r0 - is * y0, t1 = r1 - is * y1, t2 = r2 - is * y2;
+        if (EPI == 1) {
+            out[o] = t0; out[o + 1] = t1; out[o + 2] = t2;
+        } else {
+            const float2 *d2 = (const float2 *)(dinv6 + 6 * (int64_t)node);
+            const float2 u0 = d2[0], u1 = d2[1], u2 = d2[2];   // xx xy | xz yy | yz zz
+            const double *xo = x + o;      // the FP64 x of the row's own node (the window in LDS holds FP32 roundings)
+            const double z0 = xo[0] + c0 * ((double)u0.x * t0 + (double)u0.y * t1 + (double)u1.x * t2);
+            const double z1 = xo[1] + c0 * ((double)u0.y * t0 + (double)u1.y * t1 + (double)u2.x * t2);
+            const double z2 = xo[2] + c0 * ((double)u1.x * t0 + (double)u2.x * t1 + (double)u2.y * t2);
+            out[o] = z0; out[o + 1] = z1; out[o + 2] = z2;
+            rz = r0 * z0 + r1 * z1 + r2 * z2;
+            rr = r0 * r0 + r1 * r1 + r2 * r2;
+        }
+    }
+    if (EPI == 2) {
+        rz = wave_sum(rz);
+        rr = wave_sum(rr);
+        if (lane == 0) { sh[wig] = rz; sh[WAVES + wig] = rr; }
+        __syncthreads();
+        if (tid == 0) {
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < WAVES; i++) { a0 += sh[i]; a1 += sh[WAVES + i]; }
+            partial[g] = a0;
+            partial[ngroups + g] = a1;
         }
     }
 }

@@ -63,6 +63,7 @@ SIGNATURES = {
     "fcvm_set_precond": [_vp, _int, _int, _int, _f64, _f64],
     "fcvm_precond_info": [_vp, _pf64],
     "fcvm_set_mg_cycle": [_vp, _int, _f64],
+    "fcvm_get_mg_cycle": [_vp, C.POINTER(C.c_int), _pf64, C.POINTER(C.c_int)],
     "fcvm_mg_coarse_nodes": [_vp, _vp, _vp],
     "fcvm_mg_coarse_to_coo": [_vp, _vp, _vp, _vp],
     "fcvm_mg_set_level2": [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _int, _f64],

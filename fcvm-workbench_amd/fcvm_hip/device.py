@@ -277,6 +277,10 @@ class Context:
         call("fcvm_precond_info", self.h, o)
         d = dict(mode="mg" if o[0] == 1 else "bj", coarse_nodes=int(o[1]), lmax0=o[2], lmax1=o[3],
                  coarse_nnz_blocks=int(o[4]), vcycle_fine_spmv=int(o[5]), l2_aggregates=int(o[6]), l2_unknowns=int(o[7]))
+        form, wgt, lo = C.c_int(0), C.c_double(0.0), C.c_int(0)
+        call("fcvm_get_mg_cycle", self.h, C.byref(form), C.byref(wgt), C.byref(lo))
+        # the form that runs: 2 needs the 16-bit copy (window format), without it the FP64 multiplicative form stands in
+        d["cycle_form"], d["cycle_weight"] = (form.value if form.value != 2 or lo.value else 0), wgt.value
         sp = (C.c_int64 * 4)()
         call("fcvm_mg_sparse_info", self.h, sp)
         d["l2_sparse"], d["l3_super_aggregates"], d["l3_unknowns"] = bool(sp[0]), int(sp[2]), int(sp[3])
@@ -289,7 +293,9 @@ class Context:
         return d
 
     def set_mg_cycle(self, additive=True, weight=1.0):
-        call("fcvm_set_mg_cycle", self.h, 1 if additive else 0, float(weight))
+        """form of the level-0 part of the cycle: True / 1 additive, False / 0 multiplicative with FP64 smoother SpMVs, 2 multiplicative
+        V(1,1) whose two smoother SpMVs stream a 16-bit fixed-point copy of the matrix (takes effect at the next assemble)"""
+        call("fcvm_set_mg_cycle", self.h, int(additive), float(weight))
 
     def build_level2(self, target=None, k1s=None, alpha1s=None):
         """Third multigrid level (aggregates of tet4 nodes); call after assemble().  Skipped for
@@ -320,6 +326,10 @@ class Context:
             # level-1 Chebyshev steps before / after the aggregate correction: larger aggregates leave more for the
             # smoother to do (1 M cube with 1400-node aggregates: 95 PCG iterations with 2 steps, 79 with 3; 2800: 113 / 87 with 4)
             k1s = 2 if target <= 250 else (3 if target <= 1000 else 4)
+            # the multiplicative cycle (form 2) leaves the level-1 solve as the weakest part: one more step pays there
+            # (1 M plate: 53.7 -> 46.1 PCG iterations, 3.64 -> 3.30 s of solves; Embankment 337k: 82.1 -> 75.1, gpurun_out/r03g)
+            if pi.get("cycle_form") == 2 and k1s == 2:
+                k1s = 3
         if alpha1s is None and os.environ.get("FCVM_MG_ALPHA1S"):
             alpha1s = float(os.environ["FCVM_MG_ALPHA1S"])
         if alpha1s is None:

@@ -45,7 +45,7 @@ def build_rank_model(rank, world, cells, material, traction, device_index, backe
     return model, be, ops
 
 
-def run(args, ctl, material, traction, rtol, hbm_peak, cpu_baseline):
+def run(args, ctl, material, traction, rtol, hbm_peak):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if os.environ.get("FCVM_DIST_DEBUG"):   # where does a stuck rank stand? tracebacks of all threads every N seconds

@@ -195,6 +195,11 @@ int fcvm_unpack_sum(fcvm_ctx *c, int64_t nshared, const int64_t *node, const int
 /* level-0 part of the V-cycle: additive != 0 (default): x = weight*c0*Dinv b + P M1^-1 P^T b, i.e. no
  * fine-level SpMV inside the preconditioner; additive == 0: multiplicative Chebyshev pre/post smoothing */
 int fcvm_set_mg_cycle(fcvm_ctx *c, int additive, double weight);
+/* additive == 2: multiplicative V(1,1) with one damped block-Jacobi step before and after the coarse correction whose two
+ * fine-level SpMVs stream a 16-bit fixed-point copy of the matrix (20 instead of 74 bytes per 3x3 block; written by the next
+ * fcvm_assemble; needs the window format, otherwise the FP64 form 0 runs).  The PCG itself -- p.Ap, the residual
+ * recurrence and the convergence test -- stays on the FP64 matrix. */
+int fcvm_get_mg_cycle(fcvm_ctx *c, int *form, double *weight, int *fp16_copy_in_use);
 /* out[0]=mode, out[1]=coarse nodes, out[2]=lmax level 0, out[3]=lmax level 1, out[4]=coarse nnz
  * blocks, out[5]=fine SpMV launches inside V-cycles of the last solve, out[6]=level-2 aggregates,
  * out[7]=level-2 unknowns (0 = no level 2) */

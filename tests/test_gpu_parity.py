@@ -210,6 +210,52 @@ def test_both_preconditioners_solve_the_embankment_system(embankment, mode):
         assert info["iterations"] < 200 and c.precond_info()["coarse_nodes"] > 0
 
 
+def test_16bit_smoother_cycle_is_a_symmetric_preconditioner_and_solves(monkeypatch):
+    """The multiplicative V(1,1) cycle whose two fine-level smoother SpMVs stream a 16-bit fixed-point copy of the matrix (cycle form 2,
+    k_spmv_win_lo): as an operator z = B r it must be symmetric and positive definite (PCG's requirement; checked with random
+    vectors through fcvm_mg_apply), the PCG built on it must reach the solution of the FP64 matrix (true residual from the
+    FP64 SpMV, sparse direct solve of the matrix read back), in fewer iterations than the additive cycle, and with groups
+    of 4 waves as well (windows forced small).  Embankment refined twice (unstructured, nu = 0.45) and a cube with split rows."""
+    from fcvm_hip import examples, meshgen
+    from fcvm_hip.device import Context
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import GpuModel
+    emb = examples.embankment(refine=2)
+    cube = meshgen.cube_case(12, l=10.0, traction=(0.0, 0.0, 1.0))
+    cube["material"] = (210000.0, 0.3, 7.8e-6)
+    rng = np.random.default_rng(11)
+    for case, grav in ((emb, (0.0, 0.0, -10.0)), (cube, (0.0, 0.0, 0.0))):
+        its = {}
+        for form, small in ((1, False), (2, False), (2, True)):
+            if small:
+                monkeypatch.setenv("FCVM_WIN_MAX", str(wmax - 1))
+            ctx = Context(0)
+            ctx.set_mg_cycle(form)
+            m = GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"], Loads(), ctx=ctx)
+            monkeypatch.delenv("FCVM_WIN_MAX", raising=False)
+            c = m.ctx
+            wmax = c.spmv_info()["max_window"]
+            assert c.spmv_info()["waves_per_group"] == (4 if small else 8)
+            glv, modf, _, _ = m.calc_gsm(grav, want_x=False)
+            f = c.mul(m.fixdof, glv) if np.abs(glv.get()).max() > 0 else c.array(m.fixdof_h * rng.standard_normal(m.ndof))
+            if form == 2:   # B symmetric positive definite on the free dofs
+                a, b = (c.array(m.fixdof_h * rng.standard_normal(m.ndof)) for _ in range(2))
+                Ba, Bb = c.mg_apply(a, c.empty(m.ndof)), c.mg_apply(b, c.empty(m.ndof))
+                ab, ba, aa, bb = c.dot(b, Ba), c.dot(a, Bb), c.dot(a, Ba), c.dot(b, Bb)
+                assert abs(ab - ba) <= 1e-6 * np.sqrt(aa * bb), (ab, ba)    # rounding of K_ij / K_ji may differ in the last bit
+                assert aa > 0 and bb > 0
+            u, info = c.solve(f, rtol=1e-12)
+            r = c.axpby(1.0, f, -1.0, c.spmv(u, c.empty(m.ndof)))
+            assert c.norm(r) <= 5e-12 * c.norm(f)
+            if not small:
+                K = gpu_matrix(m)
+                assert rel(u.get(), spla.spsolve(K.tocsc(), f.get())) < 1e-8
+            its[(form, small)] = info["iterations"]
+            c.close()
+        assert its[(2, False)] < 0.8 * its[(1, False)], its
+        assert abs(its[(2, True)] - its[(2, False)]) <= 2, its
+
+
 def test_window_format_spmv_and_pcg_match_sliced_ell(monkeypatch):
     """The SpMV's second storage of the fine matrix (window format: Morton groups, x of a group's column nodes in LDS,
     16-bit window columns, prefix storage without padding, long rows cut into segments) against the sliced-ELL kernel and
@@ -781,8 +827,8 @@ def test_bench_line_contract():
     import subprocess
     import sys
     from conftest import REPO
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--cells", "10", "--steps", "2", "--warmup", "1", "--no-plate"],
-                       capture_output=True, text=True, timeout=600, cwd=REPO)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--plate-h", "8", "--cpu-plate-h", "10", "--cells", "8", "--steps", "3",
+                        "--warmup", "2"], capture_output=True, text=True, timeout=600, cwd=REPO)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
@@ -790,14 +836,18 @@ def test_bench_line_contract():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert d["higher_is_better"] is True and d["unit"] == "elements*GP/s" and "workload" in d["config"] and "model" not in d["config"]
     ro = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in ro, k
     assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb and "CHOLMOD" in cb["solver_note"]
+    # the timed region is cut from the real collapse analysis: same control file, same load history as the whole run
+    ns = d["north_star_workload"]
+    assert ns["steps"] == 10 and 0.2 < ns["collapse_load_factor"] < 0.26 and ns["newton_iterations"] >= 5
+    assert abs(d["value"] - d["newton_iterations_per_s"] * 4 * float(d["config"]["workload"].split(": ")[1].split(" tet10")[0])) < 1e-6 * d["value"]
 
 
 def test_command_line_entry_point(tmp_path):

@@ -28,6 +28,7 @@ PRESETS = {
     "mult1": dict(additive=0, k0=1),
     "mult2": dict(additive=0, k0=2),
     "mult3": dict(additive=0, k0=3, alpha0=8.0),
+    "lo": dict(additive=2),
 }
 
 
@@ -47,7 +48,7 @@ def run(case, label, cfg, rtol):
     try:
         ctx = Context(0)
         ctx.set_precond("mg", k0=int(cfg.get("k0", 1)), alpha0=float(cfg.get("alpha0", 4.0)))
-        ctx.set_mg_cycle(bool(int(cfg.get("additive", 1))), float(cfg.get("w", 1.0)))
+        ctx.set_mg_cycle(int(cfg.get("additive", 1)), float(cfg.get("w", 1.0)))
         m = GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"],
                      Loads(ufaces=case["ufaces"], uloads=case["uloads"]) if "ufaces" in case else None, ctx=ctx)
         st = {}
