@@ -104,7 +104,7 @@ def cpu_baseline(plate_h=6.0, iters=5):
     ne, nn = len(pc["elNodes"]), len(pc["nocoord"])
     pdt, p_asm, p_fac = _cpu_newton_iterations(orc, pc["elNodes"], pc["nocoord"], pc["material"], pc["fix"],
                                                orc.Loads(ufaces=pc["ufaces"], uloads=pc["uloads"]), iters, float(pc["ctl"]["sig_yield"]))
-    gpu = collapse_run(pc, 0, 10 ** 9)["analysis"]
+    gpu = collapse_run(pc, 0, None)["analysis"]
     return {"value": ne * 4 / pdt, "unit": "elements*GP/s", "cores": 1, "kind": "port",
             "newton_iterations_per_s": 1.0 / pdt,
             "sample": "%s: %d tet10 / %d dof, %d Newton iterations (SuperLU back-substitution + update_stress_load); one-time "
@@ -167,7 +167,7 @@ def collapse_run(case, warmup, steps):
         reg["n"] += 1
         if reg["n"] == warmup:
             mark("start")
-        if reg["n"] == warmup + steps:
+        if steps is not None and reg["n"] == warmup + steps:
             mark("end")
             if first_pass_done:
                 raise _Stop
@@ -197,7 +197,7 @@ def collapse_run(case, warmup, steps):
                             "elements_gp_per_s": st["newton_iterations"] * model.ne * 4 / dt, "linear_solves": st["solves"],
                             "pcg_iterations_per_solve": st["pcg_iterations"] / max(st["solves"], 1),
                             "collapse_load_factor": float(d.lbd[-1]), "setup_s_inside": t_setup}
-            if "end" in reg or d.mrr or d.elastic_only:
+            if steps is None or "end" in reg or d.mrr or d.elastic_only:   # steps None: the first pass (the analysis) only
                 break
             d.next_pass()
     except _Stop:
@@ -255,6 +255,7 @@ def run_single(args):
     s0, s1, dt = reg["stats0"], reg["stats1"], reg["s"]
     info = c.pattern_info()
     ndof, ne = info["ndof"], model.ne
+    label = precond_label(c)      # (before the block-Jacobi detour below: the label reads the state of the cycle that ran)
     # one-time work of an analysis, timed on its own after the run: the bare assembly (calcGSM on the GPU), and assembly + hierarchy
     t_pat = model.t_pattern
     model.calc_gsm((0.0, 0.0, 0.0), want_x=False)
@@ -307,7 +308,7 @@ def run_single(args):
                                "Newton/Riks iteration of that collapse analysis (iterations %d..%d of it, start_step / end_step between them "
                                "included; %d of %d Gauss points plastic at the end of the region)" %
                                (case["name"], ne, ndof, ne, args.warmup + 1, args.warmup + args.steps, plastic, 4 * ne),
-                   "pcg_rtol": RTOL, "preconditioner": precond_label(c)},
+                   "pcg_rtol": RTOL, "preconditioner": label},
         "newton_iterations_per_s": args.steps / dt,
         "pcg_iterations_per_step": pcg_its / args.steps,
         "pcg_iterations_per_solve": pcg_its / max(solves, 1),

@@ -300,8 +300,14 @@ __device__ __forceinline__ void win_fma_lo(const WinSlotLo &t, bool active, cons
     y2 += (float)(int)t.a[6] * a0 + (float)(int)t.a[7] * a1 + (float)(int)t.t.q8 * a2;
 }
 
+#ifndef FCVM_LO_MINWAVES
+#define FCVM_LO_MINWAVES 4
+#endif
+#ifndef FCVM_LO_INFLIGHT
+#define FCVM_LO_INFLIGHT 8
+#endif
 template <int EPI, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 4) void k_spmv_win_lo(int64_t ngroups, int64_t wmax, const int64_t *__restrict__ gptr,
+__global__ __launch_bounds__(64 * WAVES, FCVM_LO_MINWAVES) void k_spmv_win_lo(int64_t ngroups, int64_t wmax, const int64_t *__restrict__ gptr,
                                                                 const int32_t *__restrict__ gextra, const int32_t *__restrict__ wlist,
                                                                 const int64_t *__restrict__ woff, const uint16_t *__restrict__ rowlen,
                                                                 const int32_t *__restrict__ rownode, const uint32_t *__restrict__ seg,
@@ -340,31 +346,31 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_spmv_win_lo(int64_t ngroups, 
     }
     __syncthreads();
     float y0 = 0.f, y1 = 0.f, y2 = 0.f;
-    {   // eight blocks in flight (24 bytes each)
-        WinSlotLo s[8];
+    {   // NB blocks in flight (24 bytes each)
+        constexpr int NB = FCVM_LO_INFLIGHT;
+        WinSlotLo s[NB];
         float z0 = 0.f, z1 = 0.f, z2 = 0.f, u0 = 0.f, u1 = 0.f, u2 = 0.f, w0 = 0.f, w1 = 0.f, w2 = 0.f;
-        for (; j + 8 <= L; j += 8) {
-            bool p[8];
-            int n[8];
+        for (; j + NB <= L; j += NB) {
+            bool p[NB];
+            int n[NB];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < NB; k++) {
                 p[k] = len > j + k;
                 n[k] = __popcll(__builtin_amdgcn_ballot_w64(p[k]));
             }
             int64_t o = off;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < NB; k++) {
                 win_load_lo(s[k], lo8, lo2, o, n[k], lane);
                 o += n[k];
             }
-            win_fma_lo(s[0], p[0], xsf, y0, y1, y2);
-            win_fma_lo(s[1], p[1], xsf, z0, z1, z2);
-            win_fma_lo(s[2], p[2], xsf, u0, u1, u2);
-            win_fma_lo(s[3], p[3], xsf, w0, w1, w2);
-            win_fma_lo(s[4], p[4], xsf, y0, y1, y2);
-            win_fma_lo(s[5], p[5], xsf, z0, z1, z2);
-            win_fma_lo(s[6], p[6], xsf, u0, u1, u2);
-            win_fma_lo(s[7], p[7], xsf, w0, w1, w2);
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                if ((k & 3) == 0) win_fma_lo(s[k], p[k], xsf, y0, y1, y2);
+                else if ((k & 3) == 1) win_fma_lo(s[k], p[k], xsf, z0, z1, z2);
+                else if ((k & 3) == 2) win_fma_lo(s[k], p[k], xsf, u0, u1, u2);
+                else win_fma_lo(s[k], p[k], xsf, w0, w1, w2);
+            }
             off = o;
         }
         for (; j + 2 <= L; j += 2) {

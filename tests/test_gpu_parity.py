@@ -215,12 +215,12 @@ def test_16bit_smoother_cycle_is_a_symmetric_preconditioner_and_solves(monkeypat
     k_spmv_win_lo): as an operator z = B r it must be symmetric and positive definite (PCG's requirement; checked with random
     vectors through fcvm_mg_apply), the PCG built on it must reach the solution of the FP64 matrix (true residual from the
     FP64 SpMV, sparse direct solve of the matrix read back), in fewer iterations than the additive cycle, and with groups
-    of 4 waves as well (windows forced small).  Embankment refined twice (unstructured, nu = 0.45) and a cube with split rows."""
+    of 4 waves as well (windows forced small).  Embankment refined once (unstructured, nu = 0.45) and a cube with split rows."""
     from fcvm_hip import examples, meshgen
     from fcvm_hip.device import Context
     from fcvm_hip.loads import Loads
     from fcvm_hip.solver import GpuModel
-    emb = examples.embankment(refine=2)
+    emb = examples.embankment(refine=1)
     cube = meshgen.cube_case(12, l=10.0, traction=(0.0, 0.0, 1.0))
     cube["material"] = (210000.0, 0.3, 7.8e-6)
     rng = np.random.default_rng(11)

@@ -46,3 +46,15 @@ for _ in range(a.solves):
     c.sync()
     dt = time.perf_counter() - t0
     print("solve: %d iterations, %.1f ms, %.3f ms per iteration" % (info["iterations"], dt * 1e3, dt * 1e3 / max(info["iterations"], 1)))
+x, y = c.array(np.random.default_rng(0).standard_normal(m.ndof)), c.empty(m.ndof)
+for _ in range(3):
+    c.spmv(x, y)
+c.sync()
+t0 = time.perf_counter()
+for _ in range(12):
+    c.spmv(x, y)       # k_spmv_win<false>: every launch live (counter passes: traffic per launch without the PCG's no-op launches)
+c.sync()
+info = c.pattern_info()
+print("plain SpMV back to back: %.4f ms; nnz blocks %d, dof %d, window format blocks %d" %
+      ((time.perf_counter() - t0) / 12 * 1e3, info["nnz_blocks"], info["ndof"], c.spmv_info()["blocks"]))
+print("stream read %.0f GB/s" % c.membench(3 << 30))
