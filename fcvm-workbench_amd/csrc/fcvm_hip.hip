@@ -69,6 +69,16 @@ struct L2sDev {   // device state of the sparse aggregate level (owned by fcvm_c
     double *x = nullptr, *r = nullptr, *d = nullptr, *t = nullptr, *r3 = nullptr, *e3 = nullptr;
 };
 
+// Work vectors of the multigrid PCG for a second right-hand side (fcvm_solve2): the cycle's code works on the context's own
+// pointers, so the second state is brought in by swapping pointers between launches (kernel arguments are taken at launch).
+struct MgAlt {
+    bool ready = false;
+    int64_t nn = 0, nc = 0, n2 = 0, nagg2 = 0, n3 = 0, ngroups = 0;
+    double *r = nullptr, *z = nullptr, *p = nullptr, *q = nullptr, *S = nullptr, *part_vec = nullptr, *part_spmv = nullptr, *part_lo = nullptr;
+    double *md = nullptr, *mr = nullptr, *mt = nullptr, *x1 = nullptr, *rr1 = nullptr, *d1 = nullptr, *t1 = nullptr, *r2 = nullptr, *e2 = nullptr;
+    double *sx = nullptr, *sr = nullptr, *sd = nullptr, *st = nullptr, *sr3 = nullptr, *se3 = nullptr;   // sparse aggregate level
+};
+
 struct fcvm_ctx {
     int device = 0;
     hipStream_t own = nullptr, stream = nullptr;
@@ -110,6 +120,7 @@ struct fcvm_ctx {
     double row_spread = 0.0;
     bool row_order_morton = false;
     // window-format copies of the matrices for the SpMV (fcvm_spmv_win.hip.h); 0: the sliced-ELL kernel does it
+    bool win2_ok = false;           // twice the window fits the LDS: k_spmv_win2 can run
     int spmv_win = 1, win_v2 = 1;   // win_v2: value components in 16-byte pairs (FCVM_WIN_V2=0: nine 8-byte runs)
     WinDev win;                     // the fine matrix.  (The level-1 matrix of the multigrid cycle was tried on the same format with
                                     // FP32 values and the smoother epilogue: 31.0 against 28.3 us per launch -- 686 workgroups are too
@@ -159,6 +170,8 @@ struct fcvm_ctx {
     double *d_Z = nullptr, *d_A2inv = nullptr, *d_r2 = nullptr, *d_e2 = nullptr;
     std::vector<hipEvent_t> evpool;
     double *h_pcgS = nullptr;      // pinned copies of the PCG scalars, one per queued chunk (fcvm_mg.inc)
+    double *h_pcgS2 = nullptr;     // the same for the two states of fcvm_solve2
+    MgAlt alt;                     // second PCG state (fcvm_solve2), allocated on first use
     int64_t mg_last_iters = 0, mg_prev_iters = 0;   // iterations of the two previous multigrid-PCG solves: they size the first chunk of the next one
 };
 
@@ -285,6 +298,33 @@ static void launch_spmv_win_lo(fcvm_ctx *c, const double *x, const double *r, do
                            w.pat.wmax, w.gptr, w.gextra, w.wlist, w.woff, w.rowlen, w.rownode, w.seg, w.lo8, w.lo2, w.lo_scale, x,
                            r, out, c0, (const float *)c->d_dinv6f, w.part_lo, done);
 }
+// two right-hand sides: one pass over the matrix for both (k_spmv_win2 / k_spmv_win_lo2); LDS holds both windows
+static void launch_spmv_win2(fcvm_ctx *c, const double *xA, const double *xB, double *yA, double *yB, double *partA, double *partB,
+                             const double *doneA, const double *doneB) {
+    const WinDev &w = c->win;
+    if (w.pat.waves == 4)
+        hipLaunchKernelGGL((k_spmv_win2<true, 4>), dim3((unsigned)w.pat.ngroups), dim3(256), 2 * w.lds, c->stream, w.pat.ngroups, w.pat.wmax, w.gptr,
+                           w.gextra, w.wlist, w.woff, w.rowlen, w.rownode, w.seg, w.own, w.cols, (const double *)w.vals, xA, xB, yA, yB, partA,
+                           partB, doneA, doneB);
+    else
+        hipLaunchKernelGGL((k_spmv_win2<true, WIN_WAVES>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), 2 * w.lds, c->stream, w.pat.ngroups,
+                           w.pat.wmax, w.gptr, w.gextra, w.wlist, w.woff, w.rowlen, w.rownode, w.seg, w.own, w.cols, (const double *)w.vals, xA, xB,
+                           yA, yB, partA, partB, doneA, doneB);
+}
+template <int EPI>
+static void launch_spmv_win_lo2(fcvm_ctx *c, const double *xA, const double *xB, const double *rA, const double *rB, double *outA, double *outB,
+                                double c0, double *partA, double *partB, const double *doneA, const double *doneB) {
+    const WinDev &w = c->win;
+    if (w.pat.waves == 4)
+        hipLaunchKernelGGL((k_spmv_win_lo2<EPI, 4>), dim3((unsigned)w.pat.ngroups), dim3(256), w.lds, c->stream, w.pat.ngroups, w.pat.wmax, w.gptr,
+                           w.gextra, w.wlist, w.woff, w.rowlen, w.rownode, w.seg, w.lo8, w.lo2, w.lo_scale, xA, xB, rA, rB, outA, outB, c0,
+                           (const float *)c->d_dinv6f, partA, partB, doneA, doneB);
+    else
+        hipLaunchKernelGGL((k_spmv_win_lo2<EPI, WIN_WAVES>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), w.lds, c->stream, w.pat.ngroups,
+                           w.pat.wmax, w.gptr, w.gextra, w.wlist, w.woff, w.rowlen, w.rownode, w.seg, w.lo8, w.lo2, w.lo_scale, xA, xB, rA, rB,
+                           outA, outB, c0, (const float *)c->d_dinv6f, partA, partB, doneA, doneB);
+}
+
 // the multiplicative cycle with the 16-bit smoother matrix needs the window format and its 16-bit copy
 static inline bool mg_use_lo(const fcvm_ctx *c) { return c->mg_additive == 2 && c->win.on && c->win.lo_valid; }
 
@@ -296,6 +336,7 @@ static int dot_common(fcvm_ctx *c, int64_t n, const double *w, const double *x, 
     HCHK(hipGetLastError());
     return 0;
 }
+static void alt_free(fcvm_ctx *c);
 #include "fcvm_mg.inc"
 
 static void win_free(WinDev &w) {
@@ -400,8 +441,14 @@ static int setup_window_format(fcvm_ctx *c, const double *nocoord) {
         win_allow_lds(k_spmv_win<true, WIN_WAVES, false>, lds) || win_allow_lds(k_spmv_win<false, WIN_WAVES, false>, lds) ||
         win_allow_lds(k_spmv_win<true, 4, true>, lds) || win_allow_lds(k_spmv_win<false, 4, true>, lds) ||
         win_allow_lds(k_spmv_win_lo<1, WIN_WAVES>, lds) || win_allow_lds(k_spmv_win_lo<2, WIN_WAVES>, lds) ||
-        win_allow_lds(k_spmv_win_lo<1, 4>, lds) || win_allow_lds(k_spmv_win_lo<2, 4>, lds))
+        win_allow_lds(k_spmv_win_lo<1, 4>, lds) || win_allow_lds(k_spmv_win_lo<2, 4>, lds) ||
+        win_allow_lds(k_spmv_win_lo2<1, WIN_WAVES>, lds) || win_allow_lds(k_spmv_win_lo2<2, WIN_WAVES>, lds) ||
+        win_allow_lds(k_spmv_win_lo2<1, 4>, lds) || win_allow_lds(k_spmv_win_lo2<2, 4>, lds))
         return 1;
+    // the two-vector FP64 SpMV keeps both windows in LDS: only where twice the window fits (fcvm_solve2 solves one after the
+    // other otherwise)
+    c->win2_ok = 2 * lds <= (size_t)lds_cap;
+    if (c->win2_ok && (win_allow_lds(k_spmv_win2<true, WIN_WAVES>, 2 * lds) || win_allow_lds(k_spmv_win2<true, 4>, 2 * lds))) return 1;
     if (getenv("FCVM_VERBOSE"))
         fprintf(stderr, "fcvm: window format: %lld groups of %d waves, windows mean %.0f / max %lld nodes (%zu B LDS of %d), %lld entries\n",
                 (long long)w.ngroups, w.waves, w.wmean, (long long)w.wmax, lds, lds_cap, (long long)w.nblocks);
@@ -616,6 +663,14 @@ int fcvm_create(int device, fcvm_ctx **out) {
     return 0;
 }
 
+static void alt_free(fcvm_ctx *c) {
+    MgAlt &a = c->alt;
+    dfree(a.r); dfree(a.z); dfree(a.p); dfree(a.q); dfree(a.S); dfree(a.part_vec); dfree(a.part_spmv); dfree(a.part_lo);
+    dfree(a.md); dfree(a.mr); dfree(a.mt); dfree(a.x1); dfree(a.rr1); dfree(a.d1); dfree(a.t1); dfree(a.r2); dfree(a.e2);
+    dfree(a.sx); dfree(a.sr); dfree(a.sd); dfree(a.st); dfree(a.sr3); dfree(a.se3);
+    a = MgAlt();
+}
+
 static void free_mesh(fcvm_ctx *c) {
     dfree(c->d_el); dfree(c->d_cols); dfree(c->d_rownode); dfree(c->d_noce); dfree(c->d_sptr);
     dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
@@ -624,6 +679,7 @@ static void free_mesh(fcvm_ctx *c) {
     dfree(c->d_vals); dfree(c->d_vals_g); dfree(c->d_dblk); dfree(c->d_dinv); dfree(c->d_dinv6f); dfree(c->d_r); dfree(c->d_z); dfree(c->d_p);
     dfree(c->d_q); dfree(c->d_part_vec); dfree(c->d_part_spmv); dfree(c->d_part_misc); dfree(c->d_pidx);
     mg_free(c);
+    alt_free(c);
     c->have_mesh = c->assembled = false;
 }
 
@@ -635,6 +691,7 @@ int fcvm_destroy(fcvm_ctx *c) {
     dfree(c->d_S); dfree(c->d_out8); dfree(c->d_part_mdot);
     for (auto e : c->evpool) (void)hipEventDestroy(e);
     if (c->h_pcgS) (void)hipHostFree(c->h_pcgS);
+    if (c->h_pcgS2) (void)hipHostFree(c->h_pcgS2);
     if (c->asm_fork) (void)hipEventDestroy(c->asm_fork);
     for (int b = 0; b < fcvm_ctx::ASM_BUCKETS; b++) {
         if (c->asm_join[b]) (void)hipEventDestroy(c->asm_join[b]);
@@ -1101,6 +1158,53 @@ int fcvm_solve(fcvm_ctx *c, const double *f, double *u, double rtol, int64_t max
     if (!done) return fail("fcvm_solve: PCG did not converge in " + std::to_string(maxit) + " iterations (rel. residual " +
                            std::to_string(info ? info[1] : -1.0) + ")");
     return 0;
+}
+
+/* K uA = fA and K uB = fB in lockstep: two multigrid PCG iterations that share every pass over the matrix (cycle form 2 on the
+ * window format; otherwise, or when twice the window does not fit the LDS, the two systems are solved one after the other).
+ * Each result is bitwise what fcvm_solve returns for that right-hand side.  info[6] = {iterations, relative residual,
+ * SpMV launches} of A, then of B. */
+int fcvm_solve2(fcvm_ctx *c, const double *fA, const double *fB, double *uA, double *uB, double rtolA, double rtolB, int64_t maxit,
+                double info[6]) {
+    NEED(c && c->have_mesh && c->assembled, "fcvm_solve2: assemble the matrix first");
+    NEED(fA && fB && uA && uB && fA != uA && fB != uB && uA != uB, "fcvm_solve2: four distinct device arrays");
+    NEED(aligned16(fA) && aligned16(fB) && aligned16(uA) && aligned16(uB), "fcvm_solve2: device vectors must be 16-byte aligned");
+    if (c->precond_mode == 1 && mg_use_lo(c) && c->win2_ok) return mg_pcg2(c, fA, fB, uA, uB, rtolA, rtolB, maxit, info);
+    if (getenv("FCVM_VERBOSE"))
+        fprintf(stderr, "fcvm_solve2: one after the other (preconditioner mode %d, 16-bit cycle %d, two windows fit LDS %d)\n", c->precond_mode,
+                (int)mg_use_lo(c), (int)c->win2_ok);
+    if (fcvm_solve(c, fA, uA, rtolA, maxit, info)) return 1;
+    return fcvm_solve(c, fB, uB, rtolB, maxit, info ? info + 3 : nullptr);
+}
+
+/* yA = K xA and yB = K xB with one pass over the matrix (k_spmv_win2); each bitwise what fcvm_spmv gives.  Window format with
+ * room for two windows in LDS, otherwise two ordinary launches. */
+int fcvm_spmv2(fcvm_ctx *c, const double *xA, const double *xB, double *yA, double *yB) {
+    NEED(c && c->have_mesh, "fcvm_spmv2: no mesh");
+    NEED(xA && xB && yA && yB && xA != yA && xB != yB && yA != yB && xA != yB && xB != yA, "fcvm_spmv2: x and y must not alias");
+    NEED(aligned16(xA) && aligned16(xB) && aligned16(yA) && aligned16(yB), "fcvm_spmv2: device vectors must be 16-byte aligned");
+    if (c->win.on && c->win2_ok && c->win.part_lo) {
+        launch_spmv_win2(c, xA, xB, yA, yB, c->d_part_spmv, c->win.part_lo, nullptr, nullptr);   // (p.Ap partials: scratch here)
+    } else {
+        launch_spmv(c, false, xA, yA, nullptr);
+        launch_spmv(c, false, xB, yB, nullptr);
+    }
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+/* zA = M^-1 rA and zB = M^-1 rB: the preconditioner of fcvm_solve2 applied to two vectors, its two 16-bit matrix passes shared
+ * (bitwise fcvm_mg_apply of each).  Falls back to two applications where fcvm_solve2 would. */
+int fcvm_mg_apply2(fcvm_ctx *c, const double *rA, const double *rB, double *zA, double *zB) {
+    NEED(c && c->have_mesh && c->assembled && c->precond_mode == 1, "fcvm_mg_apply2: assemble with the multigrid preconditioner first");
+    NEED(rA && rB && zA && zB && rA != zA && rB != zB && zA != zB, "fcvm_mg_apply2: distinct device vectors");
+    NEED(aligned16(rA) && aligned16(rB) && aligned16(zA) && aligned16(zB), "fcvm_mg_apply2: device vectors must be 16-byte aligned");
+    c->mg_done = nullptr;
+    if (!(mg_use_lo(c) && c->win2_ok)) {
+        if (mg_vcycle(c, rA, zA)) return 1;
+        return mg_vcycle(c, rB, zB);
+    }
+    return mg_vcycle2(c, rA, rB, zA, zB);
 }
 
 /* z = M^-1 r : one application of the multigrid preconditioner of fcvm_solve (r, z: device vectors, r != z) */

@@ -271,6 +271,135 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_spmv_win(int64_t ngroups, int
     }
 }
 
+// ---- two right-hand sides: the matrix stream is read once for both ------------------------------------------------------------
+// The PCG pairs of the GNLY Newton iteration (K ue = f and K due = r with one tangent matrix, fcVM.py:1351-1401) and of the
+// buckling subspace iteration run in lockstep (fcvm_solve2); their three matrix passes per iteration use these kernels.
+// LDS: x of the window for both vectors, interleaved per node [node][rhs][3]; a block's six x values are 48 contiguous bytes.
+__device__ __forceinline__ void win_fma2(const WinSlot &t, bool active, const double *xs, double *y) {
+    const double *xa = xs + 6 * t.col;
+    const double a0 = active ? xa[0] : 0.0, a1 = active ? xa[1] : 0.0, a2 = active ? xa[2] : 0.0;
+    const double b0 = active ? xa[3] : 0.0, b1 = active ? xa[4] : 0.0, b2 = active ? xa[5] : 0.0;
+    y[0] += t.v[0] * a0 + t.v[1] * a1 + t.v[2] * a2;
+    y[1] += t.v[3] * a0 + t.v[4] * a1 + t.v[5] * a2;
+    y[2] += t.v[6] * a0 + t.v[7] * a1 + t.v[8] * a2;
+    y[3] += t.v[0] * b0 + t.v[1] * b1 + t.v[2] * b2;
+    y[4] += t.v[3] * b0 + t.v[4] * b1 + t.v[5] * b2;
+    y[5] += t.v[6] * b0 + t.v[7] * b1 + t.v[8] * b2;
+}
+__device__ __forceinline__ void win_stage2(double *xs, int i, const double *__restrict__ x, int32_t nd, int rhs) {
+    const double *xa = x + 3 * (int64_t)nd;
+    const int o = nd & 1;            // 8 + 16 byte loads: even nodes are 16-byte aligned, odd ones 8 off
+    const double2 wv = *(const double2 *)(xa + o);
+    const double sv = xa[o ? 0 : 2];
+    double *d = xs + 6 * i + 3 * rhs;
+    d[0] = o ? sv : wv.x;
+    d[1] = o ? wv.x : wv.y;
+    d[2] = o ? wv.y : sv;
+}
+
+template <bool DOT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 2) void k_spmv_win2(int64_t ngroups, int64_t wmax, const int64_t *__restrict__ gptr,
+                                                              const int32_t *__restrict__ gextra, const int32_t *__restrict__ wlist,
+                                                              const int64_t *__restrict__ woff, const uint16_t *__restrict__ rowlen,
+                                                              const int32_t *__restrict__ rownode, const uint32_t *__restrict__ seg,
+                                                              const uint16_t *__restrict__ own, const uint16_t *__restrict__ cols,
+                                                              const double *__restrict__ vals, const double *__restrict__ xA,
+                                                              const double *__restrict__ xB, double *__restrict__ yA, double *__restrict__ yB,
+                                                              double *__restrict__ partA, double *__restrict__ partB,
+                                                              const double *__restrict__ doneA, const double *__restrict__ doneB) {
+    extern __shared__ double xs[];
+    __shared__ double sh[2 * WAVES];
+    constexpr int WIN_THREADS = 64 * WAVES;
+    if (doneA && doneB && *doneA != 0.0 && *doneB != 0.0) return;
+    const int64_t b = blockIdx.x;
+    const int64_t q = ngroups >> 3, r = ngroups & 7, xcd = b & 7;
+    const int64_t g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wig = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t wave = g * WAVES + wig, row = wave * 64 + lane;
+    const int len = rowlen[row];
+    const int L = __builtin_amdgcn_readfirstlane(len);
+    int64_t off = woff[wave];
+    {
+        const int64_t w0 = gptr[g];
+        const int W = (int)(gptr[g + 1] - w0);
+        for (int i = tid; i < W; i += WIN_THREADS) {
+            const int32_t nd = wlist[w0 + i];
+            win_stage2(xs, i, xA, nd, 0);
+            win_stage2(xs, i, xB, nd, 1);
+        }
+    }
+    __syncthreads();
+    double y[6] = {0, 0, 0, 0, 0, 0};
+    {
+        WinSlot a, bb, cc, dd;
+        double z[6] = {0, 0, 0, 0, 0, 0}, u[6] = {0, 0, 0, 0, 0, 0}, w[6] = {0, 0, 0, 0, 0, 0};
+        int j = 0;
+        for (; j + 4 <= L; j += 4) {
+            const bool p0 = len > j, p1 = len > j + 1, p2 = len > j + 2, p3 = len > j + 3;
+            const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0)), n1 = __popcll(__builtin_amdgcn_ballot_w64(p1)),
+                      n2 = __popcll(__builtin_amdgcn_ballot_w64(p2)), n3 = __popcll(__builtin_amdgcn_ballot_w64(p3));
+            win_load<true>(a, cols, vals, off, n0, lane);
+            win_load<true>(bb, cols, vals, off + n0, n1, lane);
+            win_load<true>(cc, cols, vals, off + n0 + n1, n2, lane);
+            win_load<true>(dd, cols, vals, off + n0 + n1 + n2, n3, lane);
+            win_fma2(a, p0, xs, y);
+            win_fma2(bb, p1, xs, z);
+            win_fma2(cc, p2, xs, u);
+            win_fma2(dd, p3, xs, w);
+            off += n0 + n1 + n2 + n3;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) y[k] += z[k] + u[k] + w[k];
+        for (; j < L; j++) {
+            const bool p0 = len > j;
+            const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0));
+            win_load<true>(a, cols, vals, off, n0, lane);
+            win_fma2(a, p0, xs, y);
+            off += n0;
+        }
+    }
+    const int32_t node = rownode[row];
+    const uint32_t sc = seg[row];
+    const int nseg = (int)(sc & 255u);
+    if (gextra[g] > 0) {
+        double *yp = xs + 6 * wmax + 6 * (int)(sc >> 8);
+        if (node >= 0 && nseg == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) yp[k] = y[k];
+        }
+        __syncthreads();
+        for (int s2 = 0; s2 + 1 < nseg; s2++) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) y[k] += yp[6 * s2 + k];
+        }
+    }
+    if (node >= 0 && nseg > 0) {
+        double *ya = yA + 3 * (int64_t)node, *yb = yB + 3 * (int64_t)node;
+        ya[0] = y[0]; ya[1] = y[1]; ya[2] = y[2];
+        yb[0] = y[3]; yb[1] = y[4]; yb[2] = y[5];
+    }
+    if (DOT) {
+        double dA = 0.0, dB = 0.0;
+        if (node >= 0 && nseg > 0) {
+            const double *xo = xs + 6 * (int)own[row];
+            dA = y[0] * xo[0] + y[1] * xo[1] + y[2] * xo[2];
+            dB = y[3] * xo[3] + y[4] * xo[4] + y[5] * xo[5];
+        }
+        dA = wave_sum(dA);
+        dB = wave_sum(dB);
+        if (lane == 0) { sh[wig] = dA; sh[WAVES + wig] = dB; }
+        __syncthreads();
+        if (tid == 0) {
+            double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < WAVES; i++) { t0 += sh[i]; t1 += sh[WAVES + i]; }
+            partA[g] = t0;
+            partB[g] = t1;
+        }
+    }
+}
+
 // ---- the same SpMV on the 16-bit copy of the values, for the smoother of the multiplicative cycle ---------------------------
 // 24 instead of 74 bytes per block; x, the accumulation and everything written are FP64.  The SpMV result never leaves the
 // registers: the epilogue is the cycle's step that needs it (no reference counterpart, see the header of this file).
@@ -288,6 +417,11 @@ __device__ __forceinline__ void win_load_lo(WinSlotLo &t, const short8 *__restri
     const u32x2 w = __builtin_nontemporal_load((const u32x2 *)(lo2 + off + l));
     t.t = __builtin_bit_cast(WinLoTail, w);
 }
+// q . a with one fixed operation order (a product and two fused multiply-adds, written out: the compiler picks different
+// contractions -- packed FP32 pairs -- for the one- and the two-vector kernels otherwise, and their results must be bitwise equal)
+__device__ __forceinline__ float win_dot3(float q0, float q1, float q2, float a0, float a1, float a2) {
+    return __builtin_fmaf(q2, a2, __builtin_fmaf(q1, a1, q0 * a0));
+}
 // FP32 inside the block products: q (16-bit integer) and x rounded to FP32 carry 2^-24 relative error against 2^-16 of the
 // quantisation; the conversions and products run at the full VALU rate and x of the window takes half the LDS
 __device__ __forceinline__ void win_fma_lo(const WinSlotLo &t, bool active, const float *xs, float &y0, float &y1, float &y2) {
@@ -295,9 +429,9 @@ __device__ __forceinline__ void win_fma_lo(const WinSlotLo &t, bool active, cons
     const int e = (int)t.t.e;
     const float sc = active ? __builtin_bit_cast(float, (127 + (e < -126 ? -126 : e)) << 23) : 0.0f;   // 2^e on x (exact)
     const float a0 = xa[0] * sc, a1 = xa[1] * sc, a2 = xa[2] * sc;
-    y0 += (float)(int)t.a[0] * a0 + (float)(int)t.a[1] * a1 + (float)(int)t.a[2] * a2;
-    y1 += (float)(int)t.a[3] * a0 + (float)(int)t.a[4] * a1 + (float)(int)t.a[5] * a2;
-    y2 += (float)(int)t.a[6] * a0 + (float)(int)t.a[7] * a1 + (float)(int)t.t.q8 * a2;
+    y0 += win_dot3((float)(int)t.a[0], (float)(int)t.a[1], (float)(int)t.a[2], a0, a1, a2);
+    y1 += win_dot3((float)(int)t.a[3], (float)(int)t.a[4], (float)(int)t.a[5], a0, a1, a2);
+    y2 += win_dot3((float)(int)t.a[6], (float)(int)t.a[7], (float)(int)t.t.q8, a0, a1, a2);
 }
 
 #ifndef FCVM_LO_MINWAVES
@@ -373,20 +507,31 @@ __global__ __launch_bounds__(64 * WAVES, FCVM_LO_MINWAVES) void k_spmv_win_lo(in
             }
             off = o;
         }
-        for (; j + 2 <= L; j += 2) {
-            const bool p0 = len > j, p1 = len > j + 1;
-            const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0)), n1 = __popcll(__builtin_amdgcn_ballot_w64(p1));
+        // the rest: block j always goes to accumulator set j & 3 (the chunk length is a multiple of 4), so the summation order
+        // does not depend on the number of blocks in flight -- k_spmv_win_lo2 keeps the same order: bitwise the same result
+        for (; j + 4 <= L; j += 4) {
+            const bool p0 = len > j, p1 = len > j + 1, p2 = len > j + 2, p3 = len > j + 3;
+            const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0)), n1 = __popcll(__builtin_amdgcn_ballot_w64(p1)),
+                      n2 = __popcll(__builtin_amdgcn_ballot_w64(p2)), n3 = __popcll(__builtin_amdgcn_ballot_w64(p3));
             win_load_lo(s[0], lo8, lo2, off, n0, lane);
             win_load_lo(s[1], lo8, lo2, off + n0, n1, lane);
+            win_load_lo(s[2], lo8, lo2, off + n0 + n1, n2, lane);
+            win_load_lo(s[3], lo8, lo2, off + n0 + n1 + n2, n3, lane);
             win_fma_lo(s[0], p0, xsf, y0, y1, y2);
             win_fma_lo(s[1], p1, xsf, z0, z1, z2);
-            off += n0 + n1;
+            win_fma_lo(s[2], p2, xsf, u0, u1, u2);
+            win_fma_lo(s[3], p3, xsf, w0, w1, w2);
+            off += n0 + n1 + n2 + n3;
         }
         for (; j < L; j++) {
             const bool p0 = len > j;
             const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0));
             win_load_lo(s[0], lo8, lo2, off, n0, lane);
-            win_fma_lo(s[0], p0, xsf, y0, y1, y2);
+            const int a = j & 3;
+            if (a == 0) win_fma_lo(s[0], p0, xsf, y0, y1, y2);
+            else if (a == 1) win_fma_lo(s[0], p0, xsf, z0, z1, z2);
+            else if (a == 2) win_fma_lo(s[0], p0, xsf, u0, u1, u2);
+            else win_fma_lo(s[0], p0, xsf, w0, w1, w2);
             off += n0;
         }
         y0 += z0 + u0 + w0; y1 += z1 + u1 + w1; y2 += z2 + u2 + w2;
@@ -431,6 +576,164 @@ __global__ __launch_bounds__(64 * WAVES, FCVM_LO_MINWAVES) void k_spmv_win_lo(in
             for (int i = 0; i < WAVES; i++) { a0 += sh[i]; a1 += sh[WAVES + i]; }
             partial[g] = a0;
             partial[ngroups + g] = a1;
+        }
+    }
+}
+
+// ---- the 16-bit smoother passes for two right-hand sides (see k_spmv_win2) ------------------------------------------------------
+__device__ __forceinline__ void win_fma_lo2(const WinSlotLo &t, bool active, const float *xs, float *y) {
+    const float *xa = xs + 6 * (int)t.t.col;
+    const int e = (int)t.t.e;
+    const float sc = active ? __builtin_bit_cast(float, (127 + (e < -126 ? -126 : e)) << 23) : 0.0f;
+    const float a0 = xa[0] * sc, a1 = xa[1] * sc, a2 = xa[2] * sc, b0 = xa[3] * sc, b1 = xa[4] * sc, b2 = xa[5] * sc;
+    const float q0 = (float)(int)t.a[0], q1 = (float)(int)t.a[1], q2 = (float)(int)t.a[2], q3 = (float)(int)t.a[3], q4 = (float)(int)t.a[4],
+                q5 = (float)(int)t.a[5], q6 = (float)(int)t.a[6], q7 = (float)(int)t.a[7], q8 = (float)(int)t.t.q8;
+    y[0] += win_dot3(q0, q1, q2, a0, a1, a2);
+    y[1] += win_dot3(q3, q4, q5, a0, a1, a2);
+    y[2] += win_dot3(q6, q7, q8, a0, a1, a2);
+    y[3] += win_dot3(q0, q1, q2, b0, b1, b2);
+    y[4] += win_dot3(q3, q4, q5, b0, b1, b2);
+    y[5] += win_dot3(q6, q7, q8, b0, b1, b2);
+}
+
+// one right-hand side's share of the epilogue of k_spmv_win_lo (same arithmetic, same order)
+template <int EPI>
+__device__ __forceinline__ void win_lo_epilogue(int64_t o, double is, float y0, float y1, float y2, const double *__restrict__ x,
+                                                const double *__restrict__ r, double *__restrict__ out, double c0,
+                                                const float *__restrict__ dinv6, int64_t node, double &rz, double &rr) {
+    const double r0 = r[o], r1 = r[o + 1], r2 = r[o + 2];
+    const double t0 = r0 - is * y0, t1 = r1 - is * y1, t2 = r2 - is * y2;
+    if (EPI == 1) {
+        out[o] = t0; out[o + 1] = t1; out[o + 2] = t2;
+    } else {
+        const float2 *d2 = (const float2 *)(dinv6 + 6 * node);
+        const float2 u0 = d2[0], u1 = d2[1], u2 = d2[2];   // xx xy | xz yy | yz zz
+        const double *xo = x + o;
+        const double z0 = xo[0] + c0 * ((double)u0.x * t0 + (double)u0.y * t1 + (double)u1.x * t2);
+        const double z1 = xo[1] + c0 * ((double)u0.y * t0 + (double)u1.y * t1 + (double)u2.x * t2);
+        const double z2 = xo[2] + c0 * ((double)u1.x * t0 + (double)u2.x * t1 + (double)u2.y * t2);
+        out[o] = z0; out[o + 1] = z1; out[o + 2] = z2;
+        rz = r0 * z0 + r1 * z1 + r2 * z2;
+        rr = r0 * r0 + r1 * r1 + r2 * r2;
+    }
+}
+
+template <int EPI, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 4) void k_spmv_win_lo2(int64_t ngroups, int64_t wmax, const int64_t *__restrict__ gptr,
+                                                                 const int32_t *__restrict__ gextra, const int32_t *__restrict__ wlist,
+                                                                 const int64_t *__restrict__ woff, const uint16_t *__restrict__ rowlen,
+                                                                 const int32_t *__restrict__ rownode, const uint32_t *__restrict__ seg,
+                                                                 const short8 *__restrict__ lo8, const WinLoTail *__restrict__ lo2,
+                                                                 const double *__restrict__ lo_scale, const double *__restrict__ xA,
+                                                                 const double *__restrict__ xB, const double *__restrict__ rA,
+                                                                 const double *__restrict__ rB, double *__restrict__ outA,
+                                                                 double *__restrict__ outB, double c0, const float *__restrict__ dinv6,
+                                                                 double *__restrict__ partA, double *__restrict__ partB,
+                                                                 const double *__restrict__ doneA, const double *__restrict__ doneB) {
+    extern __shared__ float xsf[];      // [window node][rhs][3] in FP32, then the partial results of later segments
+    __shared__ double sh[4 * WAVES];
+    constexpr int WIN_THREADS = 64 * WAVES;
+    const bool liveA = !(doneA && *doneA != 0.0), liveB = !(doneB && *doneB != 0.0);
+    if (!liveA && !liveB) return;
+    const int64_t b = blockIdx.x;
+    const int64_t q = ngroups >> 3, rr8 = ngroups & 7, xcd = b & 7;
+    const int64_t g = (xcd < rr8 ? xcd * (q + 1) : rr8 * (q + 1) + (xcd - rr8) * q) + (b >> 3);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wig = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t wave = g * WAVES + wig, row = wave * 64 + lane;
+    const int len = rowlen[row];
+    const int L = __builtin_amdgcn_readfirstlane(len);
+    int64_t off = woff[wave];
+    {
+        const int64_t w0 = gptr[g];
+        const int W = (int)(gptr[g + 1] - w0);
+        for (int i = tid; i < W; i += WIN_THREADS) {
+            const int32_t nd = wlist[w0 + i];
+            const int o = nd & 1;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const double *xa = (h ? xB : xA) + 3 * (int64_t)nd;
+                const double2 wv = *(const double2 *)(xa + o);
+                const double sv = xa[o ? 0 : 2];
+                xsf[6 * i + 3 * h] = (float)(o ? sv : wv.x);
+                xsf[6 * i + 3 * h + 1] = (float)(o ? wv.x : wv.y);
+                xsf[6 * i + 3 * h + 2] = (float)(o ? wv.y : sv);
+            }
+        }
+    }
+    __syncthreads();
+    float y[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    {
+        constexpr int NB = 4;
+        WinSlotLo s[NB];
+        float z[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, u[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, w[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int j = 0;
+        for (; j + NB <= L; j += NB) {
+            bool p[NB];
+            int n[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                p[k] = len > j + k;
+                n[k] = __popcll(__builtin_amdgcn_ballot_w64(p[k]));
+            }
+            int64_t o = off;
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                win_load_lo(s[k], lo8, lo2, o, n[k], lane);
+                o += n[k];
+            }
+            win_fma_lo2(s[0], p[0], xsf, y);
+            win_fma_lo2(s[1], p[1], xsf, z);
+            win_fma_lo2(s[2], p[2], xsf, u);
+            win_fma_lo2(s[3], p[3], xsf, w);
+            off = o;
+        }
+        for (; j < L; j++) {    // block j -> accumulator set j & 3, as in k_spmv_win_lo
+            const bool p0 = len > j;
+            const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0));
+            win_load_lo(s[0], lo8, lo2, off, n0, lane);
+            const int a = j & 3;
+            if (a == 0) win_fma_lo2(s[0], p0, xsf, y);
+            else if (a == 1) win_fma_lo2(s[0], p0, xsf, z);
+            else if (a == 2) win_fma_lo2(s[0], p0, xsf, u);
+            else win_fma_lo2(s[0], p0, xsf, w);
+            off += n0;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) y[k] += z[k] + u[k] + w[k];
+    }
+    const int32_t node = rownode[row];
+    const uint32_t sc = seg[row];
+    const int nseg = (int)(sc & 255u);
+    if (gextra[g] > 0) {
+        float *yp = xsf + 6 * wmax + 6 * (int)(sc >> 8);
+        if (node >= 0 && nseg == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) yp[k] = y[k];
+        }
+        __syncthreads();
+        for (int s2 = 0; s2 + 1 < nseg; s2++) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) y[k] += yp[6 * s2 + k];
+        }
+    }
+    double rzA = 0.0, rrA = 0.0, rzB = 0.0, rrB = 0.0;
+    if (node >= 0 && nseg > 0) {
+        const double is = lo_scale[1];
+        const int64_t o = 3 * (int64_t)node;
+        if (liveA) win_lo_epilogue<EPI>(o, is, y[0], y[1], y[2], xA, rA, outA, c0, dinv6, node, rzA, rrA);
+        if (liveB) win_lo_epilogue<EPI>(o, is, y[3], y[4], y[5], xB, rB, outB, c0, dinv6, node, rzB, rrB);
+    }
+    if (EPI == 2) {
+        rzA = wave_sum(rzA); rrA = wave_sum(rrA); rzB = wave_sum(rzB); rrB = wave_sum(rrB);
+        if (lane == 0) { sh[wig] = rzA; sh[WAVES + wig] = rrA; sh[2 * WAVES + wig] = rzB; sh[3 * WAVES + wig] = rrB; }
+        __syncthreads();
+        if (tid == 0) {
+            double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < WAVES; i++) { a0 += sh[i]; a1 += sh[WAVES + i]; b0 += sh[2 * WAVES + i]; b1 += sh[3 * WAVES + i]; }
+            if (liveA) { partA[g] = a0; partA[ngroups + g] = a1; }
+            if (liveB) { partB[g] = b0; partB[ngroups + g] = b1; }
         }
     }
 }

@@ -55,6 +55,9 @@ SIGNATURES = {
     "fcvm_vec_max_node_norm": [_vp, _i64, _vp, _pf64],
     "fcvm_solve_timing": [_vp, _pf64],
     "fcvm_mg_apply": [_vp, _vp, _vp],
+    "fcvm_solve2": [_vp, _vp, _vp, _vp, _vp, _f64, _f64, _i64, _pf64],
+    "fcvm_spmv2": [_vp, _vp, _vp, _vp, _vp],
+    "fcvm_mg_apply2": [_vp, _vp, _vp, _vp, _vp],
     "fcvm_host_pattern_check": [_i64, _i64, _vp, _pi64],
     "fcvm_spmv_info": [_vp, _pi64],
     "fcvm_mem_info": [_vp, _pi64],

@@ -56,7 +56,13 @@ def buckling_factors(model, grav, k=2, sigma=0.1, block=6, tol=1e-10, maxit=80, 
     for it in range(maxit):
         for j in range(m):
             G(X[j], Y[j])
-        Z = [c.solve(Y[j], rtol=rtol_solve)[0] for j in range(m)]  # Z = A^-1 G X,  so A Z = Y
+        # Z = A^-1 G X,  so A Z = Y: the block's systems two at a time, every matrix pass shared (Context.solve2)
+        Z = []
+        for j in range(0, m, 2):
+            if j + 1 < m and hasattr(c, "solve2"):
+                Z += list(c.solve2(Y[j], Y[j + 1], rtol=(rtol_solve, rtol_solve))[:2])
+            else:
+                Z += [c.solve(Y[jj], rtol=rtol_solve)[0] for jj in range(j, min(j + 2, m))]
         GZ = []
         for j in range(m):
             g = c.empty(ndof)

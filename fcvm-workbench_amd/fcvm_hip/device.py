@@ -236,6 +236,24 @@ class Context:
         call("fcvm_solve", self.h, f.ptr, u.ptr, float(rtol), int(maxit), info)
         return u, dict(iterations=int(info[0]), rel_residual=info[1], spmv=int(info[2]))
 
+    def spmv2(self, xa, xb, ya, yb):
+        call("fcvm_spmv2", self.h, xa.ptr, xb.ptr, ya.ptr, yb.ptr)
+        return ya, yb
+
+    def mg_apply2(self, ra, rb, za, zb):
+        call("fcvm_mg_apply2", self.h, ra.ptr, rb.ptr, za.ptr, zb.ptr)
+        return za, zb
+
+    def solve2(self, fa, fb, ua=None, ub=None, rtol=(1e-10, 1e-10), maxit=20000):
+        """K ua = fa and K ub = fb in lockstep, every pass over the matrix shared (fcvm_solve2); each result is bitwise what
+        solve() returns for that right-hand side.  Returns (ua, ub, info_a, info_b)."""
+        ua = ua if ua is not None else self.empty(fa.n)
+        ub = ub if ub is not None else self.empty(fb.n)
+        info = (C.c_double * 6)()
+        call("fcvm_solve2", self.h, fa.ptr, fb.ptr, ua.ptr, ub.ptr, float(rtol[0]), float(rtol[1]), int(maxit), info)
+        return (ua, ub, dict(iterations=int(info[0]), rel_residual=info[1], spmv=int(info[2])),
+                dict(iterations=int(info[3]), rel_residual=info[4], spmv=int(info[5])))
+
     # -- linear-buckling pre-analysis (fcvm_hip/buckling.py) ------------------------------------
     def assemble_buckling(self, sig, sigma):
         call("fcvm_assemble_buckling", self.h, sig.ptr, float(sigma))

@@ -838,11 +838,50 @@ def _local_loads(part, loads):
     return Loads(**out)
 
 
+def spatial_element_order(elNodes, nocoord, bits=20):
+    """Permutation of the elements along a Morton (Z-order) curve through their centroids: consecutive ranges of it are
+    compact chunks of the mesh whatever the caller's element numbering (a mesh generator's locality is not guaranteed --
+    a shuffled list cut into ranges would make every node an interface node).  Ties keep the caller's order (stable)."""
+    el = np.asarray(elNodes, dtype=np.int64)
+    xyz = np.asarray(nocoord, dtype=np.float64)
+    cen = xyz[el[:, :4] - 1].mean(axis=1)
+    lo, span = cen.min(axis=0), np.maximum(cen.max(axis=0) - cen.min(axis=0), 1e-300)
+    q = np.minimum(((cen - lo) / span.max() * ((1 << bits) - 1)).astype(np.uint64), (1 << bits) - 1)
+
+    def spread(v):      # bits of v to every third position (21-bit input)
+        v = v & np.uint64(0x1FFFFF)
+        v = (v | (v << np.uint64(32))) & np.uint64(0x1F00000000FFFF)
+        v = (v | (v << np.uint64(16))) & np.uint64(0x1F0000FF0000FF)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x100F00F00F00F00F)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x10C30C30C30C30C3)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
+        return v
+    key = spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1)) | (spread(q[:, 2]) << np.uint64(2))
+    return np.argsort(key, kind="stable")
+
+
+def interface_node_counts(elNodes, order, world):
+    """Nodes of each rank's element range that another rank holds too (what every shared-node exchange moves), and the
+    nodes each rank holds: the quality of an element-range partition, computed without any communication."""
+    el = np.asarray(elNodes, dtype=np.int64)
+    ne, nn = len(el), int(el.max())
+    order = np.arange(ne) if order is None else np.asarray(order)
+    holders = np.zeros(nn + 1, dtype=np.int32)
+    sets = []
+    for r in range(world):
+        nodes = np.unique(el[order[r * ne // world:(r + 1) * ne // world]])
+        holders[nodes] += 1
+        sets.append(nodes)
+    return [int((holders[nd] > 1).sum()) for nd in sets], [len(nd) for nd in sets]
+
+
 def partition_model(elNodes, nocoord, material, fix, loads, device_index=0, device=None, group=None, precond="mg", order=None,
                     ops_factory=None, pcg_check_every=25, mg_options=None):
     """One rank's DistModel of the element-range partition of a global model (the 1 -> N split of north_star): elements
-    [rank * ne / world, (rank + 1) * ne / world) of the global list (or of `order`, a permutation of it), the nodes they
-    touch, the supports and load entities that fall on them.  Collective: every rank of `group` calls it.
+    [rank * ne / world, (rank + 1) * ne / world) of `order`, the nodes they touch, the supports and load entities that fall
+    on them.  order: a permutation of the elements; None (default) = spatial_element_order (Morton curve through the element
+    centroids: compact ranges for any numbering); "given" = the caller's element order as it stands.
+    Collective: every rank of `group` calls it.
     ops_factory(part, nocoord_local, material, fix_local, element_offset) -> LocalOps: the rank's kernels (default: HipLocalOps on
     GPU `device_index`; the CPU tests pass their oracle-backed LocalOps and device = torch.device("cpu"))."""
     from .loads import Loads, external_loads
@@ -851,7 +890,9 @@ def partition_model(elNodes, nocoord, material, fix, loads, device_index=0, devi
     el = np.asarray(elNodes)
     ne = len(el)
     lo, hi = rank * ne // world, (rank + 1) * ne // world
-    sel = np.arange(lo, hi) if order is None else np.asarray(order)[lo:hi]
+    if order is None and world > 1:
+        order = spatial_element_order(el, nocoord)
+    sel = np.arange(lo, hi) if (order is None or isinstance(order, str)) else np.asarray(order)[lo:hi]
     part = Partition(el[sel], group=group)
     xyz_loc = np.ascontiguousarray(np.asarray(nocoord, dtype=np.float64)[part.gnodes - 1])
     gd = np.array(sorted(fix), dtype=np.int64)

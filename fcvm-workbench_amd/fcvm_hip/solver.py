@@ -243,6 +243,48 @@ class RiksDriver:
         st["spmv_total"] = st.get("spmv_total", 0) + info["spmv"]    # incl. the SpMVs inside V-cycles
         return u
 
+    def solve_pair(self, rhs_a, guess_a, rhs_b):
+        """The two back substitutions of a GNLY Newton iteration with its new tangent matrix (fcVM.py:1351-1401: ue = factor(f),
+        due = factor(relax * r)) as ONE lockstep solve: every pass over the matrix serves both systems (Context.solve2).
+        K ua = rhs_a starts from guess_a (the previous tangent's answer to nearly the same load; true residual from one SpMV),
+        K ub = rhs_b from zero.  Returns (ua, ub); backends without solve2 (distributed) solve one after the other."""
+        c, st = self.c, self.st
+        if not hasattr(c, "solve2") or self.proj_depth <= 0 or os.environ.get("FCVM_SOLVE2", "1") == "0":
+            ua = self.solve(rhs_a, guess=guess_a)
+            return ua, self.solve(rhs_b)
+        t0 = time.perf_counter()
+        x0 = guess_a.clone()
+        r0 = c.spmv(x0, c.empty(rhs_a.n))                 # true residual of the start vector
+        c.axpby(1.0, rhs_a, -1.0, r0, out=r0)
+        st["projection_spmv"] = st.get("projection_spmv", 0) + 1
+        nf, n0 = c.norm(rhs_a), c.norm(r0)
+        if not np.isfinite(n0) or n0 >= nf:
+            x0, r0, n0 = None, rhs_a, nf
+        if x0 is not None and n0 <= self.rtol * nf:        # the old ue still solves the new system: only due is left
+            st["solve_s"] += time.perf_counter() - t0
+            st["solves"] += 1
+            return x0, self.solve(rhs_b)
+        rt_a = min(1.0, self.rtol * nf / n0) if x0 is not None else self.rtol
+        da, ub, ia, ib = c.solve2(r0, rhs_b, rtol=(rt_a, self.rtol), maxit=self.maxit)
+        ua = da if x0 is None else c.axpby(1.0, x0, 1.0, da, out=da)
+        # history for the start vectors of later solves with this matrix (none in GNLY once Gauss points are plastic: the
+        # next iteration assembles a new tangent)
+        self._hist = [(ua, rhs_a.clone()), (ub, rhs_b.clone())]
+        g = np.zeros((2, 2))
+        for j in range(2):
+            col = self.dots([ua, ub], self._hist[j][1])
+            g[0, j], g[1, j] = col[0], col[1]
+        self._gram = 0.5 * (g + g.T)
+        st["solve_s"] += time.perf_counter() - t0
+        st["pcg_iterations"] += ia["iterations"] + ib["iterations"]
+        st["paired_iterations"] = st.get("paired_iterations", 0) + max(ia["iterations"], ib["iterations"])
+        st["solves"] += 2
+        tm = c.solve_timing()
+        st["spmv_ms"] += tm["spmv_ms"]
+        st["spmv_launches"] += tm.get("spmv_timed", 0)
+        st["spmv_total"] = st.get("spmv_total", 0) + tm.get("spmv_timed", 0)
+        return ua, ub
+
     def usl(self, d_u):
         """update_stress_load with the current state (fcVM.py:1325, 1442, 1478)"""
         self.c.update_stress_load(self.sig_yield, self.disp_new, d_u, self.sig_old, self.sig_new, self.sig_test,
@@ -294,11 +336,14 @@ class RiksDriver:
             self._hist, self._gram = [], None   # new tangent matrix: the stored K U products are stale
             c.mul(self.model.fixdof, self.glv, out=self.f)
             c.axpby(1.0, self.f, 1.0, self.modf, out=self.f)
-            self.ue = self.solve(self.f, guess=self.ue)   # the previous tangent's answer to (nearly) the same load
+            f2 = c.axpby(self.relax, self.r, 0.0, None)
+            # ue (start: the previous tangent's answer to nearly the same load) and due in one lockstep solve
+            self.ue, due = self.solve_pair(self.f, self.ue, f2)
             self.a = self.ue.clone()
             c.axpby(c.norm(self.du) / c.norm(self.a), self.a, 0.0, None, out=self.a)
-        c.axpby(self.relax, self.r, 0.0, None, out=self.f)
-        due = self.solve(self.f)
+        else:
+            c.axpby(self.relax, self.r, 0.0, None, out=self.f)
+            due = self.solve(self.f)
         a_due, a_ue, a_a = self.dots([due, self.ue, self.a], self.a)
         self.dl = -a_due / a_ue  # fcVM.py:1414-1417 Riks correction
         lbd[step + 1] += self.dl

@@ -166,6 +166,21 @@ int fcvm_dist_pcg_scalars(fcvm_ctx *c, int phase, double *S, const double *in);
 int fcvm_any_u8(fcvm_ctx *c, int64_t n, const uint8_t *a, int *result_host);
 int fcvm_vec_max_node_norm(fcvm_ctx *c, int64_t nnodes, const double *u, double *result_host);
 
+/* Two systems with the same matrix, K uA = fA and K uB = fB, solved in lockstep: the pair of back substitutions the reference
+ * makes with one tangent factor per GNLY Newton iteration (ue = factor(f), due = factor(relax * r), fcVM.py:1351-1401) and
+ * the block solves of the buckling pre-analysis (fcVM.py:1199-1214).  Every pass over the matrix -- the FP64 SpMV and the two
+ * 16-bit smoother passes of the cycle -- serves both right-hand sides (k_spmv_win2 / k_spmv_win_lo2); each result is bitwise
+ * what fcvm_solve returns for that right-hand side.  Needs cycle form 2 on the window format with room for two windows in
+ * LDS, otherwise the systems are solved one after the other.  info[6]: {iterations, relative residual, timed SpMV launches}
+ * of A, then of B.  All vectors [dev, 16-byte aligned], pairwise distinct. */
+int fcvm_solve2(fcvm_ctx *c, const double *fA, const double *fB, double *uA, double *uB, double rtolA, double rtolB, int64_t maxit,
+                double info[6]);
+
+/* the two shared-pass building blocks of fcvm_solve2 on their own: yA = K xA, yB = K xB (bitwise fcvm_spmv of each) and
+ * zA = M^-1 rA, zB = M^-1 rB (bitwise fcvm_mg_apply of each); for block methods and for the tests */
+int fcvm_spmv2(fcvm_ctx *c, const double *xA, const double *xB, double *yA, double *yB);
+int fcvm_mg_apply2(fcvm_ctx *c, const double *rA, const double *rB, double *zA, double *zB);
+
 /* z = M^-1 r: one application of the multigrid preconditioner fcvm_solve uses (mode 1), r != z [dev, 16-byte aligned].
  * No reference counterpart (CHOLMOD's factor(f), fcVM.py:1130, is replaced by PCG); used by the solver-space tools and tests. */
 int fcvm_mg_apply(fcvm_ctx *c, const double *r, double *z);

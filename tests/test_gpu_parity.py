@@ -256,6 +256,43 @@ def test_16bit_smoother_cycle_is_a_symmetric_preconditioner_and_solves(monkeypat
         assert abs(its[(2, True)] - its[(2, False)]) <= 2, its
 
 
+def test_two_right_hand_sides_in_lockstep_match_single_solves_bitwise():
+    """fcvm_solve2 (the GNLY pair K ue = f, K due = r of fcVM.py:1351-1401): every matrix pass serves both right-hand sides
+    (k_spmv_win2, k_spmv_win_lo2), the rest of each PCG runs on its own state.  Each result must be bitwise what fcvm_solve
+    gives for that right-hand side alone -- also when the two converge at different iterations (different tolerances: the
+    finished one idles) and with split rows (cube corner nodes); and it must solve the system (true residual)."""
+    from fcvm_hip import examples, meshgen
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import GpuModel
+    emb = examples.embankment(refine=2)
+    cube = meshgen.cube_case(12, l=10.0, traction=(0.0, 0.0, 1.0))
+    cube["material"] = (210000.0, 0.3, 7.8e-6)
+    rng = np.random.default_rng(5)
+    for case, grav in ((emb, (0.0, 0.0, -10.0)), (cube, (0.0, 0.0, 0.0))):
+        m = GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"],
+                     Loads(ufaces=case["ufaces"], uloads=case["uloads"]) if "ufaces" in case else Loads())
+        c = m.ctx
+        glv, modf, _, _ = m.calc_gsm(grav, want_x=False)
+        assert c.spmv_info()["window_format"] and c.precond_info()["cycle_form"] == 2
+        fa = c.mul(m.fixdof, glv)
+        fb = c.array(m.fixdof_h * rng.standard_normal(m.ndof))
+        e = lambda: c.empty(m.ndof)  # noqa: E731
+        ya, yb = c.spmv2(fa, fb, e(), e())                      # the shared FP64 pass on its own ...
+        assert np.array_equal(ya.get(), c.spmv(fa, e()).get()) and np.array_equal(yb.get(), c.spmv(fb, e()).get())
+        za, zb = c.mg_apply2(fa, fb, e(), e())                  # ... and the cycle with its two shared 16-bit passes
+        assert np.array_equal(za.get(), c.mg_apply(fa, e()).get()) and np.array_equal(zb.get(), c.mg_apply(fb, e()).get())
+        for rtol in ((1e-11, 1e-11), (1e-12, 1e-6), (1e-5, 1e-11)):
+            ua, ia = c.solve(fa, rtol=rtol[0])
+            ub, ib = c.solve(fb, rtol=rtol[1])
+            va, vb, ja, jb = c.solve2(fa, fb, rtol=rtol)
+            assert (ja["iterations"], jb["iterations"]) == (ia["iterations"], ib["iterations"]), (ia, ib, ja, jb)
+            assert np.array_equal(va.get(), ua.get()) and np.array_equal(vb.get(), ub.get())
+            for f, v, t in ((fa, va, rtol[0]), (fb, vb, rtol[1])):
+                r = c.axpby(1.0, f, -1.0, c.spmv(v, c.empty(m.ndof)))
+                assert c.norm(r) <= 5.0 * t * c.norm(f)
+        c.close()
+
+
 def test_window_format_spmv_and_pcg_match_sliced_ell(monkeypatch):
     """The SpMV's second storage of the fine matrix (window format: Morton groups, x of a group's column nodes in LDS,
     16-bit window columns, prefix storage without padding, long rows cut into segments) against the sliced-ELL kernel and

@@ -307,3 +307,25 @@ def test_calcSum_and_avr_format(tmp_path):
     assert lines[5].split() == ["Length", "peeq", "CSR", "svmises", "edge"]
     assert lines[6].split() == ["4.00e+00", "1.60e+01", "8.00e+00", "1.00e+00", "Box(Cube).Edge1"]
     assert lines[10].split() == ["Area", "peeq", "CSR", "svmises", "face"]
+
+
+def test_spatial_element_order_bounds_the_interfaces_of_a_shuffled_mesh():
+    """partition_model's default element order (Morton curve through the centroids): on the Embankment mesh refined twice
+    (42k tet10) with SHUFFLED element numbering an 8-way range partition keeps its interfaces small, where ranges of the
+    shuffled list share nearly every node; on the unshuffled list it is no worse than the mesh generator's own locality."""
+    from fcvm_hip import examples
+    from fcvm_hip.dist import interface_node_counts, spatial_element_order
+    case = examples.embankment(refine=2)
+    el, xyz = case["elNodes"], case["nocoord"]
+    perm = np.random.default_rng(7).permutation(len(el))
+    shuffled = el[perm]
+    order = spatial_element_order(shuffled, xyz)
+    assert np.array_equal(np.sort(order), np.arange(len(el)))
+    shared_s, held_s = interface_node_counts(shuffled, order, 8)
+    shared_r, held_r = interface_node_counts(shuffled, None, 8)
+    shared_g, held_g = interface_node_counts(el, None, 8)
+    shared_o, held_o = interface_node_counts(el, spatial_element_order(el, xyz), 8)
+    assert min(s / h for s, h in zip(shared_r, held_r)) > 0.95          # ranges of a shuffled list: everything is interface
+    assert max(s / h for s, h in zip(shared_s, held_s)) < 0.30          # Morton ranges: a surface-to-volume share
+    assert sum(shared_s) == sum(shared_o) and sum(shared_o) < 1.3 * sum(shared_g)
+    assert max(held_s) < 1.25 * len(xyz) / 8 + max(shared_s)
