@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -132,6 +133,7 @@ struct fcvm_ctx {
     std::vector<double> h_coord;
     std::vector<uint8_t> h_fixmask;
     std::vector<int32_t> h_c2f;   // level-1 node -> fine node
+    std::vector<int32_t> h_morton;   // Morton order of the nodes (fcvm_set_mesh -> setup_window_format), released afterwards
     // p-multigrid preconditioner (mode 1): level 1 = linear tets on the corner nodes
     int precond_mode = 0, mg_k0 = 1, mg_k1 = 60;
     double mg_alpha0 = 4.0, mg_alpha1 = 1000.0, mg_lmax0 = 0, mg_lmax1 = 0;
@@ -400,11 +402,12 @@ static int setup_window_format(fcvm_ctx *c, const double *nocoord) {
     try {
         int split = WIN_SPLIT;
         if (const char *v = getenv("FCVM_WIN_SPLIT")) split = std::min(512, std::max(4, atoi(v)));
-        bool built = build_window_format(c->pat, nocoord, nt, max_window, w, WIN_WAVES, split);
+        const int32_t *mo = c->h_morton.size() == (size_t)c->nn ? c->h_morton.data() : nullptr;   // the order fcvm_set_mesh computed
+        bool built = build_window_format(c->pat, nocoord, nt, max_window, w, WIN_WAVES, split, mo);
         if (!built) {   // smaller groups have smaller windows (at the price of more x traffic from the L2)
             const long long w8 = (long long)w.wmax;
             w = WinPattern();
-            built = build_window_format(c->pat, nocoord, nt, max_window, w, 4, split);
+            built = build_window_format(c->pat, nocoord, nt, max_window, w, 4, split, mo);
             if (getenv("FCVM_VERBOSE"))
                 fprintf(stderr, "fcvm: window format: largest window of 512-row groups %lld nodes, of 256-row groups %lld\n", w8, (long long)w.wmax);
             if (built) c->win_v2 = 1;
@@ -756,6 +759,14 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     HCHK(hipSetDevice(c->device));
     HCHK(hipStreamSynchronize(c->stream));
     free_mesh(c);
+    const bool timing = getenv("FCVM_PATTERN_TIMING") != nullptr;
+    auto tprev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "fcvm set_mesh: %-30s %.3f s\n", what, std::chrono::duration<double>(t - tprev).count());
+        tprev = t;
+    };
     std::vector<int32_t> el(ne * 10);
     for (int64_t i = 0; i < ne * 10; i++) {
         int64_t v = elNodes[i] - 1;
@@ -777,10 +788,14 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
         // with the window format the sliced-ELL rows follow the same Morton curve: k_repack_win then copies between two
         // layouts whose neighbourhoods coincide (its scattered 8-byte reads are absorbed by the L2 instead of going to HBM)
         const bool use_morton = mode == 1 || (mode < 0 && nn > 4096 && (c->row_spread > 0.05 || c->spmv_win));
+        lap("conversion, numbering spread");
         std::vector<int32_t> order;
         if (use_morton) order = morton_order(nn, nocoord);
+        c->h_morton = order;      // (the window format walks the same curve)
+        lap("Morton order");
         c->row_order_morton = use_morton;
         build_pattern(ne, nn, el.data(), c->pat, nt, win, 10, use_morton ? order.data() : nullptr);
+        lap("sliced-ELL pattern (total)");
     } catch (const std::exception &ex) {
         return fail(std::string("fcvm_set_mesh: ") + ex.what());
     }
@@ -821,10 +836,15 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     HCHK(hipMemsetAsync(c->d_fixval, 0, sizeof(double) * nn * 3, s));
     HCHK(hipMemsetAsync(c->d_vals, 0, sizeof(double) * p.value_count(), s));
     HCHK(hipStreamSynchronize(s));
+    lap("allocation, upload");
     c->ne = ne;
     c->nn = nn;
     if (build_asm_items(c)) return 1;
+    lap("assembly work items");
     if (setup_window_format(c, nocoord)) return 1;
+    lap("window format (build + upload)");
+    c->h_morton.clear();
+    c->h_morton.shrink_to_fit();
     if (!c->win.on && tune_matrix_placement(c)) return 1;
     // the element->slot map is only needed on the device from here on
     c->pat.emap.clear();

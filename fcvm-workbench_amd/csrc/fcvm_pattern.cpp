@@ -13,9 +13,11 @@
 
 namespace fcvm {
 
-static void parallel_for(int64_t n, int nthreads, const std::function<void(int64_t, int64_t, int)> &fn) {
+// min_parallel: below this many items the loop runs on the calling thread (items of the per-node loops are tiny; the window
+// format's items are whole groups of 512 rows: 3400 of them at 1 M elements, which the default threshold kept serial)
+static void parallel_for(int64_t n, int nthreads, const std::function<void(int64_t, int64_t, int)> &fn, int64_t min_parallel = 4096) {
     if (nthreads < 1) nthreads = 1;
-    if (n < 4096 || nthreads == 1) {
+    if (n < min_parallel || nthreads == 1) {
         fn(0, n, 0);
         return;
     }
@@ -200,18 +202,33 @@ std::vector<int32_t> morton_order(int64_t nn, const double *xyz) {
         v = (v | v << 2) & 0x1249249249249249ull;
         return v;
     };
-    std::vector<std::pair<uint64_t, int32_t>> key(nn);
+    std::vector<uint64_t> key(nn), key2(nn);
+    std::vector<int32_t> order(nn), order2(nn);
     for (int64_t i = 0; i < nn; i++) {
         uint64_t q[3];
         for (int k = 0; k < 3; k++) {
             double ext = hi[k] - lo[k];
             q[k] = ext > 0 ? (uint64_t)((xyz[3 * i + k] - lo[k]) / ext * 2097151.0) : 0;
         }
-        key[i] = {spread(q[0]) | spread(q[1]) << 1 | spread(q[2]) << 2, (int32_t)i};
+        key[i] = spread(q[0]) | spread(q[1]) << 1 | spread(q[2]) << 2;
+        order[i] = (int32_t)i;
     }
-    std::sort(key.begin(), key.end());
-    std::vector<int32_t> order(nn);
-    for (int64_t i = 0; i < nn; i++) order[i] = key[i].second;
+    // stable LSD radix sort of the 63-bit keys (four passes of 16 bits): equal keys keep ascending node numbers, i.e. the
+    // order std::sort gave the (key, node) pairs before -- at a fifth of its time for 1.4 M nodes
+    std::vector<int64_t> cnt(65536 + 1);
+    for (int pass = 0; pass < 4; pass++) {
+        const int sh = 16 * pass;
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (int64_t i = 0; i < nn; i++) cnt[((key[i] >> sh) & 0xffff) + 1]++;
+        for (int b = 0; b < 65536; b++) cnt[b + 1] += cnt[b];
+        for (int64_t i = 0; i < nn; i++) {
+            const int64_t at = cnt[(key[i] >> sh) & 0xffff]++;
+            key2[at] = key[i];
+            order2[at] = order[i];
+        }
+        key.swap(key2);
+        order.swap(order2);
+    }
     return order;
 }
 
@@ -228,13 +245,23 @@ double numbering_spread(int64_t ne, int64_t nn, const int32_t *el, int npe) {
     return ne > 0 && nn > 0 ? s / (double)ne / (double)nn : 0.0;
 }
 
-bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int64_t max_window, WinPattern &w, int waves, int split) {
+bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int64_t max_window, WinPattern &w, int waves, int split,
+                         const int32_t *given_order) {
     const int64_t nn = p.nn, WV = waves, R = WV * SLICE;
     w.waves = waves;
     w.split = split;
     const bool deal = getenv("FCVM_WIN_DEAL") && atoi(getenv("FCVM_WIN_DEAL")) == 1;
     if (p.maxlen > 65535) return false;
-    std::vector<int32_t> order = morton_order(nn, xyz);
+    const bool timing = getenv("FCVM_PATTERN_TIMING") != nullptr;
+    auto tprev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "fcvm window format: %-25s %.3f s\n", what, std::chrono::duration<double>(t - tprev).count());
+        tprev = t;
+    };
+    std::vector<int32_t> order = given_order ? std::vector<int32_t>(given_order, given_order + nn) : morton_order(nn, xyz);
+    lap("Morton order");
     auto nseg_of = [&](int32_t nd) { return (int)((p.rowptr[nd + 1] - p.rowptr[nd] + split - 1) / split); };
     // the segment count of a row is packed into 8 bits of `seg`, and a row's segments must all lie in ONE group: refuse
     // (the caller falls back to the sliced-ELL kernel) instead of corrupting the tables
@@ -309,7 +336,8 @@ bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int6
             wl.shrink_to_fit();
             w.gptr[g + 1] = (int64_t)wl.size();
         }
-    });
+    }, 16);
+    lap("pass 1 (rows, windows)");
     w.wmax = 0;
     w.xmax = 0;
     for (int64_t g = 0; g < ng; g++) {
@@ -351,7 +379,8 @@ bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int6
                 }
             }
         }
-    });
+    }, 16);
+    lap("pass 2 (columns)");
     return true;
 }
 

@@ -108,7 +108,7 @@ struct WinPattern {
 };
 // false: the mesh does not suit the format (a window larger than max_window nodes)
 bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int64_t max_window, WinPattern &w, int waves = WIN_WAVES,
-                         int split = WIN_SPLIT);
+                         int split = WIN_SPLIT, const int32_t *given_order = nullptr);   // given_order: morton_order(nn, xyz) if at hand
 
 // nodes sorted along a Morton (Z-order) curve through their coordinates: a locality-preserving order in which
 // the SpMV walks the rows when the caller's node numbering has none (unstructured meshes)
