@@ -17,6 +17,8 @@ The local compute is delegated to a `LocalOps` object.  The product implementati
 HipLocalOps (libfcvm_hip kernels on raw device pointers, no fallback); the CPU tests inject an
 oracle-backed implementation to exercise partitioning, exchange and the distributed PCG.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -119,6 +121,7 @@ class Exchanger:
         self.nn = part.nn if nn is None else nn
         self.ops = ops if (ops is not None and hasattr(ops, "pack")) else None
         self.ranks = sorted(s for s, ix in shared.items() if len(ix))
+        self.count = None      # dict with an "exchanges" entry (DistBackend.comm): every call is counted, with or without neighbours
         self.offs, rows = {}, 0
         for s in self.ranks:
             self.offs[s] = (rows, rows + len(shared[s]))
@@ -151,6 +154,8 @@ class Exchanger:
     def interface_sum(self, t, ncomp):
         """t: flat tensor [nn*ncomp]; in place."""
         p = self.part
+        if self.count is not None:
+            self.count["exchanges"] += 1
         if p.world == 1 or not self.ranks:
             return t
         send = torch.empty(self.rows * ncomp, dtype=t.dtype, device=t.device)
@@ -192,6 +197,11 @@ class DistBackend:
     def __init__(self, part, ops, device, pcg_check_every=25):
         self.part, self.ops, self.device = part, ops, device
         self.ex = Exchanger(part, device, ops=ops)
+        # communication steps since the start (shared-node exchanges of any level, all-reduces, device -> host reads of the
+        # solver): solve() reports them per PCG iteration in its info, the tests bound them
+        self.comm = dict(exchanges=0, allreduces=0, host_syncs=0)
+        self.ex.count = self.comm
+        self.single_reduction = os.environ.get("FCVM_DIST_CG", "single") != "classic"
         self.nn, self.ne = part.nn, len(part.elNodes)
         w = np.repeat(part.owned.astype(np.float64), 3)
         self.w = torch.as_tensor(w, device=device)
@@ -221,9 +231,22 @@ class DistBackend:
 
     # -- reductions ---------------------------------------------------------------------------
     def _allreduce(self, t, op=dist.ReduceOp.SUM):
+        self.comm["allreduces"] += 1
         if self.part.world > 1:
             dist.all_reduce(t, op=op, group=self.group)
         return t
+
+    def dot3_t(self, r, z, w):
+        """(r.z, w.z, r.r), owner-weighted, ONE all-reduce for the three (single-reduction CG)"""
+        out = torch.empty(3, dtype=torch.float64, device=self.device)
+        if hasattr(self.ops, "wdot"):
+            self.ops.wdot(self.w, r, z, out[0:1])
+            self.ops.wdot(self.w, w, z, out[1:2])
+            self.ops.wdot(self.w, r, r, out[2:3])
+        else:
+            wz = self.w * z
+            out[0], out[1], out[2] = torch.sum(wz * r), torch.sum(wz * w), torch.sum(self.w * r * r)
+        return self._allreduce(out)
 
     def dot_t(self, x, y):
         """owner-weighted dot product of two consistent vectors, result stays on the device"""
@@ -392,6 +415,8 @@ class DistBackend:
             info = self.ops.solve_local(f, u, rtol, maxit)
             self._timing = self.ops.c.solve_timing()
             return u, info
+        if self.single_reduction:
+            return self._solve_single_reduction(f, u, rtol, maxit)
         x, r = u.t, f.t.clone()
         x.zero_()
         z, q = self.empty(f.n), self.empty(f.n)
@@ -473,6 +498,75 @@ class DistBackend:
             raise RuntimeError("distributed PCG did not converge in %d iterations" % maxit)
         return u, info
 
+    def _solve_single_reduction(self, f, u, rtol, maxit):
+        """Preconditioned CG in the Chronopoulos-Gear form: the SpMV is applied to z = M^-1 r (w = K z), s = K p follows from
+        the recurrence s = w + beta s, and r.z, w.z, r.r of an iteration travel in ONE all-reduce (the classic form needs p.Kp
+        before and r.z after the update: two).  Same device-side convergence masking as the classic loop: after
+        convergence alpha = beta = 0, queued iterations change nothing.  FCVM_DIST_CG=classic selects the two-reduction loop."""
+        c0 = dict(self.comm)
+        dev = self.device
+        x, r = u.t, f.t.clone()
+        x.zero_()
+        z, w = self.empty(f.n), self.empty(f.n)
+        self.precond(TVec(r), z)
+        self.spmv(z, w)
+        g3 = self.dot3_t(r, z.t, w.t)
+        gamma, delta, bb = g3[0:1].clone(), g3[1:2].clone(), g3[2:3].clone()
+        bb_h = float(bb.item())
+        self.comm["host_syncs"] += 1
+        info = dict(iterations=0, rel_residual=0.0, spmv=1)
+        if bb_h == 0.0:
+            return u, info
+        if not np.isfinite(bb_h):
+            raise RuntimeError("distributed PCG: non-finite right-hand side")
+        thresh = torch.full((1,), rtol * rtol * bb_h, dtype=torch.float64, device=dev)
+        zero, one = torch.zeros(1, dtype=torch.float64, device=dev), torch.ones(1, dtype=torch.float64, device=dev)
+        done = torch.zeros(1, dtype=torch.bool, device=dev)
+        it_t = torch.zeros(1, dtype=torch.float64, device=dev)
+        rr = bb.clone()
+        alpha = torch.where(delta != 0.0, gamma / torch.where(delta != 0.0, delta, one), zero)
+        p, sv = TVec(z.t.clone()), TVec(w.t.clone())
+        fused = self.mg is not None and self.mg.ready and self.mg.additive
+        queued, chunk, spmvs, finished = 0, 1, 1, False
+        while queued < maxit and not finished:
+            n = min(chunk, maxit - queued)
+            for _ in range(n):
+                if fused:
+                    self.mg.update_and_vcycle(alpha, p, sv, TVec(x), TVec(r), z)   # x += alpha p, r -= alpha s, z = M^-1 r
+                else:
+                    x.addcmul_(p.t, alpha)
+                    r.addcmul_(sv.t, -alpha)
+                    self.precond(TVec(r), z)
+                self.spmv(z, w)
+                spmvs += 1
+                g3 = self.dot3_t(r, z.t, w.t)
+                live = ~done
+                it_t += live
+                rr = torch.where(live, g3[2:3], rr)
+                done = done | (rr <= thresh) | ~torch.isfinite(rr)
+                live = ~done
+                gn = g3[0:1]
+                beta = torch.where(live & (gamma != 0.0), gn / torch.where(gamma != 0.0, gamma, one), zero)
+                den = g3[1:2] - beta * gn / torch.where(alpha != 0.0, alpha, one)
+                alpha = torch.where(live & (den != 0.0) & (alpha != 0.0), gn / torch.where(den != 0.0, den, one), zero)
+                gamma = torch.where(live, gn, gamma)
+                torch.addcmul(z.t, p.t, beta, out=p.t)       # p = z + beta p
+                torch.addcmul(w.t, sv.t, beta, out=sv.t)     # s = w + beta s   (= K p)
+            queued += n
+            chunk = min(self.check_every, 2 * chunk) if queued >= 2 else 1
+            finished = bool(done.item())
+            self.comm["host_syncs"] += 1
+        it = int(it_t.item())
+        rr_h = float(rr.item())
+        info.update(iterations=it, rel_residual=float(np.sqrt(rr_h / bb_h)) if np.isfinite(rr_h) else float("nan"), spmv=spmvs)
+        info["comm"] = {k: self.comm[k] - c0[k] for k in self.comm}
+        info["comm_per_iteration"] = {k: (self.comm[k] - c0[k]) / max(queued + 1, 1) for k in ("exchanges", "allreduces")}
+        if not np.isfinite(rr_h):
+            raise RuntimeError("distributed PCG broke down")
+        if rr_h > float(thresh.item()):
+            raise RuntimeError("distributed PCG did not converge in %d iterations" % maxit)
+        return u, info
+
     def solve_timing(self):
         return self._timing
 
@@ -524,6 +618,7 @@ class DistMG:
             cix = f2c[ix]
             shared1[s] = cix[cix >= 0]  # shared corner nodes, same (global id) order on both sides
         self.ex1 = Exchanger(part, dev, shared=shared1, nn=self.nc, ops=self.ops)
+        self.ex1.count = be.comm
         ones = torch.ones(part.nn, dtype=torch.float64, device=dev)
         be.ex.interface_sum(ones, 1)
         self.w0 = (1.0 / ones).repeat_interleave(3)           # 1 / (ranks holding the node), per dof

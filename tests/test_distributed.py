@@ -164,6 +164,11 @@ def test_four_rank_multigrid_solve(orc, tmp_path):
     for g in got:
         assert np.abs(g["u"].reshape(-1, 3) - ref[g["gnodes"] - 1]).max() < 1e-8 * np.abs(ref).max()
         assert 20 < g["info"]["iterations"] < 80
+        # communication per PCG iteration of the single-reduction CG with the additive three-level cycle: shared-node exchanges after
+        # the fine SpMV, the restriction and the four level-1 SpMVs; all-reduces: one for r.z, w.z, r.r together (the classic form: two)
+        # and two for the aggregate level (right-hand side, solution rows)
+        cpi = g["info"]["comm_per_iteration"]
+        assert 5.9 < cpi["exchanges"] < 6.2 and 2.9 < cpi["allreduces"] < 3.2, cpi
 
 
 @pytest.mark.timeout(600)
