@@ -134,78 +134,17 @@ def precond_label(c):
     return ("p-multigrid, %s: tet10 (block-Jacobi smoothing) -> tet4 on %d corner nodes%s" % (form, pi["coarse_nodes"], pi.get("level2", "")))
 
 
-class _Stop(Exception):
-    pass
-
-
 def collapse_run(case, warmup, steps):
-    """The headline workload as the reference runs it (fcVM.py:1304-1559): calcGSM, elastic solve, then the arc-length steps of
-    the control file with its own error_max -- predictor (start_step), Newton iterations, step bookkeeping (end_step).
-    The timed region covers Newton iterations warmup+1 .. warmup+steps of that analysis, with whatever start_step / end_step
-    calls fall between them.  If the control file's steps are used up before the region ends, the analysis is continued the
-    way the reference's plot window does ("add": another pass of nstep steps).  Returns the region's measurements and the
-    whole first pass (= the analysis the reference's .out file documents)."""
+    """The headline workload on one GPU: GpuModel of `case` + solver.collapse_run (see there).  Returns its dict extended with the
+    model and the pattern / upload time."""
     from fcvm_hip.loads import Loads
-    from fcvm_hip.solver import GpuModel, RiksDriver
+    from fcvm_hip.solver import GpuModel, collapse_run as run
     t0 = time.perf_counter()
     model = GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"],
                      Loads(ufaces=case["ufaces"], uloads=case["uloads"]))
     t_model = time.perf_counter() - t0
-    c = model.ctx
-    st = {}
-    t_begin = time.perf_counter()
-    d = RiksDriver(model, case["ctl"], rtol=RTOL, stats=st)     # calcGSM + multigrid hierarchy + elastic solve
-    c.sync()
-    t_setup = time.perf_counter() - t_begin
-    reg = {"n": 0}
-
-    def mark(key):
-        c.sync()
-        reg[key] = (time.perf_counter(), dict(st))
-
-    def after_iteration(first_pass_done):
-        reg["n"] += 1
-        if reg["n"] == warmup:
-            mark("start")
-        if steps is not None and reg["n"] == warmup + steps:
-            mark("end")
-            if first_pass_done:
-                raise _Stop
-    if warmup == 0:
-        mark("start")
-    analysis, passes = None, 0
-    try:
-        while True:
-            pstep = 0
-            while pstep < d.nstep and not d.mrr:
-                pstep += 1
-                error = d.start_step()
-                while error > d.error_max and not d.mrr:
-                    error = d.iteration()
-                    after_iteration(passes > 0)
-                    if d.iterat > d.iterat_max:
-                        d.restart()
-                        error = d.error
-                if d.end_step():
-                    break
-            passes += 1
-            if passes == 1:
-                c.sync()
-                dt = time.perf_counter() - t_begin
-                analysis = {"analysis_s": dt, "steps": len(d.lbd) - 1, "newton_iterations": st["newton_iterations"],
-                            "newton_iterations_per_s": st["newton_iterations"] / dt,
-                            "elements_gp_per_s": st["newton_iterations"] * model.ne * 4 / dt, "linear_solves": st["solves"],
-                            "pcg_iterations_per_solve": st["pcg_iterations"] / max(st["solves"], 1),
-                            "collapse_load_factor": float(d.lbd[-1]), "setup_s_inside": t_setup}
-            if steps is None or "end" in reg or d.mrr or d.elastic_only:   # steps None: the first pass (the analysis) only
-                break
-            d.next_pass()
-    except _Stop:
-        pass
-    out = {"model": model, "driver": d, "analysis": analysis, "pattern_and_upload_s": t_model, "passes": passes}
-    if "start" in reg and "end" in reg:
-        (ta, sa), (tb, sb) = reg["start"], reg["end"]
-        out["region"] = {"s": tb - ta, "stats0": sa, "stats1": sb}
+    out = run(model, case["ctl"], warmup, steps, rtol=RTOL)
+    out.update(model=model, pattern_and_upload_s=t_model)
     return out
 
 
@@ -330,7 +269,7 @@ def run_single(args):
                      "csr_equivalent_GBs": (info["nnz_blocks"] * 9 * 12 + 2 * ndof * 8) / (avg_ms * 1e-3) / 1e9},
         # the whole analysis the timed region is cut from (first pass = what the reference's .out documents), wall clock from
         # calcGSM to the last step, set-up (assembly, hierarchy, elastic solve) included
-        "north_star_workload": dict(an, workload="%s: %d tet10, %d dof, control file of the reference example (10 Riks steps to collapse)"
+        "north_star_workload": dict(an, elements_gp_per_s=an["newton_iterations"] * ne * 4 / an["analysis_s"], workload="%s: %d tet10, %d dof, control file of the reference example (10 Riks steps to collapse)"
                                                  % (case["name"], ne, ndof),
                                     mesh_s=t_mesh, pattern_and_upload_s=run["pattern_and_upload_s"],
                                     reference_out_load_factor_395_elements=0.232),

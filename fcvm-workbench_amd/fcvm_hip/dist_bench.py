@@ -46,6 +46,10 @@ def build_rank_model(rank, world, cells, material, traction, device_index, backe
 
 
 def run(args, ctl, material, traction, rtol, hbm_peak):
+    """N > 1: the headline workload of N = 1 -- the reference's Plate_with_hole_Example, its control file, Newton iterations
+    warmup+1 .. warmup+steps of the collapse analysis -- on a mesh of N x (the one-GPU size) elements (weak scaling: h =
+    plate_h / N^(1/3)), cut into N element ranges along a Morton curve (partition_model).  FCVM_DIST_WORKLOAD=column runs
+    the stacked-cube column of rounds 1-2 instead (ctl / material / traction are that workload's)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if os.environ.get("FCVM_DIST_DEBUG"):   # where does a stuck rank stand? tracebacks of all threads every N seconds
@@ -65,6 +69,90 @@ def run(args, ctl, material, traction, rtol, hbm_peak):
     # a stuck collective should end the run with an error well inside the caller's time limit, not sit out the default 10 min
     dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(minutes=4))
     try:
+        if os.environ.get("FCVM_DIST_WORKLOAD", "plate") == "column":
+            return _run_column(args, ctl, material, traction, rtol, hbm_peak, rank, world, dev_index, device, backend)
+        from . import examples
+        from .dist import partition_model
+        from .solver import collapse_run
+        t0 = time.perf_counter()
+        case = examples.plate_with_hole(args.plate_h / world ** (1.0 / 3.0))      # every rank builds the same global mesh
+        t_mesh = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        model = partition_model(case["elNodes"], case["nocoord"], case["material"], case["fix"],
+                                Loads(ufaces=case["ufaces"], uloads=case["uloads"]), device_index=dev_index, device=device,
+                                precond=os.environ.get("FCVM_PRECOND", "mg"))
+        be, ops = model.ctx, model.ctx.ops
+        t_part = time.perf_counter() - t0
+
+        def sync():
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+        run_ = collapse_run(model, case["ctl"], args.warmup, args.steps, rtol=rtol, sync=sync)
+        if "region" not in run_:
+            raise SystemExit("bench.py: the analysis ended before %d + %d Newton iterations" % (args.warmup, args.steps))
+        reg = run_["region"]
+        tmax = torch.tensor([reg["s"]], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        s0, s1 = reg["stats0"], reg["stats1"]
+        # local SpMV timing for the roofline object (HIP events on the stream the kernel runs on): the stand-alone kernel on
+        # rank 0's matrix, not the in-solver launches (those are followed by the shared-node exchange)
+        x, y = be.array(np.random.default_rng(rank).standard_normal(3 * model.nn)), be.empty(3 * model.nn)
+        for _ in range(3):
+            ops.spmv(x, y)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 30
+        e0.record()
+        for _ in range(reps):
+            ops.spmv(x, y)
+        e1.record()
+        torch.cuda.synchronize()
+        avg_ms = e0.elapsed_time(e1) / reps
+        info = ops.c.pattern_info()
+        alg = info["nnz_blocks"] * 76 + 2 * info["ndof"] * 8
+        ne_total = len(case["elNodes"])
+        pcg = s1["pcg_iterations"] - s0["pcg_iterations"]
+        solves = s1["solves"] - s0["solves"]
+        shared = int(sum(len(ix) for ix in model.part.shared.values()))
+        sh_all = [None] * world
+        dist.all_gather_object(sh_all, (model.ne, model.nn, shared))
+        if rank == 0:
+            achieved = alg / (avg_ms * 1e-3) / 1e9
+            an = run_["analysis"]
+            out = {
+                "metric": "elements*GP/s over Newton iterations (Newton iterations/s x elements x 4 GP), 1M tet10 per GPU",
+                "value": ne_total * 4 * args.steps / dt, "unit": "elements*GP/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "%s: %d tet10 (%d per GPU on average), %d dof -- the reference's Plate_with_hole_Example with its control "
+                                       "file on a mesh of %d x the one-GPU size, elements cut into %d ranges along a Morton curve; a step = one "
+                                       "Newton/Riks iteration of the collapse analysis (iterations %d..%d)" %
+                                       (case["name"], ne_total, ne_total // world, 3 * len(case["nocoord"]), world, world, args.warmup + 1,
+                                        args.warmup + args.steps),
+                           "pcg_rtol": rtol,
+                           "preconditioner": (("distributed p-multigrid, additive cycle (tet10 -> tet4 -> %d aggregates x rigid-body modes, dense "
+                                               "inverse split by rows over the ranks), single-reduction CG" % be.mg.nagg) if be.mg is not None else
+                                              ("the one-GPU p-multigrid PCG of the library (single rank: nothing to exchange)" if be.local_solver
+                                               else "block-Jacobi 3x3")), "parallelism": "element-partition x%d" % world,
+                           "partition": {"elements_nodes_interface_nodes_per_rank": sh_all},
+                           "exchange": "point-to-point shared-node sums after every SpMV and the restriction, scalar and aggregate-level "
+                                       "all-reduces (%s); per PCG iteration: %s" % (backend, run_["stats"].get("comm_per_iteration", "n/a"))},
+                "newton_iterations_per_s": args.steps / dt, "pcg_iterations_per_step": pcg / args.steps,
+                "pcg_iterations_per_solve": pcg / max(solves, 1),
+                "setup_s": {"mesh": t_mesh, "partition_pattern_upload": t_part, "inside_analysis": run_["setup_s"]},
+                "north_star_workload": dict(an, elements_gp_per_s=an["newton_iterations"] * ne_total * 4 / an["analysis_s"]),
+                "roofline": {"bound": "hbm", "kernel": "k_spmv_win (rank 0, local matrix, stand-alone launches after the timed region)",
+                             "achieved": achieved, "peak": hbm_peak, "unit": "GB/s", "frac": achieved / hbm_peak, "traffic": None,
+                             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms},
+            }
+            print(json.dumps(out))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_column(args, ctl, material, traction, rtol, hbm_peak, rank, world, dev_index, device, backend):
+    if True:
         model, be, ops = build_rank_model(rank, world, args.cells, material, traction, dev_index, device)
         stats = {}
         drv = RiksDriver(model, ctl, rtol=rtol, stats=stats)
@@ -122,5 +210,3 @@ def run(args, ctl, material, traction, rtol, hbm_peak):
                              "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms},
             }
             print(json.dumps(out))
-    finally:
-        dist.destroy_process_group()

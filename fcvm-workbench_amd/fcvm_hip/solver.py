@@ -235,6 +235,8 @@ class RiksDriver:
         st["solve_s"] += time.perf_counter() - t0
         st["pcg_iterations"] += info["iterations"]
         st["solves"] += 1
+        if "comm_per_iteration" in info:      # distributed backend: exchanges / all-reduces per PCG iteration of the last solve
+            st["comm_per_iteration"] = info["comm_per_iteration"]
         if info["iterations"] == 0 and info["spmv"] == 0:
             return u
         tm = self.c.solve_timing()
@@ -466,6 +468,78 @@ def calc_disp(model, ctl, log=None, rtol=1e-10, maxit=50000, max_passes=1, stats
         if cnt:
             d.next_pass(pass_targets[passes - 1] if pass_targets is not None and passes - 1 < len(pass_targets) else None)
     return d.result()
+
+
+class _Stop(Exception):
+    pass
+
+
+def collapse_run(model, ctl, warmup, steps, rtol=1e-10, sync=None):
+    """A whole analysis as the reference runs it (fcVM.py:1304-1559: calcGSM, elastic solve, then the arc-length steps of the
+    control file with its own error_max -- predictor start_step, Newton iterations, end_step bookkeeping) with a timed
+    region cut out of it: Newton iterations warmup+1 .. warmup+steps, with whatever start_step / end_step calls fall between
+    them (bench.py's headline).  steps None: no region, the first pass only.  If the control file's steps are used up before
+    the region ends, the analysis is continued the way the reference's plot window does ("add": another pass of nstep
+    steps).  sync: called before a clock is read (default: the backend's stream synchronisation; the multi-GPU bench adds
+    a barrier).  Returns dict(driver, analysis = the whole first pass (what the reference's .out documents), region =
+    {s, stats0, stats1} or absent, passes, setup_s)."""
+    c = model.ctx
+    sync = sync if sync is not None else c.sync
+    st = {}
+    sync()
+    t_begin = time.perf_counter()
+    d = RiksDriver(model, ctl, rtol=rtol, stats=st)     # calcGSM + multigrid hierarchy + elastic solve
+    sync()
+    t_setup = time.perf_counter() - t_begin
+    reg = {"n": 0}
+
+    def mark(key):
+        sync()
+        reg[key] = (time.perf_counter(), dict(st))
+
+    def after_iteration(first_pass_done):
+        reg["n"] += 1
+        if reg["n"] == warmup:
+            mark("start")
+        if steps is not None and reg["n"] == warmup + steps:
+            mark("end")
+            if first_pass_done:
+                raise _Stop
+    if warmup == 0:
+        mark("start")
+    analysis, passes = None, 0
+    try:
+        while True:
+            pstep = 0
+            while pstep < d.nstep and not d.mrr:
+                pstep += 1
+                error = d.start_step()
+                while error > d.error_max and not d.mrr:
+                    error = d.iteration()
+                    after_iteration(passes > 0)
+                    if d.iterat > d.iterat_max:
+                        d.restart()
+                        error = d.error
+                if d.end_step():
+                    break
+            passes += 1
+            if passes == 1:
+                sync()
+                dt = time.perf_counter() - t_begin
+                analysis = {"analysis_s": dt, "steps": len(d.lbd) - 1, "newton_iterations": st["newton_iterations"],
+                            "newton_iterations_per_s": st["newton_iterations"] / dt, "linear_solves": st["solves"],
+                            "pcg_iterations_per_solve": st["pcg_iterations"] / max(st["solves"], 1),
+                            "collapse_load_factor": float(d.lbd[-1]), "setup_s_inside": t_setup}
+            if steps is None or "end" in reg or d.mrr or d.elastic_only:   # steps None: the first pass (the analysis) only
+                break
+            d.next_pass()
+    except _Stop:
+        pass
+    out = {"driver": d, "analysis": analysis, "passes": passes, "setup_s": t_setup, "stats": st}
+    if "start" in reg and "end" in reg:
+        (ta, sa), (tb, sb) = reg["start"], reg["end"]
+        out["region"] = {"s": tb - ta, "stats0": sa, "stats1": sb}
+    return out
 
 
 def run_analysis(elNodes, nocoord, material, fix, loads, ctl, device=0, log=None, rtol=1e-10, model=None, max_passes=1, pass_targets=None):
