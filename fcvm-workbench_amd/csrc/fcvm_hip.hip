@@ -445,6 +445,7 @@ static int setup_window_format(fcvm_ctx *c, const double *nocoord) {
         win_allow_lds(k_spmv_win<true, 4, true>, lds) || win_allow_lds(k_spmv_win<false, 4, true>, lds) ||
         win_allow_lds(k_spmv_win_lo<1, WIN_WAVES>, lds) || win_allow_lds(k_spmv_win_lo<2, WIN_WAVES>, lds) ||
         win_allow_lds(k_spmv_win_lo<1, 4>, lds) || win_allow_lds(k_spmv_win_lo<2, 4>, lds) ||
+        win_allow_lds(k_spmv_win_lo<0, WIN_WAVES>, lds) || win_allow_lds(k_spmv_win_lo<0, 4>, lds) ||
         win_allow_lds(k_spmv_win_lo2<1, WIN_WAVES>, lds) || win_allow_lds(k_spmv_win_lo2<2, WIN_WAVES>, lds) ||
         win_allow_lds(k_spmv_win_lo2<1, 4>, lds) || win_allow_lds(k_spmv_win_lo2<2, 4>, lds))
         return 1;
@@ -937,7 +938,7 @@ static int refresh_precond(fcvm_ctx *c) {   // after every assembly into d_vals
     if (c->win.on) {
         WinDev &w = c->win;
         const int64_t nrows = w.pat.nwaves * SLICE;
-        const bool lo = c->precond_mode == 1 && c->mg_additive == 2;   // the multiplicative cycle smooths with a 16-bit fixed-point copy
+        const bool lo = c->precond_mode >= 1 && c->mg_additive == 2;   // the multiplicative cycle smooths with a 16-bit fixed-point copy (mode 2: the multi-GPU layer's cycle)
         w.lo_valid = false;
         if (lo) {
             if (!w.lo8 && (dalloc(&w.lo8, w.pat.nblocks) || dalloc(&w.lo2, w.pat.nblocks) || dalloc(&w.lo_scale, 2) ||
@@ -1195,6 +1196,17 @@ int fcvm_solve2(fcvm_ctx *c, const double *fA, const double *fB, double *uA, dou
                 (int)mg_use_lo(c), (int)c->win2_ok);
     if (fcvm_solve(c, fA, uA, rtolA, maxit, info)) return 1;
     return fcvm_solve(c, fB, uB, rtolB, maxit, info ? info + 3 : nullptr);
+}
+
+/* y = K~ x with the 16-bit block-scaled copy of the matrix the multiplicative cycle smooths with (the FP64 product where
+ * no copy exists) */
+int fcvm_spmv_lo(fcvm_ctx *c, const double *x, double *y) {
+    NEED(c && c->have_mesh, "fcvm_spmv_lo: no mesh");
+    NEED(x && y && x != y && aligned16(x) && aligned16(y), "fcvm_spmv_lo: x and y must be distinct 16-byte aligned device vectors");
+    if (mg_use_lo(c)) launch_spmv_win_lo<0>(c, x, nullptr, y, 0.0, nullptr);
+    else launch_spmv(c, false, x, y, nullptr);
+    HCHK(hipGetLastError());
+    return 0;
 }
 
 /* yA = K xA and yB = K xB with one pass over the matrix (k_spmv_win2); each bitwise what fcvm_spmv gives.  Window format with

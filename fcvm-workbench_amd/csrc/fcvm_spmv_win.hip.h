@@ -403,6 +403,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_spmv_win2(int64_t ngroups, in
 // ---- the same SpMV on the 16-bit copy of the values, for the smoother of the multiplicative cycle ---------------------------
 // 24 instead of 74 bytes per block; x, the accumulation and everything written are FP64.  The SpMV result never leaves the
 // registers: the epilogue is the cycle's step that needs it (no reference counterpart, see the header of this file).
+//   EPI 0:                        out = K~ x                                               (multi-GPU layer: summed over the ranks first)
 //   EPI 1 (after pre-smoothing):  out = r - K~ x                                           (residual for the coarse correction)
 //   EPI 2 (post-smoothing):       out = x + c0 * Dinv (r - K~ x) ; partials of r.out and r.r (the PCG's z, r.z, r.r)
 struct WinSlotLo {
@@ -546,6 +547,14 @@ __global__ __launch_bounds__(64 * WAVES, FCVM_LO_MINWAVES) void k_spmv_win_lo(in
         for (int k = 0; k + 1 < nseg; k++) { y0 += yp[3 * k]; y1 += yp[3 * k + 1]; y2 += yp[3 * k + 2]; }
     }
     double rz = 0.0, rr = 0.0;
+    if (EPI == 0) {     // plain product out = K~ x (the host-driven cycle of the multi-GPU layer exchanges it before using it)
+        if (node >= 0 && nseg > 0) {
+            const double is = lo_scale[1];
+            const int64_t o = 3 * (int64_t)node;
+            out[o] = is * y0; out[o + 1] = is * y1; out[o + 2] = is * y2;
+        }
+        return;
+    }
     if (node >= 0 && nseg > 0) {
         const double is = lo_scale[1];
         const int64_t o = 3 * (int64_t)node;

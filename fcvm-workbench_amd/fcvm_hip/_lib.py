@@ -57,6 +57,7 @@ SIGNATURES = {
     "fcvm_mg_apply": [_vp, _vp, _vp],
     "fcvm_solve2": [_vp, _vp, _vp, _vp, _vp, _f64, _f64, _i64, _pf64],
     "fcvm_spmv2": [_vp, _vp, _vp, _vp, _vp],
+    "fcvm_spmv_lo": [_vp, _vp, _vp],
     "fcvm_mg_apply2": [_vp, _vp, _vp, _vp, _vp],
     "fcvm_host_pattern_check": [_i64, _i64, _vp, _pi64],
     "fcvm_spmv_info": [_vp, _pi64],

@@ -431,7 +431,7 @@ class DistBackend:
         if not np.isfinite(bb_h):
             raise RuntimeError("distributed PCG: non-finite right-hand side")
         dev = self.device
-        fused = self.mg is not None and self.mg.ready and self.mg.additive
+        fused = self.mg is not None and self.mg.ready and self.mg.fused
         queued, chunk, spmvs = 0, 1, 0
         finished = False
         if hasattr(self.ops, "pcg_scalars"):
@@ -526,7 +526,7 @@ class DistBackend:
         rr = bb.clone()
         alpha = torch.where(delta != 0.0, gamma / torch.where(delta != 0.0, delta, one), zero)
         p, sv = TVec(z.t.clone()), TVec(w.t.clone())
-        fused = self.mg is not None and self.mg.ready and self.mg.additive
+        fused = self.mg is not None and self.mg.ready and self.mg.fused
         queued, chunk, spmvs, finished = 0, 1, 1, False
         while queued < maxit and not finished:
             n = min(chunk, maxit - queued)
@@ -596,13 +596,27 @@ class DistMG:
     all-reduces per cycle); its dense inverse is distributed by row blocks, so the number of aggregates can grow
     with the rank count (about 1000 * world^(2/3): each rank streams n2^2 / world matrix entries per cycle)."""
 
-    def __init__(self, be, nocoord_local, k0=1, alpha0=4.0, k1s=2, alpha1s=8.0, target=None, check_every=4, additive=True,
+    def __init__(self, be, nocoord_local, k0=1, alpha0=4.0, k1s=None, alpha1s=None, target=None, check_every=4, additive=None,
                  weight=1.0):
         self.be, self.ops, self.part = be, be.ops, be.part
         self.xyz = np.ascontiguousarray(nocoord_local, dtype=np.float64)
+        # form of the level-0 part, as on one GPU (csrc/fcvm_mg.inc): 2 = multiplicative V(1,1), one damped block-Jacobi step before
+        # and after the coarse correction, its two fine products on the 16-bit copy of every rank's matrix and summed over the
+        # shared nodes (round 3; default where the local kernels offer spmv_lo); 1 = additive (rounds 1-2: no fine product inside
+        # the preconditioner); 0 = multiplicative Chebyshev on the FP64 matrix.  FCVM_DIST_CYCLE=additive forces form 1.
+        if additive is None:
+            additive = not hasattr(be.ops, "spmv_lo") or os.environ.get("FCVM_DIST_CYCLE", "") == "additive"
+            self.form = 1 if additive else 2
+        else:
+            self.form = 1 if additive else 0
+        if k1s is None:
+            k1s = 3 if self.form == 2 else 2         # the multiplicative cycle leaves the level-1 solve as the weakest part
+        if alpha1s is None:
+            alpha1s = 4.0 * k1s
         self.k0, self.alpha0, self.k1s, self.alpha1s, self.target = k0, alpha0, k1s, alpha1s, target
         self.check_every = check_every
-        self.additive, self.weight = additive, weight
+        self.additive, self.weight = self.form == 1, weight
+        self.fused = self.form in (1, 2)             # the PCG update x, r and the start of the cycle in one kernel
         self.ready = False
         self.topo = False
 
@@ -628,6 +642,7 @@ class DistMG:
         n0, n1 = 3 * part.nn, 3 * self.nc
         mk = lambda n: TVec(torch.zeros(n, dtype=torch.float64, device=dev))  # noqa: E731
         self.r0, self.d0, self.t0 = mk(n0), mk(n0), mk(n0)
+        self.x2, self.z0 = mk(n0), mk(n0)       # form 2: x after the coarse correction; a scratch vector
         self.r1, self.x1, self.rr1, self.d1, self.t1 = mk(n1), mk(n1), mk(n1), mk(n1), mk(n1)
         self.topo = True
 
@@ -841,8 +856,27 @@ class DistMG:
         self.ops.mg_l2_prolong(self.e2, self.d1)
         self._post(1, self.ch1, self.k1s, self.x1, self.rr1, self.d1, self.t1)
 
+    def _cycle_lo(self, b, x):
+        """form 2 from x1 = c0 Dinv b in self.d0:  x2 = x1 + P M1^-1 P^T (b - K~ x1);  x = x2 + c0 Dinv (b - K~ x2), K~ = the sum
+        over the ranks of the 16-bit copies of their local matrices (two fine-level exchanges)"""
+        be, c0 = self.be, self.weight * self.ch0.c0
+        self.ops.spmv_lo(self.d0, self.t0)
+        be.ex.interface_sum(self.t0.t, 3)
+        torch.sub(b.t, self.t0.t, out=self.r0.t)
+        self._coarse(self.r0)
+        self.ops.mg_prolong_add(self.x1, self.d0, self.x2)
+        self.ops.spmv_lo(self.x2, self.t0)
+        be.ex.interface_sum(self.t0.t, 3)
+        torch.sub(b.t, self.t0.t, out=self.r0.t)
+        self.ops.mg_cheb_init(0, self.r0, self.z0, self.r0, self.t0, c0)     # t0 = c0 Dinv (b - K~ x2)
+        torch.add(self.x2.t, self.t0.t, out=x.t)
+
     def vcycle(self, b, x):
         """x = M^-1 b (consistent fine vectors)"""
+        if self.form == 2:
+            self.ops.mg_cheb_init(0, b, self.z0, b, self.d0, self.weight * self.ch0.c0)   # x1 = c0 Dinv b
+            self._cycle_lo(b, x)
+            return
         if self.additive:   # x = w c0 Dinv b + P M1^-1 P^T b : no fine-level SpMV / exchange in the preconditioner
             self.ops.mg_cheb_init(0, b, x, self.r0, self.d0, self.weight * self.ch0.c0)
             self._coarse(b)
@@ -857,6 +891,9 @@ class DistMG:
         """additive cycle fused with the PCG update: x += alpha p, r -= alpha q, z = w c0 Dinv r + P M1^-1 P^T r
         (alpha: 1-element device tensor)"""
         self.ops.pcg_update_xr_z0(alpha, p, q, x, r, self.d0, self.weight * self.ch0.c0)
+        if self.form == 2:      # d0 = x1 = c0 Dinv r is the pre-smoothing step
+            self._cycle_lo(r, z)
+            return
         self._coarse(r)
         self.ops.mg_prolong_add(self.x1, self.d0, z)
 
@@ -1139,6 +1176,11 @@ class HipLocalOps:
     def mg_spmv(self, level, x, y):
         from ._lib import call
         call("fcvm_spmv_level", self.c.h, level, x.ptr, y.ptr)
+
+    def spmv_lo(self, x, y):
+        """y = K~ x with the 16-bit copy of the rank's matrix (the smoother passes of the multiplicative cycle)"""
+        from ._lib import call
+        call("fcvm_spmv_lo", self.c.h, x.ptr, y.ptr)
 
     def mg_get_diag(self, level, dblk):
         from ._lib import call

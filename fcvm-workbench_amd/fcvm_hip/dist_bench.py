@@ -131,8 +131,10 @@ def run(args, ctl, material, traction, rtol, hbm_peak):
                                        (case["name"], ne_total, ne_total // world, 3 * len(case["nocoord"]), world, world, args.warmup + 1,
                                         args.warmup + args.steps),
                            "pcg_rtol": rtol,
-                           "preconditioner": (("distributed p-multigrid, additive cycle (tet10 -> tet4 -> %d aggregates x rigid-body modes, dense "
-                                               "inverse split by rows over the ranks), single-reduction CG" % be.mg.nagg) if be.mg is not None else
+                           "preconditioner": (("distributed p-multigrid, %s (tet10 -> tet4 -> %d aggregates x rigid-body modes, dense "
+                                               "inverse split by rows over the ranks), single-reduction CG" %
+                                               ({2: "multiplicative V(1,1) with 16-bit smoother products per rank", 1: "additive cycle",
+                                                 0: "multiplicative Chebyshev cycle"}[be.mg.form], be.mg.nagg)) if be.mg is not None else
                                               ("the one-GPU p-multigrid PCG of the library (single rank: nothing to exchange)" if be.local_solver
                                                else "block-Jacobi 3x3")), "parallelism": "element-partition x%d" % world,
                            "partition": {"elements_nodes_interface_nodes_per_rank": sh_all},

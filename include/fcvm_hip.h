@@ -176,6 +176,9 @@ int fcvm_vec_max_node_norm(fcvm_ctx *c, int64_t nnodes, const double *u, double 
 int fcvm_solve2(fcvm_ctx *c, const double *fA, const double *fB, double *uA, double *uB, double rtolA, double rtolB, int64_t maxit,
                 double info[6]);
 
+/* y = K~ x: the product with the 16-bit copy of the matrix that cycle form 2 smooths with (the multi-GPU layer drives its
+ * cycle from the host and exchanges the product over the shared nodes before using it); the FP64 product where no copy exists */
+int fcvm_spmv_lo(fcvm_ctx *c, const double *x, double *y);
 /* the two shared-pass building blocks of fcvm_solve2 on their own: yA = K xA, yB = K xB (bitwise fcvm_spmv of each) and
  * zA = M^-1 rA, zB = M^-1 rB (bitwise fcvm_mg_apply of each); for block methods and for the tests */
 int fcvm_spmv2(fcvm_ctx *c, const double *xA, const double *xB, double *yA, double *yB);

@@ -136,6 +136,10 @@ class OracleLocalOps:
     def mg_spmv(self, level, x, y):
         y.set(self._A(level) @ x.get())
 
+    def spmv_lo(self, x, y):
+        """the smoother's product of the multiplicative cycle (the HIP path streams a 16-bit copy; the exact matrix here)"""
+        y.set(self.K @ x.get())
+
     def mg_get_diag(self, level, dblk):
         A = self._A(level)
         n = A.shape[0] // 3

@@ -168,7 +168,10 @@ def test_four_rank_multigrid_solve(orc, tmp_path):
         # the fine SpMV, the restriction and the four level-1 SpMVs; all-reduces: one for r.z, w.z, r.r together (the classic form: two)
         # and two for the aggregate level (right-hand side, solution rows)
         cpi = g["info"]["comm_per_iteration"]
-        assert 5.9 < cpi["exchanges"] < 6.2 and 2.9 < cpi["allreduces"] < 3.2, cpi
+        print("four ranks:", g["info"]["iterations"], "iterations,", cpi)
+        # multiplicative cycle (form 2, default): two more fine-level exchanges (the smoother's products) and, with three level-1
+        # smoothing steps, two more level-1 exchanges than the additive cycle's six -- for about half its iterations
+        assert 9.9 < cpi["exchanges"] < 10.3 and 2.9 < cpi["allreduces"] < 3.2, cpi
 
 
 @pytest.mark.timeout(600)
