@@ -137,7 +137,7 @@ struct fcvm_ctx {
     // p-multigrid preconditioner (mode 1): level 1 = linear tets on the corner nodes
     int precond_mode = 0, mg_k0 = 1, mg_k1 = 60;
     double mg_alpha0 = 4.0, mg_alpha1 = 1000.0, mg_lmax0 = 0, mg_lmax1 = 0;
-    bool mg_topo = false, mg_lmax_stale = true;
+    bool mg_topo = false, mg_lmax_stale = true, fixmask1_valid = false;
     int64_t nc = 0, nb_spmv1 = 0;
     Pattern pat1;
     int32_t *d_el4 = nullptr, *d_cols1 = nullptr, *d_rownode1 = nullptr, *d_c2f = nullptr, *d_mids = nullptr, *d_pa = nullptr,
@@ -329,6 +329,9 @@ static void launch_spmv_win_lo2(fcvm_ctx *c, const double *xA, const double *xB,
 
 // the multiplicative cycle with the 16-bit smoother matrix needs the window format and its 16-bit copy
 static inline bool mg_use_lo(const fcvm_ctx *c) { return c->mg_additive == 2 && c->win.on && c->win.lo_valid; }
+// the form that runs: 2 without the window format (tiny meshes, windows beyond the LDS) becomes the additive form -- the FP64
+// multiplicative form would stream the sliced-ELL matrix three times per iteration there
+static inline int mg_form(const fcvm_ctx *c) { return c->mg_additive == 2 ? (mg_use_lo(c) ? 2 : 1) : c->mg_additive; }
 
 static int dot_common(fcvm_ctx *c, int64_t n, const double *w, const double *x, const double *y, double *result_dev) {
     NEED(c && c->d_part_misc, "vector reductions need a mesh (work buffers)");
@@ -882,6 +885,7 @@ int fcvm_set_fix(fcvm_ctx *c, int64_t nfix, const int64_t *dofs, const double *v
     }
     c->h_fixmask = mask;
     c->mg_lmax_stale = true;
+    c->fixmask1_valid = false;
     HCHK(hipMemcpyAsync(c->d_fixmask, mask.data(), c->nn, hipMemcpyHostToDevice, c->stream));
     HCHK(hipMemcpyAsync(c->d_fixval, val.data(), sizeof(double) * c->nn * 3, hipMemcpyHostToDevice, c->stream));
     HCHK(hipStreamSynchronize(c->stream));
@@ -1746,7 +1750,7 @@ int fcvm_set_mg_cycle(fcvm_ctx *c, int additive, double weight) {
 
 int fcvm_get_mg_cycle(fcvm_ctx *c, int *form, double *weight, int *fp16_copy_in_use) {
     NEED(c && form && weight && fp16_copy_in_use, "fcvm_get_mg_cycle: bad arguments");
-    *form = c->mg_additive;
+    *form = mg_form(c);
     *weight = c->mg_add_w;
     *fp16_copy_in_use = mg_use_lo(c) ? 1 : 0;
     return 0;

@@ -297,8 +297,8 @@ class Context:
                  coarse_nnz_blocks=int(o[4]), vcycle_fine_spmv=int(o[5]), l2_aggregates=int(o[6]), l2_unknowns=int(o[7]))
         form, wgt, lo = C.c_int(0), C.c_double(0.0), C.c_int(0)
         call("fcvm_get_mg_cycle", self.h, C.byref(form), C.byref(wgt), C.byref(lo))
-        # the form that runs: 2 needs the 16-bit copy (window format), without it the FP64 multiplicative form stands in
-        d["cycle_form"], d["cycle_weight"] = (form.value if form.value != 2 or lo.value else 0), wgt.value
+        # the form that runs (2 needs the 16-bit copy, i.e. the window format; without it the additive form stands in)
+        d["cycle_form"], d["cycle_weight"] = form.value, wgt.value
         sp = (C.c_int64 * 4)()
         call("fcvm_mg_sparse_info", self.h, sp)
         d["l2_sparse"], d["l3_super_aggregates"], d["l3_unknowns"] = bool(sp[0]), int(sp[2]), int(sp[3])

@@ -613,6 +613,8 @@ class DistMG:
             k1s = 3 if self.form == 2 else 2         # the multiplicative cycle leaves the level-1 solve as the weakest part
         if alpha1s is None:
             alpha1s = 4.0 * k1s
+        if self.form == 2:
+            alpha0 = max(alpha0, 16.0)               # damping of the Jacobi step as in csrc/fcvm_mg.inc (mg_smoother_weight)
         self.k0, self.alpha0, self.k1s, self.alpha1s, self.target = k0, alpha0, k1s, alpha1s, target
         self.check_every = check_every
         self.additive, self.weight = self.form == 1, weight
