@@ -122,6 +122,13 @@ struct fcvm_ctx {
     bool row_order_morton = false;
     // window-format copies of the matrices for the SpMV (fcvm_spmv_win.hip.h); 0: the sliced-ELL kernel does it
     bool win2_ok = false;           // twice the window fits the LDS: k_spmv_win2 can run
+    int level1_overlap = 1;         // FCVM_LEVEL1_OVERLAP=0: the level-1 operator of a tangent refresh after the fine assembly, on the main stream
+    hipStream_t level1_stream = nullptr;
+    hipEvent_t level1_fork = nullptr, level1_done = nullptr;
+    int repack_overlap = 1;         // FCVM_REPACK_OVERLAP=0: the copy into the window storage on the main stream
+    hipStream_t repack_stream = nullptr;
+    hipEvent_t repack_fork = nullptr, repack_done = nullptr;
+    bool repack_pending = false;
     int spmv_win = 1, win_v2 = 1;   // win_v2: value components in 16-byte pairs (FCVM_WIN_V2=0: nine 8-byte runs)
     WinDev win;                     // the fine matrix.  (The level-1 matrix of the multigrid cycle was tried on the same format with
                                     // FP32 values and the smoother epilogue: 31.0 against 28.3 us per launch -- 686 workgroups are too
@@ -657,6 +664,8 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_WIN_V2")) c->win_v2 = atoi(v) != 0;
     if (const char *v = getenv("FCVM_ASSEMBLE_LDS")) c->assemble_lds = atoi(v);
     if (const char *v = getenv("FCVM_ASSEMBLE_OVERLAP")) c->asm_overlap = atoi(v);
+    if (const char *v = getenv("FCVM_REPACK_OVERLAP")) c->repack_overlap = atoi(v);
+    if (const char *v = getenv("FCVM_LEVEL1_OVERLAP")) c->level1_overlap = atoi(v);
     if (const char *v = getenv("FCVM_QIN_ATOMIC")) c->qin_atomic = atoi(v);
     if (const char *v = getenv("FCVM_SPMV_SPW")) c->spmv_spw = std::min(4, std::max(1, atoi(v)));   // slices (waves) per workgroup
     if (const char *v = getenv("FCVM_MG_ADDITIVE")) c->mg_additive = std::min(2, std::max(0, atoi(v)));
@@ -699,6 +708,12 @@ int fcvm_destroy(fcvm_ctx *c) {
     for (auto e : c->evpool) (void)hipEventDestroy(e);
     if (c->h_pcgS) (void)hipHostFree(c->h_pcgS);
     if (c->h_pcgS2) (void)hipHostFree(c->h_pcgS2);
+    if (c->level1_fork) (void)hipEventDestroy(c->level1_fork);
+    if (c->level1_done) (void)hipEventDestroy(c->level1_done);
+    if (c->level1_stream) (void)hipStreamDestroy(c->level1_stream);
+    if (c->repack_fork) (void)hipEventDestroy(c->repack_fork);
+    if (c->repack_done) (void)hipEventDestroy(c->repack_done);
+    if (c->repack_stream) (void)hipStreamDestroy(c->repack_stream);
     if (c->asm_fork) (void)hipEventDestroy(c->asm_fork);
     for (int b = 0; b < fcvm_ctx::ASM_BUCKETS; b++) {
         if (c->asm_join[b]) (void)hipEventDestroy(c->asm_join[b]);
@@ -937,6 +952,15 @@ int fcvm_matrix_to_coo(fcvm_ctx *c, int64_t *row, int64_t *col, double *val) {
     return 0;
 }
 
+// main stream waits for a copy into the window storage that is still running on its side stream (refresh_precond)
+static int win_join(fcvm_ctx *c) {
+    if (c->repack_pending) {
+        HCHK(hipStreamWaitEvent(c->stream, c->repack_done, 0));
+        c->repack_pending = false;
+    }
+    return 0;
+}
+
 static int refresh_precond(fcvm_ctx *c) {   // after every assembly into d_vals
     hipLaunchKernelGGL(k_diag_get, dim3(cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_diagoff, c->d_vals, c->d_dblk);
     if (c->win.on) {
@@ -951,9 +975,27 @@ static int refresh_precond(fcvm_ctx *c) {   // after every assembly into d_vals
             hipLaunchKernelGGL(k_absmax_partial, dim3(1024), dim3(256), 0, c->stream, 9 * c->nn, c->d_dblk, c->d_part_misc);
             hipLaunchKernelGGL(k_lo_scale, dim3(1), dim3(256), 0, c->stream, c->d_part_misc, (int64_t)1024, w.lo_scale);
         }
-        hipLaunchKernelGGL(k_repack_win, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, c->stream, nrows, w.srcslot, w.rowlen,
+        // the copy into the SpMV's storage (1.5 ms at 1 M elements, bandwidth-bound) runs on a stream of its own next to what
+        // follows on the main stream -- diagonal inverses and, with the multigrid preconditioner, the tet4 level's assembly and the
+        // eigenvalue estimates, none of which reads the window storage; win_join() makes the main stream wait for it
+        hipStream_t rs = c->stream;
+        if (c->repack_overlap) {
+            if (!c->repack_stream) {
+                HCHK(hipStreamCreateWithFlags(&c->repack_stream, hipStreamNonBlocking));
+                HCHK(hipEventCreateWithFlags(&c->repack_fork, hipEventDisableTiming));
+                HCHK(hipEventCreateWithFlags(&c->repack_done, hipEventDisableTiming));
+            }
+            HCHK(hipEventRecord(c->repack_fork, c->stream));
+            HCHK(hipStreamWaitEvent(c->repack_stream, c->repack_fork, 0));
+            rs = c->repack_stream;
+        }
+        hipLaunchKernelGGL(k_repack_win, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, rs, nrows, w.srcslot, w.rowlen,
                            w.jstart, w.woff, c->d_sptr, c->d_vals, (double *)w.vals, c->win_v2, lo ? w.lo_scale : (const double *)nullptr,
                            lo ? w.lo8 : (short8 *)nullptr, lo ? w.lo2 : (WinLoTail *)nullptr, (const uint16_t *)w.cols);
+        if (c->repack_overlap) {
+            HCHK(hipEventRecord(c->repack_done, rs));
+            c->repack_pending = true;
+        }
         w.lo_valid = lo;
     }
     hipLaunchKernelGGL(k_diag_invert, dim3(cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_dblk, c->d_dinv);
@@ -977,6 +1019,7 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
     dim3 block(256);
     const int64_t nslots = c->pat.nslices * SLICE;
     dim3 rgrid((unsigned)cdiv(nslots, 256));
+    const bool level1_early = mg_level1_early(c, sig ? disp : nullptr, sig, pgp, Et_E);   // a refresh: beside the fine assembly
     if (use_lds) {  // quarter slices accumulated in LDS, written once (fcvm_assemble_lds.hip.h)
         if (sig ? launch_assemble_lds<true>(c, disp, sig, pgp, mc, grav, glv_grav, modf, xgp, c->d_part_vol, 0)
                 : launch_assemble_lds<false>(c, disp, nullptr, nullptr, mc, grav, glv_grav, modf, xgp, c->d_part_vol, 0))
@@ -997,11 +1040,12 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
     if (refresh_precond(c)) return 1;
     if (c->precond_mode >= 1) {
         HCHK(hipStreamSynchronize(s));
-        if (mg_setup(c, sig ? disp : nullptr, sig, pgp, Et_E)) return 1;
+        if (mg_setup(c, sig ? disp : nullptr, sig, pgp, Et_E, level1_early)) return 1;
     }
     if (volume) {
         HCHK(hipMemcpyAsync(volume, c->d_out8, sizeof(double), hipMemcpyDeviceToHost, s));
     }
+    if (win_join(c)) return 1;
     HCHK(hipStreamSynchronize(s));
     c->assembled = true;
     return 0;
@@ -1796,6 +1840,7 @@ int fcvm_assemble_buckling(fcvm_ctx *c, const double *sig, double shift) {
         if (mg_setup(c)) return 1;
         c->mg_lmax_stale = true;  // and the next ordinary assembly is different again
     }
+    if (win_join(c)) return 1;
     HCHK(hipStreamSynchronize(s));
     c->assembled = true;
     return 0;

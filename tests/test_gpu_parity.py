@@ -311,7 +311,9 @@ def test_window_format_spmv_and_pcg_match_sliced_ell(monkeypatch):
             monkeypatch.setenv("FCVM_SPMV_WIN", "0" if win == "0" else "1")
             if win == "small":
                 monkeypatch.setenv("FCVM_WIN_MAX", str(models["1"].ctx.spmv_info()["max_window"] - 1))
-            m = GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"], Loads(), ctx=Context(0))
+            ctx = Context(0)
+            ctx.set_mg_cycle(1)     # one cycle form for all three storages (form 2 needs the window format: its own test)
+            m = GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"], Loads(), ctx=ctx)
             assert m.ctx.spmv_info()["waves_per_group"] == {"1": 8, "0": 0, "small": 4}[win]
             models[win] = m
         monkeypatch.delenv("FCVM_SPMV_WIN")
