@@ -161,6 +161,10 @@ struct fcvm_ctx {
     int mg_additive = 2;   // 1: additive; 0: multiplicative, FP64 smoother SpMVs; 2: multiplicative V(1,1), smoother SpMVs on a 16-bit fixed-point copy
     int mg_fp32 = 1;           // coarse levels: level-1 matrix and aggregate inverse stored in FP32 (FP64 vectors / accumulation)
     float *d_vals1f = nullptr, *d_A2invf = nullptr;
+    int mg_l1_16 = 1;              // level-1 SpMVs of the cycle on a 16-bit block-scaled copy of the level-1 matrix (FCVM_MG_L1_16=0: FP32)
+    int4v *d_l1A = nullptr, *d_l1B = nullptr, *d_l1C = nullptr;
+    int64_t *d_rp16 = nullptr;
+    double *d_l1_scale = nullptr;  // [1024 partial maxima | exponent, unit value]
     float *d_dinv1_6f = nullptr;   // the same for level 1 (SpMV epilogue of the Chebyshev smoother)
     float *d_dinv6f = nullptr;     // FP32 copy of the six distinct entries of every fine inverse diagonal block (PCG update kernel)
     bool l2_has_inverse = false;
@@ -229,10 +233,16 @@ struct MatView {
     const double *vals;
     const int32_t *rownode;
     const float *vals32 = nullptr;  // optional FP32 copy of the values (coarse multigrid level)
+    // optional 16-bit block-scaled copy (level 1, k_spmv_l1_i16): records per block pair, see fcvm_spmv_win.hip.h
+    const int4v *A16 = nullptr, *B16 = nullptr, *C16 = nullptr;
+    const int64_t *rp16 = nullptr;
+    const double *scale16 = nullptr;
 };
 static MatView fine_view(const fcvm_ctx *c) { return {c->pat.nslices, c->nb_spmv, c->d_sptr, c->d_cols, c->d_vals, c->d_rownode}; }
 static MatView coarse_view(const fcvm_ctx *c) {
-    return {c->pat1.nslices, c->nb_spmv1, c->d_sptr1, c->d_cols1, c->d_vals1, c->d_rownode1, c->mg_fp32 ? c->d_vals1f : nullptr};
+    MatView m{c->pat1.nslices, c->nb_spmv1, c->d_sptr1, c->d_cols1, c->d_vals1, c->d_rownode1, c->mg_fp32 ? c->d_vals1f : nullptr};
+    if (c->mg_l1_16 && c->d_l1A) { m.A16 = c->d_l1A; m.B16 = c->d_l1B; m.C16 = c->d_l1C; m.rp16 = c->d_rp16; m.scale16 = c->d_l1_scale + 1024; }
+    return m;
 }
 
 template <bool DOT, int WAVES, bool V2>
@@ -261,6 +271,11 @@ static void launch_spmv_t(fcvm_ctx *c, const MatView &m, const double *x, double
 }
 // SpMV t = A d fused with a Chebyshev smoother step on the same rows (see ChebEpi); nothing is written but epi's vectors
 static void launch_spmv_cheb(fcvm_ctx *c, const MatView &m, const double *x, const double *done, const ChebEpi &epi) {
+    if (m.A16) {   // level 1 on its 16-bit copy: 24 instead of 40 bytes per block
+        hipLaunchKernelGGL(k_spmv_l1_i16<1>, dim3((unsigned)m.nslices), dim3(64), 0, c->stream, m.nslices, m.rp16, m.A16, m.B16, m.C16, m.scale16,
+                           m.rownode, x, (double *)nullptr, done, epi);
+        return;
+    }
     dim3 grid((unsigned)m.nb), block(64 * c->spmv_spw);
     double *y = nullptr, *part = nullptr;
     if (m.vals32) FCVM_SPMV_LAUNCH(false, false, 4, float2, 1, m.vals32, epi);
@@ -671,6 +686,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_MG_ADDITIVE")) c->mg_additive = std::min(2, std::max(0, atoi(v)));
     if (const char *v = getenv("FCVM_MG_MAX_AGGREGATES")) c->mg_max_dense = std::max(8, atoi(v));
     if (const char *v = getenv("FCVM_MG_FP32")) c->mg_fp32 = atoi(v);
+    if (const char *v = getenv("FCVM_MG_L1_16")) c->mg_l1_16 = atoi(v);
     if (const char *v = getenv("FCVM_MG_ADD_W")) c->mg_add_w = atof(v);
     HCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
     c->stream = c->own;

@@ -747,4 +747,160 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_spmv_win_lo2(int64_t ngroups,
     }
 }
 
+// ---- level-1 matrix (sliced-ELL, tet4 on the corner nodes) in the same 16-bit block-scaled form ---------------------------------
+// The V-cycle streams the level-1 matrix 2 * K1S times per PCG iteration (six at 1 M tet10): 40 B per block in FP32, 24 B here.
+// One record per block PAIR and lane, three 16-byte vectors in separate arrays (coalesced over the lanes):
+//   A = block 0 components 0..7;  B = {block 0 component 8, block 1 components 0..6};
+//   C = {block 1 components 7, 8; exponents e0, e1 (int8); column nodes c0, c1 (int32)}
+// value = q * 2^(E + e - 15), E = exponent of the largest diagonal entry of the level-1 matrix.  A slice of odd length ends in a
+// record whose second block is empty (q = 0, column = the first block's).
+typedef int int4v __attribute__((ext_vector_type(4)));
+
+// thread = slot (slice, lane) of the level-1 pattern; walks the row's block pairs in the FP64 sliced-ELL array
+__global__ __launch_bounds__(256) void k_l1_to_i16(int64_t nslots, const int64_t *__restrict__ sptr, const int64_t *__restrict__ rp,
+                                                   const int32_t *__restrict__ cols, const double *__restrict__ vals,
+                                                   const double *__restrict__ scale, int4v *__restrict__ A, int4v *__restrict__ B,
+                                                   int4v *__restrict__ C) {
+    const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (slot >= nslots) return;
+    const int64_t s = slot >> 6, l = slot & 63;
+    const int64_t jb = sptr[s], len = sptr[s + 1] - jb;
+    const int e0 = (int)scale[0];
+    const int64_t P = (len + 1) >> 1;
+    for (int64_t p = 0; p < P; p++) {
+        short q[18];
+        int e[2], col[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int64_t j = 2 * p + h;
+            double v[9];
+            if (j < len) {
+                const bool single = (len & 1) && j == len - 1;
+                const int64_t unit = jb + (single ? j : (j & ~(int64_t)1));
+                const double *sp = vals + unit * 576 + (single ? l : 2 * l + (j & 1));
+                const int cs = single ? 64 : 128;
+#pragma unroll
+                for (int c = 0; c < 9; c++) v[c] = sp[c * cs];
+                col[h] = single ? cols[(jb + j) * 64 + l] : cols[(jb + (j & ~(int64_t)1)) * 64 + 2 * l + (j & 1)];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 9; c++) v[c] = 0.0;
+                col[h] = col[0];
+            }
+            double m = 0.0;
+#pragma unroll
+            for (int c = 0; c < 9; c++) m = fmax(m, fabs(v[c]));
+            int eb = -127;
+            if (m > 0.0) {
+                int ex;
+                (void)frexp(m, &ex);
+                eb = ex - e0;
+                eb = eb < -127 ? -127 : (eb > 127 ? 127 : eb);
+            }
+            e[h] = eb;
+            const int sh = 15 - (e0 + eb);
+#pragma unroll
+            for (int c = 0; c < 9; c++) {
+                double t = rint(ldexp(v[c], sh));
+                t = t > 32767.0 ? 32767.0 : (t < -32767.0 ? -32767.0 : t);
+                q[9 * h + c] = (short)(int)t;
+            }
+        }
+        auto pk = [](short a, short b) { return (int)((unsigned)(unsigned short)a | ((unsigned)(unsigned short)b << 16)); };
+        const int64_t at = (rp[s] + p) * 64 + l;
+        A[at] = int4v{pk(q[0], q[1]), pk(q[2], q[3]), pk(q[4], q[5]), pk(q[6], q[7])};
+        B[at] = int4v{pk(q[8], q[9]), pk(q[10], q[11]), pk(q[12], q[13]), pk(q[14], q[15])};
+        C[at] = int4v{pk(q[16], q[17]), (int)((unsigned)(unsigned char)(signed char)e[0] | ((unsigned)(unsigned char)(signed char)e[1] << 8)), col[0], col[1]};
+    }
+}
+
+struct L1Rec {
+    int4v a, b, c;
+};
+__device__ __forceinline__ void l1_load(L1Rec &t, const int4v *__restrict__ A, const int4v *__restrict__ B, const int4v *__restrict__ C, int64_t at) {
+    t.a = __builtin_nontemporal_load(A + at);
+    t.b = __builtin_nontemporal_load(B + at);
+    t.c = __builtin_nontemporal_load(C + at);
+}
+__device__ __forceinline__ float lo16(int w) { return (float)(int)(short)(w & 0xffff); }
+__device__ __forceinline__ float hi16(int w) { return (float)(w >> 16); }
+__device__ __forceinline__ void l1_gather(const double *__restrict__ x, int node, float sc, float &a0, float &a1, float &a2) {
+    const double *xa = x + 3 * (int64_t)node;
+    const int o = node & 1;
+    const double2 wv = *(const double2 *)(xa + o);
+    const double sv = xa[o ? 0 : 2];
+    a0 = (float)(o ? sv : wv.x) * sc; a1 = (float)(o ? wv.x : wv.y) * sc; a2 = (float)(o ? wv.y : sv) * sc;
+}
+__device__ __forceinline__ void l1_fma(const L1Rec &t, const double *__restrict__ x, float &y0, float &y1, float &y2) {
+    const int e0 = (int)(signed char)(t.c[1] & 0xff), e1 = (int)(signed char)((t.c[1] >> 8) & 0xff);
+    const float s0 = __builtin_bit_cast(float, (127 + (e0 < -126 ? -126 : e0)) << 23), s1 = __builtin_bit_cast(float, (127 + (e1 < -126 ? -126 : e1)) << 23);
+    float a0, a1, a2, b0, b1, b2;
+    l1_gather(x, t.c[2], s0, a0, a1, a2);
+    l1_gather(x, t.c[3], s1, b0, b1, b2);
+    y0 += win_dot3(lo16(t.a[0]), hi16(t.a[0]), lo16(t.a[1]), a0, a1, a2) + win_dot3(hi16(t.b[0]), lo16(t.b[1]), hi16(t.b[1]), b0, b1, b2);
+    y1 += win_dot3(hi16(t.a[1]), lo16(t.a[2]), hi16(t.a[2]), a0, a1, a2) + win_dot3(lo16(t.b[2]), hi16(t.b[2]), lo16(t.b[3]), b0, b1, b2);
+    y2 += win_dot3(lo16(t.a[3]), hi16(t.a[3]), lo16(t.b[0]), a0, a1, a2) + win_dot3(hi16(t.b[3]), lo16(t.c[0]), hi16(t.c[0]), b0, b1, b2);
+}
+
+// SpMV t = A1 d on the 16-bit copy with the Chebyshev smoother step of the row's node as epilogue (ChebEpi, as k_spmv<EPI = 1>);
+// EPI 0: y = A1 x.  One wavefront per slice, one row per lane, four records in flight.
+template <int EPI>
+__global__ __launch_bounds__(64) void k_spmv_l1_i16(int64_t nslices, const int64_t *__restrict__ rp, const int4v *__restrict__ A,
+                                                    const int4v *__restrict__ B, const int4v *__restrict__ C,
+                                                    const double *__restrict__ scale, const int32_t *__restrict__ rownode,
+                                                    const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ done,
+                                                    ChebEpi epi) {
+    if (done && *done != 0.0) return;
+    const int64_t b = blockIdx.x, nb = nslices;
+    const int64_t q = nb >> 3, r = nb & 7, xcd = b & 7;
+    const int64_t s = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int lane = threadIdx.x;
+    const int64_t p0 = rp[s], P = rp[s + 1] - p0;
+    float y0 = 0.f, y1 = 0.f, y2 = 0.f, z0 = 0.f, z1 = 0.f, z2 = 0.f, u0 = 0.f, u1 = 0.f, u2 = 0.f, w0 = 0.f, w1 = 0.f, w2 = 0.f;
+    int64_t at = p0 * 64 + lane, p = 0;
+    L1Rec ra, rb, rc, rd;
+    for (; p + 4 <= P; p += 4) {
+        l1_load(ra, A, B, C, at); l1_load(rb, A, B, C, at + 64); l1_load(rc, A, B, C, at + 128); l1_load(rd, A, B, C, at + 192);
+        l1_fma(ra, x, y0, y1, y2);
+        l1_fma(rb, x, z0, z1, z2);
+        l1_fma(rc, x, u0, u1, u2);
+        l1_fma(rd, x, w0, w1, w2);
+        at += 256;
+    }
+    for (; p < P; p++) {
+        l1_load(ra, A, B, C, at);
+        l1_fma(ra, x, y0, y1, y2);
+        at += 64;
+    }
+    const double is = scale[1];
+    const double t0 = is * (double)(y0 + z0 + u0 + w0), t1 = is * (double)(y1 + z1 + u1 + w1), t2 = is * (double)(y2 + z2 + u2 + w2);
+    const int node = rownode[s * 64 + lane];
+    if (node < 0) return;
+    const int64_t o = 3 * (int64_t)node;
+    if (EPI == 0) {
+        y[o] = t0; y[o + 1] = t1; y[o + 2] = t2;
+        return;
+    }
+    const double d0 = x[o], d1 = x[o + 1], d2 = x[o + 2];
+    const double r0 = epi.r[o] - t0, r1 = epi.r[o + 1] - t1, r2 = epi.r[o + 2] - t2;
+    epi.r[o] = r0; epi.r[o + 1] = r1; epi.r[o + 2] = r2;
+    double a0 = d0, a1 = d1, a2 = d2;
+    if (epi.update_d) {
+        double zz0, zz1, zz2;
+        if (epi.dinv6) {
+            const float2 *q2 = (const float2 *)(epi.dinv6 + 6 * (int64_t)node);
+            const float2 v0 = q2[0], v1 = q2[1], v2 = q2[2];   // xx xy | xz yy | yz zz
+            zz0 = (double)v0.x * r0 + (double)v0.y * r1 + (double)v1.x * r2;
+            zz1 = (double)v0.y * r0 + (double)v1.y * r1 + (double)v2.x * r2;
+            zz2 = (double)v1.x * r0 + (double)v2.x * r1 + (double)v2.y * r2;
+        } else {
+            apply_dinv(epi.dinv + (int64_t)node * 9, r0, r1, r2, zz0, zz1, zz2);
+        }
+        const double n0 = epi.cdd * d0 + epi.cdr * zz0, n1 = epi.cdd * d1 + epi.cdr * zz1, n2 = epi.cdd * d2 + epi.cdr * zz2;
+        epi.dout[o] = n0; epi.dout[o + 1] = n1; epi.dout[o + 2] = n2;
+        if (epi.add_dout) { a0 += n0; a1 += n1; a2 += n2; }
+    }
+    epi.x[o] += a0; epi.x[o + 1] += a1; epi.x[o + 2] += a2;
+}
+
 }  // namespace fcvm
