@@ -416,9 +416,13 @@ static int win_allow_lds(K kernel, size_t bytes) {
 }
 
 // Second storage of the fine matrix for the SpMV (WinPattern): built when every group's window fits the LDS twice per CU
-static int setup_window_format(fcvm_ctx *c, const double *nocoord) {
-    win_free(c->win);
-    if (!c->spmv_win || c->nn < 2048) return 0;
+// host part of the window format (pattern only, no GPU call): runs on a thread of its own beside the uploads of fcvm_set_mesh
+struct WinBuild {
+    bool built = false;
+    std::string err;
+};
+static void win_build_host(fcvm_ctx *c, const double *nocoord, WinBuild *res) {
+    if (!c->spmv_win || c->nn < 2048) return;
     int nt = (int)std::thread::hardware_concurrency();
     nt = std::min(std::max(nt, 1), 32);
     int64_t max_window = 3200;   // 2 x 24 B x (3200 + partial-result slots) < 160 KB: two workgroups per CU
@@ -440,11 +444,18 @@ static int setup_window_format(fcvm_ctx *c, const double *nocoord) {
         if (!built) {
             if (getenv("FCVM_VERBOSE")) fprintf(stderr, "fcvm: window format not used (largest window %lld nodes)\n", (long long)w.wmax);
             w = WinPattern();
-            return 0;
+            return;
         }
+        res->built = true;
     } catch (const std::exception &ex) {
-        return fail(std::string("fcvm_set_mesh (window format): ") + ex.what());
+        res->err = std::string("fcvm_set_mesh (window format): ") + ex.what();
     }
+}
+
+static int setup_window_format(fcvm_ctx *c, const WinBuild &res) {
+    if (!res.err.empty()) return fail(res.err);
+    if (!res.built) return 0;
+    WinPattern &w = c->win.pat;
     if (win_upload(c, c->win)) return 1;
     // the window kernel leaves one p.Ap partial per GROUP: more than the sliced-ELL kernel's one per workgroup when several
     // slices share a workgroup (FCVM_SPMV_SPW > 1) or when cut rows add virtual rows
@@ -836,6 +847,10 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     }
     c->ne = ne;
     c->nn = nn;
+    // the window format's host work (0.07 s at 1 M elements) beside the allocations and uploads below
+    WinBuild winres;
+    std::thread winthread(win_build_host, c, nocoord, &winres);
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{winthread};
     c->h_el = el;
     c->h_coord.assign(nocoord, nocoord + 3 * nn);
     c->h_fixmask.assign(nn, 0);
@@ -876,8 +891,9 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     c->nn = nn;
     if (build_asm_items(c)) return 1;
     lap("assembly work items");
-    if (setup_window_format(c, nocoord)) return 1;
-    lap("window format (build + upload)");
+    winthread.join();
+    if (setup_window_format(c, winres)) return 1;
+    lap("window format (rest of the build + upload)");
     c->h_morton.clear();
     c->h_morton.shrink_to_fit();
     if (!c->win.on && tune_matrix_placement(c)) return 1;

@@ -51,10 +51,10 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
     // node -> element incidence
     if (ne >= (int64_t(1) << 27)) throw std::runtime_error("more than 2^27 elements per device are not supported");
     std::vector<int64_t> &nptr = p.nptr;
-    std::vector<int32_t> &nel = p.nel;   // element << 4 | local node index, ascending element order per node
+    RawVec<int32_t> &nel = p.nel;   // element << 4 | local node index, ascending element order per node
     int nt = std::max(1, nthreads);
     nptr.assign(nn + 1, 0);
-    nel.assign(ne * npe, 0);
+    nel.resize(ne * npe);
     if (ne * npe < (int64_t)1 << 20 || nt == 1) {
         for (int64_t i = 0; i < ne * npe; i++) nptr[el[i] + 1]++;
         for (int64_t i = 0; i < nn; i++) nptr[i + 1] += nptr[i];
@@ -91,16 +91,18 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
         cbeg[t] = b;
         cend[t] = e;
         std::vector<int32_t> tmp;
+        std::vector<int32_t> stamp(nn, -1);   // row that last listed a node: the ~140 candidates of a row shrink to its ~28
+                                              // distinct neighbours before anything is sorted
         auto &out = chunks[t];
         for (int64_t i = b; i < e; i++) {
             tmp.clear();
             for (int64_t q = nptr[i]; q < nptr[i + 1]; q++) {
                 const int32_t *nd = el + (int64_t)(nel[q] >> 4) * npe;
-                tmp.insert(tmp.end(), nd, nd + npe);
+                for (int k = 0; k < npe; k++)
+                    if (stamp[nd[k]] != (int32_t)i) { stamp[nd[k]] = (int32_t)i; tmp.push_back(nd[k]); }
             }
             if (tmp.empty()) tmp.push_back((int32_t)i);  // isolated node: keep a diagonal block
             std::sort(tmp.begin(), tmp.end());
-            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
             len[i] = (int64_t)tmp.size();
             out.insert(out.end(), tmp.begin(), tmp.end());
         }
@@ -168,7 +170,7 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
     if ((uint64_t)p.sptr[p.nslices] >= (1ull << 30))
         throw std::runtime_error("matrix too large for the packed 32-bit block locations (2^30 half chunks)");
     lap("slice lengths");
-    p.cols.assign(p.nslots, 0);
+    p.cols.resize(p.nslots);      // every entry is written below
     parallel_for(p.nslices, nt, [&](int64_t b, int64_t e, int) {
         for (int64_t s = b; s < e; s++) {
             int64_t L = p.sptr[s + 1] - p.sptr[s];

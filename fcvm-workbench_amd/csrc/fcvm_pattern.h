@@ -2,6 +2,8 @@
 // the SpMV / assembly kernels use (see DESIGN.md "Matrix layout in HBM").
 #pragma once
 #include <cstdint>
+#include <memory>
+#include <utility>
 #include <vector>
 
 namespace fcvm {
@@ -15,6 +17,19 @@ constexpr int64_t HALF = 9 * SLICE;   // doubles of one block of all 64 lanes of
 // load per lane); if len is odd the last block stands alone, its components stored as 64 contiguous doubles each.
 // A slice occupies exactly len half chunks (HALF doubles each), starting at half chunk sptr[s]: no rounding of odd
 // lengths to pairs (round 2; 3.3 % of the matrix bytes on the cube meshes, whose row lengths 19 / 27 / 65 are all odd).
+// std::vector whose resize() leaves new elements uninitialised: the big index arrays (element map 400 MB, columns 160 MB at
+// 1 M elements) are written completely by the worker threads right after being sized, and value-initialising them first was a
+// single-threaded pass over all of it (and the first touch of every page by one thread)
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    template <class U, class... A> void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
+        else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using RawVec = std::vector<T, NoInitAlloc<T>>;
+
 struct Pattern {
     int64_t ne = 0, nn = 0;
     int npe = 10;           // nodes per element (10: tet10 fine level, 4: tet4 coarse level)
@@ -23,15 +38,15 @@ struct Pattern {
     int64_t nslots = 0;     // stored block slots (sum over slices of 64 * slice length)
     int64_t maxlen = 0;
     std::vector<int64_t> rowptr;    // [nn+1] CSR over nodes (sorted columns, diagonal included)
-    std::vector<int32_t> colidx;    // [nnzb]
+    RawVec<int32_t> colidx;         // [nnzb]
     std::vector<int64_t> sptr;      // [nslices+1] cumulative slice lengths (blocks per lane) = first half chunk of a slice
     std::vector<int32_t> rownode;   // [nslices*64] node of slot, -1 = padding
     std::vector<int32_t> slotof;    // [nn] slot (slice*64+lane) of node
-    std::vector<int32_t> cols;      // [sptr[nslices]*64] column nodes: see col_index
-    std::vector<uint32_t> emap;     // [ne*npe*npe] packed location of element block (a,b), see pack_offset
+    RawVec<int32_t> cols;           // [sptr[nslices]*64] column nodes: see col_index
+    RawVec<uint32_t> emap;          // [ne*npe*npe] packed location of element block (a,b), see pack_offset
     std::vector<uint64_t> diagoff;  // [nn] location of the diagonal block of a node, see abs_offset
     std::vector<int64_t> nptr;      // [nn+1] node -> element incidence (CSR)
-    std::vector<int32_t> nel;       // [ne*npe] element << 4 | local node index, ascending elements per node
+    RawVec<int32_t> nel;            // [ne*npe] element << 4 | local node index, ascending elements per node
 
     inline int64_t slice_len(int64_t s) const { return sptr[s + 1] - sptr[s]; }
     inline bool is_single(int64_t s, int64_t j) const { const int64_t len = slice_len(s); return (len & 1) && j == len - 1; }
