@@ -1388,7 +1388,7 @@ int fcvm_vec_wdot_dev(fcvm_ctx *c, int64_t n, const double *w, const double *x, 
     return dot_common(c, n, w, x, y, result_dev);
 }
 int fcvm_dist_pcg_scalars(fcvm_ctx *c, int phase, double *S, const double *in) {
-    NEED(c && S && in && (phase == 0 || phase == 1), "fcvm_dist_pcg_scalars: bad arguments");
+    NEED(c && S && in && phase >= 0 && phase <= 3, "fcvm_dist_pcg_scalars: bad arguments");
     hipLaunchKernelGGL(k_dist_pcg_scalars, dim3(1), dim3(1), 0, c->stream, phase, S, in);
     HCHK(hipGetLastError());
     return 0;

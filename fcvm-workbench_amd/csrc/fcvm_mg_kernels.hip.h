@@ -561,6 +561,31 @@ __global__ __launch_bounds__(256) void k_add_if(int64_t n, const double *__restr
 // (all-reduced) -> beta, rz, rr, iterations, done.  After convergence (done != 0) alpha = beta = 0: queued iterations change
 // nothing.  One thread: this replaces a dozen one-element tensor operations per iteration.
 __global__ void k_dist_pcg_scalars(int phase, double *__restrict__ S, const double *__restrict__ in) {
+    // phases 2 / 3: the single-reduction (Chronopoulos-Gear) loop, in = {r.z, w.z, r.r} with w = K z (all-reduced).
+    // 3 = start (S[2] = threshold set by the host): alpha = gamma / delta, beta = 0.  2 = after x += alpha p, r -= alpha s:
+    // iteration count, convergence, then beta = gamma_new / gamma, alpha = gamma_new / (delta - beta gamma_new / alpha).
+    if (phase == 3) {
+        S[0] = in[0]; S[1] = in[2]; S[3] = 0.0; S[4] = 0.0;
+        S[5] = in[1] != 0.0 ? in[0] / in[1] : 0.0;
+        S[6] = 0.0;
+        return;
+    }
+    if (phase == 2) {
+        const double gn = in[0], delta = in[1], rrn = in[2];
+        if (S[3] == 0.0) {
+            S[4] += 1.0;
+            S[1] = rrn;
+            if (rrn <= S[2] || !isfinite(rrn)) S[3] = 1.0;
+        }
+        const bool go = S[3] == 0.0;
+        const double beta = (go && S[0] != 0.0) ? gn / S[0] : 0.0;
+        const double den = delta - beta * gn / (S[5] != 0.0 ? S[5] : 1.0);
+        const double alpha = (go && den != 0.0 && S[5] != 0.0) ? gn / den : 0.0;
+        if (go) S[0] = gn;
+        S[5] = alpha;
+        S[6] = beta;
+        return;
+    }
     const bool live = S[3] == 0.0;
     if (phase == 0) {
         const double pq = in[0];

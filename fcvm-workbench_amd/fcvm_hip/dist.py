@@ -122,6 +122,7 @@ class Exchanger:
         self.ops = ops if (ops is not None and hasattr(ops, "pack")) else None
         self.ranks = sorted(s for s, ix in shared.items() if len(ix))
         self.count = None      # dict with an "exchanges" entry (DistBackend.comm): every call is counted, with or without neighbours
+        self._bufs = {}        # (ncomp, dtype, device, staged) -> send buffer, staged send, receive buffer, P2P op list
         self.offs, rows = {}, 0
         for s in self.ranks:
             self.offs[s] = (rows, rows + len(shared[s]))
@@ -158,21 +159,29 @@ class Exchanger:
             self.count["exchanges"] += 1
         if p.world == 1 or not self.ranks:
             return t
-        send = torch.empty(self.rows * ncomp, dtype=t.dtype, device=t.device)
+        # gloo has no GPU point-to-point: stage through the host there (CPU tests / shared-GPU rehearsal);
+        # with nccl (= RCCL) the buffers go GPU to GPU over xGMI
+        stage = t.is_cuda and dist.get_backend(p.group) == "gloo"
+        key = (ncomp, t.dtype, t.device, stage)
+        cached = self._bufs.get(key)
+        if cached is None:     # send / receive buffers and the point-to-point op list are built once per vector shape and reused:
+                               # an exchange happens ten times per PCG iteration and its host-side cost is on the critical path
+            send = torch.empty(self.rows * ncomp, dtype=t.dtype, device=t.device)
+            sbuf = torch.empty(self.rows * ncomp, dtype=t.dtype) if stage else send
+            rbuf = torch.empty_like(sbuf)
+            ops = []
+            for s in self.ranks:
+                a, b = self.offs[s]
+                ops.append(dist.P2POp(dist.isend, sbuf[a * ncomp:b * ncomp], s, group=p.group))
+                ops.append(dist.P2POp(dist.irecv, rbuf[a * ncomp:b * ncomp], s, group=p.group))
+            cached = self._bufs[key] = (send, sbuf, rbuf, ops)
+        send, sbuf, rbuf, ops = cached
         if self.ops is not None and t.is_cuda:
             self.ops.pack(self.idx_all, ncomp, t, send)
         else:
             send.copy_(t.view(self.nn, ncomp).index_select(0, self.idx_all).reshape(-1))
-        # gloo has no GPU point-to-point: stage through the host there (CPU tests / shared-GPU rehearsal);
-        # with nccl (= RCCL) the buffers go GPU to GPU over xGMI
-        stage = t.is_cuda and dist.get_backend(p.group) == "gloo"
-        sbuf = send.cpu() if stage else send
-        rbuf = torch.empty_like(sbuf)
-        ops = []
-        for s in self.ranks:
-            a, b = self.offs[s]
-            ops.append(dist.P2POp(dist.isend, sbuf[a * ncomp:b * ncomp], s, group=p.group))
-            ops.append(dist.P2POp(dist.irecv, rbuf[a * ncomp:b * ncomp], s, group=p.group))
+        if stage:
+            sbuf.copy_(send)
         for w in dist.batch_isend_irecv(ops):
             w.wait()
         recv = rbuf.to(t.device) if stage else rbuf
@@ -520,15 +529,44 @@ class DistBackend:
         if not np.isfinite(bb_h):
             raise RuntimeError("distributed PCG: non-finite right-hand side")
         thresh = torch.full((1,), rtol * rtol * bb_h, dtype=torch.float64, device=dev)
-        zero, one = torch.zeros(1, dtype=torch.float64, device=dev), torch.ones(1, dtype=torch.float64, device=dev)
-        done = torch.zeros(1, dtype=torch.bool, device=dev)
-        it_t = torch.zeros(1, dtype=torch.float64, device=dev)
-        rr = bb.clone()
-        alpha = torch.where(delta != 0.0, gamma / torch.where(delta != 0.0, delta, one), zero)
         p, sv = TVec(z.t.clone()), TVec(w.t.clone())
         fused = self.mg is not None and self.mg.ready and self.mg.fused
         queued, chunk, spmvs, finished = 0, 1, 1, False
-        while queued < maxit and not finished:
+        dev_scalars = hasattr(self.ops, "pcg_scalars")
+        if dev_scalars:
+            # scalars on the device, one single-thread kernel per iteration (fcvm_dist_pcg_scalars phases 3 / 2) instead of the
+            # fifteen one-element tensor operations of the loop below
+            S = torch.zeros(7, dtype=torch.float64, device=dev)       # gamma, rr, thresh, done, iterations, alpha, beta
+            S[2] = rtol * rtol * bb_h
+            self.ops.pcg_scalars(3, S, g3)
+            alpha, beta = S[5:6], S[6:7]
+            while queued < maxit and not finished:
+                n = min(chunk, maxit - queued)
+                for _ in range(n):
+                    if fused:
+                        self.mg.update_and_vcycle(alpha, p, sv, TVec(x), TVec(r), z)
+                    else:
+                        x.addcmul_(p.t, alpha)
+                        r.addcmul_(sv.t, -alpha)
+                        self.precond(TVec(r), z)
+                    self.spmv(z, w)
+                    spmvs += 1
+                    self.ops.pcg_scalars(2, S, self.dot3_t(r, z.t, w.t))
+                    torch.addcmul(z.t, p.t, beta, out=p.t)       # p = z + beta p
+                    torch.addcmul(w.t, sv.t, beta, out=sv.t)     # s = w + beta s   (= K p)
+                queued += n
+                chunk = min(self.check_every, 2 * chunk) if queued >= 2 else 1
+                finished = bool(S[3].item() != 0.0)
+                self.comm["host_syncs"] += 1
+            Sh = S.cpu()
+            rr, it_t = Sh[1:2], Sh[4:5]
+        else:
+            zero, one = torch.zeros(1, dtype=torch.float64, device=dev), torch.ones(1, dtype=torch.float64, device=dev)
+            done = torch.zeros(1, dtype=torch.bool, device=dev)
+            it_t = torch.zeros(1, dtype=torch.float64, device=dev)
+            rr = bb.clone()
+            alpha = torch.where(delta != 0.0, gamma / torch.where(delta != 0.0, delta, one), zero)
+        while not dev_scalars and queued < maxit and not finished:
             n = min(chunk, maxit - queued)
             for _ in range(n):
                 if fused:

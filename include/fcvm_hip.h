@@ -162,6 +162,8 @@ int fcvm_vec_wdot_dev(fcvm_ctx *c, int64_t n, const double *w, const double *x, 
  * phase 0: in [dev, 1] = p.q -> alpha; phase 1: in [dev, 2] = {r.z, r.r} -> beta, rz, rr, iterations, done (alpha = beta = 0 once
  * done): one launch instead of a dozen one-element tensor operations per iteration */
 int fcvm_dist_pcg_scalars(fcvm_ctx *c, int phase, double *S, const double *in);
+/* (phases 2 / 3: the single-reduction CG of round 3, in [dev, 3] = {r.z, w.z, r.r} with w = K z -- 3 starts the loop (S[2] =
+ * threshold set by the caller), 2 follows every update: iteration count, convergence flag, beta and the next alpha) */
 /* *result_host = 1 if any of the n bytes at a (device) is non-zero (the "any plastic Gauss point?" test of fcVM.py:1351) */
 int fcvm_any_u8(fcvm_ctx *c, int64_t n, const uint8_t *a, int *result_host);
 int fcvm_vec_max_node_norm(fcvm_ctx *c, int64_t nnodes, const double *u, double *result_host);
