@@ -122,7 +122,7 @@ class Exchanger:
         self.ops = ops if (ops is not None and hasattr(ops, "pack")) else None
         self.ranks = sorted(s for s, ix in shared.items() if len(ix))
         self.count = None      # dict with an "exchanges" entry (DistBackend.comm): every call is counted, with or without neighbours
-        self._bufs = {}        # (ncomp, dtype, device, staged) -> send buffer, staged send, receive buffer, P2P op list
+        self._bufs = {}        # (ncomp, dtype, device, staged) -> send buffer, staged send, receive buffer
         self.offs, rows = {}, 0
         for s in self.ranks:
             self.offs[s] = (rows, rows + len(shared[s]))
@@ -164,18 +164,19 @@ class Exchanger:
         stage = t.is_cuda and dist.get_backend(p.group) == "gloo"
         key = (ncomp, t.dtype, t.device, stage)
         cached = self._bufs.get(key)
-        if cached is None:     # send / receive buffers and the point-to-point op list are built once per vector shape and reused:
-                               # an exchange happens ten times per PCG iteration and its host-side cost is on the critical path
+        if cached is None:     # send / receive buffers are allocated once per vector shape and reused: an exchange happens ten times
+                               # per PCG iteration and its host-side cost is on the critical path.  (The P2POp list is rebuilt every
+                               # time: cached ops keep the process group alive past destroy_process_group and a rank aborted at exit.)
             send = torch.empty(self.rows * ncomp, dtype=t.dtype, device=t.device)
             sbuf = torch.empty(self.rows * ncomp, dtype=t.dtype) if stage else send
             rbuf = torch.empty_like(sbuf)
-            ops = []
-            for s in self.ranks:
-                a, b = self.offs[s]
-                ops.append(dist.P2POp(dist.isend, sbuf[a * ncomp:b * ncomp], s, group=p.group))
-                ops.append(dist.P2POp(dist.irecv, rbuf[a * ncomp:b * ncomp], s, group=p.group))
-            cached = self._bufs[key] = (send, sbuf, rbuf, ops)
-        send, sbuf, rbuf, ops = cached
+            cached = self._bufs[key] = (send, sbuf, rbuf)
+        send, sbuf, rbuf = cached
+        ops = []
+        for s in self.ranks:
+            a, b = self.offs[s]
+            ops.append(dist.P2POp(dist.isend, sbuf[a * ncomp:b * ncomp], s, group=p.group))
+            ops.append(dist.P2POp(dist.irecv, rbuf[a * ncomp:b * ncomp], s, group=p.group))
         if self.ops is not None and t.is_cuda:
             self.ops.pack(self.idx_all, ncomp, t, send)
         else:
