@@ -194,11 +194,15 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
         }
         __syncthreads();   // one wavefront: orders the LDS records of the quad before they are read
         // ---- blocks K_ab, b = h, h + 4, h + 8, Gauss points outermost ----
-        double M[3][9];
+        double M[3][9], Pl[TANGENT ? 3 : 1][9];   // Pl: plastic part of the tangent blocks
 #pragma unroll
         for (int t = 0; t < 3; t++)
 #pragma unroll
             for (int k = 0; k < 9; k++) M[t][k] = 0.0;
+#pragma unroll
+        for (int t = 0; t < (TANGENT ? 3 : 1); t++)
+#pragma unroll
+            for (int k = 0; k < 9; k++) Pl[t][k] = 0.0;
         double gam = 0.0, vol = 0.0;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -233,28 +237,27 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                 const double *db = reload_each_time<ASM_RELOAD_DB>(tab + 30 * g + 3 * b);
                 double gb[3];
                 to_global(xsi, db[0], db[1], db[2], gb[0], gb[1], gb[2]);
-                if (!TANGENT) {
-                    // constant D over the Gauss points: only M = sum_g w_g ga_g gb_g^T is integrated, D is applied below
+                {   // M = sum_g w_g ga_g gb_g^T; the constant elastic D is applied once after the loop
                     const double a0 = wg_ * ga[0], a1 = wg_ * ga[1], a2 = wg_ * ga[2];
                     M[t][0] += a0 * gb[0]; M[t][1] += a0 * gb[1]; M[t][2] += a0 * gb[2];
                     M[t][3] += a1 * gb[0]; M[t][4] += a1 * gb[1]; M[t][5] += a1 * gb[2];
                     M[t][6] += a2 * gb[0]; M[t][7] += a2 * gb[1]; M[t][8] += a2 * gb[2];
-                } else {
-                    const double dot = ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2];
-                    double tb[3];
-                    tb[0] = gb[0] * Sg[0] + gb[1] * Sg[3] + gb[2] * Sg[4];
-                    tb[1] = gb[1] * Sg[1] + gb[0] * Sg[3] + gb[2] * Sg[5];
-                    tb[2] = gb[2] * Sg[2] + gb[0] * Sg[4] + gb[1] * Sg[5];
-#pragma unroll
-                    for (int r = 0; r < 3; r++)
-#pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            double val;
-                            if (r == c) val = mc.D11 * ga[r] * gb[r] + mc.D44 * (dot - ga[r] * gb[r]);
-                            else val = mc.D12 * ga[r] * gb[c] + mc.D44 * ga[c] * gb[r];
-                            val -= pf * ta[r] * tb[c];
-                            M[t][r * 3 + c] += wg_ * val;
-                        }
+                }
+                if (TANGENT) {
+                    // D_t = D - pf s s^T per Gauss point: the elastic part went through M, the plastic part is the rank-one
+                    // update (B_a^T s)(s^T B_b) -- 9 + 12 multiply-adds per Gauss point and block instead of the ~100 flops of
+                    // evaluating B_a^T D_t B_b entry by entry (round 3: the tangent form's corner-node class took 7.5 ms per
+                    // refresh at 1 M elements against 4.2 ms of the elastic form)
+                    if (pf != 0.0) {   // (same for the whole quad: the Gauss point is the element's)
+                        double tb[3];
+                        tb[0] = gb[0] * Sg[0] + gb[1] * Sg[3] + gb[2] * Sg[4];
+                        tb[1] = gb[1] * Sg[1] + gb[0] * Sg[3] + gb[2] * Sg[5];
+                        tb[2] = gb[2] * Sg[2] + gb[0] * Sg[4] + gb[1] * Sg[5];
+                        const double p0 = wg_ * pf * ta[0], p1 = wg_ * pf * ta[1], p2 = wg_ * pf * ta[2];
+                        Pl[t][0] += p0 * tb[0]; Pl[t][1] += p0 * tb[1]; Pl[t][2] += p0 * tb[2];
+                        Pl[t][3] += p1 * tb[0]; Pl[t][4] += p1 * tb[1]; Pl[t][5] += p1 * tb[2];
+                        Pl[t][6] += p2 * tb[0]; Pl[t][7] += p2 * tb[1]; Pl[t][8] += p2 * tb[2];
+                    }
                 }
             }
         }
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
             const int b = h + 4 * t;
             if (active && b < 10) {
                 double K[9];
-                if (!TANGENT) {   // K = D12 M + D44 M^T + (D11 - D12 - D44) diag(M) + D44 tr(M) I (fcVM.py:769-771 regrouped)
+                {   // K = D12 M + D44 M^T + (D11 - D12 - D44) diag(M) + D44 tr(M) I (fcVM.py:769-771 regrouped)
                     const double tr = M[t][0] + M[t][4] + M[t][8];
 #pragma unroll
                     for (int r = 0; r < 3; r++)
@@ -275,9 +278,10 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                         for (int c = 0; c < 3; c++)
                             K[r * 3 + c] = (r == c) ? mc.D11 * M[t][r * 3 + r] + mc.D44 * (tr - M[t][r * 3 + r])
                                                     : mc.D12 * M[t][r * 3 + c] + mc.D44 * M[t][c * 3 + r];
-                } else {
+                }
+                if (TANGENT) {   // minus the plastic part sum_g w_g pf_g (B_a^T s_g)(s_g^T B_b)  (fcVM.py:983-998)
 #pragma unroll
-                    for (int k = 0; k < 9; k++) K[k] = M[t][k];
+                    for (int k = 0; k < 9; k++) K[k] -= Pl[t][k];
                 }
                 // boundary conditions folded in (fcVM.py:773-800) and accumulation into the row's LDS image
                 const uint32_t em = G0.em[t];
