@@ -272,8 +272,15 @@ static void launch_spmv_t(fcvm_ctx *c, const MatView &m, const double *x, double
 // SpMV t = A d fused with a Chebyshev smoother step on the same rows (see ChebEpi); nothing is written but epi's vectors
 static void launch_spmv_cheb(fcvm_ctx *c, const MatView &m, const double *x, const double *done, const ChebEpi &epi) {
     if (m.A16) {   // level 1 on its 16-bit copy: 24 instead of 40 bytes per block
-        hipLaunchKernelGGL(k_spmv_l1_i16<1>, dim3((unsigned)m.nslices), dim3(64), 0, c->stream, m.nslices, m.rp16, m.A16, m.B16, m.C16, m.scale16,
-                           m.rownode, x, (double *)nullptr, done, epi);
+        // plain loads by default: the level-1 matrix (tens of MB) is read six times per V-cycle and stays in the memory-side cache
+        // between those passes (1 M plate: 24.1 -> 21.2 us per pass, gpurun_out/r03ag); FCVM_L1_NT=1: nontemporal loads
+        static const bool nt = getenv("FCVM_L1_NT") && atoi(getenv("FCVM_L1_NT")) != 0;
+        if (nt)
+            hipLaunchKernelGGL((k_spmv_l1_i16<1, true>), dim3((unsigned)m.nslices), dim3(64), 0, c->stream, m.nslices, m.rp16, m.A16, m.B16, m.C16,
+                               m.scale16, m.rownode, x, (double *)nullptr, done, epi);
+        else
+            hipLaunchKernelGGL((k_spmv_l1_i16<1, false>), dim3((unsigned)m.nslices), dim3(64), 0, c->stream, m.nslices, m.rp16, m.A16, m.B16, m.C16,
+                               m.scale16, m.rownode, x, (double *)nullptr, done, epi);
         return;
     }
     dim3 grid((unsigned)m.nb), block(64 * c->spmv_spw);
@@ -819,6 +826,7 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
         NEED(v >= 0 && v < nn, "fcvm_set_mesh: element node number out of range (expected 1..nn)");
         el[i] = (int32_t)v;
     }
+    bool emap_host = false;
     try {
         int nt = (int)std::thread::hardware_concurrency();
         if (nt < 1) nt = 1;
@@ -840,7 +848,9 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
         c->h_morton = order;      // (the window format walks the same curve)
         lap("Morton order");
         c->row_order_morton = use_morton;
-        build_pattern(ne, nn, el.data(), c->pat, nt, win, 10, use_morton ? order.data() : nullptr);
+        // the element map is filled on the device below unless FCVM_EMAP_HOST=1 asks for the host's
+        emap_host = getenv("FCVM_EMAP_HOST") && atoi(getenv("FCVM_EMAP_HOST")) != 0;
+        build_pattern(ne, nn, el.data(), c->pat, nt, win, 10, use_morton ? order.data() : nullptr, emap_host);
         lap("sliced-ELL pattern (total)");
     } catch (const std::exception &ex) {
         return fail(std::string("fcvm_set_mesh: ") + ex.what());
@@ -877,7 +887,15 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     HCHK(hipMemcpyAsync(c->d_rownode, p.rownode.data(), sizeof(int32_t) * p.nslices * SLICE, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_noce, noce.data(), sizeof(int32_t) * nn, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_sptr, p.sptr.data(), sizeof(int64_t) * (p.nslices + 1), hipMemcpyHostToDevice, s));
-    HCHK(hipMemcpyAsync(c->d_emap, p.emap.data(), sizeof(uint32_t) * ne * 100, hipMemcpyHostToDevice, s));
+    int32_t *d_slotof = nullptr;
+    if (emap_host) {
+        HCHK(hipMemcpyAsync(c->d_emap, p.emap.data(), sizeof(uint32_t) * ne * 100, hipMemcpyHostToDevice, s));
+    } else {   // (after d_el, d_cols and d_sptr above, in stream order)
+        if (dalloc(&d_slotof, nn)) return 1;
+        HCHK(hipMemcpyAsync(d_slotof, p.slotof.data(), sizeof(int32_t) * nn, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_build_emap, dim3((unsigned)cdiv(ne * 10, 256)), dim3(256), 0, s, ne, c->d_el, d_slotof, c->d_sptr, c->d_cols, c->d_emap);
+        HCHK(hipGetLastError());
+    }
     HCHK(hipMemcpyAsync(c->d_diagoff, p.diagoff.data(), sizeof(uint64_t) * nn, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_nptr, p.nptr.data(), sizeof(int64_t) * (nn + 1), hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_nel, p.nel.data(), sizeof(int32_t) * ne * 10, hipMemcpyHostToDevice, s));
@@ -886,6 +904,7 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     HCHK(hipMemsetAsync(c->d_fixval, 0, sizeof(double) * nn * 3, s));
     HCHK(hipMemsetAsync(c->d_vals, 0, sizeof(double) * p.value_count(), s));
     HCHK(hipStreamSynchronize(s));
+    dfree(d_slotof);
     lap("allocation, upload");
     c->ne = ne;
     c->nn = nn;
@@ -1486,6 +1505,31 @@ int fcvm_host_window_check(int64_t ne, int64_t nn, const int64_t *elNodes, const
             if (w.wlist[i] <= w.wlist[i - 1]) bad++;                          // ascending, unique
     if (rows < nn || blocks != p.nnzb || w.nblocks < p.nnzb || w.nblocks >= p.nnzb + 16 * w.nwaves) bad++;
     out[1] = w.ngroups; out[3] = (int64_t)(w.wmean + 0.5); out[4] = bad; out[5] = w.nblocks; out[6] = p.nnzb; out[7] = p.nslots;
+    return 0;
+}
+
+int fcvm_check_device_emap(fcvm_ctx *c, int64_t out[2]) {
+    // the element map on the device (k_build_emap, or the uploaded host map under FCVM_EMAP_HOST=1) against the host
+    // builder's rule: block (a, b) of element e is block lower_bound(columns of row el[e][a], el[e][b]) of that row
+    NEED(c && c->have_mesh && out, "fcvm_check_device_emap: no mesh");
+    HCHK(hipSetDevice(c->device));
+    const Pattern &p = c->pat;
+    const int64_t ne = c->ne;
+    std::vector<uint32_t> dev(ne * 100);
+    HCHK(hipStreamSynchronize(c->stream));
+    HCHK(hipMemcpy(dev.data(), c->d_emap, sizeof(uint32_t) * ne * 100, hipMemcpyDeviceToHost));
+    int64_t bad = 0;
+    for (int64_t e = 0; e < ne; e++)
+        for (int a = 0; a < 10; a++) {
+            const int32_t i = c->h_el[e * 10 + a];
+            const int32_t *rb = p.colidx.data() + p.rowptr[i], *re = p.colidx.data() + p.rowptr[i + 1];
+            for (int b = 0; b < 10; b++) {
+                const int32_t *at = std::lower_bound(rb, re, c->h_el[e * 10 + b]);
+                if (at == re || *at != c->h_el[e * 10 + b] || dev[(e * 10 + a) * 10 + b] != p.pack_offset(p.slotof[i], at - rb)) bad++;
+            }
+        }
+    out[0] = ne * 100;
+    out[1] = bad;
     return 0;
 }
 

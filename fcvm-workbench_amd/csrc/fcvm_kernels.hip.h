@@ -105,6 +105,42 @@ __device__ __forceinline__ int64_t unpack_offset(uint32_t em, int lane, int &str
     stride = single ? 64 : 128;
     return (int64_t)(em >> 2) * 576 + (single ? lane : 2 * lane + (int)((em >> 1) & 1u));
 }
+// Element map on the device (Pattern::emap, fcvm_pattern.cpp "element map"): one lane per (element, local row node a) walks the
+// column entries of that row in the sliced-ELL layout (Pattern::col_index) and notes, for each of the element's ten nodes, the
+// packed location (Pattern::pack_offset) of the block whose column it is.  Columns ascend and the padding behind a row's last
+// block repeats the row's own node, whose real entry comes earlier: the first hit is the block.  The rows of an element's
+// neighbours are read by all their elements -- L2 hits; at 1 M elements the kernel replaces 0.07 s of host searches and a
+// 400 MB upload.
+__global__ __launch_bounds__(256) void k_build_emap(int64_t ne, const int32_t *__restrict__ el, const int32_t *__restrict__ slotof,
+                                                    const int64_t *__restrict__ sptr, const int32_t *__restrict__ cols,
+                                                    uint32_t *__restrict__ emap) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ne * 10) return;
+    const int64_t e = t / 10;
+    int32_t nd[10];
+#pragma unroll
+    for (int b = 0; b < 10; b++) nd[b] = el[e * 10 + b];
+    const int32_t slot = slotof[el[t]];
+    const int64_t s = slot >> 6, l = slot & 63;
+    const int64_t p0 = sptr[s], L = sptr[s + 1] - p0;
+    const bool odd = L & 1;
+    uint32_t out[10];
+#pragma unroll
+    for (int b = 0; b < 10; b++) out[b] = 0xffffffffu;
+    int found = 0;
+    for (int64_t j = 0; j < L && found != 0x3ff; j++) {
+        const bool single = odd && j == L - 1;
+        const int64_t unit = p0 + (single ? j : (j & ~(int64_t)1));
+        const int32_t c = cols[single ? unit * 64 + l : unit * 64 + 2 * l + (j & 1)];
+        const uint32_t loc = (uint32_t)(((uint64_t)unit << 2) | (single ? 1u : (uint32_t)((j & 1) << 1)));
+#pragma unroll
+        for (int b = 0; b < 10; b++)
+            if (!((found >> b) & 1) && nd[b] == c) { out[b] = loc; found |= 1 << b; }
+    }
+#pragma unroll
+    for (int b = 0; b < 10; b++) emap[t * 10 + b] = out[b];
+}
+
 // the 64-bit form (Pattern::abs_offset: offset << 1 | single) of tables that are read without knowing the lane
 __device__ __forceinline__ int64_t unpack_abs(uint64_t loc, int &stride) {
     stride = (loc & 1ull) ? 64 : 128;

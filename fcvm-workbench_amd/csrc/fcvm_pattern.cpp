@@ -33,7 +33,7 @@ static void parallel_for(int64_t n, int nthreads, const std::function<void(int64
 }
 
 void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nthreads, int sort_window, int npe,
-                   const int32_t *row_order) {
+                   const int32_t *row_order, bool want_emap) {
     const bool timing = getenv("FCVM_PATTERN_TIMING") != nullptr;
     auto tprev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
@@ -188,8 +188,9 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
     // element block (a,b) -> offset of its component 0
     // walked by ROW node: the row's column list stays in the cache for the searches of all its elements (by element, every
     // one of the ten rows of an element was a cache miss: 0.096 -> see FCVM_PATTERN_TIMING)
-    p.emap.resize(ne * npe * npe);
-    parallel_for(nn, nt, [&](int64_t b, int64_t e, int) {
+    if (want_emap) p.emap.resize(ne * npe * npe);
+    else p.emap.clear();     // the caller fills the map on the device (k_build_emap)
+    if (want_emap) parallel_for(nn, nt, [&](int64_t b, int64_t e, int) {
         for (int64_t i = b; i < e; i++) {
             const int32_t *rb = p.colidx.data() + p.rowptr[i];
             const int32_t *re = p.colidx.data() + p.rowptr[i + 1];
@@ -216,11 +217,26 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *el, Pattern &p, int nt
 }
 
 std::vector<int32_t> morton_order(int64_t nn, const double *xyz) {
+    int nt = (int)std::thread::hardware_concurrency();
+    if (const char *v = getenv("FCVM_MORTON_THREADS")) nt = atoi(v);
+    nt = std::max(1, std::min(nt, 16));
+    if (nn < 262144) nt = 1;
+    auto on_chunks = [&](const std::function<void(int64_t, int64_t, int)> &fn) { parallel_for(nn, nt, fn, 0); };
+    std::vector<double> tlo(3 * nt, 1e300), thi(3 * nt, -1e300);
+    on_chunks([&](int64_t b, int64_t e, int t) {
+        double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+        for (int64_t i = b; i < e; i++)
+            for (int k = 0; k < 3; k++) {
+                l[k] = std::min(l[k], xyz[3 * i + k]);
+                h[k] = std::max(h[k], xyz[3 * i + k]);
+            }
+        for (int k = 0; k < 3; k++) { tlo[3 * t + k] = l[k]; thi[3 * t + k] = h[k]; }
+    });
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int64_t i = 0; i < nn; i++)
+    for (int t = 0; t < nt; t++)
         for (int k = 0; k < 3; k++) {
-            lo[k] = std::min(lo[k], xyz[3 * i + k]);
-            hi[k] = std::max(hi[k], xyz[3 * i + k]);
+            lo[k] = std::min(lo[k], tlo[3 * t + k]);
+            hi[k] = std::max(hi[k], thi[3 * t + k]);
         }
     auto spread = [](uint64_t v) {  // 21 bits -> every third bit
         v &= 0x1fffff;
@@ -231,34 +247,50 @@ std::vector<int32_t> morton_order(int64_t nn, const double *xyz) {
         v = (v | v << 2) & 0x1249249249249249ull;
         return v;
     };
-    std::vector<uint64_t> key(nn), key2(nn);
-    std::vector<int32_t> order(nn), order2(nn);
-    for (int64_t i = 0; i < nn; i++) {
-        uint64_t q[3];
-        for (int k = 0; k < 3; k++) {
-            double ext = hi[k] - lo[k];
-            q[k] = ext > 0 ? (uint64_t)((xyz[3 * i + k] - lo[k]) / ext * 2097151.0) : 0;
+    RawVec<uint64_t> key(nn), key2(nn);
+    RawVec<int32_t> order(nn), order2(nn);
+    on_chunks([&](int64_t b, int64_t e, int) {
+        for (int64_t i = b; i < e; i++) {
+            uint64_t q[3];
+            for (int k = 0; k < 3; k++) {
+                double ext = hi[k] - lo[k];
+                q[k] = ext > 0 ? (uint64_t)((xyz[3 * i + k] - lo[k]) / ext * 2097151.0) : 0;
+            }
+            key[i] = spread(q[0]) | spread(q[1]) << 1 | spread(q[2]) << 2;
+            order[i] = (int32_t)i;
         }
-        key[i] = spread(q[0]) | spread(q[1]) << 1 | spread(q[2]) << 2;
-        order[i] = (int32_t)i;
-    }
-    // stable LSD radix sort of the 63-bit keys (four passes of 16 bits): equal keys keep ascending node numbers, i.e. the
-    // order std::sort gave the (key, node) pairs before -- at a fifth of its time for 1.4 M nodes
-    std::vector<int64_t> cnt(65536 + 1);
-    for (int pass = 0; pass < 4; pass++) {
-        const int sh = 16 * pass;
+    });
+    // stable LSD radix sort of the 63-bit keys, six passes of 11 bits, every pass on all threads: per-thread digit counts over
+    // the thread's chunk, offsets by (digit, thread), scatter.  Equal keys keep ascending node numbers: the order
+    // std::sort gives the (key, node) pairs, whatever the thread count (round 3: 0.041 -> see FCVM_PATTERN_TIMING at 1.4 M nodes)
+    constexpr int BITS = 11, NB = 1 << BITS;
+    std::vector<int64_t> cnt((size_t)NB * nt);
+    for (int pass = 0; pass * BITS < 63; pass++) {
+        const int sh = BITS * pass;
         std::fill(cnt.begin(), cnt.end(), 0);
-        for (int64_t i = 0; i < nn; i++) cnt[((key[i] >> sh) & 0xffff) + 1]++;
-        for (int b = 0; b < 65536; b++) cnt[b + 1] += cnt[b];
-        for (int64_t i = 0; i < nn; i++) {
-            const int64_t at = cnt[(key[i] >> sh) & 0xffff]++;
-            key2[at] = key[i];
-            order2[at] = order[i];
-        }
+        on_chunks([&](int64_t b, int64_t e, int t) {
+            int64_t *c = cnt.data() + (size_t)t * NB;
+            for (int64_t i = b; i < e; i++) c[(key[i] >> sh) & (NB - 1)]++;
+        });
+        int64_t at = 0;
+        for (int d = 0; d < NB; d++)
+            for (int t = 0; t < nt; t++) {
+                const int64_t n = cnt[(size_t)t * NB + d];
+                cnt[(size_t)t * NB + d] = at;
+                at += n;
+            }
+        on_chunks([&](int64_t b, int64_t e, int t) {
+            int64_t *c = cnt.data() + (size_t)t * NB;
+            for (int64_t i = b; i < e; i++) {
+                const int64_t to = c[(key[i] >> sh) & (NB - 1)]++;
+                key2[to] = key[i];
+                order2[to] = order[i];
+            }
+        });
         key.swap(key2);
         order.swap(order2);
     }
-    return order;
+    return std::vector<int32_t>(order.begin(), order.end());
 }
 
 double numbering_spread(int64_t ne, int64_t nn, const int32_t *el, int npe) {

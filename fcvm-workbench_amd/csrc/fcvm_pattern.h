@@ -77,8 +77,10 @@ struct Pattern {
 };
 
 // elnodes0: 0-based int32 [ne*10].  Throws std::runtime_error on bad input.
+// want_emap = false leaves Pattern::emap empty: fcvm_set_mesh builds the fine level's map (400 MB at 1 M elements) on the
+// device from cols / sptr / slotof instead (k_build_emap; this function's map is the reference it is checked against).
 void build_pattern(int64_t ne, int64_t nn, const int32_t *elnodes0, Pattern &p, int nthreads,
-                   int sort_window = SORT_WINDOW, int npe = 10, const int32_t *row_order = nullptr);
+                   int sort_window = SORT_WINDOW, int npe = 10, const int32_t *row_order = nullptr, bool want_emap = true);
 
 // ---------------------------------------------------------------------------------------------------------------
 // Second storage of the same matrix for the SpMV alone ("window format", round 2).  The sliced-ELL layout above is what

@@ -817,10 +817,15 @@ __global__ __launch_bounds__(256) void k_l1_to_i16(int64_t nslots, const int64_t
 struct L1Rec {
     int4v a, b, c;
 };
+template <bool NT>
 __device__ __forceinline__ void l1_load(L1Rec &t, const int4v *__restrict__ A, const int4v *__restrict__ B, const int4v *__restrict__ C, int64_t at) {
-    t.a = __builtin_nontemporal_load(A + at);
-    t.b = __builtin_nontemporal_load(B + at);
-    t.c = __builtin_nontemporal_load(C + at);
+    if (NT) {
+        t.a = __builtin_nontemporal_load(A + at);
+        t.b = __builtin_nontemporal_load(B + at);
+        t.c = __builtin_nontemporal_load(C + at);
+    } else {   // plain loads: the level-1 matrix (tens of MB) may stay in the memory-side cache between the passes of one V-cycle
+        t.a = A[at]; t.b = B[at]; t.c = C[at];
+    }
 }
 __device__ __forceinline__ float lo16(int w) { return (float)(int)(short)(w & 0xffff); }
 __device__ __forceinline__ float hi16(int w) { return (float)(w >> 16); }
@@ -844,7 +849,7 @@ __device__ __forceinline__ void l1_fma(const L1Rec &t, const double *__restrict_
 
 // SpMV t = A1 d on the 16-bit copy with the Chebyshev smoother step of the row's node as epilogue (ChebEpi, as k_spmv<EPI = 1>);
 // EPI 0: y = A1 x.  One wavefront per slice, one row per lane, four records in flight.
-template <int EPI>
+template <int EPI, bool NT = true>
 __global__ __launch_bounds__(64) void k_spmv_l1_i16(int64_t nslices, const int64_t *__restrict__ rp, const int4v *__restrict__ A,
                                                     const int4v *__restrict__ B, const int4v *__restrict__ C,
                                                     const double *__restrict__ scale, const int32_t *__restrict__ rownode,
@@ -860,7 +865,7 @@ __global__ __launch_bounds__(64) void k_spmv_l1_i16(int64_t nslices, const int64
     int64_t at = p0 * 64 + lane, p = 0;
     L1Rec ra, rb, rc, rd;
     for (; p + 4 <= P; p += 4) {
-        l1_load(ra, A, B, C, at); l1_load(rb, A, B, C, at + 64); l1_load(rc, A, B, C, at + 128); l1_load(rd, A, B, C, at + 192);
+        l1_load<NT>(ra, A, B, C, at); l1_load<NT>(rb, A, B, C, at + 64); l1_load<NT>(rc, A, B, C, at + 128); l1_load<NT>(rd, A, B, C, at + 192);
         l1_fma(ra, x, y0, y1, y2);
         l1_fma(rb, x, z0, z1, z2);
         l1_fma(rc, x, u0, u1, u2);
@@ -868,7 +873,7 @@ __global__ __launch_bounds__(64) void k_spmv_l1_i16(int64_t nslices, const int64
         at += 256;
     }
     for (; p < P; p++) {
-        l1_load(ra, A, B, C, at);
+        l1_load<NT>(ra, A, B, C, at);
         l1_fma(ra, x, y0, y1, y2);
         at += 64;
     }

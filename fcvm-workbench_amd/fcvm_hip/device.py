@@ -171,6 +171,12 @@ class Context:
         return dict(nnz_blocks=out[0], padded_slots=out[1], slices=out[2], matrix_bytes=out[3],
                     max_row_blocks=out[4], ndof=out[5], spmv_variant=out[7])
 
+    def check_element_map(self):
+        """(entries, mismatches) of the device's element -> block-location map against the host builder's rule"""
+        out = (C.c_int64 * 2)()
+        call("fcvm_check_device_emap", self.h, out)
+        return int(out[0]), int(out[1])
+
     def mem_info(self):
         """(free, total) device memory in bytes"""
         out = (C.c_int64 * 2)()

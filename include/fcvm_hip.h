@@ -259,6 +259,12 @@ int fcvm_spd_inverse(fcvm_ctx *c, int64_t n, const double *src, double *dst);
  * out[1] = ms per pass.  The HBM rate this GPU delivers right now, to put a measured SpMV time into perspective. */
 int fcvm_membench(fcvm_ctx *c, int64_t nbytes, double out[2]);
 
+/* The element -> block-location map of the assembly kernels is built on the device by fcvm_set_mesh (k_build_emap; the host
+ * builder's map under FCVM_EMAP_HOST=1).  This compares it, entry by entry, with the host rule of fcvm_pattern.cpp:
+ * out[0] = entries, out[1] = mismatches (must be 0).  Replaces nothing in the reference (its scipy COO -> CSC conversion,
+ * fcVM.py:805-816, has no such table). */
+int fcvm_check_device_emap(fcvm_ctx *c, int64_t out[2]);
+
 /* host-only self check of the sparsity pattern builder (no GPU needed): out[0]=nnz blocks,
  * out[1]=padded slots, out[2]=slices, out[3]=max row length, out[4]=number of violated invariants
  * (must be 0), out[5]=value count, out[6]=sum of slice lengths */

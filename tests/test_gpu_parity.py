@@ -63,6 +63,34 @@ def test_assemble_matches_calcGSM(orc, n):
         assert Kg[dof].nnz == 1 or abs(Kg[dof]).sum() == d[dof]
 
 
+@pytest.mark.parametrize("host_map", [False, True])
+def test_element_map_built_on_the_device_equals_the_host_builders(monkeypatch, host_map, embankment):
+    """fcvm_set_mesh fills the element -> block-location table of the assembly kernels with k_build_emap; every entry must be what
+    fcvm_pattern.cpp's rule gives (and the uploaded host table under FCVM_EMAP_HOST=1 passes the same check): the structured
+    cube (caller's row order, odd slice lengths), the unstructured Embankment mesh (Morton row order) and a shuffled mesh
+    whose slices mix long and short rows."""
+    from fcvm_hip import meshgen
+    if host_map:
+        monkeypatch.setenv("FCVM_EMAP_HOST", "1")
+    from fcvm_hip import examples
+    g, _ = embankment
+    cases = [small_case(3), meshgen.cube_case(9, l=10.0, traction=(0.0, 0.0, -1.0)), dict(elNodes=g["elNodes"], nocoord=g["nocoord"]),
+             examples.embankment(refine=1)]
+    rng = np.random.default_rng(5)
+    c9 = meshgen.cube_case(9, l=10.0, traction=(0.0, 0.0, -1.0))
+    perm = rng.permutation(len(c9["nocoord"]))            # node i of the shuffled mesh = node perm[i] of the cube
+    inv = np.empty_like(perm); inv[perm] = np.arange(len(perm))
+    el = inv[np.asarray(c9["elNodes"]) - 1] + 1
+    cases.append(dict(elNodes=el[rng.permutation(len(el))], nocoord=np.asarray(c9["nocoord"])[perm]))
+    from fcvm_hip.device import Context
+    for case in cases:
+        ctx = Context(0)
+        ctx.set_mesh(np.asarray(case["elNodes"]), np.asarray(case["nocoord"], dtype=np.float64))
+        n, bad = ctx.check_element_map()
+        assert n == 100 * len(case["elNodes"]) and bad == 0
+        ctx.close()
+
+
 def _random_state(case, rng, scale):
     nn, ne = len(case["nocoord"]), len(case["elNodes"])
     du = rng.standard_normal(3 * nn) * scale
