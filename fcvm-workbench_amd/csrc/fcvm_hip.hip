@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 #include <string>
 #include <thread>
+#include <memory>
 #include <vector>
 
 #include "fcvm_kernels.hip.h"
@@ -80,6 +81,16 @@ struct MgAlt {
     double *sx = nullptr, *sr = nullptr, *sd = nullptr, *st = nullptr, *sr3 = nullptr, *se3 = nullptr;   // sparse aggregate level
 };
 
+// host half of the level-1 (tet4) topology, see mg_topology_host in fcvm_mg.inc
+struct TopoHost {
+    bool ok = false;
+    std::string err;
+    int64_t nc = 0;
+    std::vector<int32_t> c2f, el4, pa, pb, mids;
+    std::vector<int64_t> mptr;
+    Pattern pat1;
+};
+
 struct fcvm_ctx {
     int device = 0;
     hipStream_t own = nullptr, stream = nullptr;
@@ -137,6 +148,8 @@ struct fcvm_ctx {
     double last_spmv_timed = 0;
     // host copies needed to build the coarse level
     std::vector<int32_t> h_el;
+    std::unique_ptr<TopoHost> topo_host;   // host half of the level-1 topology, built on topo_thread since fcvm_set_mesh (fcvm_mg.inc)
+    std::thread topo_thread;
     std::vector<double> h_coord;
     std::vector<uint8_t> h_fixmask;
     std::vector<int32_t> h_c2f;   // level-1 node -> fine node
@@ -211,6 +224,21 @@ static void dfree(T *&p) {
     if (p) (void)hipFree(p);
     p = nullptr;
 }
+// FCVM_SETUP_TIMING=1: wall time of the stages of the one-time set-up (hierarchy, aggregate level), each closed by a stream
+// synchronisation -- off in ordinary runs
+struct SetupLap {
+    bool on;
+    hipStream_t s;
+    std::chrono::steady_clock::time_point t;
+    SetupLap(hipStream_t st) : on(getenv("FCVM_SETUP_TIMING") != nullptr), s(st), t(std::chrono::steady_clock::now()) {}
+    void operator()(const char *what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "fcvm set-up: %-44s %.4f s\n", what, std::chrono::duration<double>(n - t).count());
+        t = n;
+    }
+};
 static MatConst matconst(const fcvm_ctx *c, double Et_E) {
     MatConst m;
     // fcVM.py:570-582 hooke and fcVM.py:2229-2234
@@ -721,7 +749,10 @@ static void alt_free(fcvm_ctx *c) {
     a = MgAlt();
 }
 
+static void mg_topology_join(fcvm_ctx *c, bool discard);
+static void mg_topology_start(fcvm_ctx *c);
 static void free_mesh(fcvm_ctx *c) {
+    mg_topology_join(c, true);
     dfree(c->d_el); dfree(c->d_cols); dfree(c->d_rownode); dfree(c->d_noce); dfree(c->d_sptr);
     dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
     dfree(c->d_nptr); dfree(c->d_nel); dfree(c->d_fe); dfree(c->d_part_vol); dfree(c->d_asm_items);
@@ -864,6 +895,7 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     c->h_el = el;
     c->h_coord.assign(nocoord, nocoord + 3 * nn);
     c->h_fixmask.assign(nn, 0);
+    mg_topology_start(c);      // level 1 of the multigrid hierarchy needs the mesh only: its host work starts here (joined at the first assembly)
     const Pattern &p = c->pat;
     std::vector<int32_t> noce(nn, 0);  // fcVM.py:183-185
     for (int64_t i = 0; i < ne * 10; i++) noce[el[i]]++;
@@ -927,6 +959,7 @@ int fcvm_set_coords(fcvm_ctx *c, const double *nocoord) {
     NEED(c && c->have_mesh, "fcvm_set_coords: no mesh");
     HCHK(hipMemcpyAsync(c->d_coord, nocoord, sizeof(double) * c->nn * 3, hipMemcpyHostToDevice, c->stream));
     HCHK(hipStreamSynchronize(c->stream));
+    mg_topology_join(c, false);    // (the thread reads h_coord for the row order of level 1; the numbering it built stays valid)
     c->h_coord.assign(nocoord, nocoord + 3 * c->nn);
     c->mg_topo = false;
     return 0;
@@ -1088,11 +1121,15 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
         hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, s, c->d_part_vol, c->pat.nslices, c->d_out8);
     }
     HCHK(hipGetLastError());
+    SetupLap lap(s);
+    lap("assemble: kernels");
     if (refresh_precond(c)) return 1;
+    lap("assemble: diagonal blocks, window-format copy");
     if (c->precond_mode >= 1) {
         HCHK(hipStreamSynchronize(s));
         if (mg_setup(c, sig ? disp : nullptr, sig, pgp, Et_E, level1_early)) return 1;
     }
+    lap("assemble: multigrid set-up (total)");
     if (volume) {
         HCHK(hipMemcpyAsync(volume, c->d_out8, sizeof(double), hipMemcpyDeviceToHost, s));
     }

@@ -602,4 +602,20 @@ __global__ void k_dist_pcg_scalars(int phase, double *__restrict__ S, const doub
     if (S[1] <= S[2] || !isfinite(S[1])) S[3] = 1.0;
 }
 
+// Start vector of the power iterations (mg_estimate_lmax): entry i is what the host loop st = st * a + c, h[i] = f(st) gave --
+// the i + 1-fold affine map by repeated squaring, so that the smoother bounds (and everything downstream) stay bitwise what the
+// host-generated vector gave, without generating and uploading 34 MB per estimate.
+__global__ __launch_bounds__(256) void k_lcg_vector(int64_t n, double *__restrict__ v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t A = 1, C = 0, pa = 6364136223846793005ull, pc = 1442695040888963407ull;
+    for (uint64_t e = (uint64_t)i + 1; e; e >>= 1) {
+        if (e & 1) { A = pa * A; C = pa * C + pc; }
+        pc = pa * pc + pc;
+        pa = pa * pa;
+    }
+    const uint64_t st = A * 0x9E3779B97F4A7C15ull + C;
+    v[i] = (double)((st >> 11) & 0xFFFFF) / 1048576.0 - 0.5;
+}
+
 }  // namespace fcvm

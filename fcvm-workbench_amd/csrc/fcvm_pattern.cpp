@@ -14,9 +14,7 @@
 
 namespace fcvm {
 
-// min_parallel: below this many items the loop runs on the calling thread (items of the per-node loops are tiny; the window
-// format's items are whole groups of 512 rows: 3400 of them at 1 M elements, which the default threshold kept serial)
-static void parallel_for(int64_t n, int nthreads, const std::function<void(int64_t, int64_t, int)> &fn, int64_t min_parallel = 4096) {
+void parallel_for(int64_t n, int nthreads, const std::function<void(int64_t, int64_t, int)> &fn, int64_t min_parallel) {
     if (nthreads < 1) nthreads = 1;
     if (n < min_parallel || nthreads == 1) {
         fn(0, n, 0);

@@ -2,6 +2,7 @@
 // the SpMV / assembly kernels use (see DESIGN.md "Matrix layout in HBM").
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <utility>
 #include <vector>
@@ -29,6 +30,11 @@ struct NoInitAlloc : std::allocator<T> {
     }
 };
 template <class T> using RawVec = std::vector<T, NoInitAlloc<T>>;
+
+// fn(begin, end, thread) over [0, n) cut into one contiguous chunk per thread (the same cut for the same n and nthreads);
+// min_parallel: below this many items the loop runs on the calling thread (items of the per-node loops are tiny; the window
+// format's items are whole groups of 512 rows: 3400 of them at 1 M elements, which the default threshold kept serial)
+void parallel_for(int64_t n, int nthreads, const std::function<void(int64_t, int64_t, int)> &fn, int64_t min_parallel = 4096);
 
 struct Pattern {
     int64_t ne = 0, nn = 0;
