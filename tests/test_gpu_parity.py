@@ -511,7 +511,8 @@ def test_cube_analysis_matches_oracle(orc):
 def test_size_independent_properties(gpu_ctx, cells):
     """Properties that need no oracle, at sizes the CPU restatement would take minutes / hours for (55 = the mesh of
     the benchmark, 998,250 tet10): K symmetric (<x,Ky> = <y,Kx>), rigid translations in the null space of the
-    unconstrained K, elastic internal force == K du, PCG solution satisfies K u = f."""
+    unconstrained K, elastic internal force == K du, PCG solution satisfies K u = f; the element map built on the device equals
+    the host rule entry by entry."""
     from fcvm_hip import meshgen
     from fcvm_hip.loads import Loads
     from fcvm_hip.solver import GpuModel
@@ -520,6 +521,7 @@ def test_size_independent_properties(gpu_ctx, cells):
     m = GpuModel(el, xyz, mat, {}, Loads())
     c = m.ctx
     glv, modf, V, _ = m.calc_gsm((0.0, 0.0, -9.81))
+    assert c.check_element_map() == (100 * m.ne, 0)       # the device-built element map, every entry, also at 1 M elements
     assert V == pytest.approx(50.0 ** 3, rel=1e-12)
     assert glv.get().reshape(-1, 3)[:, 2].sum() == pytest.approx(-9.81 * 7.8e-6 * 50.0 ** 3, rel=1e-11)
     rng = np.random.default_rng(2)
