@@ -180,6 +180,54 @@ __global__ __launch_bounds__(256) void k_trinv_row(const double *__restrict__ M,
         for (int v = 0; v < 4; v++) out[(int64_t)(4 * ty + u) * ld + 4 * tx + v] = -o[u][v];
 }
 
+// X = L^-1 by recursive doubling over the block rows (round 3; k_trinv_row above walks the block rows one launch after the
+// other with i + 1 workgroups each -- 103 dependent launches at 6536 unknowns, 36 ms of a 65 ms inverse).  With the diagonal
+// tiles inverted (Linv of k_chol_diag), level l = 0, 1, .. joins the inverses of two adjacent aligned runs of h = 2^l block rows,
+//   [ L11  0  ]^-1   [ X11            0  ]
+//   [ L21 L22 ]    = [ -X22 L21 X11  X22 ],
+// in two launches for ALL pairs of the level: T = L21 X11 (k_trinv_t, written TRANSPOSED into the unused upper triangle of M:
+// tile (j, i) holds T_ij^T, so that the next launch walks it with unit stride in k) and X21 = -X22 T (k_trinv_x).  The last
+// pair of a level may have a shorter (or no) right half: nt need not be a power of two.  2 ceil(log2 nt) launches, every one
+// a grid of independent 64 x 64 tiles with the k-loops of tile_mac.
+// grid (h, h, pairs): left block jl = blockIdx.x, right block ir = blockIdx.y of pair blockIdx.z
+__global__ __launch_bounds__(256) void k_trinv_t(double *__restrict__ M, const double *__restrict__ Xm, int64_t ld, int nt, int h) {
+    __shared__ double sA[TK][TB + TPAD], sB[TK][TB + TPAD];
+    const int a = (int)blockIdx.z * 2 * h, j = a + (int)blockIdx.x, i = a + h + (int)blockIdx.y;
+    if (i >= nt) return;
+    // T_ij = sum_{m = j}^{a + h - 1} L_im X_mj (X11 is lower block-triangular: X_mj = 0 for m < j)
+    double acc[4][4] = {};
+    tile_mac<false, true>(acc, M + ((int64_t)i * TB) * ld + (int64_t)j * TB, ld, Xm + ((int64_t)j * TB) * ld + (int64_t)j * TB, ld, (a + h - j) * TB, sA, sB);
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    double *out = M + ((int64_t)j * TB) * ld + (int64_t)i * TB;    // tile (j, i): element (c, r) = T_ij(r, c)
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) out[(int64_t)(4 * tx + v) * ld + 4 * ty + u] = acc[u][v];
+}
+__global__ __launch_bounds__(256) void k_trinv_x(const double *__restrict__ M, double *__restrict__ Xm, int64_t ld, int nt, int h) {
+    __shared__ double sA[TK][TB + TPAD], sB[TK][TB + TPAD];
+    const int a = (int)blockIdx.z * 2 * h, j = a + (int)blockIdx.x, i = a + h + (int)blockIdx.y;
+    if (i >= nt) return;
+    // X_ij = - sum_{m = a + h}^{i} X_im T_mj : A(r, k) = X[i-row r][column (a + h) TB + k], B(c, k) = T_mj(k', c) = M[(j TB + c) ld + (a + h) TB + k]
+    double acc[4][4] = {};
+    tile_mac<false, false>(acc, Xm + ((int64_t)i * TB) * ld + (int64_t)(a + h) * TB, ld, M + ((int64_t)j * TB) * ld + (int64_t)(a + h) * TB, ld,
+                           (i - (a + h) + 1) * TB, sA, sB);
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    double *out = Xm + ((int64_t)i * TB) * ld + (int64_t)j * TB;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) out[(int64_t)(4 * ty + u) * ld + 4 * tx + v] = -acc[u][v];
+}
+// X_kk = Linv_k for all k (the diagonal tiles of X; everything else of X is written by k_trinv_x or is never read: k_xtx and
+// the two kernels above touch the lower block triangle only)
+__global__ __launch_bounds__(256) void k_trinv_diag(double *__restrict__ Xm, int64_t ld, const double *__restrict__ Linv) {
+    const int k = blockIdx.x;
+    double *out = Xm + ((int64_t)k * TB) * ld + (int64_t)k * TB;
+    const double *li = Linv + (int64_t)k * TB * TB;
+    for (int e = threadIdx.x; e < TB * TB; e += 256) out[(int64_t)(e >> 6) * ld + (e & 63)] = li[e];
+}
+
 // Ainv = X^T X for lower block-triangular X: tile (a, b), b <= a: sum over block rows m >= a of X_ma^T X_mb; both
 // (a, b) and its transpose (b, a) are written
 __global__ __launch_bounds__(256) void k_xtx(const double *__restrict__ Xm, double *__restrict__ Out, int64_t ld, int nt) {

@@ -410,7 +410,7 @@ def test_dense_spd_inverse_kernels(gpu_ctx):
     from fcvm_hip._lib import call
     c = gpu_ctx
     rng = np.random.default_rng(11)
-    for n in (5, 64, 130, 700):
+    for n in (5, 64, 130, 700, 1500):   # 1, 1, 3, 11, 24 tiles: one to five doubling levels, ragged last pairs
         q = rng.standard_normal((n, n))
         a = q @ q.T + n * np.diag(rng.uniform(0.5, 2.0, n))
         d_a, d_i = c.array(a.reshape(-1)), c.empty(n * n)
