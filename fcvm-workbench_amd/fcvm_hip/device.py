@@ -340,8 +340,13 @@ class Context:
             nc = pi["coarse_nodes"]
             max_aggr = int(os.environ.get("FCVM_MG_MAX_AGGREGATES", "3000"))
             if os.environ.get("FCVM_MG_SPARSE", "1") != "0":
-                # beyond max_aggr aggregates of 176 nodes the library keeps the aggregate level sparse (fcvm_l2s.inc)
-                target = max(16, int(min(176, nc / 200.0)))
+                # beyond max_aggr aggregates of 176 nodes the library keeps the aggregate level sparse (fcvm_l2s.inc).
+                # Round 3, with the 16-bit multiplicative cycle and the cheaper dense inverse: as small as the dense level
+                # carries -- nc / 2600 nodes (the bins over the bounding box then give at most ~2900 aggregates), not below 64:
+                # 1 M plate 176 -> 72 nodes = 1090 -> 1970 aggregates: 46.1 -> 39.2 PCG iterations per solve, 3.39 -> 2.9-3.0 s of
+                # solves for 50 ms more set-up (the n2 x n2 FP32 product grows from 0.03 to 0.09 ms per iteration; 56 / 48 nodes
+                # tip the level into its sparse form: 3.4 / 3.2 s); Embankment 337k: 71.8 -> 68.7 (gpurun_out/r03an, r03ao)
+                target = max(16, int(min(176, max(-(-nc // 2600), min(64.0, nc / 200.0)))))
             else:
                 target = max(16, -(-nc // max_aggr), int(min(176, nc / 200.0)))
         if k1s is None and os.environ.get("FCVM_MG_K1S"):
