@@ -174,6 +174,7 @@ struct fcvm_ctx {
     int mg_additive = 2;   // 1: additive; 0: multiplicative, FP64 smoother SpMVs; 2: multiplicative V(1,1), smoother SpMVs on a 16-bit fixed-point copy
     int mg_fp32 = 1;           // coarse levels: level-1 matrix and aggregate inverse stored in FP32 (FP64 vectors / accumulation)
     float *d_vals1f = nullptr, *d_A2invf = nullptr;
+    double *d_symv_part = nullptr;   // [nt][nt][128] partial results of k_symv_tiles (null: k_gemv_f32x4 applies the inverse)
     int mg_l1_16 = 1;              // level-1 SpMVs of the cycle on a 16-bit block-scaled copy of the level-1 matrix (FCVM_MG_L1_16=0: FP32)
     int4v *d_l1A = nullptr, *d_l1B = nullptr, *d_l1C = nullptr;
     int64_t *d_rp16 = nullptr;
@@ -316,9 +317,27 @@ static void launch_spmv_cheb(fcvm_ctx *c, const MatView &m, const double *x, con
     if (m.vals32) FCVM_SPMV_LAUNCH(false, false, 4, float2, 1, m.vals32, epi);
     else FCVM_SPMV_LAUNCH(false, true, 4, double2, 1, m.vals, epi);
 }
+// e2 = A2^-1 r2 with the FP32 copy of the dense inverse: from its lower triangle alone where that pays (k_symv_tiles; the partial
+// buffer is allocated with the inverse, fcvm_level2.inc / fcvm_mg_set_level2), otherwise row by row
 static void launch_gemv_f32(fcvm_ctx *c, const double *r2, double *e2, const double *done) {
-    hipLaunchKernelGGL(k_gemv_f32x4, dim3((unsigned)cdiv(c->n2, 16)), dim3(256), 0, c->stream, c->n2, c->n2, (c->n2 + 3) / 4 * 4,
-                       c->d_A2invf, r2, e2, done);
+    const int64_t lda = (c->n2 + 3) / 4 * 4;
+    if (c->d_symv_part) {
+        const int nt = (int)cdiv(c->n2, SYMV_T);
+        hipLaunchKernelGGL(k_symv_tiles, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, c->stream, nt, c->n2, lda, c->d_A2invf, r2,
+                           c->d_symv_part, done);
+        hipLaunchKernelGGL(k_symv_reduce, dim3((unsigned)cdiv(c->n2, 256)), dim3(256), 0, c->stream, nt, c->n2, c->d_symv_part, e2, done);
+        return;
+    }
+    hipLaunchKernelGGL(k_gemv_f32x4, dim3((unsigned)cdiv(c->n2, 16)), dim3(256), 0, c->stream, c->n2, c->n2, lda, c->d_A2invf, r2, e2, done);
+}
+// (re)allocates the partial buffer of k_symv_tiles for the current n2, or drops it: small levels (the row kernel is launch-bound
+// there anyway) and FCVM_L2_SYMV=0
+static int symv_prepare(fcvm_ctx *c) {
+    dfree(c->d_symv_part);
+    const bool off = getenv("FCVM_L2_SYMV") && atoi(getenv("FCVM_L2_SYMV")) == 0;
+    if (off || c->n2 < 2048) return 0;
+    const int64_t nt = cdiv(c->n2, SYMV_T);
+    return dalloc(&c->d_symv_part, nt * nt * SYMV_T);
 }
 static void launch_spmv_win(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done) {
     const WinDev &w = c->win;
@@ -1712,6 +1731,8 @@ int fcvm_mg_set_level2(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg
     HCHK(hipGetLastError());
     HCHK(hipStreamSynchronize(s));
     c->nagg = nagg; c->n2 = n2; c->mg_k1s = k1s; c->mg_alpha1s = alpha1s;
+    dfree(c->d_symv_part);
+    if (A2inv && symv_prepare(c)) return 1;   // (a caller's inverse is applied from its lower triangle)
     c->l2 = true;
     c->l2_has_inverse = A2inv != nullptr;  // without it only the transfer operators exist (distributed aggregate level)
     return 0;

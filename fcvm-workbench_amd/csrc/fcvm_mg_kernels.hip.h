@@ -489,6 +489,82 @@ __global__ __launch_bounds__(256) void k_gemv_f32x4(int64_t m, int64_t n, int64_
     }
 }
 
+// y = A x for the SYMMETRIC FP32-stored dense inverse, reading its lower triangle only (round 3: with aggregates of 72 nodes
+// the 11818^2 inverse of the 1 M plate is 0.56 GB and k_gemv_f32x4 0.10 ms of every PCG iteration).  One workgroup per 128 x 128
+// tile (I, J), J <= I, numbered row by row; thread (ty, tx) of a 16 x 16 grid owns an 8 x 8 block of it and forms both
+// products of that block: rows with x_J (for y_I) and, off the diagonal, columns with x_I (for y_J).  The 16 partial sums per
+// row / column are added in a fixed order through LDS and the tile's two result vectors go to slot J of row block I and slot
+// I of row block J of `part` [nt][nt][128]; k_symv_reduce adds the nt slots of a row block in slot order: no atomics, bitwise
+// reproducible.  Rows >= n are read from row n - 1 and multiplied by zero; columns n .. lda - 1 are the zero padding.
+constexpr int SYMV_T = 128;
+__global__ __launch_bounds__(256) void k_symv_tiles(int nt, int64_t n, int64_t lda, const float *__restrict__ A, const double *__restrict__ x,
+                                                    double *__restrict__ part, const double *__restrict__ done) {
+    if (done && *done != 0.0) return;
+    __shared__ double sR[16][SYMV_T + 1], sC[16][SYMV_T + 1];
+    const int t = blockIdx.x;
+    int I = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((I + 1) * (I + 2) / 2 <= t) I++;
+    while (I * (I + 1) / 2 > t) I--;
+    const int J = t - I * (I + 1) / 2;
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    const int64_t r0 = (int64_t)I * SYMV_T + ty * 8, c0 = (int64_t)J * SYMV_T + tx * 8;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    double xJ[8], xI[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        xJ[k] = c0 + k < n ? x[c0 + k] : 0.0;
+        xI[k] = r0 + k < n ? x[r0 + k] : 0.0;
+    }
+    v4f a[8][2];
+    const bool in0 = c0 < lda, in1 = c0 + 4 < lda;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int64_t rr = r0 + r < n ? r0 + r : n - 1;
+        const v4f *row = (const v4f *)(A + rr * lda + c0);
+        a[r][0] = in0 ? __builtin_nontemporal_load(row) : (v4f)(0.0f);
+        a[r][1] = in1 ? __builtin_nontemporal_load(row + 1) : (v4f)(0.0f);
+    }
+    double cv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const double v[8] = {(double)a[r][0].x, (double)a[r][0].y, (double)a[r][0].z, (double)a[r][0].w,
+                             (double)a[r][1].x, (double)a[r][1].y, (double)a[r][1].z, (double)a[r][1].w};
+        double ru = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            ru += v[k] * xJ[k];
+            cv[k] += v[k] * xI[r];
+        }
+        sR[tx][ty * 8 + r] = ru;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) sC[ty][tx * 8 + k] = cv[k];
+    __syncthreads();
+    if (threadIdx.x < SYMV_T) {
+        double u = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) u += sR[q][threadIdx.x];
+        part[((int64_t)I * nt + J) * SYMV_T + threadIdx.x] = u;
+    } else if (I != J) {
+        const int cc = threadIdx.x - SYMV_T;
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) v += sC[q][cc];
+        part[((int64_t)J * nt + I) * SYMV_T + cc] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_symv_reduce(int nt, int64_t n, const double *__restrict__ part, double *__restrict__ y,
+                                                     const double *__restrict__ done) {
+    if (done && *done != 0.0) return;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t K = i / SYMV_T, tt = i - K * SYMV_T;
+    const double *p = part + K * nt * SYMV_T + tt;
+    double v = 0.0;
+    for (int sl = 0; sl < nt; sl++) v += p[(int64_t)sl * SYMV_T];
+    y[i] = v;
+}
+
 // A[a][b] = A[b][a] for a < b: potri(upper, column-major) leaves the inverse in the row-major lower triangle
 __global__ __launch_bounds__(256) void k_mirror_lower_to_upper(int64_t n, double *A) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -404,6 +404,45 @@ def test_sparse_aggregate_level_solves_like_the_dense_one(monkeypatch):
     assert res["sparse"][1] <= 1.15 * res["dense"][1] + 5, (res["sparse"][1], res["dense"][1])
 
 
+def test_aggregate_level_product_from_the_lower_triangle_equals_the_row_kernel(monkeypatch):
+    """e2 = A2^-1 r2 is applied from the lower triangle of the FP32 inverse (k_symv_tiles + k_symv_reduce, half the bytes of the
+    row-by-row kernel) once the level has 2048 unknowns: same result to FP64 rounding as k_gemv_f32x4 (FCVM_L2_SYMV=0) on a
+    level whose size is not a multiple of the 128-wide tiles, the same PCG iteration count, and bitwise the same on a rerun."""
+    from fcvm_hip import meshgen
+    from fcvm_hip._lib import call
+    from fcvm_hip.device import Context
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import GpuModel
+    case = meshgen.cube_case(20, l=10.0, traction=(0.0, 0.0, -1.0))
+    monkeypatch.setenv("FCVM_MG_TARGET", "12")     # 9^3 aggregates: 4374 unknowns = 34 tiles + 22 rows
+    rng = np.random.default_rng(3)
+    out = {}
+    for name in ("rows", "symv", "symv again"):
+        if name == "rows":
+            monkeypatch.setenv("FCVM_L2_SYMV", "0")
+        else:
+            monkeypatch.delenv("FCVM_L2_SYMV", raising=False)
+        m = GpuModel(case["elNodes"], case["nocoord"], (210000.0, 0.3, 7.8e-6), case["fix"],
+                     Loads(ufaces=case["ufaces"], uloads=case["uloads"]), ctx=Context(0))
+        c = m.ctx
+        glv, modf, _, _ = m.calc_gsm((0.0, 0.0, -9.81), want_x=False)
+        n2 = c.precond_info()["l2_unknowns"]
+        assert n2 >= 2048 and n2 % 128 != 0
+        if "r2" not in out:
+            out["r2"] = rng.standard_normal(n2)
+        r2, e2 = c.array(out["r2"]), c.empty(n2)
+        call("fcvm_mg_l2_solve", c.h, r2.ptr, e2.ptr)
+        f = c.mul(m.fixdof, glv)
+        c.axpby(1.0, f, 1.0, modf, out=f)
+        u, info = c.solve(f, rtol=1e-10)
+        out[name] = (e2.get(), info["iterations"], u.get())
+        c.close()
+    assert rel(out["symv"][0], out["rows"][0]) < 1e-12
+    assert abs(out["symv"][1] - out["rows"][1]) <= 1
+    assert rel(out["symv"][2], out["rows"][2]) < 1e-8
+    assert np.array_equal(out["symv"][0], out["symv again"][0]) and np.array_equal(out["symv"][2], out["symv again"][2])
+
+
 def test_dense_spd_inverse_kernels(gpu_ctx):
     """fcvm_spd_inverse (blocked Cholesky, triangular inverse, X^T X in HIP kernels: the aggregate level's solver) against
     LAPACK, sizes around the 64-wide tiles."""
