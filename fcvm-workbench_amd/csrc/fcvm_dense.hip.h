@@ -62,50 +62,62 @@ __device__ __forceinline__ void tile_mac(double (&acc)[4][4], const double *__re
 
 // Cholesky factor of the diagonal tile k (lower, in place, upper part of the tile zeroed) and the inverse of that factor
 // (lower triangular) into Linv[k].  One workgroup.  info[0] = 1 + row of the first non-positive pivot.
+// The tile kernels of a factorisation form ONE dependent chain (nt of them: 185 at 11,818 unknowns), so their latency is set-up
+// time one for one.  Round 3 (178 -> see profiles): (i) the elimination works on UNSCALED columns -- step j subtracts
+// T_ij T_mj / T_jj from the trailing triangle only (16 x 16 thread grid striding over it, no scan of the whole tile) and needs a
+// single barrier; column j is final after step j and all columns are scaled by 1 / sqrt(pivot) in one pass at the end;
+// (ii) the inverse of the factor takes four threads per column (the sum over m split four ways, combined in a fixed order).
 __global__ __launch_bounds__(256) void k_chol_diag(double *__restrict__ M, int64_t ld, int k, double *__restrict__ Linv, int *__restrict__ info) {
     __shared__ double T[TB][TB + 1];
     __shared__ double X[TB][TB + 1];
+    __shared__ double P[4][TB];
     const int t = threadIdx.x;
     double *blk = M + ((int64_t)k * TB) * ld + (int64_t)k * TB;
     for (int e = t; e < TB * TB; e += 256) T[e >> 6][e & 63] = blk[(int64_t)(e >> 6) * ld + (e & 63)];
     __syncthreads();
+    const int ti = t >> 4, tm = t & 15;
     for (int j = 0; j < TB; j++) {
         const double d = T[j][j];
-        if (!(d > 0.0)) {
+        if (!(d > 0.0)) {      // (the same value in every thread: the whole workgroup leaves)
             if (t == 0 && atomicCAS(info, 0, k * TB + j + 1) == 0) {}
             return;
         }
-        const double s = sqrt(d);
-        __syncthreads();
-        if (t > j && t < TB) T[t][j] /= s;
-        if (t == j) T[j][j] = s;
-        __syncthreads();
-        // trailing update of the lower triangle: rows i > j, columns j < m <= i
-        for (int e = t; e < TB * TB; e += 256) {
-            const int i = e >> 6, m = e & 63;
-            if (m > j && i >= m) T[i][m] -= T[i][j] * T[m][j];
+        const double inv = 1.0 / d;
+        for (int i = j + 1 + ti; i < TB; i += 16) {
+            const double lij = T[i][j] * inv;
+            for (int m = j + 1 + tm; m <= i; m += 16) T[i][m] -= lij * T[m][j];
         }
         __syncthreads();
     }
-    // inverse of the lower-triangular factor, one column per thread (forward substitution)
-    if (t < TB) {
-        const int c = t;
-        for (int i = 0; i < TB; i++) {
-            double v = (i == c) ? 1.0 : 0.0;
-            if (i >= c) {
-                for (int m = c; m < i; m++) v -= T[i][m] * X[m][c];
-                v /= T[i][i];
-            } else {
-                v = 0.0;
-            }
-            X[i][c] = v;
-        }
+    // scale: L_ij = T_ij / sqrt(T_jj), L_jj = sqrt(T_jj)
+    for (int e = t; e < TB * TB; e += 256) {
+        const int i = e >> 6, m = e & 63;
+        if (m < i) X[i][m] = T[i][m] / sqrt(T[m][m]);       // (X as scratch: T's diagonal is still being read)
+        else if (m == i) X[i][m] = sqrt(T[i][i]);
+        else X[i][m] = 0.0;
     }
     __syncthreads();
+    for (int e = t; e < TB * TB; e += 256) T[e >> 6][e & 63] = X[e >> 6][e & 63];
+    __syncthreads();
+    // inverse of the lower-triangular factor by forward substitution, column c = t / 4, the sum over m in four interleaved parts
+    const int c = t >> 2, part = t & 3;
+    for (int i = 0; i < TB; i++) {
+        double sacc = 0.0;
+        if (i > c)
+            for (int m = c + part; m < i; m += 4) sacc += T[i][m] * X[m][c];
+        P[part][c] = sacc;
+        __syncthreads();
+        if (part == 0) {
+            double v = 0.0;
+            if (i >= c) v = ((i == c ? 1.0 : 0.0) - (((P[0][c] + P[1][c]) + P[2][c]) + P[3][c])) / T[i][i];
+            X[i][c] = v;
+        }
+        __syncthreads();
+    }
     double *li = Linv + (int64_t)k * TB * TB;
     for (int e = t; e < TB * TB; e += 256) {
         const int i = e >> 6, m = e & 63;
-        blk[(int64_t)i * ld + m] = (m <= i) ? T[i][m] : 0.0;
+        blk[(int64_t)i * ld + m] = T[i][m];
         li[e] = X[i][m];
     }
 }
