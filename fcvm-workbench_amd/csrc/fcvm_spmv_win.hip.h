@@ -861,6 +861,20 @@ __global__ __launch_bounds__(64) void k_spmv_l1_i16(int64_t nslices, const int64
     const int64_t s = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     const int lane = threadIdx.x;
     const int64_t p0 = rp[s], P = rp[s + 1] - p0;
+    // the epilogue's operands do not depend on the products: their loads are issued before the record loop, not after it (the
+    // kernel is a chain of dependent round trips at 2900 one-wave workgroups: two fewer per pass)
+    const int node = rownode[s * 64 + lane];
+    const int64_t o = 3 * (int64_t)(node < 0 ? 0 : node);
+    double d0 = 0.0, d1 = 0.0, d2 = 0.0, e0 = 0.0, e1 = 0.0, e2 = 0.0;
+    float2 q0 = {0.f, 0.f}, q1 = {0.f, 0.f}, q2 = {0.f, 0.f};
+    if (EPI != 0 && node >= 0) {
+        d0 = x[o]; d1 = x[o + 1]; d2 = x[o + 2];
+        e0 = epi.r[o]; e1 = epi.r[o + 1]; e2 = epi.r[o + 2];
+        if (epi.update_d && epi.dinv6) {
+            const float2 *q2p = (const float2 *)(epi.dinv6 + 6 * (int64_t)node);
+            q0 = q2p[0]; q1 = q2p[1]; q2 = q2p[2];
+        }
+    }
     float y0 = 0.f, y1 = 0.f, y2 = 0.f, z0 = 0.f, z1 = 0.f, z2 = 0.f, u0 = 0.f, u1 = 0.f, u2 = 0.f, w0 = 0.f, w1 = 0.f, w2 = 0.f;
     int64_t at = p0 * 64 + lane, p = 0;
     L1Rec ra, rb, rc, rd;
@@ -879,22 +893,18 @@ __global__ __launch_bounds__(64) void k_spmv_l1_i16(int64_t nslices, const int64
     }
     const double is = scale[1];
     const double t0 = is * (double)(y0 + z0 + u0 + w0), t1 = is * (double)(y1 + z1 + u1 + w1), t2 = is * (double)(y2 + z2 + u2 + w2);
-    const int node = rownode[s * 64 + lane];
     if (node < 0) return;
-    const int64_t o = 3 * (int64_t)node;
     if (EPI == 0) {
         y[o] = t0; y[o + 1] = t1; y[o + 2] = t2;
         return;
     }
-    const double d0 = x[o], d1 = x[o + 1], d2 = x[o + 2];
-    const double r0 = epi.r[o] - t0, r1 = epi.r[o + 1] - t1, r2 = epi.r[o + 2] - t2;
+    const double r0 = e0 - t0, r1 = e1 - t1, r2 = e2 - t2;
     epi.r[o] = r0; epi.r[o + 1] = r1; epi.r[o + 2] = r2;
     double a0 = d0, a1 = d1, a2 = d2;
     if (epi.update_d) {
         double zz0, zz1, zz2;
         if (epi.dinv6) {
-            const float2 *q2 = (const float2 *)(epi.dinv6 + 6 * (int64_t)node);
-            const float2 v0 = q2[0], v1 = q2[1], v2 = q2[2];   // xx xy | xz yy | yz zz
+            const float2 v0 = q0, v1 = q1, v2 = q2;   // xx xy | xz yy | yz zz
             zz0 = (double)v0.x * r0 + (double)v0.y * r1 + (double)v1.x * r2;
             zz1 = (double)v0.y * r0 + (double)v1.y * r1 + (double)v2.x * r2;
             zz2 = (double)v1.x * r0 + (double)v2.x * r1 + (double)v2.y * r2;
