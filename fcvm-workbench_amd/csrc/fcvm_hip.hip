@@ -325,7 +325,7 @@ static void launch_gemv_f32(fcvm_ctx *c, const double *r2, double *e2, const dou
         const int nt = (int)cdiv(c->n2, SYMV_T);
         hipLaunchKernelGGL(k_symv_tiles, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, c->stream, nt, c->n2, lda, c->d_A2invf, r2,
                            c->d_symv_part, done);
-        hipLaunchKernelGGL(k_symv_reduce, dim3((unsigned)cdiv(c->n2, 256)), dim3(256), 0, c->stream, nt, c->n2, c->d_symv_part, e2, done);
+        hipLaunchKernelGGL(k_symv_reduce, dim3((unsigned)nt), dim3(2 * SYMV_T), 0, c->stream, nt, c->n2, c->d_symv_part, e2, done);
         return;
     }
     hipLaunchKernelGGL(k_gemv_f32x4, dim3((unsigned)cdiv(c->n2, 16)), dim3(256), 0, c->stream, c->n2, c->n2, lda, c->d_A2invf, r2, e2, done);

@@ -553,16 +553,29 @@ __global__ __launch_bounds__(256) void k_symv_tiles(int nt, int64_t n, int64_t l
         part[((int64_t)J * nt + I) * SYMV_T + cc] = v;
     }
 }
+// one workgroup per row block: thread (half, tt) adds every second slot of entry tt with four loads in flight, the two halves are
+// joined through LDS -- a fixed association, whatever the launch (a single chain of nt dependent loads took 25 us at nt = 93)
 __global__ __launch_bounds__(256) void k_symv_reduce(int nt, int64_t n, const double *__restrict__ part, double *__restrict__ y,
                                                      const double *__restrict__ done) {
     if (done && *done != 0.0) return;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int64_t K = i / SYMV_T, tt = i - K * SYMV_T;
+    __shared__ double sh[SYMV_T];
+    const int64_t K = blockIdx.x;
+    const int tt = threadIdx.x & (SYMV_T - 1), half = threadIdx.x >> 7;
     const double *p = part + K * nt * SYMV_T + tt;
-    double v = 0.0;
-    for (int sl = 0; sl < nt; sl++) v += p[(int64_t)sl * SYMV_T];
-    y[i] = v;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    int sl = half;
+    for (; sl + 6 < nt; sl += 8) {
+        v0 += p[(int64_t)sl * SYMV_T];
+        v1 += p[(int64_t)(sl + 2) * SYMV_T];
+        v2 += p[(int64_t)(sl + 4) * SYMV_T];
+        v3 += p[(int64_t)(sl + 6) * SYMV_T];
+    }
+    for (; sl < nt; sl += 2) v0 += p[(int64_t)sl * SYMV_T];
+    const double v = (v0 + v1) + (v2 + v3);
+    if (half) sh[tt] = v;
+    __syncthreads();
+    const int64_t i = K * SYMV_T + tt;
+    if (!half && i < n) y[i] = v + sh[tt];
 }
 
 // A[a][b] = A[b][a] for a < b: potri(upper, column-major) leaves the inverse in the row-major lower triangle
