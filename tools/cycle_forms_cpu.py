@@ -122,6 +122,23 @@ def main(h):
     variants.append(("block Gauss-Seidel over nodes (Morton order)", make_mult(pre, post)))
     for name, B in variants:
         t0 = time.time(); it = pcg(K, f, B); print("  mult, smoother %-40s %4d iterations  (%.1f s)" % (name, it, time.time() - t0), flush=True)
+    if os.environ.get("CYCLE_FORMS_DAMPING"):
+        # node-type-dependent damping of the block-Jacobi step (corner / mid-side weights) and a scaled coarse correction: all flat
+        # or worse than (1, 1) and 1.0 (round 3: 44 -> 46-51 iterations at 3840 tet10)
+        iscorner = np.zeros(nn, bool); iscorner[corners] = True
+        def run(wc, wm, alpha=1.0):
+            w = np.sqrt(np.repeat(np.where(iscorner, wc, wm), 3))
+            S0 = sp.diags(w) @ Dinv @ sp.diags(w)
+            lm = spla.eigsh(spla.LinearOperator((n, n), matvec=lambda v: S0 @ (K @ v)), k=1, which="LM", return_eigenvectors=False, tol=1e-3)[0]
+            h2 = 1.1 * lm; Sw = (2.0 / (h2 + h2 / 16.0)) * S0
+            def B(r):
+                z0 = Sw @ r; e = alpha * M(P.T @ (r - K @ z0)); z = z0 + P @ e
+                return z + Sw @ (r - K @ z)
+            return pcg(K, f, B)
+        for wc, wm in ((1, 1), (1, 0.7), (1, 1.5), (1, 2.0), (0.7, 1), (1.5, 1), (2, 1)):
+            print("  jacobi weights corner %.2f mid-side %.2f: %d iterations" % (wc, wm, run(wc, wm)), flush=True)
+        for al in (0.9, 1.1, 1.25):
+            print("  coarse correction scaled by %.2f: %d iterations" % (al, run(1, 1, al)), flush=True)
     print("plate h=%g: %d tet10, %d dof, %d coarse dof; nnz blocks K %d, G = K P %d (%.2f x), W %d" %
           (h, len(el), n, len(keep), K.nnz // 9, (K @ P).nnz // 9, (K @ P).nnz / K.nnz, W.nnz // 9))
     for name, B in (("mult", B_mult), ("add", B_add), ("sp", B_sp), ("sp2", B_sp2), ("sp w=2", B_sp_w(2.0)), ("sp w=0.5", B_sp_w(0.5))):
