@@ -45,6 +45,48 @@ def build_rank_model(rank, world, cells, material, traction, device_index, backe
     return model, be, ops
 
 
+def _shared_case(build, rank, world):
+    """The global model of the weak-scaling run, built ONCE per node: rank 0 generates it (numpy, tens of seconds at 8 M tet10)
+    and parks the arrays in /dev/shm, the other ranks map them after a barrier (eight copies of the generator running side by side
+    took several times as long and eight times the memory).  Single node (bench.py's contract); FCVM_DIST_SHARED_MESH=0: every
+    rank builds its own."""
+    if world == 1 or os.environ.get("FCVM_DIST_SHARED_MESH", "1") == "0" or not os.path.isdir("/dev/shm"):
+        return build()
+    base = "/dev/shm/fcvm_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getuid())
+    keys = ("elNodes", "nocoord", "material", "ufaces", "uloads")
+    if rank == 0:
+        case = build()
+        fd = np.fromiter(case["fix"].keys(), dtype=np.int64, count=len(case["fix"]))
+        fv = np.fromiter(case["fix"].values(), dtype=np.float64, count=len(case["fix"]))
+        for k in keys:
+            np.save(base + "_" + k + ".npy", np.ascontiguousarray(case[k]))
+        np.save(base + "_fixdof.npy", fd)
+        np.save(base + "_fixval.npy", fv)
+        with open(base + "_meta.json", "w") as fh:
+            json.dump({"ctl": case["ctl"], "name": case["name"]}, fh)
+    dist.barrier()
+    try:
+        if rank != 0:
+            case = {k: np.load(base + "_" + k + ".npy", mmap_mode="r") for k in keys}
+            fd, fv = np.load(base + "_fixdof.npy"), np.load(base + "_fixval.npy")
+            case["fix"] = {int(d): float(v) for d, v in zip(fd, fv)}
+            case.update(json.load(open(base + "_meta.json")))
+            case["material"] = np.array(case["material"])
+    finally:
+        dist.barrier()     # everybody has mapped the files: the names can go (the mappings stay valid)
+        if rank == 0:
+            for k in keys + ("fixdof", "fixval"):
+                try:
+                    os.remove(base + "_" + k + ".npy")
+                except OSError:
+                    pass
+            try:
+                os.remove(base + "_meta.json")
+            except OSError:
+                pass
+    return case
+
+
 def run(args, ctl, material, traction, rtol, hbm_peak):
     """N > 1: the headline workload of N = 1 -- the reference's Plate_with_hole_Example, its control file, Newton iterations
     warmup+1 .. warmup+steps of the collapse analysis -- on a mesh of N x (the one-GPU size) elements (weak scaling: h =
@@ -75,7 +117,7 @@ def run(args, ctl, material, traction, rtol, hbm_peak):
         from .dist import partition_model
         from .solver import collapse_run
         t0 = time.perf_counter()
-        case = examples.plate_with_hole(args.plate_h / world ** (1.0 / 3.0))      # every rank builds the same global mesh
+        case = _shared_case(lambda: examples.plate_with_hole(args.plate_h / world ** (1.0 / 3.0)), rank, world)
         t_mesh = time.perf_counter() - t0
         t0 = time.perf_counter()
         model = partition_model(case["elNodes"], case["nocoord"], case["material"], case["fix"],
