@@ -741,7 +741,11 @@ class DistMG:
         lo, hi = lo.cpu().numpy(), hi.cpu().numpy()
         ncg = torch.tensor([float(own.sum())], dtype=torch.float64, device=dev)
         ncg = float(be._allreduce(ncg).item())
-        target = self.target if self.target else max(16, int(round(ncg / (1000.0 * part.world ** (2.0 / 3.0)))))
+        # aggregates: FCVM_DIST_AGGREGATES x world^(2/3) (n2^2 / world matrix entries per rank and cycle, an n2^2 FP64 all-reduce
+        # and an n2^3 inverse per rank at set-up); round 3: 1000 -> 1700 with the cheaper inverse (2 x 1.0 M tet10: 1462 -> 2479
+        # aggregates, PCG iterations per solve see DESIGN.md "Multi-GPU")
+        per_rank = float(os.environ.get("FCVM_DIST_AGGREGATES", "1700"))
+        target = self.target if self.target else max(16, int(round(ncg / (per_rank * part.world ** (2.0 / 3.0)))))
         ext = np.maximum(hi - lo, 1e-300)
         live = ext > 1e-9 * ext.max()
         h = (np.prod(ext[live]) / max(1.0, ncg / target)) ** (1.0 / max(1, live.sum()))
