@@ -303,7 +303,7 @@ static void launch_spmv_cheb(fcvm_ctx *c, const MatView &m, const double *x, con
     if (m.A16) {   // level 1 on its 16-bit copy: 24 instead of 40 bytes per block
         // plain loads by default: the level-1 matrix (tens of MB) is read six times per V-cycle and stays in the memory-side cache
         // between those passes (1 M plate: 24.1 -> 21.2 us per pass, gpurun_out/r03ag); FCVM_L1_NT=1: nontemporal loads
-        static const bool nt = getenv("FCVM_L1_NT") && atoi(getenv("FCVM_L1_NT")) != 0;
+        const bool nt = getenv("FCVM_L1_NT") && atoi(getenv("FCVM_L1_NT")) != 0;
         if (nt)
             hipLaunchKernelGGL((k_spmv_l1_i16<1, true>), dim3((unsigned)m.nslices), dim3(64), 0, c->stream, m.nslices, m.rp16, m.A16, m.B16, m.C16,
                                m.scale16, m.rownode, x, (double *)nullptr, done, epi);
