@@ -54,17 +54,35 @@ def _shared_case(build, rank, world):
         return build()
     base = "/dev/shm/fcvm_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getuid())
     keys = ("elNodes", "nocoord", "material", "ufaces", "uloads")
+    shared = [True]
     if rank == 0:
         case = build()
-        fd = np.fromiter(case["fix"].keys(), dtype=np.int64, count=len(case["fix"]))
-        fv = np.fromiter(case["fix"].values(), dtype=np.float64, count=len(case["fix"]))
-        for k in keys:
-            np.save(base + "_" + k + ".npy", np.ascontiguousarray(case[k]))
-        np.save(base + "_fixdof.npy", fd)
-        np.save(base + "_fixval.npy", fv)
-        with open(base + "_meta.json", "w") as fh:
-            json.dump({"ctl": case["ctl"], "name": case["name"]}, fh)
-    dist.barrier()
+        try:
+            fd = np.fromiter(case["fix"].keys(), dtype=np.int64, count=len(case["fix"]))
+            fv = np.fromiter(case["fix"].values(), dtype=np.float64, count=len(case["fix"]))
+            for k in keys:
+                np.save(base + "_" + k + ".npy", np.ascontiguousarray(case[k]))
+            np.save(base + "_fixdof.npy", fd)
+            np.save(base + "_fixval.npy", fv)
+            with open(base + "_meta.json", "w") as fh:
+                json.dump({"ctl": case["ctl"], "name": case["name"]}, fh)
+        except OSError:       # /dev/shm not writable or full: every rank builds its own after all
+            shared = [False]
+    dist.broadcast_object_list(shared, src=0)     # (also the barrier behind which the files are complete)
+    def cleanup():
+        for k in keys + ("fixdof", "fixval"):
+            try:
+                os.remove(base + "_" + k + ".npy")
+            except OSError:
+                pass
+        try:
+            os.remove(base + "_meta.json")
+        except OSError:
+            pass
+    if not shared[0]:
+        if rank == 0:
+            cleanup()
+        return case if rank == 0 else build()
     try:
         if rank != 0:
             case = {k: np.load(base + "_" + k + ".npy", mmap_mode="r") for k in keys}
@@ -75,15 +93,7 @@ def _shared_case(build, rank, world):
     finally:
         dist.barrier()     # everybody has mapped the files: the names can go (the mappings stay valid)
         if rank == 0:
-            for k in keys + ("fixdof", "fixval"):
-                try:
-                    os.remove(base + "_" + k + ".npy")
-                except OSError:
-                    pass
-            try:
-                os.remove(base + "_meta.json")
-            except OSError:
-                pass
+            cleanup()
     return case
 
 
