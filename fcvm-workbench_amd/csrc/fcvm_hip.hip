@@ -59,6 +59,19 @@ struct WinDev {
     bool lo_valid = false;
 };
 
+// symmetric form of the window format (WinSym): its own row tables, entries and FP64 values; groups and windows are WinDev's
+struct WinSymDev {
+    bool on = false, valid = false;   // built for this mesh / holds the values of the last assembly
+    WinSym pat;
+    int64_t *woff = nullptr;
+    int32_t *rownode = nullptr, *srcslot = nullptr, *gextra = nullptr;
+    uint32_t *seg = nullptr, *cols = nullptr;
+    uint16_t *rowlen = nullptr, *own = nullptr;
+    uint8_t *jell = nullptr;
+    double *vals = nullptr;
+    size_t lds = 0;
+};
+
 struct L2sDev {   // device state of the sparse aggregate level (owned by fcvm_ctx)
     bool on = false;
     int64_t nagg = 0, nslots = 0, nsuper = 0, n3 = 0, lda3 = 0;
@@ -140,8 +153,10 @@ struct fcvm_ctx {
     hipStream_t repack_stream = nullptr;
     hipEvent_t repack_fork = nullptr, repack_done = nullptr;
     bool repack_pending = false;
+    bool wsym_use = false;      // the matrix being copied is an SPD stiffness matrix: also into the symmetric form
     int spmv_win = 1, win_v2 = 1;   // win_v2: value components in 16-byte pairs (FCVM_WIN_V2=0: nine 8-byte runs)
     WinDev win;                     // the fine matrix.  (The level-1 matrix of the multigrid cycle was tried on the same format with
+    WinSymDev wsym;     // the PCG's FP64 SpMV on the symmetric form (FCVM_WIN_SYM=0: off)
                                     // FP32 values and the smoother epilogue: 31.0 against 28.3 us per launch -- 686 workgroups are too
                                     // few and the staging barrier adds latency; it stays on the sliced-ELL kernel, profiles/r02v_*.)
     int spmv_variant = 5;  // 5 (shipped): nontemporal matrix loads, four pairs in flight, 8 + 16 byte x gathers; 4: three 8-byte gathers; 0: plain loads, one pair per iteration
@@ -341,6 +356,18 @@ static int symv_prepare(fcvm_ctx *c) {
 }
 static void launch_spmv_win(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done) {
     const WinDev &w = c->win;
+    if (c->wsym.on && c->wsym.valid) {   // symmetric form: 0.70 x the blocks, transposed products through LDS in fixed point
+        const WinSymDev &ws = c->wsym;
+        if (dot)
+            hipLaunchKernelGGL((k_spmv_win_sym<true, WIN_WAVES>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), ws.lds, c->stream,
+                               w.pat.ngroups, w.pat.wmax, ws.pat.xmax, w.gptr, ws.gextra, w.wlist, ws.woff, ws.rowlen, ws.rownode, ws.seg, ws.own,
+                               ws.cols, ws.vals, w.lo_scale, x, y, c->d_part_spmv, done);
+        else
+            hipLaunchKernelGGL((k_spmv_win_sym<false, WIN_WAVES>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), ws.lds, c->stream,
+                               w.pat.ngroups, w.pat.wmax, ws.pat.xmax, w.gptr, ws.gextra, w.wlist, ws.woff, ws.rowlen, ws.rownode, ws.seg, ws.own,
+                               ws.cols, ws.vals, w.lo_scale, x, y, (double *)nullptr, done);
+        return;
+    }
     if (w.pat.waves == 4) {   // meshes whose 512-row windows do not fit the LDS: groups of 256 rows
         if (dot) launch_spmv_win_t<true, 4, true>(c, w, x, y, done);
         else launch_spmv_win_t<false, 4, true>(c, w, x, y, done);
@@ -380,6 +407,18 @@ static void launch_spmv_win_lo(fcvm_ctx *c, const double *x, const double *r, do
 static void launch_spmv_win2(fcvm_ctx *c, const double *xA, const double *xB, double *yA, double *yB, double *partA, double *partB,
                              const double *doneA, const double *doneB) {
     const WinDev &w = c->win;
+    if (c->wsym.on && c->wsym.valid) {
+        // the symmetric form has no two-vector kernel: two launches of the one-vector kernel (0.70 x the blocks each; the
+        // same arithmetic as a single solve, so paired and single solves stay bitwise equal)
+        const WinSymDev &ws = c->wsym;
+        const double *xs2[2] = {xA, xB}, *dn[2] = {doneA, doneB};
+        double *ys2[2] = {yA, yB}, *pt[2] = {partA, partB};
+        for (int k = 0; k < 2; k++)
+            hipLaunchKernelGGL((k_spmv_win_sym<true, WIN_WAVES>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), ws.lds, c->stream,
+                               w.pat.ngroups, w.pat.wmax, ws.pat.xmax, w.gptr, ws.gextra, w.wlist, ws.woff, ws.rowlen, ws.rownode, ws.seg, ws.own,
+                               ws.cols, ws.vals, w.lo_scale, xs2[k], ys2[k], pt[k], dn[k]);
+        return;
+    }
     if (w.pat.waves == 4)
         hipLaunchKernelGGL((k_spmv_win2<true, 4>), dim3((unsigned)w.pat.ngroups), dim3(256), 2 * w.lds, c->stream, w.pat.ngroups, w.pat.wmax, w.gptr,
                            w.gextra, w.wlist, w.woff, w.rowlen, w.rownode, w.seg, w.own, w.cols, (const double *)w.vals, xA, xB, yA, yB, partA,
@@ -420,6 +459,13 @@ static int dot_common(fcvm_ctx *c, int64_t n, const double *w, const double *x, 
 static void alt_free(fcvm_ctx *c);
 #include "fcvm_mg.inc"
 
+static void wsym_free(WinSymDev &w) {
+    dfree(w.woff); dfree(w.rownode); dfree(w.srcslot); dfree(w.gextra); dfree(w.seg); dfree(w.cols); dfree(w.rowlen); dfree(w.own);
+    dfree(w.jell); dfree(w.vals);
+    w.on = w.valid = false;
+    w.pat = WinSym();
+    w.lds = 0;
+}
 static void win_free(WinDev &w) {
     dfree(w.gptr); dfree(w.woff); dfree(w.wlist); dfree(w.rownode); dfree(w.srcslot); dfree(w.gextra); dfree(w.seg); dfree(w.rowlen);
     dfree(w.own); dfree(w.cols); dfree(w.jstart);
@@ -468,6 +514,49 @@ static int win_allow_lds(K kernel, size_t bytes) {
     HCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return 0;
 }
+// device copy of the symmetric form built by win_build_host (nothing to do when it was not built); used only where two
+// workgroups of it fit the LDS of a CU
+static int wsym_upload(fcvm_ctx *c) {
+    WinSymDev &d = c->wsym;
+    const WinSym &w = d.pat;
+    if (w.nblocks <= 0 || !c->win.on) { d.pat = WinSym(); return 0; }
+    d.lds = sizeof(double) * 3 * (size_t)(c->win.pat.wmax + w.xmax) + sizeof(unsigned long long) * 3 * 64 * WIN_WAVES;
+    static size_t lds_allowed_dev[64] = {0};
+    if (2 * d.lds > (size_t)device_lds_cap(c->device)) {
+        if (getenv("FCVM_VERBOSE")) fprintf(stderr, "fcvm: symmetric window form not used (%zu B of LDS per workgroup)\n", d.lds);
+        d.pat = WinSym();
+        return 0;
+    }
+    const int64_t nrows = w.nwaves * SLICE;
+    if (dalloc(&d.woff, w.nwaves + 1) || dalloc(&d.rownode, nrows) || dalloc(&d.srcslot, nrows) || dalloc(&d.gextra, w.ngroups) ||
+        dalloc(&d.seg, nrows) || dalloc(&d.cols, w.nblocks) || dalloc(&d.rowlen, nrows) || dalloc(&d.own, nrows) ||
+        dalloc(&d.jell, w.nblocks) || dalloc(&d.vals, 9 * w.nblocks))
+        return 1;
+    hipStream_t s = c->stream;
+    HCHK(hipMemcpyAsync(d.woff, w.woff.data(), sizeof(int64_t) * (w.nwaves + 1), hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.rownode, w.rownode.data(), sizeof(int32_t) * nrows, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.srcslot, w.srcslot.data(), sizeof(int32_t) * nrows, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.gextra, w.gextra.data(), sizeof(int32_t) * w.ngroups, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.seg, w.seg.data(), sizeof(uint32_t) * nrows, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.cols, w.cols.data(), sizeof(uint32_t) * w.nblocks, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.rowlen, w.rowlen.data(), sizeof(uint16_t) * nrows, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.own, w.own.data(), sizeof(uint16_t) * nrows, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.jell, w.jell.data(), sizeof(uint8_t) * w.nblocks, hipMemcpyHostToDevice, s));
+    HCHK(hipMemsetAsync(d.vals, 0, sizeof(double) * 9 * w.nblocks, s));
+    HCHK(hipStreamSynchronize(s));
+    size_t &lds_allowed = lds_allowed_dev[c->device & 63];
+    lds_allowed = std::max(lds_allowed, d.lds);
+    if (win_allow_lds(k_spmv_win_sym<true, WIN_WAVES>, lds_allowed) || win_allow_lds(k_spmv_win_sym<false, WIN_WAVES>, lds_allowed)) return 1;
+    d.lds = lds_allowed;
+    d.pat.cols.clear(); d.pat.cols.shrink_to_fit();
+    d.pat.jell.clear(); d.pat.jell.shrink_to_fit();
+    d.on = true;
+    d.valid = false;
+    if (getenv("FCVM_VERBOSE"))
+        fprintf(stderr, "fcvm: symmetric window form: %lld entries (%.3f of the full form), %zu B LDS\n", (long long)w.nblocks,
+                (double)w.nblocks / (double)c->win.pat.nblocks, d.lds);
+    return 0;
+}
 
 // Second storage of the fine matrix for the SpMV (WinPattern): built when every group's window fits the LDS twice per CU
 // host part of the window format (pattern only, no GPU call): runs on a thread of its own beside the uploads of fcvm_set_mesh
@@ -501,6 +590,10 @@ static void win_build_host(fcvm_ctx *c, const double *nocoord, WinBuild *res) {
             return;
         }
         res->built = true;
+        // symmetric form for the PCG's FP64 SpMV (groups of WIN_WAVES waves, paired value layout)
+        c->wsym.pat = WinSym();
+        const bool sym = !(getenv("FCVM_WIN_SYM") && atoi(getenv("FCVM_WIN_SYM")) == 0);
+        if (sym && w.waves == WIN_WAVES && c->win_v2 && !build_window_sym(c->pat, w, nt, c->wsym.pat)) c->wsym.pat = WinSym();
     } catch (const std::exception &ex) {
         res->err = std::string("fcvm_set_mesh (window format): ") + ex.what();
     }
@@ -543,6 +636,7 @@ static int setup_window_format(fcvm_ctx *c, const WinBuild &res) {
     // other otherwise)
     c->win2_ok = 2 * lds <= (size_t)lds_cap;
     if (c->win2_ok && (win_allow_lds(k_spmv_win2<true, WIN_WAVES>, 2 * lds) || win_allow_lds(k_spmv_win2<true, 4>, 2 * lds))) return 1;
+    if (wsym_upload(c)) return 1;
     if (getenv("FCVM_VERBOSE"))
         fprintf(stderr, "fcvm: window format: %lld groups of %d waves, windows mean %.0f / max %lld nodes (%zu B LDS of %d), %lld entries\n",
                 (long long)w.ngroups, w.waves, w.wmean, (long long)w.wmax, lds, lds_cap, (long long)w.nblocks);
@@ -776,6 +870,7 @@ static void free_mesh(fcvm_ctx *c) {
     dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
     dfree(c->d_nptr); dfree(c->d_nel); dfree(c->d_fe); dfree(c->d_part_vol); dfree(c->d_asm_items);
     win_free(c->win);
+    wsym_free(c->wsym);
     dfree(c->d_vals); dfree(c->d_vals_g); dfree(c->d_dblk); dfree(c->d_dinv); dfree(c->d_dinv6f); dfree(c->d_r); dfree(c->d_z); dfree(c->d_p);
     dfree(c->d_q); dfree(c->d_part_vec); dfree(c->d_part_spmv); dfree(c->d_part_misc); dfree(c->d_pidx);
     mg_free(c);
@@ -1071,10 +1166,10 @@ static int refresh_precond(fcvm_ctx *c) {   // after every assembly into d_vals
         const int64_t nrows = w.pat.nwaves * SLICE;
         const bool lo = c->precond_mode >= 1 && c->mg_additive == 2;   // the multiplicative cycle smooths with a 16-bit fixed-point copy (mode 2: the multi-GPU layer's cycle)
         w.lo_valid = false;
-        if (lo) {
-            if (!w.lo8 && (dalloc(&w.lo8, w.pat.nblocks) || dalloc(&w.lo2, w.pat.nblocks) || dalloc(&w.lo_scale, 2) ||
-                           dalloc(&w.part_lo, 2 * w.pat.ngroups)))
-                return 1;
+        c->wsym.valid = false;
+        if (lo && !w.lo8 && (dalloc(&w.lo8, w.pat.nblocks) || dalloc(&w.lo2, w.pat.nblocks) || dalloc(&w.part_lo, 2 * w.pat.ngroups))) return 1;
+        if (lo || c->wsym.on) {   // exponent of the largest diagonal entry: scale of the 16-bit copy and of the fixed-point sums
+            if (!w.lo_scale && dalloc(&w.lo_scale, 2)) return 1;
             hipLaunchKernelGGL(k_absmax_partial, dim3(1024), dim3(256), 0, c->stream, 9 * c->nn, c->d_dblk, c->d_part_misc);
             hipLaunchKernelGGL(k_lo_scale, dim3(1), dim3(256), 0, c->stream, c->d_part_misc, (int64_t)1024, w.lo_scale);
         }
@@ -1095,6 +1190,12 @@ static int refresh_precond(fcvm_ctx *c) {   // after every assembly into d_vals
         hipLaunchKernelGGL(k_repack_win, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, rs, nrows, w.srcslot, w.rowlen,
                            w.jstart, w.woff, c->d_sptr, c->d_vals, (double *)w.vals, c->win_v2, lo ? w.lo_scale : (const double *)nullptr,
                            lo ? w.lo8 : (short8 *)nullptr, lo ? w.lo2 : (WinLoTail *)nullptr, (const uint16_t *)w.cols);
+        if (c->wsym.on && c->wsym_use) {   // (an SPD stiffness matrix: fcvm_assemble sets wsym_use, the buckling operators do not)
+            WinSymDev &ws = c->wsym;
+            hipLaunchKernelGGL(k_repack_sym, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, rs, nrows, ws.srcslot, ws.rowlen, ws.woff, ws.jell,
+                               c->d_sptr, c->d_vals, ws.vals);
+            ws.valid = true;
+        }
         if (c->repack_overlap) {
             HCHK(hipEventRecord(c->repack_done, rs));
             c->repack_pending = true;
@@ -1142,6 +1243,7 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
     HCHK(hipGetLastError());
     SetupLap lap(s);
     lap("assemble: kernels");
+    c->wsym_use = true;
     if (refresh_precond(c)) return 1;
     lap("assemble: diagonal blocks, window-format copy");
     if (c->precond_mode >= 1) {
@@ -1564,6 +1666,31 @@ int fcvm_host_window_check(int64_t ne, int64_t nn, const int64_t *elNodes, const
     return 0;
 }
 
+int fcvm_host_window_sym_check(int64_t ne, int64_t nn, const int64_t *elNodes, const double *nocoord, int64_t out[8]) {
+    // host-only: the symmetric form of the window format (WinSym) of a mesh and its invariants
+    NEED(ne > 0 && nn > 0 && elNodes && nocoord && out, "fcvm_host_window_sym_check: empty mesh");
+    std::vector<int32_t> el(ne * 10);
+    for (int64_t i = 0; i < ne * 10; i++) {
+        int64_t v = elNodes[i] - 1;
+        NEED(v >= 0 && v < nn, "fcvm_host_window_sym_check: element node number out of range");
+        el[i] = (int32_t)v;
+    }
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    try {
+        Pattern p;
+        WinPattern w;
+        WinSym s;
+        build_pattern(ne, nn, el.data(), p, 4, SORT_WINDOW);
+        if (!build_window_format(p, nocoord, 4, 65535, w)) return 0;
+        if (!build_window_sym(p, w, 4, s)) return 0;
+        out[0] = 1; out[1] = s.nblocks; out[2] = s.dropped; out[3] = check_window_sym(p, w, s); out[4] = w.nblocks; out[5] = s.xmax;
+        out[6] = p.nnzb; out[7] = w.wmax;
+    } catch (const std::exception &ex) {
+        return fail(std::string("fcvm_host_window_sym_check: ") + ex.what());
+    }
+    return 0;
+}
+
 int fcvm_check_device_emap(fcvm_ctx *c, int64_t out[2]) {
     // the element map on the device (k_build_emap, or the uploaded host map under FCVM_EMAP_HOST=1) against the host
     // builder's rule: block (a, b) of element e is block lower_bound(columns of row el[e][a], el[e][b]) of that row
@@ -1967,6 +2094,7 @@ int fcvm_assemble_buckling(fcvm_ctx *c, const double *sig, double shift) {
     if (shift != 0.0)
         hipLaunchKernelGGL(k_axpby, dim3((unsigned)cdiv(nv, 256)), dim3(256), 0, s, nv, 1.0, c->d_vals, shift, c->d_vals_g, c->d_vals);
     HCHK(hipGetLastError());
+    c->wsym_use = false;      // K_b + sigma K_g is not positive definite in general: the bound behind the fixed-point sums does not hold
     if (refresh_precond(c)) return 1;
     if (c->precond_mode >= 1) {
         HCHK(hipStreamSynchronize(s));

@@ -247,11 +247,17 @@ std::vector<int32_t> morton_order(int64_t nn, const double *xyz) {
     };
     RawVec<uint64_t> key(nn), key2(nn);
     RawVec<int32_t> order(nn), order2(nn);
+    // ONE scale for the three axes (the largest extent): cells of the curve are cubes in space.  Until round 3 every axis was
+    // scaled by its own extent, which on a plate of 200 x 100 x 10 cuts the thickness as finely as the length: groups of
+    // consecutive nodes came out as thin slabs with twice the surface of a compact patch (1 M plate: 35 % of the blocks inside a
+    // group of 512 rows instead of 67 %, windows of 2000 nodes instead of ...: see DESIGN.md "SpMV").  FCVM_MORTON_AXIS_SCALE=1: the old keys.
+    const bool per_axis = getenv("FCVM_MORTON_AXIS_SCALE") && atoi(getenv("FCVM_MORTON_AXIS_SCALE")) != 0;
+    const double emax = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
     on_chunks([&](int64_t b, int64_t e, int) {
         for (int64_t i = b; i < e; i++) {
             uint64_t q[3];
             for (int k = 0; k < 3; k++) {
-                double ext = hi[k] - lo[k];
+                double ext = per_axis ? hi[k] - lo[k] : emax;
                 q[k] = ext > 0 ? (uint64_t)((xyz[3 * i + k] - lo[k]) / ext * 2097151.0) : 0;
             }
             key[i] = spread(q[0]) | spread(q[1]) << 1 | spread(q[2]) << 2;
@@ -441,6 +447,183 @@ bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int6
     }, 16);
     lap("pass 2 (columns)");
     return true;
+}
+
+// group of every node = the group whose first-segment vrow carries it
+static std::vector<int32_t> window_group_of(const Pattern &p, const WinPattern &w) {
+    std::vector<int32_t> grp(p.nn, -1);
+    for (int64_t at = 0; at < w.nwaves * SLICE; at++)
+        if (w.rownode[at] >= 0 && (w.seg[at] & 255u) > 0) grp[w.rownode[at]] = (int32_t)(at / (SLICE * w.waves));
+    return grp;
+}
+// is block (i, j), i != j, both in one group, stored in row i?
+static inline bool sym_keeps(int32_t i, int32_t j) {
+    const int32_t a = std::min(i, j), b = std::max(i, j);
+    return (((a + b) & 1) == 0 ? a : b) == i;
+}
+
+bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSym &s) {
+    const int64_t nn = p.nn, WV = w.waves, R = WV * SLICE, ng = w.ngroups;
+    const int split = w.split;
+    if (p.maxlen > 255) return false;
+    s.ngroups = ng; s.nwaves = w.nwaves; s.waves = w.waves; s.split = split;
+    s.rownode.assign(s.nwaves * SLICE, -1);
+    s.srcslot.assign(s.nwaves * SLICE, 0);
+    s.rowlen.assign(s.nwaves * SLICE, 0);
+    s.own.assign(s.nwaves * SLICE, 0);
+    s.seg.assign(s.nwaves * SLICE, 1);
+    s.woff.assign(s.nwaves + 1, 0);
+    s.gextra.assign(ng, 0);
+    const std::vector<int32_t> grp = window_group_of(p, w);
+    std::vector<uint16_t> jfirst(s.nwaves * SLICE, 0);      // first kept block of the segment (index into the row's kept list)
+    std::vector<int64_t> drop(nthreads > 0 ? nthreads : 1, 0);
+    struct VRow { int64_t len; int32_t nd; int32_t j0; uint32_t seg; };
+    // kept blocks of row i of group g, in column order: calls f(block number in the row, column node, transposed product wanted)
+    auto for_kept = [&](int32_t i, int32_t g, auto &&f) {
+        for (int64_t q = p.rowptr[i]; q < p.rowptr[i + 1]; q++) {
+            const int32_t j = p.colidx[q];
+            if (j != i && grp[j] == g) {
+                if (sym_keeps(i, j)) f((int)(q - p.rowptr[i]), j, true);
+            } else {
+                f((int)(q - p.rowptr[i]), j, false);
+            }
+        }
+    };
+    // pass 1: new lengths, segments, lanes, entries per wave
+    parallel_for(ng, nthreads, [&](int64_t b, int64_t e, int t) {
+        std::vector<VRow> rows;
+        for (int64_t g = b; g < e; g++) {
+            rows.clear();
+            int32_t extra = 0;
+            for (int64_t at = g * R; at < (g + 1) * R; at++) {       // the nodes of the group in the order of the full format's lanes
+                const int32_t nd = w.rownode[at];
+                if (nd < 0 || (w.seg[at] & 255u) == 0) continue;
+                int64_t len = 0;
+                for_kept(nd, (int32_t)g, [&](int, int32_t, bool) { len++; });
+                drop[t] += (p.rowptr[nd + 1] - p.rowptr[nd]) - len;
+                const int k = (int)std::max<int64_t>(1, (len + split - 1) / split);
+                int64_t j0 = 0;
+                for (int tt = 0; tt < k; tt++) {
+                    const int64_t l = len / k + (tt < len % k ? 1 : 0);
+                    const uint32_t code = tt == 0 ? ((uint32_t)extra << 8) | (uint32_t)k : ((uint32_t)(extra + tt - 1) << 8);
+                    rows.push_back({l, nd, (int32_t)j0, code});
+                    j0 += l;
+                }
+                extra += k - 1;
+            }
+            s.gextra[g] = extra;
+            std::stable_sort(rows.begin(), rows.end(), [](const VRow &x, const VRow &y) { return x.len > y.len; });
+            for (size_t k = 0; k < rows.size(); k++) {
+                const int64_t wave = g * WV + (int64_t)k / SLICE, at = wave * SLICE + (int64_t)k % SLICE;
+                s.rownode[at] = rows[k].nd;
+                s.srcslot[at] = p.slotof[rows[k].nd];
+                s.rowlen[at] = (uint16_t)rows[k].len;
+                jfirst[at] = (uint16_t)rows[k].j0;
+                s.seg[at] = rows[k].seg;
+                s.woff[wave + 1] += rows[k].len;
+            }
+        }
+    }, 16);
+    s.dropped = 0;
+    for (int64_t v : drop) s.dropped += v;
+    s.xmax = 0;
+    for (int64_t g = 0; g < ng; g++) s.xmax = std::max<int64_t>(s.xmax, s.gextra[g]);
+    for (int64_t i = 0; i < s.nwaves; i++) s.woff[i + 1] = (s.woff[i + 1] + 15) / 16 * 16 + s.woff[i];
+    s.nblocks = s.woff[s.nwaves];
+    s.cols.resize(s.nblocks);
+    s.jell.resize(s.nblocks);
+    // pass 2: entries in the prefix layout
+    parallel_for(ng, nthreads, [&](int64_t b, int64_t e, int) {
+        std::vector<uint16_t> pos(nn, 0), slot(nn, 0);     // window position / first-segment position of a node of the current group
+        std::vector<uint32_t> ent;                         // kept entries of one row: column | target << 16
+        std::vector<uint8_t> jl;
+        for (int64_t g = b; g < e; g++) {
+            const int32_t *wl = &w.wlist[w.gptr[g]];
+            const int64_t W = w.gptr[g + 1] - w.gptr[g];
+            for (int64_t i = 0; i < W; i++) pos[wl[i]] = (uint16_t)i;
+            for (int64_t at = g * R; at < (g + 1) * R; at++)
+                if (s.rownode[at] >= 0 && (s.seg[at] & 255u) > 0) slot[s.rownode[at]] = (uint16_t)(at - g * R);
+            for (int64_t wave = g * WV; wave < (g + 1) * WV; wave++) {
+                int64_t off = s.woff[wave];
+                // pad entries of the wave (alignment) and of short lanes are never read as blocks; fill them harmlessly
+                for (int64_t q = s.woff[wave]; q < s.woff[wave + 1]; q++) { s.cols[q] = 0xFFFF0000u; s.jell[q] = 0; }
+                const uint16_t *len = &s.rowlen[wave * SLICE];
+                // gather the kept lists of the 64 lanes once
+                std::vector<std::vector<uint32_t>> le(SLICE);
+                std::vector<std::vector<uint8_t>> lj(SLICE);
+                for (int64_t l = 0; l < SLICE; l++) {
+                    const int32_t nd = s.rownode[wave * SLICE + l];
+                    if (nd < 0) continue;
+                    s.own[wave * SLICE + l] = pos[nd];
+                    ent.clear(); jl.clear();
+                    for_kept(nd, (int32_t)g, [&](int jq, int32_t col, bool tr) {
+                        ent.push_back((uint32_t)pos[col] | ((tr ? (uint32_t)slot[col] : 0xFFFFu) << 16));
+                        jl.push_back((uint8_t)jq);
+                    });
+                    const int64_t j0 = jfirst[wave * SLICE + l];
+                    le[l].assign(ent.begin() + j0, ent.begin() + j0 + len[l]);
+                    lj[l].assign(jl.begin() + j0, jl.begin() + j0 + len[l]);
+                }
+                for (int64_t j = 0; j < len[0]; j++) {
+                    int64_t n = 0;
+                    while (n < SLICE && len[n] > j) n++;
+                    for (int64_t l = 0; l < n; l++) { s.cols[off + l] = le[l][j]; s.jell[off + l] = lj[l][j]; }
+                    off += n;
+                }
+            }
+        }
+    }, 16);
+    return true;
+}
+
+int64_t check_window_sym(const Pattern &p, const WinPattern &w, const WinSym &s) {
+    int64_t bad = 0;
+    const int64_t R = (int64_t)s.waves * SLICE;
+    std::vector<uint8_t> hit(p.nnzb, 0);
+    auto mark = [&](int32_t i, int32_t j) {
+        const int32_t *rb = p.colidx.data() + p.rowptr[i], *re = p.colidx.data() + p.rowptr[i + 1];
+        const int32_t *at = std::lower_bound(rb, re, j);
+        if (at == re || *at != j) { bad++; return; }
+        if (hit[at - p.colidx.data()]++) bad++;
+    };
+    for (int64_t wave = 0; wave < s.nwaves; wave++) {
+        const int64_t g = wave / s.waves;
+        const int32_t *wl = &w.wlist[w.gptr[g]];
+        const int64_t W = w.gptr[g + 1] - w.gptr[g];
+        const uint16_t *len = &s.rowlen[wave * SLICE];
+        for (int l = 0; l < SLICE; l++) {
+            const int64_t at = wave * SLICE + l;
+            if (l > 0 && len[l] > len[l - 1]) bad++;
+            if (s.rownode[at] < 0) { if (len[l]) bad++; continue; }
+            if (len[l] > s.split) bad++;
+            if (s.own[at] >= W || wl[s.own[at]] != s.rownode[at]) bad++;
+            if (s.srcslot[at] != p.slotof[s.rownode[at]]) bad++;
+        }
+        int64_t off = s.woff[wave];
+        for (int64_t j = 0; j < len[0]; j++) {
+            int64_t n = 0;
+            while (n < SLICE && len[n] > j) n++;
+            for (int64_t l = 0; l < n; l++) {
+                const int32_t i = s.rownode[wave * SLICE + l];
+                const uint32_t en = s.cols[off + l];
+                const uint32_t cp = en & 0xFFFFu, ts = en >> 16;
+                if ((int64_t)cp >= W) { bad++; continue; }
+                const int32_t jn = wl[cp];
+                mark(i, jn);
+                if (p.colidx[p.rowptr[i] + s.jell[off + l]] != jn) bad++;           // the copy kernel's source is this block
+                if (ts != 0xFFFFu) {
+                    const int64_t tat = g * R + ts;
+                    if ((int64_t)ts >= R || s.rownode[tat] != jn || (s.seg[tat] & 255u) == 0 || jn == i) bad++;
+                    else mark(jn, i);
+                }
+            }
+            off += n;
+        }
+        if (off > s.woff[wave + 1] || s.woff[wave] % 16) bad++;
+    }
+    for (int64_t q = 0; q < p.nnzb; q++)
+        if (hit[q] != 1) bad++;
+    return bad;
 }
 
 }  // namespace fcvm

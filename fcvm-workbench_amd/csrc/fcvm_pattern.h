@@ -133,6 +133,35 @@ struct WinPattern {
 bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int64_t max_window, WinPattern &w, int waves = WIN_WAVES,
                          int split = WIN_SPLIT, const int32_t *given_order = nullptr);   // given_order: morton_order(nn, xyz) if at hand
 
+// ---------------------------------------------------------------------------------------------------------------
+// Symmetric form of the window format (round 3, the PCG's FP64 SpMV only).  K is symmetric and 2/3 of its blocks couple two
+// nodes of the SAME group (measured on the plate meshes, groups of 512 rows).  Of such a pair K_ij, K_ji = K_ij^T only one is
+// stored -- in row min(i, j) when i + j is even, in row max(i, j) otherwise, which keeps the row lengths balanced -- and the
+// kernel forms both products of it: K_ij x_j into the row's own accumulator and K_ij^T x_i into the accumulator of row j,
+// through LDS in 64-bit FIXED POINT (integer adds commute: the result does not depend on the order in which the lanes arrive,
+// so runs stay bitwise reproducible).  Blocks to other groups and the diagonal blocks are stored as before.  Same groups, same
+// windows (WinPattern::gptr / wlist are shared), same prefix layout; the rows are shorter, so the lanes of a group are sorted
+// again and rows are cut into segments by their NEW length.  Entry of a stored block: window position of its column node in the
+// low 16 bits, in the high 16 bits the position in the group (wave * 64 + lane) of the FIRST segment of the column node's row
+// when the transposed product is wanted, 0xFFFF otherwise.  jell: number of the block in its sliced-ELL row (the copy kernel's
+// source; rows are filtered, so "block j of the segment = block jstart + j of the row" no longer holds).
+struct WinSym {
+    int64_t ngroups = 0, nwaves = 0, nblocks = 0, dropped = 0;
+    int waves = WIN_WAVES, split = WIN_SPLIT;
+    int64_t xmax = 0;                 // most second-and-later segments in one group
+    std::vector<int32_t> rownode, srcslot;      // [nwaves*64]
+    std::vector<uint16_t> rowlen, own;          // [nwaves*64]
+    std::vector<uint32_t> seg;                  // [nwaves*64] as WinPattern::seg
+    std::vector<int64_t> woff;                  // [nwaves+1]
+    std::vector<int32_t> gextra;                // [ngroups]
+    RawVec<uint32_t> cols;                      // [nblocks]
+    RawVec<uint8_t> jell;                       // [nblocks]
+};
+// false: not applicable (a row with more than 255 blocks)
+bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSym &s);
+// number of violated invariants (0 = every block of the matrix is covered exactly once, directly or as a transposed product)
+int64_t check_window_sym(const Pattern &p, const WinPattern &w, const WinSym &s);
+
 // nodes sorted along a Morton (Z-order) curve through their coordinates: a locality-preserving order in which
 // the SpMV walks the rows when the caller's node numbering has none (unstructured meshes)
 std::vector<int32_t> morton_order(int64_t nn, const double *xyz);

@@ -918,4 +918,202 @@ __global__ __launch_bounds__(64) void k_spmv_l1_i16(int64_t nslices, const int64
     epi.x[o] += a0; epi.x[o + 1] += a1; epi.x[o + 2] += a2;
 }
 
+// ---- symmetric form of the window format (WinSym, fcvm_pattern.h): the PCG's FP64 SpMV on 0.70 x the blocks --------------------
+// values of the sliced-ELL array -> symmetric window storage (V2 component layout); thread = vrow, source block from jell
+__global__ __launch_bounds__(256) void k_repack_sym(int64_t nrows, const int32_t *__restrict__ srcslot, const uint16_t *__restrict__ rowlen,
+                                                    const int64_t *__restrict__ woff, const uint8_t *__restrict__ jell,
+                                                    const int64_t *__restrict__ sptr, const double *__restrict__ src, double *__restrict__ dst) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    const int len = rowlen[row];
+    const int L = __builtin_amdgcn_readfirstlane(len);
+    const int64_t slot = srcslot[row], s = slot >> 6, ls = slot & 63;
+    const int64_t jb = sptr[s], slen = sptr[s + 1] - jb;
+    int64_t off = woff[row >> 6];
+    for (int j = 0; j < L; j++) {
+        const int n = __popcll(__builtin_amdgcn_ballot_w64(len > j));
+        if (len > j) {
+            const int64_t js = jell[off + lane];
+            const bool single = (slen & 1) && js == slen - 1;
+            const int64_t unit = jb + (single ? js : (js & ~(int64_t)1));
+            const double *sp = src + unit * 576 + (single ? ls : 2 * ls + (js & 1));
+            const int cs = single ? 64 : 128;
+            double *dp = dst + 9 * off;
+            double v[9];
+#pragma unroll
+            for (int c = 0; c < 9; c++) v[c] = sp[c * cs];
+#pragma unroll
+            for (int c = 0; c < 9; c++) dp[win_value_at(c, n, lane, 1)] = v[c];
+        }
+        off += n;
+    }
+}
+
+struct WinSlotS {
+    double v[9];
+    uint32_t ct;     // window position of the column node | position in the group of its row's first segment << 16 (0xFFFF: none)
+};
+__device__ __forceinline__ void win_load_sym(WinSlotS &t, const uint32_t *__restrict__ cols, const double *__restrict__ vals, int64_t off,
+                                             int n, int lane) {
+    const int l = lane < n ? lane : n - 1;
+    t.ct = __builtin_nontemporal_load(cols + off + l);
+    const double *vp = vals + 9 * off + 2 * l;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const double2 w = ld_val<true>((const double2 *)(vp + (int64_t)2 * k * n));
+        t.v[2 * k] = w.x;
+        t.v[2 * k + 1] = w.y;
+    }
+    t.v[8] = __builtin_nontemporal_load(vals + 9 * off + (int64_t)8 * n + l);
+}
+// round(t * 2^sh) as a 64-bit two's-complement integer, |t * 2^sh| < 2^62: two native 32-bit conversions (high part in units of
+// 2^31, remainder in [-2^30, 2^30]) instead of the library's double -> int64 routine
+__device__ __forceinline__ unsigned long long fixed62(double t, int sh) {
+    const double hi = rint(ldexp(t, sh - 31));
+    const double lo = rint(fma(hi, -2147483648.0, ldexp(t, sh)));
+    return (unsigned long long)(((long long)(int)hi << 31) + (long long)(int)lo);
+}
+// y += K_ij x_j and, where wanted, the row of the column node += K_ij^T x_i in 64-bit fixed point (unit 2^-sh)
+__device__ __forceinline__ void win_fma_sym(const WinSlotS &t, bool active, const double *xs, double o0, double o1, double o2,
+                                            unsigned long long *yacc, int sh, bool tr_on, double &y0, double &y1, double &y2) {
+    const double *xa = xs + 3 * (int)(t.ct & 0xFFFFu);
+    const double a0 = active ? xa[0] : 0.0, a1 = active ? xa[1] : 0.0, a2 = active ? xa[2] : 0.0;
+    y0 += t.v[0] * a0 + t.v[1] * a1 + t.v[2] * a2;
+    y1 += t.v[3] * a0 + t.v[4] * a1 + t.v[5] * a2;
+    y2 += t.v[6] * a0 + t.v[7] * a1 + t.v[8] * a2;
+    const uint32_t ts = t.ct >> 16;
+    if (active && tr_on && ts != 0xFFFFu) {
+        const double t0 = t.v[0] * o0 + t.v[3] * o1 + t.v[6] * o2;
+        const double t1 = t.v[1] * o0 + t.v[4] * o1 + t.v[7] * o2;
+        const double t2 = t.v[2] * o0 + t.v[5] * o1 + t.v[8] * o2;
+        unsigned long long *ya = yacc + 3 * ts;
+        atomicAdd(ya, fixed62(t0, sh));
+        atomicAdd(ya + 1, fixed62(t1, sh));
+        atomicAdd(ya + 2, fixed62(t2, sh));
+    }
+}
+
+// LDS: x of the window [3 wmax], partial results of later segments [3 xseg], fixed-point accumulators [3 * 64 * WAVES].
+// kexp[0] = exponent e0 with |K entries| < 2^e0 (k_lo_scale).  The unit of the accumulators is chosen per group from the largest
+// |x| of its window: a row receives at most 64 transposed products (a node has at most 64 neighbours) of three terms below
+// 2^e0 * xmax each, so the sums stay below 2^(e0 + ex + 7.6) * ... < 2^62 units of 2^(e0 + ex + 8 - 62): no overflow; one unit is
+// 2^-54 of kmax * xmax, half an FP64 rounding error of the largest possible term (with four bits more margin the attainable
+// residual of a solve to 1e-11 rose from 5e-11 to 6e-11 of |f|: the margin was taken out).
+template <bool DOT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 4) void k_spmv_win_sym(int64_t ngroups, int64_t wmax, int64_t xseg, const int64_t *__restrict__ gptr,
+                                                                 const int32_t *__restrict__ gextra, const int32_t *__restrict__ wlist,
+                                                                 const int64_t *__restrict__ woff, const uint16_t *__restrict__ rowlen,
+                                                                 const int32_t *__restrict__ rownode, const uint32_t *__restrict__ seg,
+                                                                 const uint16_t *__restrict__ own, const uint32_t *__restrict__ cols,
+                                                                 const double *__restrict__ vals, const double *__restrict__ kexp,
+                                                                 const double *__restrict__ x, double *__restrict__ y,
+                                                                 double *__restrict__ partial, const double *__restrict__ done) {
+    extern __shared__ double xs[];
+    __shared__ double sh[WAVES];
+    constexpr int WIN_THREADS = 64 * WAVES;
+    if (done && *done != 0.0) return;
+    const int64_t b = blockIdx.x;
+    const int64_t q = ngroups >> 3, r = ngroups & 7, xcd = b & 7;
+    const int64_t g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wig = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t wave = g * WAVES + wig, row = wave * 64 + lane;
+    const int len = rowlen[row];
+    const int L = __builtin_amdgcn_readfirstlane(len);
+    int64_t off = woff[wave];
+    unsigned long long *yacc = (unsigned long long *)(xs + 3 * (wmax + xseg));
+    double xm = 0.0;
+    {
+        const int64_t w0 = gptr[g];
+        const int W = (int)(gptr[g + 1] - w0);
+        for (int i = tid; i < W; i += WIN_THREADS) {
+            const int32_t nd = wlist[w0 + i];
+            const double *xa = x + 3 * (int64_t)nd;
+            const int o = nd & 1;
+            const double2 wv = *(const double2 *)(xa + o);
+            const double sv = xa[o ? 0 : 2];
+            const double v0 = o ? sv : wv.x, v1 = o ? wv.x : wv.y, v2 = o ? wv.y : sv;
+            xs[3 * i] = v0; xs[3 * i + 1] = v1; xs[3 * i + 2] = v2;
+            xm = fmax(xm, fmax(fabs(v0), fmax(fabs(v1), fabs(v2))));
+        }
+        for (int i = tid; i < 3 * WIN_THREADS; i += WIN_THREADS) yacc[i] = 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) xm = fmax(xm, __shfl_xor(xm, o, 64));
+        if (lane == 0) sh[wig] = xm;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < WAVES; i++) xm = fmax(xm, sh[i]);
+    int ex = 0;
+    const bool tr_on = xm > 0.0 && xm < 1e300;
+    if (tr_on) (void)frexp(xm, &ex);
+    const int shf = 62 - ((int)kexp[0] + ex + 8);
+    const int32_t node = rownode[row];
+    double o0 = 0.0, o1 = 0.0, o2 = 0.0;
+    if (node >= 0) {
+        const double *xo = xs + 3 * (int)own[row];
+        o0 = xo[0]; o1 = xo[1]; o2 = xo[2];
+    }
+    __syncthreads();       // (sh is used again below)
+    WinSlotS a, bb, cc;
+    int j = 0;
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+    {   // three blocks in flight, two accumulator sets: the transposed products need registers too (four and four spilled)
+        double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+        for (; j + 3 <= L; j += 3) {
+            const bool p0 = len > j, p1 = len > j + 1, p2 = len > j + 2;
+            const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0)), n1 = __popcll(__builtin_amdgcn_ballot_w64(p1)),
+                      n2 = __popcll(__builtin_amdgcn_ballot_w64(p2));
+            win_load_sym(a, cols, vals, off, n0, lane);
+            win_load_sym(bb, cols, vals, off + n0, n1, lane);
+            win_load_sym(cc, cols, vals, off + n0 + n1, n2, lane);
+            win_fma_sym(a, p0, xs, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
+            win_fma_sym(bb, p1, xs, o0, o1, o2, yacc, shf, tr_on, z0, z1, z2);
+            win_fma_sym(cc, p2, xs, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
+            off += n0 + n1 + n2;
+        }
+        y0 += z0; y1 += z1; y2 += z2;
+    }
+    for (; j < L; j++) {
+        const bool p0 = len > j;
+        const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0));
+        win_load_sym(a, cols, vals, off, n0, lane);
+        win_fma_sym(a, p0, xs, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
+        off += n0;
+    }
+    const uint32_t sc = seg[row];
+    const int nseg = (int)(sc & 255u);
+    __syncthreads();       // every transposed product of the group has arrived
+    if (node >= 0 && nseg > 0 && tr_on) {
+        const unsigned long long *ya = yacc + 3 * (wig * 64 + lane);
+        y0 += ldexp((double)(long long)ya[0], -shf);
+        y1 += ldexp((double)(long long)ya[1], -shf);
+        y2 += ldexp((double)(long long)ya[2], -shf);
+    }
+    if (gextra[g] > 0) {
+        double *yp = xs + 3 * wmax + 3 * (int)(sc >> 8);
+        if (node >= 0 && nseg == 0) { yp[0] = y0; yp[1] = y1; yp[2] = y2; }
+        __syncthreads();
+        for (int k = 0; k + 1 < nseg; k++) { y0 += yp[3 * k]; y1 += yp[3 * k + 1]; y2 += yp[3 * k + 2]; }
+    }
+    if (node >= 0 && nseg > 0) {
+        double *yo = y + 3 * (int64_t)node;
+        yo[0] = y0; yo[1] = y1; yo[2] = y2;
+    }
+    if (DOT) {
+        double d = 0.0;
+        if (node >= 0 && nseg > 0) d = y0 * o0 + y1 * o1 + y2 * o2;
+        d = wave_sum(d);
+        if (lane == 0) sh[wig] = d;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < WAVES; i++) t += sh[i];
+            partial[g] = t;
+        }
+    }
+}
+
 }  // namespace fcvm

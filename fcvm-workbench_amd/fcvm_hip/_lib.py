@@ -61,6 +61,7 @@ SIGNATURES = {
     "fcvm_mg_apply2": [_vp, _vp, _vp, _vp, _vp],
     "fcvm_host_pattern_check": [_i64, _i64, _vp, _pi64],
     "fcvm_check_device_emap": [_vp, _pi64],
+    "fcvm_host_window_sym_check": [_i64, _i64, _vp, _vp, _pi64],
     "fcvm_spmv_info": [_vp, _pi64],
     "fcvm_mem_info": [_vp, _pi64],
     "fcvm_mg_sparse_info": [_vp, _pi64],

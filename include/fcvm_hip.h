@@ -259,6 +259,12 @@ int fcvm_spd_inverse(fcvm_ctx *c, int64_t n, const double *src, double *dst);
  * out[1] = ms per pass.  The HBM rate this GPU delivers right now, to put a measured SpMV time into perspective. */
 int fcvm_membench(fcvm_ctx *c, int64_t nbytes, double out[2]);
 
+/* host-only self check of the symmetric form of the window format (the PCG's FP64 SpMV stores one block of every pair
+ * K_ij, K_ji inside a group and forms both products): out[0] = built, out[1] = stored entries, out[2] = blocks not stored,
+ * out[3] = violated invariants (must be 0: every block of the matrix covered exactly once), out[4] = entries of the full
+ * window format, out[5] = most extra row segments in a group, out[6] = blocks of the matrix, out[7] = largest window */
+int fcvm_host_window_sym_check(int64_t ne, int64_t nn, const int64_t *elNodes, const double *nocoord, int64_t out[8]);
+
 /* The element -> block-location map of the assembly kernels is built on the device by fcvm_set_mesh (k_build_emap; the host
  * builder's map under FCVM_EMAP_HOST=1).  This compares it, entry by entry, with the host rule of fcvm_pattern.cpp:
  * out[0] = entries, out[1] = mismatches (must be 0).  Replaces nothing in the reference (its scipy COO -> CSC conversion,

@@ -404,6 +404,57 @@ def test_sparse_aggregate_level_solves_like_the_dense_one(monkeypatch):
     assert res["sparse"][1] <= 1.15 * res["dense"][1] + 5, (res["sparse"][1], res["dense"][1])
 
 
+@pytest.mark.parametrize("mesh", ["plate", "embankment", "cube"])
+def test_symmetric_window_form_spmv_equals_the_full_form(monkeypatch, mesh):
+    """The PCG's FP64 SpMV stores one block of every pair K_ij, K_ji inside a group and adds the transposed product through LDS in
+    64-bit fixed point (k_spmv_win_sym).  Against the full window form (FCVM_WIN_SYM=0): same product to FP64 rounding for random,
+    tiny, huge and zero vectors, bitwise the same on a rerun (integer sums do not depend on the arrival order), the same p.Kp
+    and PCG solution; meshes with split rows (corner nodes of tet10 meshes: 65 blocks) and unstructured numbering."""
+    from fcvm_hip import examples, meshgen
+    from fcvm_hip.device import Context
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import GpuModel
+    if mesh == "plate":
+        case = examples.plate_with_hole(4.0)
+        loads = Loads(ufaces=case["ufaces"], uloads=case["uloads"])
+    elif mesh == "embankment":
+        case = examples.embankment(refine=2)
+        loads = Loads()
+    else:
+        case = meshgen.cube_case(14, l=50.0, traction=(0.0, 0.0, -1.0))
+        case["material"] = (210000.0, 0.3, 7.8e-6)
+        loads = Loads(ufaces=case["ufaces"], uloads=case["uloads"])
+    rng = np.random.default_rng(17)
+    res = {}
+    xs = None
+    for form in ("full", "sym"):
+        if form == "full":
+            monkeypatch.setenv("FCVM_WIN_SYM", "0")
+        else:
+            monkeypatch.delenv("FCVM_WIN_SYM", raising=False)
+        m = GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"], loads, ctx=Context(0))
+        c = m.ctx
+        glv, modf, _, _ = m.calc_gsm((0.0, 0.0, -9.81), want_x=False)
+        assert c.spmv_info()["window_format"]
+        if xs is None:
+            x0 = rng.standard_normal(m.ndof)
+            xs = [x0, 1e-200 * x0, 1e150 * x0, np.zeros(m.ndof), np.where(np.arange(m.ndof) % 97 == 0, 1.0, 0.0)]
+        ys = [c.spmv(c.array(x), c.empty(m.ndof)).get() for x in xs]
+        ys2 = [c.spmv(c.array(x), c.empty(m.ndof)).get() for x in xs]
+        f = c.mul(m.fixdof, glv)
+        c.axpby(1.0, f, 1.0, modf, out=f)
+        u, info = c.solve(f, rtol=1e-10)
+        res[form] = (ys, ys2, u.get(), info["iterations"])
+        c.close()
+    for a, b in zip(res["sym"][0], res["sym"][1]):
+        assert np.array_equal(a, b)
+    for x, a, b in zip(xs, res["sym"][0], res["full"][0]):
+        scale = np.abs(b).max()
+        assert np.abs(a - b).max() <= 1e-13 * scale if scale > 0 else not a.any()
+    assert abs(res["sym"][3] - res["full"][3]) <= 1
+    assert rel(res["sym"][2], res["full"][2]) < 1e-8
+
+
 def test_aggregate_level_product_from_the_lower_triangle_equals_the_row_kernel(monkeypatch):
     """e2 = A2^-1 r2 is applied from the lower triangle of the FP32 inverse (k_symv_tiles + k_symv_reduce, half the bytes of the
     row-by-row kernel) once the level has 2048 unknowns: same result to FP64 rounding as k_gemv_f32x4 (FCVM_L2_SYMV=0) on a
