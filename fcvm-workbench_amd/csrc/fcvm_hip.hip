@@ -1128,6 +1128,21 @@ int fcvm_spmv_info(fcvm_ctx *c, int64_t out[8]) {
     return 0;
 }
 
+/* the symmetric form of the window format (the PCG's FP64 SpMV): out[0] = 1 if built for this mesh, out[1] = stored entries,
+ * out[2] = blocks of the matrix not stored (their transposes are), out[3] = bytes one launch streams from the format, out[4] =
+ * LDS bytes per workgroup, out[5] = 1 if the values of the last assembly are in it (fcvm_spmv / fcvm_solve then use it) */
+int fcvm_spmv_sym_info(fcvm_ctx *c, int64_t out[8]) {
+    NEED(c && c->have_mesh && out, "fcvm_spmv_sym_info: no mesh");
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    if (!c->wsym.on) return 0;
+    const WinSym &w = c->wsym.pat;
+    const WinPattern &f = c->win.pat;
+    out[0] = 1; out[1] = w.nblocks; out[2] = w.dropped;
+    out[3] = w.nblocks * 76 + f.gptr[f.ngroups] * 4 + w.nwaves * SLICE * 16 + (w.nwaves + w.ngroups) * 8;
+    out[4] = (int64_t)c->wsym.lds; out[5] = c->wsym.valid ? 1 : 0;
+    return 0;
+}
+
 int fcvm_matrix_to_coo(fcvm_ctx *c, int64_t *row, int64_t *col, double *val) {
     NEED(c && c->have_mesh, "fcvm_matrix_to_coo: no mesh");
     const Pattern &p = c->pat;
@@ -1187,8 +1202,11 @@ static int refresh_precond(fcvm_ctx *c) {   // after every assembly into d_vals
             HCHK(hipStreamWaitEvent(c->repack_stream, c->repack_fork, 0));
             rs = c->repack_stream;
         }
+        // with the symmetric form in charge of the FP64 products nobody reads the full FP64 window copy: only its 16-bit copy is written
+        const bool sym_now = c->wsym.on && c->wsym_use;
+        if (!sym_now || lo)
         hipLaunchKernelGGL(k_repack_win, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, rs, nrows, w.srcslot, w.rowlen,
-                           w.jstart, w.woff, c->d_sptr, c->d_vals, (double *)w.vals, c->win_v2, lo ? w.lo_scale : (const double *)nullptr,
+                           w.jstart, w.woff, c->d_sptr, c->d_vals, sym_now ? (double *)nullptr : (double *)w.vals, c->win_v2, lo ? w.lo_scale : (const double *)nullptr,
                            lo ? w.lo8 : (short8 *)nullptr, lo ? w.lo2 : (WinLoTail *)nullptr, (const uint16_t *)w.cols);
         if (c->wsym.on && c->wsym_use) {   // (an SPD stiffness matrix: fcvm_assemble sets wsym_use, the buckling operators do not)
             WinSymDev &ws = c->wsym;

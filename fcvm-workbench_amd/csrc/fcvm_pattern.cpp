@@ -535,8 +535,6 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
     // pass 2: entries in the prefix layout
     parallel_for(ng, nthreads, [&](int64_t b, int64_t e, int) {
         std::vector<uint16_t> pos(nn, 0), slot(nn, 0);     // window position / first-segment position of a node of the current group
-        std::vector<uint32_t> ent;                         // kept entries of one row: column | target << 16
-        std::vector<uint8_t> jl;
         for (int64_t g = b; g < e; g++) {
             const int32_t *wl = &w.wlist[w.gptr[g]];
             const int64_t W = w.gptr[g + 1] - w.gptr[g];
@@ -544,31 +542,33 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
             for (int64_t at = g * R; at < (g + 1) * R; at++)
                 if (s.rownode[at] >= 0 && (s.seg[at] & 255u) > 0) slot[s.rownode[at]] = (uint16_t)(at - g * R);
             for (int64_t wave = g * WV; wave < (g + 1) * WV; wave++) {
-                int64_t off = s.woff[wave];
-                // pad entries of the wave (alignment) and of short lanes are never read as blocks; fill them harmlessly
+                // pad entries of the wave (alignment) are never read as blocks; fill them harmlessly
                 for (int64_t q = s.woff[wave]; q < s.woff[wave + 1]; q++) { s.cols[q] = 0xFFFF0000u; s.jell[q] = 0; }
                 const uint16_t *len = &s.rowlen[wave * SLICE];
-                // gather the kept lists of the 64 lanes once
-                std::vector<std::vector<uint32_t>> le(SLICE);
-                std::vector<std::vector<uint8_t>> lj(SLICE);
+                // first entry of block row j of the wave: lanes are sorted by length, block row j holds the lanes with len > j
+                int64_t rowoff[256];
+                {
+                    int64_t off = s.woff[wave];
+                    int n = SLICE;
+                    for (int64_t jj = 0; jj < len[0]; jj++) {
+                        while (n > 0 && len[n - 1] <= jj) n--;
+                        rowoff[jj] = off;
+                        off += n;
+                    }
+                }
                 for (int64_t l = 0; l < SLICE; l++) {
                     const int32_t nd = s.rownode[wave * SLICE + l];
                     if (nd < 0) continue;
                     s.own[wave * SLICE + l] = pos[nd];
-                    ent.clear(); jl.clear();
+                    const int64_t j0 = jfirst[wave * SLICE + l], j1 = j0 + len[l];
+                    int64_t k = 0;
                     for_kept(nd, (int32_t)g, [&](int jq, int32_t col, bool tr) {
-                        ent.push_back((uint32_t)pos[col] | ((tr ? (uint32_t)slot[col] : 0xFFFFu) << 16));
-                        jl.push_back((uint8_t)jq);
+                        if (k >= j0 && k < j1) {
+                            s.cols[rowoff[k - j0] + l] = (uint32_t)pos[col] | ((tr ? (uint32_t)slot[col] : 0xFFFFu) << 16);
+                            s.jell[rowoff[k - j0] + l] = (uint8_t)jq;
+                        }
+                        k++;
                     });
-                    const int64_t j0 = jfirst[wave * SLICE + l];
-                    le[l].assign(ent.begin() + j0, ent.begin() + j0 + len[l]);
-                    lj[l].assign(jl.begin() + j0, jl.begin() + j0 + len[l]);
-                }
-                for (int64_t j = 0; j < len[0]; j++) {
-                    int64_t n = 0;
-                    while (n < SLICE && len[n] > j) n++;
-                    for (int64_t l = 0; l < n; l++) { s.cols[off + l] = le[l][j]; s.jell[off + l] = lj[l][j]; }
-                    off += n;
                 }
             }
         }

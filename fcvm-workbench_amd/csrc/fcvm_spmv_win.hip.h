@@ -98,8 +98,10 @@ __global__ __launch_bounds__(256) void k_repack_win(int64_t nrows, const int32_t
             double v[9];
 #pragma unroll
             for (int c = 0; c < 9; c++) v[c] = sp[c * cs];
+            if (dst) {      // (null: only the 16-bit copy is wanted -- the FP64 values go to the symmetric form, k_repack_sym)
 #pragma unroll
-            for (int c = 0; c < 9; c++) dp[win_value_at(c, n, lane, v2)] = v[c];
+                for (int c = 0; c < 9; c++) dp[win_value_at(c, n, lane, v2)] = v[c];
+            }
             if (lo8) {
                 const int e0 = (int)lo_scale[0];
                 double m = 0.0;

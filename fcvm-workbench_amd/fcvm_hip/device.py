@@ -189,6 +189,13 @@ class Context:
         return dict(window_format=bool(out[0]), waves_per_group=out[0], groups=out[1], max_window=out[2], mean_window=out[3], blocks=out[4],
                     bytes=out[5], lds_bytes=out[6], split=out[7])
 
+    def spmv_sym_info(self):
+        """the symmetric form of the window format (the PCG's FP64 SpMV): built / stored entries / blocks not stored / bytes per
+        launch / LDS bytes / in use"""
+        out = (C.c_int64 * 8)()
+        call("fcvm_spmv_sym_info", self.h, out)
+        return dict(built=bool(out[0]), blocks=out[1], dropped=out[2], bytes=out[3], lds_bytes=out[4], in_use=bool(out[5]))
+
     def matrix_coo(self):
         nnz = 9 * self.pattern_info()["nnz_blocks"]
         r, c, v = np.empty(nnz, np.int64), np.empty(nnz, np.int64), np.empty(nnz, np.float64)

@@ -59,6 +59,29 @@ def test_window_format_invariants():
         assert small[0] == 0 and small[2] == out[2]
 
 
+def test_symmetric_window_form_covers_every_block_once():
+    """Host builder of the symmetric form of the window format (fcvm_pattern.cpp build_window_sym): every block of the matrix is
+    covered exactly once -- stored, or the transpose of a stored block whose target is the first segment of its row in the same
+    group -- the copy kernel's source block is the stored block, lanes stay sorted by length, and a third of the blocks goes."""
+    from fcvm_hip import _lib, meshgen
+    from conftest import load_golden
+    el, xyz = meshgen.cube_tet10(12, 9, 7, 30.0, 20.0, 10.0)
+    emb, _ = load_golden("embankment")
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(len(xyz))                       # a numbering without locality
+    inv = np.empty_like(perm); inv[perm] = np.arange(len(perm))
+    cases = [(el, xyz), (emb["elNodes"], emb["nocoord"]), (inv[el - 1] + 1, xyz[perm])]
+    for e, x in cases:
+        e, x = np.ascontiguousarray(e, np.int64), np.ascontiguousarray(x, np.float64)
+        out = (C.c_int64 * 8)()
+        _lib.call("fcvm_host_window_sym_check", len(e), len(x), e.ctypes.data, x.ctypes.data, out)
+        if len(x) < 2048 and out[0] == 0:
+            continue
+        assert out[0] == 1 and out[3] == 0, list(out)
+        assert out[2] > 0 and out[6] - out[2] <= out[1] < out[6] - out[2] + 16 * 8 * ((len(x) + 511) // 256)   # entries = kept blocks + alignment
+        assert out[1] < 0.85 * out[4]
+
+
 def test_bad_mesh_is_rejected():
     from fcvm_hip import _lib
     import pytest
