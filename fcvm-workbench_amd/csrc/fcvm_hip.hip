@@ -70,6 +70,11 @@ struct WinSymDev {
     uint8_t *jell = nullptr;
     double *vals = nullptr;
     size_t lds = 0;
+    // 16-bit block-scaled copy in the same layout (the smoother passes of the multiplicative cycle)
+    short8 *lo8 = nullptr;
+    WinLoTailS *lo2 = nullptr;
+    size_t lds_lo = 0;
+    bool lo_valid = false;
 };
 
 struct L2sDev {   // device state of the sparse aggregate level (owned by fcvm_ctx)
@@ -154,6 +159,7 @@ struct fcvm_ctx {
     hipEvent_t repack_fork = nullptr, repack_done = nullptr;
     bool repack_pending = false;
     bool wsym_use = false;      // the matrix being copied is an SPD stiffness matrix: also into the symmetric form
+    bool wsym_lo = true;        // ... and its 16-bit copy (FCVM_WIN_SYM_LO=0: the smoother passes stay on the full form)
     int spmv_win = 1, win_v2 = 1;   // win_v2: value components in 16-byte pairs (FCVM_WIN_V2=0: nine 8-byte runs)
     WinDev win;                     // the fine matrix.  (The level-1 matrix of the multigrid cycle was tried on the same format with
     WinSymDev wsym;     // the PCG's FP64 SpMV on the symmetric form (FCVM_WIN_SYM=0: off)
@@ -392,16 +398,24 @@ static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const
 
 // smoother passes of the multiplicative cycle on the 16-bit copy (EPI 1: out = r - K~ x; EPI 2: out = x + c0 Dinv (r - K~ x) + partials)
 template <int EPI>
-static void launch_spmv_win_lo(fcvm_ctx *c, const double *x, const double *r, double *out, double c0, const double *done) {
+static void launch_spmv_win_lo(fcvm_ctx *c, const double *x, const double *r, double *out, double c0, const double *done, double *part = nullptr) {
     const WinDev &w = c->win;
+    if (!part) part = w.part_lo;
+    if (c->wsym.on && c->wsym.lo_valid) {      // symmetric form of the 16-bit copy
+        const WinSymDev &ws = c->wsym;
+        hipLaunchKernelGGL((k_spmv_win_lo_sym<EPI, WIN_WAVES>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), ws.lds_lo, c->stream, w.pat.ngroups,
+                           w.pat.wmax, ws.pat.xmax, w.gptr, ws.gextra, w.wlist, ws.woff, ws.rowlen, ws.rownode, ws.seg, ws.own, ws.lo8,
+                           (const WinLoTail *)ws.lo2, w.lo_scale, x, r, out, c0, (const float *)c->d_dinv6f, part, done);
+        return;
+    }
     if (w.pat.waves == 4)
         hipLaunchKernelGGL((k_spmv_win_lo<EPI, 4>), dim3((unsigned)w.pat.ngroups), dim3(256), w.lds / 2, c->stream, w.pat.ngroups, w.pat.wmax, w.gptr,
                            w.gextra, w.wlist, w.woff, w.rowlen, w.rownode, w.seg, w.lo8, w.lo2, w.lo_scale, x, r, out, c0,
-                           (const float *)c->d_dinv6f, w.part_lo, done);
+                           (const float *)c->d_dinv6f, part, done);
     else
         hipLaunchKernelGGL((k_spmv_win_lo<EPI, WIN_WAVES>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), w.lds / 2, c->stream, w.pat.ngroups,
                            w.pat.wmax, w.gptr, w.gextra, w.wlist, w.woff, w.rowlen, w.rownode, w.seg, w.lo8, w.lo2, w.lo_scale, x,
-                           r, out, c0, (const float *)c->d_dinv6f, w.part_lo, done);
+                           r, out, c0, (const float *)c->d_dinv6f, part, done);
 }
 // two right-hand sides: one pass over the matrix for both (k_spmv_win2 / k_spmv_win_lo2); LDS holds both windows
 static void launch_spmv_win2(fcvm_ctx *c, const double *xA, const double *xB, double *yA, double *yB, double *partA, double *partB,
@@ -432,6 +446,11 @@ template <int EPI>
 static void launch_spmv_win_lo2(fcvm_ctx *c, const double *xA, const double *xB, const double *rA, const double *rB, double *outA, double *outB,
                                 double c0, double *partA, double *partB, const double *doneA, const double *doneB) {
     const WinDev &w = c->win;
+    if (c->wsym.on && c->wsym.lo_valid) {      // no two-vector kernel on the symmetric form: the one-vector kernel twice (bitwise a single solve's)
+        launch_spmv_win_lo<EPI>(c, xA, rA, outA, c0, doneA, partA);
+        launch_spmv_win_lo<EPI>(c, xB, rB, outB, c0, doneB, partB);
+        return;
+    }
     if (w.pat.waves == 4)
         hipLaunchKernelGGL((k_spmv_win_lo2<EPI, 4>), dim3((unsigned)w.pat.ngroups), dim3(256), w.lds, c->stream, w.pat.ngroups, w.pat.wmax, w.gptr,
                            w.gextra, w.wlist, w.woff, w.rowlen, w.rownode, w.seg, w.lo8, w.lo2, w.lo_scale, xA, xB, rA, rB, outA, outB, c0,
@@ -443,7 +462,7 @@ static void launch_spmv_win_lo2(fcvm_ctx *c, const double *xA, const double *xB,
 }
 
 // the multiplicative cycle with the 16-bit smoother matrix needs the window format and its 16-bit copy
-static inline bool mg_use_lo(const fcvm_ctx *c) { return c->mg_additive == 2 && c->win.on && c->win.lo_valid; }
+static inline bool mg_use_lo(const fcvm_ctx *c) { return c->mg_additive == 2 && c->win.on && (c->win.lo_valid || (c->wsym.on && c->wsym.lo_valid)); }
 // the form that runs: 2 without the window format (tiny meshes, windows beyond the LDS) becomes the additive form -- the FP64
 // multiplicative form would stream the sliced-ELL matrix three times per iteration there
 static inline int mg_form(const fcvm_ctx *c) { return c->mg_additive == 2 ? (mg_use_lo(c) ? 2 : 1) : c->mg_additive; }
@@ -461,8 +480,8 @@ static void alt_free(fcvm_ctx *c);
 
 static void wsym_free(WinSymDev &w) {
     dfree(w.woff); dfree(w.rownode); dfree(w.srcslot); dfree(w.gextra); dfree(w.seg); dfree(w.cols); dfree(w.rowlen); dfree(w.own);
-    dfree(w.jell); dfree(w.vals);
-    w.on = w.valid = false;
+    dfree(w.jell); dfree(w.vals); dfree(w.lo8); dfree(w.lo2);
+    w.on = w.valid = w.lo_valid = false;
     w.pat = WinSym();
     w.lds = 0;
 }
@@ -548,6 +567,11 @@ static int wsym_upload(fcvm_ctx *c) {
     lds_allowed = std::max(lds_allowed, d.lds);
     if (win_allow_lds(k_spmv_win_sym<true, WIN_WAVES>, lds_allowed) || win_allow_lds(k_spmv_win_sym<false, WIN_WAVES>, lds_allowed)) return 1;
     d.lds = lds_allowed;
+    // the 16-bit passes: FP32 window and segment results (even count: the 64-bit accumulators follow), accumulators
+    d.lds_lo = sizeof(float) * (size_t)((3 * (c->win.pat.wmax + w.xmax) + 1) & ~(int64_t)1) + sizeof(unsigned long long) * 3 * 64 * WIN_WAVES;
+    if (win_allow_lds(k_spmv_win_lo_sym<0, WIN_WAVES>, d.lds) || win_allow_lds(k_spmv_win_lo_sym<1, WIN_WAVES>, d.lds) ||
+        win_allow_lds(k_spmv_win_lo_sym<2, WIN_WAVES>, d.lds))
+        return 1;
     d.pat.cols.clear(); d.pat.cols.shrink_to_fit();
     d.pat.jell.clear(); d.pat.jell.shrink_to_fit();
     d.on = true;
@@ -847,6 +871,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_MG_FP32")) c->mg_fp32 = atoi(v);
     if (const char *v = getenv("FCVM_MG_L1_16")) c->mg_l1_16 = atoi(v);
     if (const char *v = getenv("FCVM_MG_ADD_W")) c->mg_add_w = atof(v);
+    if (const char *v = getenv("FCVM_WIN_SYM_LO")) c->wsym_lo = atoi(v) != 0;
     HCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
     c->stream = c->own;
     if (dalloc(&c->d_S, S_COUNT) || dalloc(&c->d_out8, 16)) return 1;
@@ -1182,7 +1207,11 @@ static int refresh_precond(fcvm_ctx *c) {   // after every assembly into d_vals
         const bool lo = c->precond_mode >= 1 && c->mg_additive == 2;   // the multiplicative cycle smooths with a 16-bit fixed-point copy (mode 2: the multi-GPU layer's cycle)
         w.lo_valid = false;
         c->wsym.valid = false;
-        if (lo && !w.lo8 && (dalloc(&w.lo8, w.pat.nblocks) || dalloc(&w.lo2, w.pat.nblocks) || dalloc(&w.part_lo, 2 * w.pat.ngroups))) return 1;
+        const bool sym_lo = lo && c->wsym.on && c->wsym_use && c->wsym_lo;   // the 16-bit copy in the symmetric form too
+        c->wsym.lo_valid = false;
+        if (lo && !w.part_lo && dalloc(&w.part_lo, 2 * w.pat.ngroups)) return 1;
+        if (lo && !sym_lo && !w.lo8 && (dalloc(&w.lo8, w.pat.nblocks) || dalloc(&w.lo2, w.pat.nblocks))) return 1;
+        if (sym_lo && !c->wsym.lo8 && (dalloc(&c->wsym.lo8, c->wsym.pat.nblocks) || dalloc(&c->wsym.lo2, c->wsym.pat.nblocks))) return 1;
         if (lo || c->wsym.on) {   // exponent of the largest diagonal entry: scale of the 16-bit copy and of the fixed-point sums
             if (!w.lo_scale && dalloc(&w.lo_scale, 2)) return 1;
             hipLaunchKernelGGL(k_absmax_partial, dim3(1024), dim3(256), 0, c->stream, 9 * c->nn, c->d_dblk, c->d_part_misc);
@@ -1204,21 +1233,23 @@ static int refresh_precond(fcvm_ctx *c) {   // after every assembly into d_vals
         }
         // with the symmetric form in charge of the FP64 products nobody reads the full FP64 window copy: only its 16-bit copy is written
         const bool sym_now = c->wsym.on && c->wsym_use;
-        if (!sym_now || lo)
+        if (!sym_now || (lo && !sym_lo))
         hipLaunchKernelGGL(k_repack_win, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, rs, nrows, w.srcslot, w.rowlen,
                            w.jstart, w.woff, c->d_sptr, c->d_vals, sym_now ? (double *)nullptr : (double *)w.vals, c->win_v2, lo ? w.lo_scale : (const double *)nullptr,
                            lo ? w.lo8 : (short8 *)nullptr, lo ? w.lo2 : (WinLoTail *)nullptr, (const uint16_t *)w.cols);
         if (c->wsym.on && c->wsym_use) {   // (an SPD stiffness matrix: fcvm_assemble sets wsym_use, the buckling operators do not)
             WinSymDev &ws = c->wsym;
             hipLaunchKernelGGL(k_repack_sym, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, rs, nrows, ws.srcslot, ws.rowlen, ws.woff, ws.jell,
-                               c->d_sptr, c->d_vals, ws.vals);
+                               c->d_sptr, c->d_vals, ws.vals, sym_lo ? w.lo_scale : (const double *)nullptr, sym_lo ? ws.lo8 : (short8 *)nullptr,
+                               sym_lo ? ws.lo2 : (WinLoTailS *)nullptr, (const uint32_t *)ws.cols);
             ws.valid = true;
+            ws.lo_valid = sym_lo;
         }
         if (c->repack_overlap) {
             HCHK(hipEventRecord(c->repack_done, rs));
             c->repack_pending = true;
         }
-        w.lo_valid = lo;
+        w.lo_valid = lo && !sym_lo;      // (the full-form 16-bit copy was written)
     }
     hipLaunchKernelGGL(k_diag_invert, dim3(cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_dblk, c->d_dinv);
     hipLaunchKernelGGL(k_dinv_pack6f, dim3(cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_dinv, c->d_dinv6f);

@@ -41,6 +41,15 @@ struct __attribute__((aligned(8))) WinLoTail {
     signed char pad[3];
 };
 static_assert(sizeof(WinLoTail) == 8, "WinLoTail must be 8 bytes");
+// the same eight bytes in the symmetric form (WinSym layout): the spare bytes carry the position of the column node's row
+struct __attribute__((aligned(8))) WinLoTailS {
+    short q8;
+    unsigned short col;
+    signed char e;
+    signed char pad;
+    unsigned short ts;      // position in the group of the first segment of the column node's row, 0xFFFF: no transposed product
+};
+static_assert(sizeof(WinLoTailS) == 8, "WinLoTailS must be 8 bytes");
 
 // out[0] = e0 (as a double): frexp exponent of max |dblk| -- every entry of an SPD matrix is bounded by its largest diagonal
 // entry, so block exponents relative to e0 are <= 0.  part: block maxima of |dblk| (k_absmax_partial).
@@ -924,7 +933,9 @@ __global__ __launch_bounds__(64) void k_spmv_l1_i16(int64_t nslices, const int64
 // values of the sliced-ELL array -> symmetric window storage (V2 component layout); thread = vrow, source block from jell
 __global__ __launch_bounds__(256) void k_repack_sym(int64_t nrows, const int32_t *__restrict__ srcslot, const uint16_t *__restrict__ rowlen,
                                                     const int64_t *__restrict__ woff, const uint8_t *__restrict__ jell,
-                                                    const int64_t *__restrict__ sptr, const double *__restrict__ src, double *__restrict__ dst) {
+                                                    const int64_t *__restrict__ sptr, const double *__restrict__ src, double *__restrict__ dst,
+                                                    const double *__restrict__ lo_scale = nullptr, short8 *__restrict__ lo8 = nullptr,
+                                                    WinLoTailS *__restrict__ lo2 = nullptr, const uint32_t *__restrict__ cols = nullptr) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (row >= nrows) return;
     const int lane = threadIdx.x & 63;
@@ -947,6 +958,39 @@ __global__ __launch_bounds__(256) void k_repack_sym(int64_t nrows, const int32_t
             for (int c = 0; c < 9; c++) v[c] = sp[c * cs];
 #pragma unroll
             for (int c = 0; c < 9; c++) dp[win_value_at(c, n, lane, 1)] = v[c];
+            if (lo8) {      // 16-bit block-scaled copy, quantised exactly as in k_repack_win
+                const int e0 = (int)lo_scale[0];
+                double m = 0.0;
+#pragma unroll
+                for (int c = 0; c < 9; c++) m = fmax(m, fabs(v[c]));
+                int e = -127;
+                if (m > 0.0) {
+                    int eb;
+                    (void)frexp(m, &eb);
+                    e = eb - e0;
+                    e = e < -127 ? -127 : (e > 127 ? 127 : e);
+                }
+                const int sh = 15 - (e0 + e);
+                short8 h;
+                int q[9];
+#pragma unroll
+                for (int c = 0; c < 9; c++) {
+                    double t = rint(ldexp(v[c], sh));
+                    t = t > 32767.0 ? 32767.0 : (t < -32767.0 ? -32767.0 : t);
+                    q[c] = (int)t;
+                }
+#pragma unroll
+                for (int c = 0; c < 8; c++) h[c] = (short)q[c];
+                lo8[off + lane] = h;
+                const uint32_t ct = cols[off + lane];
+                WinLoTailS tl;
+                tl.q8 = (short)q[8];
+                tl.col = (unsigned short)(ct & 0xFFFFu);
+                tl.e = (signed char)e;
+                tl.pad = 0;
+                tl.ts = (unsigned short)(ct >> 16);
+                lo2[off + lane] = tl;
+            }
         }
         off += n;
     }
@@ -1114,6 +1158,203 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_spmv_win_sym(int64_t ngroups,
 #pragma unroll
             for (int i = 0; i < WAVES; i++) t += sh[i];
             partial[g] = t;
+        }
+    }
+}
+
+// direct product as win_fma_lo; K~_ij^T x_i of a stored in-group block goes to row j's accumulator in 64-bit fixed point
+__device__ __forceinline__ void win_fma_lo_sym(const WinSlotLo &t, bool active, const float *xs, float o0, float o1, float o2,
+                                               unsigned long long *yacc, int sh, bool tr_on, float &y0, float &y1, float &y2) {
+    const float *xa = xs + 3 * (int)t.t.col;
+    const int e = (int)t.t.e;
+    const float sc = active ? __builtin_bit_cast(float, (127 + (e < -126 ? -126 : e)) << 23) : 0.0f;
+    const float a0 = xa[0] * sc, a1 = xa[1] * sc, a2 = xa[2] * sc;
+    const float q0 = (float)(int)t.a[0], q1 = (float)(int)t.a[1], q2 = (float)(int)t.a[2], q3 = (float)(int)t.a[3], q4 = (float)(int)t.a[4],
+                q5 = (float)(int)t.a[5], q6 = (float)(int)t.a[6], q7 = (float)(int)t.a[7], q8 = (float)(int)t.t.q8;
+    y0 += win_dot3(q0, q1, q2, a0, a1, a2);
+    y1 += win_dot3(q3, q4, q5, a0, a1, a2);
+    y2 += win_dot3(q6, q7, q8, a0, a1, a2);
+    const unsigned ts = (unsigned)__builtin_bit_cast(WinLoTailS, t.t).ts;
+    if (active && tr_on && ts != 0xFFFFu) {
+        const float b0 = o0 * sc, b1 = o1 * sc, b2 = o2 * sc;
+        unsigned long long *ya = yacc + 3 * ts;
+        atomicAdd(ya, fixed62((double)win_dot3(q0, q3, q6, b0, b1, b2), sh));
+        atomicAdd(ya + 1, fixed62((double)win_dot3(q1, q4, q7, b0, b1, b2), sh));
+        atomicAdd(ya + 2, fixed62((double)win_dot3(q2, q5, q8, b0, b1, b2), sh));
+    }
+}
+template <int EPI, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, FCVM_LO_MINWAVES) void k_spmv_win_lo_sym(int64_t ngroups, int64_t wmax, int64_t xseg, const int64_t *__restrict__ gptr,
+                                                                const int32_t *__restrict__ gextra, const int32_t *__restrict__ wlist,
+                                                                const int64_t *__restrict__ woff, const uint16_t *__restrict__ rowlen,
+                                                                const int32_t *__restrict__ rownode, const uint32_t *__restrict__ seg, const uint16_t *__restrict__ own,
+                                                                const short8 *__restrict__ lo8, const WinLoTail *__restrict__ lo2,
+                                                                const double *__restrict__ lo_scale, const double *__restrict__ x,
+                                                                const double *__restrict__ r, double *__restrict__ out, double c0,
+                                                                const float *__restrict__ dinv6, double *__restrict__ partial,
+                                                                const double *__restrict__ done) {
+    extern __shared__ float xsf[];      // x of the window in FP32 (3 per window node), then the partial results of later segments
+    __shared__ double sh[2 * WAVES];
+    constexpr int WIN_THREADS = 64 * WAVES;
+    if (done && *done != 0.0) return;
+    const int64_t b = blockIdx.x;
+    const int64_t q = ngroups >> 3, rr8 = ngroups & 7, xcd = b & 7;
+    const int64_t g = (xcd < rr8 ? xcd * (q + 1) : rr8 * (q + 1) + (xcd - rr8) * q) + (b >> 3);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wig = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t wave = g * WAVES + wig, row = wave * 64 + lane;
+    const int len = rowlen[row];
+    const int L = __builtin_amdgcn_readfirstlane(len);
+    int64_t off = woff[wave];
+    int j = 0;
+    unsigned long long *yacc = (unsigned long long *)(xsf + ((3 * (wmax + xseg) + 1) & ~(int64_t)1));
+    __shared__ float shx[WAVES];
+    float xm = 0.f;
+    {
+        const int64_t w0 = gptr[g];
+        const int W = (int)(gptr[g + 1] - w0);
+        for (int i = tid; i < W; i += WIN_THREADS) {
+            const int32_t nd = wlist[w0 + i];
+            const double *xa = x + 3 * (int64_t)nd;
+            const int o = nd & 1;
+            const double2 wv = *(const double2 *)(xa + o);
+            const double sv = xa[o ? 0 : 2];
+            const float v0 = (float)(o ? sv : wv.x), v1 = (float)(o ? wv.x : wv.y), v2 = (float)(o ? wv.y : sv);
+            xsf[3 * i] = v0; xsf[3 * i + 1] = v1; xsf[3 * i + 2] = v2;
+            xm = fmaxf(xm, fmaxf(fabsf(v0), fmaxf(fabsf(v1), fabsf(v2))));
+        }
+        for (int i = tid; i < 3 * WIN_THREADS; i += WIN_THREADS) yacc[i] = 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) xm = fmaxf(xm, __shfl_xor(xm, o, 64));
+        if (lane == 0) shx[wig] = xm;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < WAVES; i++) xm = fmaxf(xm, shx[i]);
+    int ex = 0;
+    const bool tr_on = xm > 0.f && xm < 3e38f;
+    if (tr_on) (void)frexpf(xm, &ex);
+    // products are in units of 2^(e0 - 15): |q 2^e| < 2^15, three terms, at most 64 transposed products per row (see k_spmv_win_sym)
+    const int shf = 62 - (15 + ex + 8);
+    const int32_t node = rownode[row];
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (node >= 0) {
+        const float *xo = xsf + 3 * (int)own[row];
+        o0 = xo[0]; o1 = xo[1]; o2 = xo[2];
+    }
+    float y0 = 0.f, y1 = 0.f, y2 = 0.f;
+    {   // NB blocks in flight (24 bytes each)
+        constexpr int NB = 6;
+        WinSlotLo s[NB];
+        float z0 = 0.f, z1 = 0.f, z2 = 0.f, u0 = 0.f, u1 = 0.f, u2 = 0.f, w0 = 0.f, w1 = 0.f, w2 = 0.f;
+        for (; j + NB <= L; j += NB) {
+            bool p[NB];
+            int n[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                p[k] = len > j + k;
+                n[k] = __popcll(__builtin_amdgcn_ballot_w64(p[k]));
+            }
+            int64_t o = off;
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                win_load_lo(s[k], lo8, lo2, o, n[k], lane);
+                o += n[k];
+            }
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                if ((k & 3) == 0) win_fma_lo_sym(s[k], p[k], xsf, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
+                else if ((k & 3) == 1) win_fma_lo_sym(s[k], p[k], xsf, o0, o1, o2, yacc, shf, tr_on, z0, z1, z2);
+                else if ((k & 3) == 2) win_fma_lo_sym(s[k], p[k], xsf, o0, o1, o2, yacc, shf, tr_on, u0, u1, u2);
+                else win_fma_lo_sym(s[k], p[k], xsf, o0, o1, o2, yacc, shf, tr_on, w0, w1, w2);
+            }
+            off = o;
+        }
+        // the rest: block j always goes to accumulator set j & 3 (the chunk length is a multiple of 4), so the summation order
+        // does not depend on the number of blocks in flight -- k_spmv_win_lo2 keeps the same order: bitwise the same result
+        for (; j + 4 <= L; j += 4) {
+            const bool p0 = len > j, p1 = len > j + 1, p2 = len > j + 2, p3 = len > j + 3;
+            const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0)), n1 = __popcll(__builtin_amdgcn_ballot_w64(p1)),
+                      n2 = __popcll(__builtin_amdgcn_ballot_w64(p2)), n3 = __popcll(__builtin_amdgcn_ballot_w64(p3));
+            win_load_lo(s[0], lo8, lo2, off, n0, lane);
+            win_load_lo(s[1], lo8, lo2, off + n0, n1, lane);
+            win_load_lo(s[2], lo8, lo2, off + n0 + n1, n2, lane);
+            win_load_lo(s[3], lo8, lo2, off + n0 + n1 + n2, n3, lane);
+            win_fma_lo_sym(s[0], p0, xsf, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
+            win_fma_lo_sym(s[1], p1, xsf, o0, o1, o2, yacc, shf, tr_on, z0, z1, z2);
+            win_fma_lo_sym(s[2], p2, xsf, o0, o1, o2, yacc, shf, tr_on, u0, u1, u2);
+            win_fma_lo_sym(s[3], p3, xsf, o0, o1, o2, yacc, shf, tr_on, w0, w1, w2);
+            off += n0 + n1 + n2 + n3;
+        }
+        for (; j < L; j++) {
+            const bool p0 = len > j;
+            const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0));
+            win_load_lo(s[0], lo8, lo2, off, n0, lane);
+            const int a = j & 3;
+            if (a == 0) win_fma_lo_sym(s[0], p0, xsf, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
+            else if (a == 1) win_fma_lo_sym(s[0], p0, xsf, o0, o1, o2, yacc, shf, tr_on, z0, z1, z2);
+            else if (a == 2) win_fma_lo_sym(s[0], p0, xsf, o0, o1, o2, yacc, shf, tr_on, u0, u1, u2);
+            else win_fma_lo_sym(s[0], p0, xsf, o0, o1, o2, yacc, shf, tr_on, w0, w1, w2);
+            off += n0;
+        }
+        y0 += z0 + u0 + w0; y1 += z1 + u1 + w1; y2 += z2 + u2 + w2;
+    }
+    const uint32_t sc = seg[row];
+    const int nseg = (int)(sc & 255u);
+    __syncthreads();       // every transposed product of the group has arrived
+    if (gextra[g] > 0) {
+        float *yp = xsf + 3 * wmax + 3 * (int)(sc >> 8);
+        if (node >= 0 && nseg == 0) { yp[0] = y0; yp[1] = y1; yp[2] = y2; }
+        __syncthreads();
+        for (int k = 0; k + 1 < nseg; k++) { y0 += yp[3 * k]; y1 += yp[3 * k + 1]; y2 += yp[3 * k + 2]; }
+    }
+    // the row's sum in FP64: its own FP32 sums + the fixed-point sum of the transposed products
+    double yd0 = (double)y0, yd1 = (double)y1, yd2 = (double)y2;
+    if (node >= 0 && nseg > 0 && tr_on) {
+        const unsigned long long *ya = yacc + 3 * (wig * 64 + lane);
+        yd0 += ldexp((double)(long long)ya[0], -shf);
+        yd1 += ldexp((double)(long long)ya[1], -shf);
+        yd2 += ldexp((double)(long long)ya[2], -shf);
+    }
+    double rz = 0.0, rr = 0.0;
+    if (EPI == 0) {     // plain product out = K~ x (the host-driven cycle of the multi-GPU layer exchanges it before using it)
+        if (node >= 0 && nseg > 0) {
+            const double is = lo_scale[1];
+            const int64_t o = 3 * (int64_t)node;
+            out[o] = is * yd0; out[o + 1] = is * yd1; out[o + 2] = is * yd2;
+        }
+        return;
+    }
+    if (node >= 0 && nseg > 0) {
+        const double is = lo_scale[1];
+        const int64_t o = 3 * (int64_t)node;
+        const double r0 = r[o], r1 = r[o + 1], r2 = r[o + 2];
+        const double t0 = r0 - is * yd0, t1 = r1 - is * yd1, t2 = r2 - is * yd2;
+        if (EPI == 1) {
+            out[o] = t0; out[o + 1] = t1; out[o + 2] = t2;
+        } else {
+            const float2 *d2 = (const float2 *)(dinv6 + 6 * (int64_t)node);
+            const float2 u0 = d2[0], u1 = d2[1], u2 = d2[2];   // xx xy | xz yy | yz zz
+            const double *xo = x + o;      // the FP64 x of the row's own node (the window in LDS holds FP32 roundings)
+            const double z0 = xo[0] + c0 * ((double)u0.x * t0 + (double)u0.y * t1 + (double)u1.x * t2);
+            const double z1 = xo[1] + c0 * ((double)u0.y * t0 + (double)u1.y * t1 + (double)u2.x * t2);
+            const double z2 = xo[2] + c0 * ((double)u1.x * t0 + (double)u2.x * t1 + (double)u2.y * t2);
+            out[o] = z0; out[o + 1] = z1; out[o + 2] = z2;
+            rz = r0 * z0 + r1 * z1 + r2 * z2;
+            rr = r0 * r0 + r1 * r1 + r2 * r2;
+        }
+    }
+    if (EPI == 2) {
+        rz = wave_sum(rz);
+        rr = wave_sum(rr);
+        if (lane == 0) { sh[wig] = rz; sh[WAVES + wig] = rr; }
+        __syncthreads();
+        if (tid == 0) {
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < WAVES; i++) { a0 += sh[i]; a1 += sh[WAVES + i]; }
+            partial[g] = a0;
+            partial[ngroups + g] = a1;
         }
     }
 }

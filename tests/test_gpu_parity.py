@@ -441,16 +441,28 @@ def test_symmetric_window_form_spmv_equals_the_full_form(monkeypatch, mesh):
             xs = [x0, 1e-200 * x0, 1e150 * x0, np.zeros(m.ndof), np.where(np.arange(m.ndof) % 97 == 0, 1.0, 0.0)]
         ys = [c.spmv(c.array(x), c.empty(m.ndof)).get() for x in xs]
         ys2 = [c.spmv(c.array(x), c.empty(m.ndof)).get() for x in xs]
+        # the product with the 16-bit copy (FP32 arithmetic) on the same two forms
+        from fcvm_hip._lib import call
+        los = []
+        for x in (xs[0], xs[4]):
+            dx, dy = c.array(x), c.empty(m.ndof)
+            call("fcvm_spmv_lo", c.h, dx.ptr, dy.ptr)
+            los.append(dy.get())
+        assert c.spmv_sym_info()["in_use"] == (form == "sym")
         f = c.mul(m.fixdof, glv)
         c.axpby(1.0, f, 1.0, modf, out=f)
         u, info = c.solve(f, rtol=1e-10)
-        res[form] = (ys, ys2, u.get(), info["iterations"])
+        res[form] = (ys, ys2, u.get(), info["iterations"], los)
         c.close()
     for a, b in zip(res["sym"][0], res["sym"][1]):
         assert np.array_equal(a, b)
     for x, a, b in zip(xs, res["sym"][0], res["full"][0]):
         scale = np.abs(b).max()
         assert np.abs(a - b).max() <= 1e-13 * scale if scale > 0 else not a.any()
+    for a, b in zip(res["sym"][4], res["full"][4]):
+        assert np.abs(a - b).max() <= 5e-6 * np.abs(b).max()     # FP32 products in another order; both ~1e-5 off the FP64 product
+    for a, b in zip(res["sym"][4], (res["full"][0][0], res["full"][0][4])):
+        assert np.abs(a - b).max() <= 1e-3 * np.abs(b).max()
     assert abs(res["sym"][3] - res["full"][3]) <= 1
     assert rel(res["sym"][2], res["full"][2]) < 1e-8
 
