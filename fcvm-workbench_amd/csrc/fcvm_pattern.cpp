@@ -512,6 +512,9 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
                 extra += k - 1;
             }
             s.gextra[g] = extra;
+            // sorted over the whole group (uniform lengths inside a wave).  Sorting inside each wave only would keep a wave's rows
+            // on one or two sliced-ELL slices and the copy kernel at 2.6 instead of 3.3 ms per assembly, but the 16-bit passes
+            // lose 4 % to the ragged block rows (gpurun_out/r03bi, r03bj): the passes run 80 times per Newton iteration
             std::stable_sort(rows.begin(), rows.end(), [](const VRow &x, const VRow &y) { return x.len > y.len; });
             for (size_t k = 0; k < rows.size(); k++) {
                 const int64_t wave = g * WV + (int64_t)k / SLICE, at = wave * SLICE + (int64_t)k % SLICE;

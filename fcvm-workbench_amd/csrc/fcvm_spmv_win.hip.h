@@ -944,10 +944,28 @@ __global__ __launch_bounds__(256) void k_repack_sym(int64_t nrows, const int32_t
     const int64_t slot = srcslot[row], s = slot >> 6, ls = slot & 63;
     const int64_t jb = sptr[s], slen = sptr[s + 1] - jb;
     int64_t off = woff[row >> 6];
+    // the source block numbers of the lane, four block rows ahead of the copy (a dependent load per block row otherwise)
+    int jq[4] = {0, 0, 0, 0};
+    {
+        int64_t o2 = off;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int n = __popcll(__builtin_amdgcn_ballot_w64(len > k));
+            if (len > k) jq[k] = jell[o2 + lane];
+            o2 += n;
+        }
+    }
+    int64_t offp = off;      // first entry of block row j + 4
+    for (int k = 0; k < 4; k++) offp += __popcll(__builtin_amdgcn_ballot_w64(len > k));
     for (int j = 0; j < L; j++) {
         const int n = __popcll(__builtin_amdgcn_ballot_w64(len > j));
+        const int np = __popcll(__builtin_amdgcn_ballot_w64(len > j + 4));
+        const int64_t js_now = jq[0];
+        jq[0] = jq[1]; jq[1] = jq[2]; jq[2] = jq[3];
+        jq[3] = len > j + 4 ? (int)jell[offp + lane] : 0;
+        offp += np;
         if (len > j) {
-            const int64_t js = jell[off + lane];
+            const int64_t js = js_now;
             const bool single = (slen & 1) && js == slen - 1;
             const int64_t unit = jb + (single ? js : (js & ~(int64_t)1));
             const double *sp = src + unit * 576 + (single ? ls : 2 * ls + (js & 1));
