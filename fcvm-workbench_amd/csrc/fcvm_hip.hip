@@ -163,6 +163,7 @@ struct fcvm_ctx {
     int spmv_win = 1, win_v2 = 1;   // win_v2: value components in 16-byte pairs (FCVM_WIN_V2=0: nine 8-byte runs)
     WinDev win;                     // the fine matrix.  (The level-1 matrix of the multigrid cycle was tried on the same format with
     WinSymDev wsym;     // the PCG's FP64 SpMV on the symmetric form (FCVM_WIN_SYM=0: off)
+    std::thread sym_thread;   // host build of the symmetric form, beside the upload of the full form (joined by wsym_upload)
                                     // FP32 values and the smoother epilogue: 31.0 against 28.3 us per launch -- 686 workgroups are too
                                     // few and the staging barrier adds latency; it stays on the sliced-ELL kernel, profiles/r02v_*.)
     int spmv_variant = 5;  // 5 (shipped): nontemporal matrix loads, four pairs in flight, 8 + 16 byte x gathers; 4: three 8-byte gathers; 0: plain loads, one pair per iteration
@@ -521,9 +522,6 @@ static int win_upload(fcvm_ctx *c, WinDev &d) {
     HCHK(hipMemsetAsync(d.vals, 0, (size_t)value_bytes * 9 * (size_t)w.nblocks, s));
     HCHK(hipStreamSynchronize(s));
     d.lds = sizeof(double) * 3 * (size_t)(w.wmax + w.xmax);
-    // the host copies are not needed again
-    d.pat.wlist.clear(); d.pat.wlist.shrink_to_fit();
-    d.pat.cols.clear(); d.pat.cols.shrink_to_fit();
     d.on = true;
     return 0;
 }
@@ -536,6 +534,7 @@ static int win_allow_lds(K kernel, size_t bytes) {
 // device copy of the symmetric form built by win_build_host (nothing to do when it was not built); used only where two
 // workgroups of it fit the LDS of a CU
 static int wsym_upload(fcvm_ctx *c) {
+    if (c->sym_thread.joinable()) c->sym_thread.join();
     WinSymDev &d = c->wsym;
     const WinSym &w = d.pat;
     if (w.nblocks <= 0 || !c->win.on) { d.pat = WinSym(); return 0; }
@@ -617,7 +616,14 @@ static void win_build_host(fcvm_ctx *c, const double *nocoord, WinBuild *res) {
         // symmetric form for the PCG's FP64 SpMV (groups of WIN_WAVES waves, paired value layout)
         c->wsym.pat = WinSym();
         const bool sym = !(getenv("FCVM_WIN_SYM") && atoi(getenv("FCVM_WIN_SYM")) == 0);
-        if (sym && w.waves == WIN_WAVES && c->win_v2 && !build_window_sym(c->pat, w, nt, c->wsym.pat)) c->wsym.pat = WinSym();
+        if (sym && w.waves == WIN_WAVES && c->win_v2)
+            c->sym_thread = std::thread([c, nt]() {
+                try {
+                    if (!build_window_sym(c->pat, c->win.pat, nt, c->wsym.pat)) c->wsym.pat = WinSym();
+                } catch (const std::exception &) {      // (out of memory: the full form stays in charge)
+                    c->wsym.pat = WinSym();
+                }
+            });
     } catch (const std::exception &ex) {
         res->err = std::string("fcvm_set_mesh (window format): ") + ex.what();
     }
@@ -641,6 +647,8 @@ static int setup_window_format(fcvm_ctx *c, const WinBuild &res) {
     const int lds_cap = device_lds_cap(c->device);
     if (c->win.lds > (size_t)lds_cap) {
         if (getenv("FCVM_VERBOSE")) fprintf(stderr, "fcvm: window format not used (%zu B of LDS needed, device offers %d)\n", c->win.lds, lds_cap);
+        if (c->sym_thread.joinable()) c->sym_thread.join();      // (it reads the pattern that goes away here)
+        c->wsym.pat = WinSym();
         win_free(c->win);
         return 0;
     }
@@ -661,6 +669,9 @@ static int setup_window_format(fcvm_ctx *c, const WinBuild &res) {
     c->win2_ok = 2 * lds <= (size_t)lds_cap;
     if (c->win2_ok && (win_allow_lds(k_spmv_win2<true, WIN_WAVES>, 2 * lds) || win_allow_lds(k_spmv_win2<true, 4>, 2 * lds))) return 1;
     if (wsym_upload(c)) return 1;
+    // the host copies of the big tables are not needed again (the symmetric form's builder has read them)
+    w.wlist.clear(); w.wlist.shrink_to_fit();
+    w.cols.clear(); w.cols.shrink_to_fit();
     if (getenv("FCVM_VERBOSE"))
         fprintf(stderr, "fcvm: window format: %lld groups of %d waves, windows mean %.0f / max %lld nodes (%zu B LDS of %d), %lld entries\n",
                 (long long)w.ngroups, w.waves, w.wmean, (long long)w.wmax, lds, lds_cap, (long long)w.nblocks);
@@ -891,6 +902,7 @@ static void mg_topology_join(fcvm_ctx *c, bool discard);
 static void mg_topology_start(fcvm_ctx *c);
 static void free_mesh(fcvm_ctx *c) {
     mg_topology_join(c, true);
+    if (c->sym_thread.joinable()) c->sym_thread.join();
     dfree(c->d_el); dfree(c->d_cols); dfree(c->d_rownode); dfree(c->d_noce); dfree(c->d_sptr);
     dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
     dfree(c->d_nptr); dfree(c->d_nel); dfree(c->d_fe); dfree(c->d_part_vol); dfree(c->d_asm_items);

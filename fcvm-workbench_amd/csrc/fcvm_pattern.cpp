@@ -474,7 +474,16 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
     s.seg.assign(s.nwaves * SLICE, 1);
     s.woff.assign(s.nwaves + 1, 0);
     s.gextra.assign(ng, 0);
+    const bool timing = getenv("FCVM_PATTERN_TIMING") != nullptr;
+    auto tprev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "fcvm symmetric form: %-24s %.3f s\n", what, std::chrono::duration<double>(t - tprev).count());
+        tprev = t;
+    };
     const std::vector<int32_t> grp = window_group_of(p, w);
+    lap("group of every node");
     std::vector<uint16_t> jfirst(s.nwaves * SLICE, 0);      // first kept block of the segment (index into the row's kept list)
     std::vector<int64_t> drop(nthreads > 0 ? nthreads : 1, 0);
     struct VRow { int64_t len; int32_t nd; int32_t j0; uint32_t seg; };
@@ -527,6 +536,7 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
             }
         }
     }, 16);
+    lap("pass 1 (lengths, lanes)");
     s.dropped = 0;
     for (int64_t v : drop) s.dropped += v;
     s.xmax = 0;
@@ -535,6 +545,7 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
     s.nblocks = s.woff[s.nwaves];
     s.cols.resize(s.nblocks);
     s.jell.resize(s.nblocks);
+    lap("offsets, allocation");
     // pass 2: entries in the prefix layout
     parallel_for(ng, nthreads, [&](int64_t b, int64_t e, int) {
         std::vector<uint16_t> pos(nn, 0), slot(nn, 0);     // window position / first-segment position of a node of the current group
@@ -576,6 +587,7 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
             }
         }
     }, 16);
+    lap("pass 2 (entries)");
     return true;
 }
 
