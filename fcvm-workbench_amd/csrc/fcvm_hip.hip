@@ -506,7 +506,8 @@ static int win_upload(fcvm_ctx *c, WinDev &d) {
         dalloc(&d.rownode, nrows) || dalloc(&d.srcslot, nrows) || dalloc(&d.rowlen, nrows) || dalloc(&d.own, nrows) ||
         dalloc(&d.cols, w.nblocks) || dalloc(&d.gextra, w.ngroups) || dalloc(&d.seg, nrows) || dalloc(&d.jstart, nrows))
         return 1;
-    if (hipMalloc(&d.vals, (size_t)value_bytes * 9 * (size_t)w.nblocks) != hipSuccess) return fail("out of device memory (window format values)");
+    // (the FP64 values of the full form are allocated when first needed, win_values_ensure: with the symmetric form in charge
+    // only the buckling operators use them)
     hipStream_t s = c->stream;
     HCHK(hipMemcpyAsync(d.gptr, w.gptr.data(), sizeof(int64_t) * (w.ngroups + 1), hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(d.woff, w.woff.data(), sizeof(int64_t) * (w.nwaves + 1), hipMemcpyHostToDevice, s));
@@ -519,13 +520,21 @@ static int win_upload(fcvm_ctx *c, WinDev &d) {
     HCHK(hipMemcpyAsync(d.seg, w.seg.data(), sizeof(uint32_t) * nrows, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(d.gextra, w.gextra.data(), sizeof(int32_t) * w.ngroups, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(d.cols, w.cols.data(), sizeof(uint16_t) * w.nblocks, hipMemcpyHostToDevice, s));
-    HCHK(hipMemsetAsync(d.vals, 0, (size_t)value_bytes * 9 * (size_t)w.nblocks, s));
     HCHK(hipStreamSynchronize(s));
+    (void)value_bytes;
     d.lds = sizeof(double) * 3 * (size_t)(w.wmax + w.xmax);
     d.on = true;
     return 0;
 }
 
+// FP64 values of the full window form, allocated at first use
+static int win_values_ensure(fcvm_ctx *c) {
+    WinDev &d = c->win;
+    if (d.vals) return 0;
+    if (hipMalloc(&d.vals, sizeof(double) * 9 * (size_t)d.pat.nblocks) != hipSuccess) return fail("out of device memory (window format values)");
+    HCHK(hipMemsetAsync(d.vals, 0, sizeof(double) * 9 * (size_t)d.pat.nblocks, c->stream));
+    return 0;
+}
 template <class K>
 static int win_allow_lds(K kernel, size_t bytes) {
     HCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -1232,6 +1241,8 @@ static int refresh_precond(fcvm_ctx *c) {   // after every assembly into d_vals
         // the copy into the SpMV's storage (1.5 ms at 1 M elements, bandwidth-bound) runs on a stream of its own next to what
         // follows on the main stream -- diagonal inverses and, with the multigrid preconditioner, the tet4 level's assembly and the
         // eigenvalue estimates, none of which reads the window storage; win_join() makes the main stream wait for it
+        const bool sym_now = c->wsym.on && c->wsym_use;
+        if (!sym_now && win_values_ensure(c)) return 1;      // (zero-filled on the main stream: before the copy stream forks off)
         hipStream_t rs = c->stream;
         if (c->repack_overlap) {
             if (!c->repack_stream) {
@@ -1244,7 +1255,6 @@ static int refresh_precond(fcvm_ctx *c) {   // after every assembly into d_vals
             rs = c->repack_stream;
         }
         // with the symmetric form in charge of the FP64 products nobody reads the full FP64 window copy: only its 16-bit copy is written
-        const bool sym_now = c->wsym.on && c->wsym_use;
         if (!sym_now || (lo && !sym_lo))
         hipLaunchKernelGGL(k_repack_win, dim3((unsigned)cdiv(nrows, 256)), dim3(256), 0, rs, nrows, w.srcslot, w.rowlen,
                            w.jstart, w.woff, c->d_sptr, c->d_vals, sym_now ? (double *)nullptr : (double *)w.vals, c->win_v2, lo ? w.lo_scale : (const double *)nullptr,
