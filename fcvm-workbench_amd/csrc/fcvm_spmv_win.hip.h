@@ -1214,9 +1214,15 @@ __device__ __forceinline__ void win_fma_lo_sym(const WinSlotLo &t, bool active, 
     if (active && tr_on && ts != 0xFFFFu) {
         const float b0 = o0 * sc, b1 = o1 * sc, b2 = o2 * sc;
         unsigned long long *ya = yacc + 3 * ts;
+#ifdef FCVM_AB_LO_F64CONV      // (A/B build: the FP32 product widened and converted as a double)
+        atomicAdd(ya, fixed62((double)win_dot3(q0, q3, q6, b0, b1, b2), sh));
+        atomicAdd(ya + 1, fixed62((double)win_dot3(q1, q4, q7, b0, b1, b2), sh));
+        atomicAdd(ya + 2, fixed62((double)win_dot3(q2, q5, q8, b0, b1, b2), sh));
+#else
         atomicAdd(ya, fixed62f(win_dot3(q0, q3, q6, b0, b1, b2), sh));
         atomicAdd(ya + 1, fixed62f(win_dot3(q1, q4, q7, b0, b1, b2), sh));
         atomicAdd(ya + 2, fixed62f(win_dot3(q2, q5, q8, b0, b1, b2), sh));
+#endif
     }
 }
 template <int EPI, int WAVES>
