@@ -1082,8 +1082,14 @@ __device__ __forceinline__ void win_fma_sym(const WinSlotS &t, bool active, cons
 // 2^e0 * xmax each, so the sums stay below 2^(e0 + ex + 7.6) * ... < 2^62 units of 2^(e0 + ex + 8 - 62): no overflow; one unit is
 // 2^-54 of kmax * xmax, half an FP64 rounding error of the largest possible term (with four bits more margin the attainable
 // residual of a solve to 1e-11 rose from 5e-11 to 6e-11 of |f|: the margin was taken out).
+#ifndef FCVM_SYM_MINWAVES
+#define FCVM_SYM_MINWAVES 4
+#endif
+#ifndef FCVM_SYM_INFLIGHT
+#define FCVM_SYM_INFLIGHT 3
+#endif
 template <bool DOT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 4) void k_spmv_win_sym(int64_t ngroups, int64_t wmax, int64_t xseg, const int64_t *__restrict__ gptr,
+__global__ __launch_bounds__(64 * WAVES, FCVM_SYM_MINWAVES) void k_spmv_win_sym(int64_t ngroups, int64_t wmax, int64_t xseg, const int64_t *__restrict__ gptr,
                                                                  const int32_t *__restrict__ gextra, const int32_t *__restrict__ wlist,
                                                                  const int64_t *__restrict__ woff, const uint16_t *__restrict__ rowlen,
                                                                  const int32_t *__restrict__ rownode, const uint32_t *__restrict__ seg,
@@ -1143,6 +1149,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_spmv_win_sym(int64_t ngroups,
     double y0 = 0.0, y1 = 0.0, y2 = 0.0;
     {   // three blocks in flight, two accumulator sets: the transposed products need registers too (four and four spilled)
         double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+#if FCVM_SYM_INFLIGHT == 3
         for (; j + 3 <= L; j += 3) {
             const bool p0 = len > j, p1 = len > j + 1, p2 = len > j + 2;
             const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0)), n1 = __popcll(__builtin_amdgcn_ballot_w64(p1)),
@@ -1155,6 +1162,18 @@ __global__ __launch_bounds__(64 * WAVES, 4) void k_spmv_win_sym(int64_t ngroups,
             win_fma_sym(cc, p2, xs, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
             off += n0 + n1 + n2;
         }
+#else
+        for (; j + 2 <= L; j += 2) {
+            const bool p0 = len > j, p1 = len > j + 1;
+            const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0)), n1 = __popcll(__builtin_amdgcn_ballot_w64(p1));
+            win_load_sym(a, cols, vals, off, n0, lane);
+            win_load_sym(bb, cols, vals, off + n0, n1, lane);
+            win_fma_sym(a, p0, xs, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
+            win_fma_sym(bb, p1, xs, o0, o1, o2, yacc, shf, tr_on, z0, z1, z2);
+            off += n0 + n1;
+        }
+        (void)cc;
+#endif
         y0 += z0; y1 += z1; y2 += z2;
     }
     for (; j < L; j++) {
@@ -1225,8 +1244,14 @@ __device__ __forceinline__ void win_fma_lo_sym(const WinSlotLo &t, bool active, 
 #endif
     }
 }
+#ifndef FCVM_LOSYM_MINWAVES
+#define FCVM_LOSYM_MINWAVES 6      // three workgroups per CU (31 KB of LDS each) with three blocks in flight: 179 / 149 against 192 / 157 us with two and six
+#endif
+#ifndef FCVM_LOSYM_INFLIGHT
+#define FCVM_LOSYM_INFLIGHT 3
+#endif
 template <int EPI, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, FCVM_LO_MINWAVES) void k_spmv_win_lo_sym(int64_t ngroups, int64_t wmax, int64_t xseg, const int64_t *__restrict__ gptr,
+__global__ __launch_bounds__(64 * WAVES, FCVM_LOSYM_MINWAVES) void k_spmv_win_lo_sym(int64_t ngroups, int64_t wmax, int64_t xseg, const int64_t *__restrict__ gptr,
                                                                 const int32_t *__restrict__ gextra, const int32_t *__restrict__ wlist,
                                                                 const int64_t *__restrict__ woff, const uint16_t *__restrict__ rowlen,
                                                                 const int32_t *__restrict__ rownode, const uint32_t *__restrict__ seg, const uint16_t *__restrict__ own,
@@ -1286,7 +1311,7 @@ __global__ __launch_bounds__(64 * WAVES, FCVM_LO_MINWAVES) void k_spmv_win_lo_sy
     }
     float y0 = 0.f, y1 = 0.f, y2 = 0.f;
     {   // NB blocks in flight (24 bytes each)
-        constexpr int NB = 6;
+        constexpr int NB = FCVM_LOSYM_INFLIGHT;      // (eight in flight spill beside the transposed products)
         WinSlotLo s[NB];
         float z0 = 0.f, z1 = 0.f, z2 = 0.f, u0 = 0.f, u1 = 0.f, u2 = 0.f, w0 = 0.f, w1 = 0.f, w2 = 0.f;
         for (; j + NB <= L; j += NB) {
@@ -1314,6 +1339,7 @@ __global__ __launch_bounds__(64 * WAVES, FCVM_LO_MINWAVES) void k_spmv_win_lo_sy
         }
         // the rest: block j always goes to accumulator set j & 3 (the chunk length is a multiple of 4), so the summation order
         // does not depend on the number of blocks in flight -- k_spmv_win_lo2 keeps the same order: bitwise the same result
+#if FCVM_LOSYM_INFLIGHT >= 4
         for (; j + 4 <= L; j += 4) {
             const bool p0 = len > j, p1 = len > j + 1, p2 = len > j + 2, p3 = len > j + 3;
             const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0)), n1 = __popcll(__builtin_amdgcn_ballot_w64(p1)),
@@ -1328,6 +1354,7 @@ __global__ __launch_bounds__(64 * WAVES, FCVM_LO_MINWAVES) void k_spmv_win_lo_sy
             win_fma_lo_sym(s[3], p3, xsf, o0, o1, o2, yacc, shf, tr_on, w0, w1, w2);
             off += n0 + n1 + n2 + n3;
         }
+#endif
         for (; j < L; j++) {
             const bool p0 = len > j;
             const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0));
