@@ -339,10 +339,13 @@ static void launch_spmv_cheb(fcvm_ctx *c, const MatView &m, const double *x, con
     if (m.vals32) FCVM_SPMV_LAUNCH(false, false, 4, float2, 1, m.vals32, epi);
     else FCVM_SPMV_LAUNCH(false, true, 4, double2, 1, m.vals, epi);
 }
+// leading dimension of the FP32 copy of the aggregate-level inverse: rows start on 128-byte lines (32 floats), so the 512-byte row
+// segments of k_symv_tiles touch four lines, not five (PMC: 350 MB per launch for a 286 MB triangle with rows padded to 16 bytes)
+static inline int64_t a2_lda(int64_t n2) { return (n2 + 31) / 32 * 32; }
 // e2 = A2^-1 r2 with the FP32 copy of the dense inverse: from its lower triangle alone where that pays (k_symv_tiles; the partial
 // buffer is allocated with the inverse, fcvm_level2.inc / fcvm_mg_set_level2), otherwise row by row
 static void launch_gemv_f32(fcvm_ctx *c, const double *r2, double *e2, const double *done) {
-    const int64_t lda = (c->n2 + 3) / 4 * 4;
+    const int64_t lda = a2_lda(c->n2);
     if (c->d_symv_part) {
         const int nt = (int)cdiv(c->n2, SYMV_T);
         hipLaunchKernelGGL(k_symv_tiles, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, c->stream, nt, c->n2, lda, c->d_A2invf, r2,
@@ -1922,7 +1925,7 @@ int fcvm_mg_set_level2(fcvm_ctx *c, int64_t nagg, int64_t n2, const int32_t *agg
     dfree(c->d_A2invf);
     if (A2inv) {
         HCHK(hipMemcpyAsync(c->d_A2inv, A2inv, sizeof(double) * n2 * n2, hipMemcpyHostToDevice, s));
-        const int64_t lda = (n2 + 3) / 4 * 4;
+        const int64_t lda = a2_lda(n2);
         if (dalloc(&c->d_A2invf, n2 * lda)) return 1;
         hipLaunchKernelGGL(k_to_f32_padded, dim3((unsigned)cdiv(n2 * lda, 256)), dim3(256), 0, s, n2, lda, c->d_A2inv, c->d_A2invf);
     }
