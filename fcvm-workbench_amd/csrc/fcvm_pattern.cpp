@@ -482,6 +482,7 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
         fprintf(stderr, "fcvm symmetric form: %-24s %.3f s\n", what, std::chrono::duration<double>(t - tprev).count());
         tprev = t;
     };
+    const bool flagged_first = !(getenv("FCVM_SYM_FLAGGED_FIRST") && atoi(getenv("FCVM_SYM_FLAGGED_FIRST")) == 0);
     const std::vector<int32_t> grp = window_group_of(p, w);
     lap("group of every node");
     std::vector<uint16_t> jfirst(s.nwaves * SLICE, 0);      // first kept block of the segment (index into the row's kept list)
@@ -574,14 +575,19 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
                     const int32_t nd = s.rownode[wave * SLICE + l];
                     if (nd < 0) continue;
                     s.own[wave * SLICE + l] = pos[nd];
+                    // the row's kept blocks with the ones that want a transposed product FIRST: beyond the largest such count
+                    // of a wave no lane has one and the wave skips that code altogether (in column order every block row had some)
                     const int64_t j0 = jfirst[wave * SLICE + l], j1 = j0 + len[l];
-                    int64_t k = 0;
+                    int64_t nflag = 0;
+                    for_kept(nd, (int32_t)g, [&](int, int32_t, bool tr) { nflag += tr ? 1 : 0; });
+                    if (!flagged_first) nflag = -1;
+                    int64_t kf = 0, ku = nflag, kall = 0;
                     for_kept(nd, (int32_t)g, [&](int jq, int32_t col, bool tr) {
+                        const int64_t k = nflag < 0 ? kall++ : (tr ? kf++ : ku++);
                         if (k >= j0 && k < j1) {
                             s.cols[rowoff[k - j0] + l] = (uint32_t)pos[col] | ((tr ? (uint32_t)slot[col] : 0xFFFFu) << 16);
                             s.jell[rowoff[k - j0] + l] = (uint8_t)jq;
                         }
-                        k++;
                     });
                 }
             }
