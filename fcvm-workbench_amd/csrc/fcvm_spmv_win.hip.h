@@ -1162,6 +1162,22 @@ __global__ __launch_bounds__(64 * WAVES, FCVM_SYM_MINWAVES) void k_spmv_win_sym(
             win_fma_sym(cc, p2, xs, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
             off += n0 + n1 + n2;
         }
+#elif FCVM_SYM_INFLIGHT == 4
+        for (; j + 4 <= L; j += 4) {
+            const bool p0 = len > j, p1 = len > j + 1, p2 = len > j + 2, p3 = len > j + 3;
+            const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0)), n1 = __popcll(__builtin_amdgcn_ballot_w64(p1)),
+                      n2 = __popcll(__builtin_amdgcn_ballot_w64(p2)), n3 = __popcll(__builtin_amdgcn_ballot_w64(p3));
+            WinSlotS dd;
+            win_load_sym(a, cols, vals, off, n0, lane);
+            win_load_sym(bb, cols, vals, off + n0, n1, lane);
+            win_load_sym(cc, cols, vals, off + n0 + n1, n2, lane);
+            win_load_sym(dd, cols, vals, off + n0 + n1 + n2, n3, lane);
+            win_fma_sym(a, p0, xs, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
+            win_fma_sym(bb, p1, xs, o0, o1, o2, yacc, shf, tr_on, z0, z1, z2);
+            win_fma_sym(cc, p2, xs, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
+            win_fma_sym(dd, p3, xs, o0, o1, o2, yacc, shf, tr_on, z0, z1, z2);
+            off += n0 + n1 + n2 + n3;
+        }
 #else
         for (; j + 2 <= L; j += 2) {
             const bool p0 = len > j, p1 = len > j + 1;
