@@ -160,6 +160,8 @@ struct fcvm_ctx {
     bool repack_pending = false;
     bool wsym_use = false;      // the matrix being copied is an SPD stiffness matrix: also into the symmetric form
     bool wsym_lo = true;        // ... and its 16-bit copy (FCVM_WIN_SYM_LO=0: the smoother passes stay on the full form)
+    bool mg_fuse_prolong = false;  // FCVM_MG_FUSE_PROLONG=1: x + P e1 formed while the post-smoothing pass stages x instead of by k_prolong_add
+                                   // (measured: 212 us against 177 + 29 -- every window node is staged by 2.9 groups -- so off)
     int spmv_win = 1, win_v2 = 1;   // win_v2: value components in 16-byte pairs (FCVM_WIN_V2=0: nine 8-byte runs)
     WinDev win;                     // the fine matrix.  (The level-1 matrix of the multigrid cycle was tried on the same format with
     WinSymDev wsym;     // the PCG's FP64 SpMV on the symmetric form (FCVM_WIN_SYM=0: off)
@@ -402,14 +404,16 @@ static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const
 
 // smoother passes of the multiplicative cycle on the 16-bit copy (EPI 1: out = r - K~ x; EPI 2: out = x + c0 Dinv (r - K~ x) + partials)
 template <int EPI>
-static void launch_spmv_win_lo(fcvm_ctx *c, const double *x, const double *r, double *out, double c0, const double *done, double *part = nullptr) {
+static void launch_spmv_win_lo(fcvm_ctx *c, const double *x, const double *r, double *out, double c0, const double *done, double *part = nullptr,
+                               const double *fuse_e1 = nullptr) {
     const WinDev &w = c->win;
     if (!part) part = w.part_lo;
     if (c->wsym.on && c->wsym.lo_valid) {      // symmetric form of the 16-bit copy
         const WinSymDev &ws = c->wsym;
+        const ProlongFuse pf{c->d_pa, c->d_pb, c->d_fixmask, fuse_e1};      // (fuse_e1: x + P e1 is formed while x is staged, EPI 2 only)
         hipLaunchKernelGGL((k_spmv_win_lo_sym<EPI, WIN_WAVES>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), ws.lds_lo, c->stream, w.pat.ngroups,
                            w.pat.wmax, ws.pat.xmax, w.gptr, ws.gextra, w.wlist, ws.woff, ws.rowlen, ws.rownode, ws.seg, ws.own, ws.lo8,
-                           (const WinLoTail *)ws.lo2, w.lo_scale, x, r, out, c0, (const float *)c->d_dinv6f, part, done);
+                           (const WinLoTail *)ws.lo2, w.lo_scale, x, r, out, c0, (const float *)c->d_dinv6f, part, done, pf);
         return;
     }
     if (w.pat.waves == 4)
@@ -465,6 +469,8 @@ static void launch_spmv_win_lo2(fcvm_ctx *c, const double *xA, const double *xB,
                            outA, outB, c0, (const float *)c->d_dinv6f, partA, partB, doneA, doneB);
 }
 
+// the post-smoothing pass forms x + P e1 itself (k_spmv_win_lo_sym): the separate prolongation kernel is not needed
+static inline bool mg_fuse_prolong(const fcvm_ctx *c) { return c->wsym.on && c->wsym.lo_valid && c->mg_fuse_prolong; }
 // the multiplicative cycle with the 16-bit smoother matrix needs the window format and its 16-bit copy
 static inline bool mg_use_lo(const fcvm_ctx *c) { return c->mg_additive == 2 && c->win.on && (c->win.lo_valid || (c->wsym.on && c->wsym.lo_valid)); }
 // the form that runs: 2 without the window format (tiny meshes, windows beyond the LDS) becomes the additive form -- the FP64
@@ -895,6 +901,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_MG_L1_16")) c->mg_l1_16 = atoi(v);
     if (const char *v = getenv("FCVM_MG_ADD_W")) c->mg_add_w = atof(v);
     if (const char *v = getenv("FCVM_WIN_SYM_LO")) c->wsym_lo = atoi(v) != 0;
+    if (const char *v = getenv("FCVM_MG_FUSE_PROLONG")) c->mg_fuse_prolong = atoi(v) != 0;
     HCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
     c->stream = c->own;
     if (dalloc(&c->d_S, S_COUNT) || dalloc(&c->d_out8, 16)) return 1;

@@ -1260,6 +1260,23 @@ __device__ __forceinline__ void win_fma_lo_sym(const WinSlotLo &t, bool active, 
 #endif
     }
 }
+// the prolongation of the coarse correction fused into the staging of the post-smoothing pass: x := x + P e1 (k_prolong_add's
+// arithmetic, node by node in FP64, so the pass sees bitwise the vector the separate kernel would have written); e1 = null: off
+struct ProlongFuse {
+    const int32_t *pa, *pb;
+    const uint8_t *fixmask;
+    const double *e1;
+};
+__device__ __forceinline__ void prolong_fuse_add(const ProlongFuse &pf, int32_t nd, double &v0, double &v1, double &v2) {
+    const int64_t a = pf.pa[nd];
+    if (a < 0) return;
+    const int64_t b = pf.pb[nd];
+    const int fm = pf.fixmask[nd];
+    const double *ea = pf.e1 + 3 * a, *eb = pf.e1 + 3 * b;
+    v0 += (fm & 1) ? 0.0 : 0.5 * (ea[0] + eb[0]);
+    v1 += (fm & 2) ? 0.0 : 0.5 * (ea[1] + eb[1]);
+    v2 += (fm & 4) ? 0.0 : 0.5 * (ea[2] + eb[2]);
+}
 #ifndef FCVM_LOSYM_MINWAVES
 #define FCVM_LOSYM_MINWAVES 6      // three workgroups per CU (31 KB of LDS each) with three blocks in flight: 179 / 149 against 192 / 157 us with two and six
 #endif
@@ -1275,7 +1292,7 @@ __global__ __launch_bounds__(64 * WAVES, FCVM_LOSYM_MINWAVES) void k_spmv_win_lo
                                                                 const double *__restrict__ lo_scale, const double *__restrict__ x,
                                                                 const double *__restrict__ r, double *__restrict__ out, double c0,
                                                                 const float *__restrict__ dinv6, double *__restrict__ partial,
-                                                                const double *__restrict__ done) {
+                                                                const double *__restrict__ done, ProlongFuse pf) {
     extern __shared__ float xsf[];      // x of the window in FP32 (3 per window node), then the partial results of later segments
     __shared__ double sh[2 * WAVES];
     constexpr int WIN_THREADS = 64 * WAVES;
@@ -1302,7 +1319,9 @@ __global__ __launch_bounds__(64 * WAVES, FCVM_LOSYM_MINWAVES) void k_spmv_win_lo
             const int o = nd & 1;
             const double2 wv = *(const double2 *)(xa + o);
             const double sv = xa[o ? 0 : 2];
-            const float v0 = (float)(o ? sv : wv.x), v1 = (float)(o ? wv.x : wv.y), v2 = (float)(o ? wv.y : sv);
+            double d0 = o ? sv : wv.x, d1 = o ? wv.x : wv.y, d2 = o ? wv.y : sv;
+            if (EPI == 2 && pf.e1) prolong_fuse_add(pf, nd, d0, d1, d2);
+            const float v0 = (float)d0, v1 = (float)d1, v2 = (float)d2;
             xsf[3 * i] = v0; xsf[3 * i + 1] = v1; xsf[3 * i + 2] = v2;
             xm = fmaxf(xm, fmaxf(fabsf(v0), fmaxf(fabsf(v1), fabsf(v2))));
         }
@@ -1421,9 +1440,11 @@ __global__ __launch_bounds__(64 * WAVES, FCVM_LOSYM_MINWAVES) void k_spmv_win_lo
             const float2 *d2 = (const float2 *)(dinv6 + 6 * (int64_t)node);
             const float2 u0 = d2[0], u1 = d2[1], u2 = d2[2];   // xx xy | xz yy | yz zz
             const double *xo = x + o;      // the FP64 x of the row's own node (the window in LDS holds FP32 roundings)
-            const double z0 = xo[0] + c0 * ((double)u0.x * t0 + (double)u0.y * t1 + (double)u1.x * t2);
-            const double z1 = xo[1] + c0 * ((double)u0.y * t0 + (double)u1.y * t1 + (double)u2.x * t2);
-            const double z2 = xo[2] + c0 * ((double)u1.x * t0 + (double)u2.x * t1 + (double)u2.y * t2);
+            double x0 = xo[0], x1 = xo[1], x2 = xo[2];
+            if (pf.e1) prolong_fuse_add(pf, node, x0, x1, x2);
+            const double z0 = x0 + c0 * ((double)u0.x * t0 + (double)u0.y * t1 + (double)u1.x * t2);
+            const double z1 = x1 + c0 * ((double)u0.y * t0 + (double)u1.y * t1 + (double)u2.x * t2);
+            const double z2 = x2 + c0 * ((double)u1.x * t0 + (double)u2.x * t1 + (double)u2.y * t2);
             out[o] = z0; out[o + 1] = z1; out[o + 2] = z2;
             rz = r0 * z0 + r1 * z1 + r2 * z2;
             rr = r0 * r0 + r1 * r1 + r2 * r2;
