@@ -1278,10 +1278,10 @@ __device__ __forceinline__ void prolong_fuse_add(const ProlongFuse &pf, int32_t 
     v2 += (fm & 4) ? 0.0 : 0.5 * (ea[2] + eb[2]);
 }
 #ifndef FCVM_LOSYM_MINWAVES
-#define FCVM_LOSYM_MINWAVES 6      // three workgroups per CU (31 KB of LDS each) with three blocks in flight: 179 / 149 against 192 / 157 us with two and six
+#define FCVM_LOSYM_MINWAVES 8      // four workgroups per CU (31 KB of LDS, 58 registers) with two blocks in flight: 177 / 150 us; three with three: 181 / 152; two with six: 192 / 157
 #endif
 #ifndef FCVM_LOSYM_INFLIGHT
-#define FCVM_LOSYM_INFLIGHT 3
+#define FCVM_LOSYM_INFLIGHT 2
 #endif
 template <int EPI, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, FCVM_LOSYM_MINWAVES) void k_spmv_win_lo_sym(int64_t ngroups, int64_t wmax, int64_t xseg, const int64_t *__restrict__ gptr,

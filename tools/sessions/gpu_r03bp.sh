@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3: A/B of the FP32 -> fixed-point conversion in the 16-bit symmetric passes (integer shift vs widening to FP64), one box, long runs
+# round 3: A/B of two builds (default vs fcvm_hip/libfcvm_hip_ab.so), one box, long runs; "f64" = the alternative build
 O=gpurun_out/r03bp
 mkdir -p $O
 export TMPDIR=/tmp
