@@ -566,8 +566,13 @@ static int wsym_upload(fcvm_ctx *c) {
     const int64_t nrows = w.nwaves * SLICE;
     if (dalloc(&d.woff, w.nwaves + 1) || dalloc(&d.rownode, nrows) || dalloc(&d.srcslot, nrows) || dalloc(&d.gextra, w.ngroups) ||
         dalloc(&d.seg, nrows) || dalloc(&d.cols, w.nblocks) || dalloc(&d.rowlen, nrows) || dalloc(&d.own, nrows) ||
-        dalloc(&d.jell, w.nblocks) || dalloc(&d.vals, 9 * w.nblocks))
-        return 1;
+        dalloc(&d.jell, w.nblocks) || dalloc(&d.vals, 9 * w.nblocks)) {
+        // no memory for the second copy: the full window form stays in charge instead of failing the mesh
+        (void)hipGetLastError();
+        if (getenv("FCVM_VERBOSE")) fprintf(stderr, "fcvm: symmetric window form not used (out of device memory)\n");
+        wsym_free(d);
+        return 0;
+    }
     hipStream_t s = c->stream;
     HCHK(hipMemcpyAsync(d.woff, w.woff.data(), sizeof(int64_t) * (w.nwaves + 1), hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(d.rownode, w.rownode.data(), sizeof(int32_t) * nrows, hipMemcpyHostToDevice, s));
@@ -647,7 +652,16 @@ static void win_build_host(fcvm_ctx *c, const double *nocoord, WinBuild *res) {
     }
 }
 
+static int setup_window_format_body(fcvm_ctx *c, const WinBuild &res);
+// every return leaves no builder thread behind: the thread reads c->pat / c->win.pat, which the caller may rebuild or free next
+// (a failed fcvm_set_mesh followed by another one on the same context)
 static int setup_window_format(fcvm_ctx *c, const WinBuild &res) {
+    const int rc = setup_window_format_body(c, res);
+    if (c->sym_thread.joinable()) c->sym_thread.join();
+    if (rc) { wsym_free(c->wsym); }
+    return rc;
+}
+static int setup_window_format_body(fcvm_ctx *c, const WinBuild &res) {
     if (!res.err.empty()) return fail(res.err);
     if (!res.built) return 0;
     WinPattern &w = c->win.pat;
@@ -1061,7 +1075,8 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     // the window format's host work (0.07 s at 1 M elements) beside the allocations and uploads below
     WinBuild winres;
     std::thread winthread(win_build_host, c, nocoord, &winres);
-    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{winthread};
+    // joined on every return path, the symmetric form's builder (started by winthread) after it
+    struct Joiner { std::thread &t; std::thread &t2; ~Joiner() { if (t.joinable()) t.join(); if (t2.joinable()) t2.join(); } } joiner{winthread, c->sym_thread};
     c->h_el = el;
     c->h_coord.assign(nocoord, nocoord + 3 * nn);
     c->h_fixmask.assign(nn, 0);

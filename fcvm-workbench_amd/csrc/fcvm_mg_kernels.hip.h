@@ -655,7 +655,8 @@ __global__ void k_dist_pcg_scalars(int phase, double *__restrict__ S, const doub
     // iteration count, convergence, then beta = gamma_new / gamma, alpha = gamma_new / (delta - beta gamma_new / alpha).
     if (phase == 3) {
         S[0] = in[0]; S[1] = in[2]; S[3] = 0.0; S[4] = 0.0;
-        S[5] = in[1] != 0.0 ? in[0] / in[1] : 0.0;
+        S[5] = in[1] > 0.0 && in[0] >= 0.0 ? in[0] / in[1] : 0.0;
+        if (in[2] > S[2] && (in[1] <= 0.0 || in[0] < 0.0)) S[3] = 2.0;       // breakdown at the start (see phase 2)
         S[6] = 0.0;
         return;
     }
@@ -666,10 +667,13 @@ __global__ void k_dist_pcg_scalars(int phase, double *__restrict__ S, const doub
             S[1] = rrn;
             if (rrn <= S[2] || !isfinite(rrn)) S[3] = 1.0;
         }
-        const bool go = S[3] == 0.0;
-        const double beta = (go && S[0] != 0.0) ? gn / S[0] : 0.0;
+        bool go = S[3] == 0.0;
+        double beta = (go && S[0] != 0.0) ? gn / S[0] : 0.0;
         const double den = delta - beta * gn / (S[5] != 0.0 ? S[5] : 1.0);
-        const double alpha = (go && den != 0.0 && S[5] != 0.0) ? gn / den : 0.0;
+        // p.Kp (= den) <= 0 or r.M^-1 r (= gn) < 0: operator or preconditioner not positive definite -- S[3] = 2 stops the loop
+        // as a breakdown (the host raises) instead of iterating on
+        if (go && (den <= 0.0 || gn < 0.0)) { S[3] = 2.0; go = false; beta = 0.0; }
+        const double alpha = (go && S[5] != 0.0) ? gn / den : 0.0;
         if (go) S[0] = gn;
         S[5] = alpha;
         S[6] = beta;

@@ -499,12 +499,20 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
             }
         }
     };
+    // transposed products every row receives (the kernels' 64-bit fixed-point sums are sized for SYM_MAX_RECEIVED of them):
+    // recv[j] is written by the thread that owns j's group only -- both nodes of a counted pair are in that group
+    std::vector<uint16_t> recv(nn, 0);
     // pass 1: new lengths, segments, lanes, entries per wave
     parallel_for(ng, nthreads, [&](int64_t b, int64_t e, int t) {
         std::vector<VRow> rows;
         for (int64_t g = b; g < e; g++) {
             rows.clear();
             int32_t extra = 0;
+            for (int64_t at = g * R; at < (g + 1) * R; at++) {
+                const int32_t nd = w.rownode[at];
+                if (nd < 0 || (w.seg[at] & 255u) == 0) continue;
+                for_kept(nd, (int32_t)g, [&](int, int32_t col, bool tr) { if (tr) recv[col]++; });
+            }
             for (int64_t at = g * R; at < (g + 1) * R; at++) {       // the nodes of the group in the order of the full format's lanes
                 const int32_t nd = w.rownode[at];
                 if (nd < 0 || (w.seg[at] & 255u) == 0) continue;
@@ -540,6 +548,9 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
     lap("pass 1 (lengths, lanes)");
     s.dropped = 0;
     for (int64_t v : drop) s.dropped += v;
+    s.trmax = 0;
+    for (int64_t i = 0; i < nn; i++) s.trmax = std::max<int64_t>(s.trmax, recv[i]);
+    if (s.trmax > SYM_MAX_RECEIVED) return false;      // (the full form stays in charge)
     s.xmax = 0;
     for (int64_t g = 0; g < ng; g++) s.xmax = std::max<int64_t>(s.xmax, s.gextra[g]);
     for (int64_t i = 0; i < s.nwaves; i++) s.woff[i + 1] = (s.woff[i + 1] + 15) / 16 * 16 + s.woff[i];
@@ -601,6 +612,7 @@ int64_t check_window_sym(const Pattern &p, const WinPattern &w, const WinSym &s)
     int64_t bad = 0;
     const int64_t R = (int64_t)s.waves * SLICE;
     std::vector<uint8_t> hit(p.nnzb, 0);
+    std::vector<int32_t> recv(p.nn, 0);      // transposed products per receiving row: bounded, see SYM_MAX_RECEIVED
     auto mark = [&](int32_t i, int32_t j) {
         const int32_t *rb = p.colidx.data() + p.rowptr[i], *re = p.colidx.data() + p.rowptr[i + 1];
         const int32_t *at = std::lower_bound(rb, re, j);
@@ -635,7 +647,7 @@ int64_t check_window_sym(const Pattern &p, const WinPattern &w, const WinSym &s)
                 if (ts != 0xFFFFu) {
                     const int64_t tat = g * R + ts;
                     if ((int64_t)ts >= R || s.rownode[tat] != jn || (s.seg[tat] & 255u) == 0 || jn == i) bad++;
-                    else mark(jn, i);
+                    else { mark(jn, i); recv[jn]++; }
                 }
             }
             off += n;
@@ -644,6 +656,9 @@ int64_t check_window_sym(const Pattern &p, const WinPattern &w, const WinSym &s)
     }
     for (int64_t q = 0; q < p.nnzb; q++)
         if (hit[q] != 1) bad++;
+    int64_t most = 0;
+    for (int64_t i = 0; i < p.nn; i++) most = std::max<int64_t>(most, recv[i]);
+    if (most != s.trmax || most > SYM_MAX_RECEIVED) bad++;
     return bad;
 }
 

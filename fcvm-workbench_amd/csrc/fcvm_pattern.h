@@ -145,8 +145,14 @@ bool build_window_format(const Pattern &p, const double *xyz, int nthreads, int6
 // low 16 bits, in the high 16 bits the position in the group (wave * 64 + lane) of the FIRST segment of the column node's row
 // when the transposed product is wanted, 0xFFFF otherwise.  jell: number of the block in its sliced-ELL row (the copy kernel's
 // source; rows are filtered, so "block j of the segment = block jstart + j of the row" no longer holds).
+// Most transposed products a row may receive: each is three terms below kmax * xmax, the accumulators' unit is
+// 2^(8 - 62) kmax * xmax (k_spmv_win_sym), so |sum| <= 3 * 85 * 2^54 < 2^62 units -- no wrap-around of the signed 64-bit sums.
+// A row receives one product per in-group neighbour whose row keeps the pair, about half of its in-group neighbours: 85 means
+// some 170 in-group neighbours (tet10 corner nodes have 65 neighbours in all on structured meshes, ~100 at 40 incident tets).
+constexpr int SYM_MAX_RECEIVED = 85;
 struct WinSym {
     int64_t ngroups = 0, nwaves = 0, nblocks = 0, dropped = 0;
+    int64_t trmax = 0;                // most transposed products any row receives (<= SYM_MAX_RECEIVED, or the form is declined)
     int waves = WIN_WAVES, split = WIN_SPLIT;
     int64_t xmax = 0;                 // most second-and-later segments in one group
     std::vector<int32_t> rownode, srcslot;      // [nwaves*64]
@@ -157,7 +163,7 @@ struct WinSym {
     RawVec<uint32_t> cols;                      // [nblocks]
     RawVec<uint8_t> jell;                       // [nblocks]
 };
-// false: not applicable (a row with more than 255 blocks)
+// false: not applicable (a row with more than 255 blocks, or one that would receive more than SYM_MAX_RECEIVED transposed products)
 bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSym &s);
 // number of violated invariants (0 = every block of the matrix is covered exactly once, directly or as a transposed product)
 int64_t check_window_sym(const Pattern &p, const WinPattern &w, const WinSym &s);

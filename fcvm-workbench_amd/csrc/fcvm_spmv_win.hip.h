@@ -1078,10 +1078,14 @@ __device__ __forceinline__ void win_fma_sym(const WinSlotS &t, bool active, cons
 
 // LDS: x of the window [3 wmax], partial results of later segments [3 xseg], fixed-point accumulators [3 * 64 * WAVES].
 // kexp[0] = exponent e0 with |K entries| < 2^e0 (k_lo_scale).  The unit of the accumulators is chosen per group from the largest
-// |x| of its window: a row receives at most 64 transposed products (a node has at most 64 neighbours) of three terms below
-// 2^e0 * xmax each, so the sums stay below 2^(e0 + ex + 7.6) * ... < 2^62 units of 2^(e0 + ex + 8 - 62): no overflow; one unit is
+// |x| of its window: a row receives at most SYM_MAX_RECEIVED = 85 transposed products (counted by build_window_sym, which declines
+// the form beyond that; recounted by check_window_sym) of three terms below 2^e0 * xmax each, so the sums stay below
+// 3 * 85 * 2^(e0 + ex) < 2^(e0 + ex + 8) = 2^62 units of 2^(e0 + ex + 8 - 62): no wrap-around of the signed sums; one unit is
 // 2^-54 of kmax * xmax, half an FP64 rounding error of the largest possible term (with four bits more margin the attainable
-// residual of a solve to 1e-11 rose from 5e-11 to 6e-11 of |f|: the margin was taken out).
+// residual of a solve to 1e-11 rose from 5e-11 to 6e-11 of |f|: the margin was taken out).  The unit follows the GLOBAL
+// kmax: on a mesh graded by a factor s in element size the transposed products of the region of smallest entries carry a relative
+// error of 2^-54 * kmax / K_local = 2^-54 * s (tet10 stiffness entries scale with h): 1e-13 at s = 1000 -- far below the PCG
+// tolerances in use (1e-10 .. 1e-12); a mesh graded beyond 1e4 should run with FCVM_WIN_SYM=0.
 #ifndef FCVM_SYM_MINWAVES
 #define FCVM_SYM_MINWAVES 4
 #endif
@@ -1124,6 +1128,7 @@ __global__ __launch_bounds__(64 * WAVES, FCVM_SYM_MINWAVES) void k_spmv_win_sym(
             const double v0 = o ? sv : wv.x, v1 = o ? wv.x : wv.y, v2 = o ? wv.y : sv;
             xs[3 * i] = v0; xs[3 * i + 1] = v1; xs[3 * i + 2] = v2;
             xm = fmax(xm, fmax(fabs(v0), fmax(fabs(v1), fabs(v2))));
+            if (!(fabs(v0) + fabs(v1) + fabs(v2) < 1e300)) xm = __builtin_huge_val();     // (fmax drops a NaN: carry it as Inf)
         }
         for (int i = tid; i < 3 * WIN_THREADS; i += WIN_THREADS) yacc[i] = 0ull;
 #pragma unroll
@@ -1134,7 +1139,10 @@ __global__ __launch_bounds__(64 * WAVES, FCVM_SYM_MINWAVES) void k_spmv_win_sym(
 #pragma unroll
     for (int i = 0; i < WAVES; i++) xm = fmax(xm, sh[i]);
     int ex = 0;
-    const bool tr_on = xm > 0.0 && xm < 1e300;
+    // x of the window not finite or beyond 1e300: the fixed-point unit cannot be formed.  The transposed products are not
+    // silently left out (that would be the product with an unsymmetric matrix): the group's rows are written as NaN
+    const bool poison = !(xm < 1e300);
+    const bool tr_on = xm > 0.0 && !poison;
     if (tr_on) (void)frexp(xm, &ex);
     const int shf = 62 - ((int)kexp[0] + ex + 8);
     const int32_t node = rownode[row];
@@ -1214,6 +1222,7 @@ __global__ __launch_bounds__(64 * WAVES, FCVM_SYM_MINWAVES) void k_spmv_win_sym(
         __syncthreads();
         for (int k = 0; k + 1 < nseg; k++) { y0 += yp[3 * k]; y1 += yp[3 * k + 1]; y2 += yp[3 * k + 2]; }
     }
+    if (poison) y0 = y1 = y2 = __builtin_nan("");
     if (node >= 0 && nseg > 0) {
         double *yo = y + 3 * (int64_t)node;
         yo[0] = y0; yo[1] = y1; yo[2] = y2;
@@ -1324,6 +1333,7 @@ __global__ __launch_bounds__(64 * WAVES, FCVM_LOSYM_MINWAVES) void k_spmv_win_lo
             const float v0 = (float)d0, v1 = (float)d1, v2 = (float)d2;
             xsf[3 * i] = v0; xsf[3 * i + 1] = v1; xsf[3 * i + 2] = v2;
             xm = fmaxf(xm, fmaxf(fabsf(v0), fmaxf(fabsf(v1), fabsf(v2))));
+            if (!(fabsf(v0) + fabsf(v1) + fabsf(v2) < 3e38f)) xm = __builtin_huge_valf();
         }
         for (int i = tid; i < 3 * WIN_THREADS; i += WIN_THREADS) yacc[i] = 0ull;
 #pragma unroll
@@ -1334,7 +1344,8 @@ __global__ __launch_bounds__(64 * WAVES, FCVM_LOSYM_MINWAVES) void k_spmv_win_lo
 #pragma unroll
     for (int i = 0; i < WAVES; i++) xm = fmaxf(xm, shx[i]);
     int ex = 0;
-    const bool tr_on = xm > 0.f && xm < 3e38f;
+    const bool poison = !(xm < 3e38f);          // as in k_spmv_win_sym: NaN out instead of a product without its transposed half
+    const bool tr_on = xm > 0.f && !poison;
     if (tr_on) (void)frexpf(xm, &ex);
     // products are in units of 2^(e0 - 15): |q 2^e| < 2^15, three terms, at most 64 transposed products per row (see k_spmv_win_sym)
     const int shf = 62 - (15 + ex + 8);
@@ -1414,6 +1425,7 @@ __global__ __launch_bounds__(64 * WAVES, FCVM_LOSYM_MINWAVES) void k_spmv_win_lo
     }
     // the row's sum in FP64: its own FP32 sums + the fixed-point sum of the transposed products
     double yd0 = (double)y0, yd1 = (double)y1, yd2 = (double)y2;
+    if (poison) yd0 = yd1 = yd2 = __builtin_nan("");
     if (node >= 0 && nseg > 0 && tr_on) {
         const unsigned long long *ya = yacc + 3 * (wig * 64 + lane);
         yd0 += ldexp((double)(long long)ya[0], -shf);

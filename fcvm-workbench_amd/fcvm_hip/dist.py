@@ -380,9 +380,34 @@ class DistBackend:
         o = self.ops.update_peeq_csr(*args)
         if self.part.world == 1:
             return o
-        # global argmax(csr) with numpy's first-occurrence rule on the GLOBAL Gauss point index
+        # global argmax(csr) with numpy's first-occurrence rule on the GLOBAL Gauss point index.  The rank's elements are
+        # a range of a PERMUTATION of the caller's list (partition_model's spatial order), so the local Gauss point goes
+        # back through element_ids (global number of every local element) -- an offset only describes contiguous ranges
         o = dict(o)
-        o["maxloc"] = int(o["maxloc"]) + 4 * self.ops.element_offset
+        ml = int(o["maxloc"])
+        ids = getattr(self, "element_ids", None)
+        if ids is not None:
+            if getattr(self, "_ids_ascending", None) is None:
+                self._ids_ascending = bool(np.all(np.diff(ids) > 0)) if len(ids) > 1 else True
+                if not self._ids_ascending:
+                    self._gp_ids = torch.as_tensor(np.repeat(4 * ids, 4) + np.tile(np.arange(4), len(ids)), device=self.device)
+            if not self._ids_ascending:
+                # ties (csr = 0 everywhere before the first yield, or equal maxima): the kernel's first LOCAL occurrence is
+                # not the first GLOBAL one when the local list is a permutation -- take the tied entry with the lowest
+                # global Gauss point and re-read the values reported with it
+                names = dict(peeq=4, csr_max=5, triax=6, pressure=7, sigmises=8, ecr=9)
+                csr_t = args[5].t
+                tied = csr_t == csr_t[ml]
+                g = int(self._gp_ids[tied].min().item())
+                self.comm["host_syncs"] += 1
+                if g != 4 * int(ids[ml // 4]) + ml % 4:
+                    ml = int(torch.nonzero(self._gp_ids == g)[0].item())
+                    for k, a in names.items():
+                        if k in o:
+                            o[k] = float(args[a].t[ml].item())
+            o["maxloc"] = 4 * int(ids[ml // 4]) + ml % 4
+        else:
+            o["maxloc"] = ml + 4 * self.ops.element_offset
         allo = [None] * self.part.world
         dist.all_gather_object(allo, o, group=self.group)
         best = max(allo, key=lambda d: (d["csr_max"], -d["maxloc"]))
@@ -508,102 +533,141 @@ class DistBackend:
             raise RuntimeError("distributed PCG did not converge in %d iterations" % maxit)
         return u, info
 
-    def _solve_single_reduction(self, f, u, rtol, maxit):
+    def _solve_single_reduction(self, f, u, rtol, maxit, max_refine=3):
         """Preconditioned CG in the Chronopoulos-Gear form: the SpMV is applied to z = M^-1 r (w = K z), s = K p follows from
         the recurrence s = w + beta s, and r.z, w.z, r.r of an iteration travel in ONE all-reduce (the classic form needs p.Kp
         before and r.z after the update: two).  Same device-side convergence masking as the classic loop: after
-        convergence alpha = beta = 0, queued iterations change nothing.  FCVM_DIST_CG=classic selects the two-reduction loop."""
+        convergence alpha = beta = 0, queued iterations change nothing.  FCVM_DIST_CG=classic selects the two-reduction loop.
+        Both r and s = K p are recurrences here, so the r.r the loop converges on can drift from the true residual at tight
+        tolerances: after convergence f - K x is formed once (one more SpMV, exchange and all-reduce); when it misses the
+        threshold by more than a factor two in norm the loop restarts from it (at most max_refine times), and what is reported is
+        the TRUE relative residual.  p.Kp <= 0 or r.z < 0 (an indefinite operator or preconditioner) stop the loop as a
+        breakdown instead of going unnoticed."""
         c0 = dict(self.comm)
         dev = self.device
         x, r = u.t, f.t.clone()
         x.zero_()
         z, w = self.empty(f.n), self.empty(f.n)
-        self.precond(TVec(r), z)
-        self.spmv(z, w)
-        g3 = self.dot3_t(r, z.t, w.t)
-        gamma, delta, bb = g3[0:1].clone(), g3[1:2].clone(), g3[2:3].clone()
-        bb_h = float(bb.item())
-        self.comm["host_syncs"] += 1
-        info = dict(iterations=0, rel_residual=0.0, spmv=1)
-        if bb_h == 0.0:
-            return u, info
-        if not np.isfinite(bb_h):
-            raise RuntimeError("distributed PCG: non-finite right-hand side")
-        thresh = torch.full((1,), rtol * rtol * bb_h, dtype=torch.float64, device=dev)
-        p, sv = TVec(z.t.clone()), TVec(w.t.clone())
+        info = dict(iterations=0, rel_residual=0.0, spmv=0, refinements=0)
         fused = self.mg is not None and self.mg.ready and self.mg.fused
-        queued, chunk, spmvs, finished = 0, 1, 1, False
         dev_scalars = hasattr(self.ops, "pcg_scalars")
-        if dev_scalars:
-            # scalars on the device, one single-thread kernel per iteration (fcvm_dist_pcg_scalars phases 3 / 2) instead of the
-            # fifteen one-element tensor operations of the loop below
-            S = torch.zeros(7, dtype=torch.float64, device=dev)       # gamma, rr, thresh, done, iterations, alpha, beta
-            S[2] = rtol * rtol * bb_h
-            self.ops.pcg_scalars(3, S, g3)
-            alpha, beta = S[5:6], S[6:7]
-            while queued < maxit and not finished:
-                n = min(chunk, maxit - queued)
-                for _ in range(n):
-                    if fused:
-                        self.mg.update_and_vcycle(alpha, p, sv, TVec(x), TVec(r), z)
-                    else:
-                        x.addcmul_(p.t, alpha)
-                        r.addcmul_(sv.t, -alpha)
-                        self.precond(TVec(r), z)
-                    self.spmv(z, w)
-                    spmvs += 1
-                    self.ops.pcg_scalars(2, S, self.dot3_t(r, z.t, w.t))
-                    torch.addcmul(z.t, p.t, beta, out=p.t)       # p = z + beta p
-                    torch.addcmul(w.t, sv.t, beta, out=sv.t)     # s = w + beta s   (= K p)
-                queued += n
-                chunk = min(self.check_every, 2 * chunk) if queued >= 2 else 1
-                finished = bool(S[3].item() != 0.0)
+        total_it, spmvs, queued_all = 0, 0, 0
+        bb_h = thresh_h = None
+        for attempt in range(1 + max_refine):
+            self.precond(TVec(r), z)
+            self.spmv(z, w)
+            spmvs += 1
+            g3 = self.dot3_t(r, z.t, w.t)
+            gamma, delta = g3[0:1].clone(), g3[1:2].clone()
+            if attempt == 0:
+                bb_h = float(g3[2].item())
                 self.comm["host_syncs"] += 1
-            Sh = S.cpu()
-            rr, it_t = Sh[1:2], Sh[4:5]
-        else:
-            zero, one = torch.zeros(1, dtype=torch.float64, device=dev), torch.ones(1, dtype=torch.float64, device=dev)
-            done = torch.zeros(1, dtype=torch.bool, device=dev)
-            it_t = torch.zeros(1, dtype=torch.float64, device=dev)
-            rr = bb.clone()
-            alpha = torch.where(delta != 0.0, gamma / torch.where(delta != 0.0, delta, one), zero)
-        while not dev_scalars and queued < maxit and not finished:
-            n = min(chunk, maxit - queued)
-            for _ in range(n):
-                if fused:
-                    self.mg.update_and_vcycle(alpha, p, sv, TVec(x), TVec(r), z)   # x += alpha p, r -= alpha s, z = M^-1 r
-                else:
-                    x.addcmul_(p.t, alpha)
-                    r.addcmul_(sv.t, -alpha)
-                    self.precond(TVec(r), z)
-                self.spmv(z, w)
-                spmvs += 1
-                g3 = self.dot3_t(r, z.t, w.t)
-                live = ~done
-                it_t += live
-                rr = torch.where(live, g3[2:3], rr)
-                done = done | (rr <= thresh) | ~torch.isfinite(rr)
-                live = ~done
-                gn = g3[0:1]
-                beta = torch.where(live & (gamma != 0.0), gn / torch.where(gamma != 0.0, gamma, one), zero)
-                den = g3[1:2] - beta * gn / torch.where(alpha != 0.0, alpha, one)
-                alpha = torch.where(live & (den != 0.0) & (alpha != 0.0), gn / torch.where(den != 0.0, den, one), zero)
-                gamma = torch.where(live, gn, gamma)
-                torch.addcmul(z.t, p.t, beta, out=p.t)       # p = z + beta p
-                torch.addcmul(w.t, sv.t, beta, out=sv.t)     # s = w + beta s   (= K p)
-            queued += n
-            chunk = min(self.check_every, 2 * chunk) if queued >= 2 else 1
-            finished = bool(done.item())
+                if bb_h == 0.0:
+                    info["spmv"] = spmvs
+                    return u, info
+                if not np.isfinite(bb_h):
+                    raise RuntimeError("distributed PCG: non-finite right-hand side")
+                thresh_h = rtol * rtol * bb_h
+            thresh = torch.full((1,), thresh_h, dtype=torch.float64, device=dev)
+            p, sv = TVec(z.t.clone()), TVec(w.t.clone())
+            queued, chunk, finished = 0, 1, False
+            budget = maxit - queued_all
+            if dev_scalars:
+                # scalars on the device, one single-thread kernel per iteration (fcvm_dist_pcg_scalars phases 3 / 2) instead of
+                # the fifteen one-element tensor operations of the loop below
+                S = torch.zeros(7, dtype=torch.float64, device=dev)       # gamma, rr, thresh, done, iterations, alpha, beta
+                S[2] = thresh_h
+                self.ops.pcg_scalars(3, S, g3)
+                alpha, beta = S[5:6], S[6:7]
+                while queued < budget and not finished:
+                    n = min(chunk, budget - queued)
+                    for _ in range(n):
+                        if fused:
+                            self.mg.update_and_vcycle(alpha, p, sv, TVec(x), TVec(r), z)
+                        else:
+                            x.addcmul_(p.t, alpha)
+                            r.addcmul_(sv.t, -alpha)
+                            self.precond(TVec(r), z)
+                        self.spmv(z, w)
+                        spmvs += 1
+                        self.ops.pcg_scalars(2, S, self.dot3_t(r, z.t, w.t))
+                        torch.addcmul(z.t, p.t, beta, out=p.t)       # p = z + beta p
+                        torch.addcmul(w.t, sv.t, beta, out=sv.t)     # s = w + beta s   (= K p)
+                    queued += n
+                    chunk = min(self.check_every, 2 * chunk) if queued >= 2 else 1
+                    finished = bool(S[3].item() != 0.0)
+                    self.comm["host_syncs"] += 1
+                Sh = S.cpu()
+                rr_h, it, flag = float(Sh[1]), int(Sh[4]), float(Sh[3])
+            else:
+                zero, one = torch.zeros(1, dtype=torch.float64, device=dev), torch.ones(1, dtype=torch.float64, device=dev)
+                done = torch.zeros(1, dtype=torch.bool, device=dev)
+                broke = torch.zeros(1, dtype=torch.bool, device=dev)
+                it_t = torch.zeros(1, dtype=torch.float64, device=dev)
+                rr = g3[2:3].clone()
+                broke = broke | (delta <= 0.0) | (gamma < 0.0)
+                done = done | broke
+                alpha = torch.where(~done, gamma / torch.where(delta != 0.0, delta, one), zero)
+                while queued < budget and not finished:
+                    n = min(chunk, budget - queued)
+                    for _ in range(n):
+                        if fused:
+                            self.mg.update_and_vcycle(alpha, p, sv, TVec(x), TVec(r), z)   # x += alpha p, r -= alpha s, z = M^-1 r
+                        else:
+                            x.addcmul_(p.t, alpha)
+                            r.addcmul_(sv.t, -alpha)
+                            self.precond(TVec(r), z)
+                        self.spmv(z, w)
+                        spmvs += 1
+                        g3 = self.dot3_t(r, z.t, w.t)
+                        live = ~done
+                        it_t += live
+                        rr = torch.where(live, g3[2:3], rr)
+                        done = done | (rr <= thresh) | ~torch.isfinite(rr)
+                        live = ~done
+                        gn = g3[0:1]
+                        beta = torch.where(live & (gamma != 0.0), gn / torch.where(gamma != 0.0, gamma, one), zero)
+                        den = g3[1:2] - beta * gn / torch.where(alpha != 0.0, alpha, one)
+                        bad = live & ((den <= 0.0) | (gn < 0.0))       # p.Kp <= 0 or r.M^-1 r < 0: not SPD
+                        broke = broke | bad
+                        done = done | bad
+                        live = ~done
+                        beta = torch.where(live, beta, zero)
+                        alpha = torch.where(live & (alpha != 0.0), gn / torch.where(den != 0.0, den, one), zero)
+                        gamma = torch.where(live, gn, gamma)
+                        torch.addcmul(z.t, p.t, beta, out=p.t)       # p = z + beta p
+                        torch.addcmul(w.t, sv.t, beta, out=sv.t)     # s = w + beta s   (= K p)
+                    queued += n
+                    chunk = min(self.check_every, 2 * chunk) if queued >= 2 else 1
+                    finished = bool(done.item())
+                    self.comm["host_syncs"] += 1
+                rr_h, it, flag = float(rr.item()), int(it_t.item()), 2.0 if bool(broke.item()) else float(done.item())
+            total_it += it
+            queued_all += queued
+            if not np.isfinite(rr_h):
+                raise RuntimeError("distributed PCG broke down (non-finite residual)")
+            if flag == 2.0:
+                raise RuntimeError("distributed PCG broke down: p.Kp <= 0 or r.M^-1 r < 0 (operator or preconditioner not positive "
+                                   "definite) after %d iterations" % total_it)
+            if rr_h > thresh_h:
+                break           # iteration budget used up: reported below
+            # the true residual of what the recurrences converged to
+            self.spmv(TVec(x), w)
+            spmvs += 1
+            rt = f.t - w.t
+            rr_true = float(self.dot_t(rt, rt).item())
             self.comm["host_syncs"] += 1
-        it = int(it_t.item())
-        rr_h = float(rr.item())
-        info.update(iterations=it, rel_residual=float(np.sqrt(rr_h / bb_h)) if np.isfinite(rr_h) else float("nan"), spmv=spmvs)
+            rr_h = rr_true
+            if rr_true <= 4.0 * thresh_h or attempt == max_refine or queued_all >= maxit:
+                break
+            r = rt
+            info["refinements"] += 1
+        info.update(iterations=total_it, rel_residual=float(np.sqrt(rr_h / bb_h)), spmv=spmvs)
         info["comm"] = {k: self.comm[k] - c0[k] for k in self.comm}
-        info["comm_per_iteration"] = {k: (self.comm[k] - c0[k]) / max(queued + 1, 1) for k in ("exchanges", "allreduces")}
-        if not np.isfinite(rr_h):
-            raise RuntimeError("distributed PCG broke down")
-        if rr_h > float(thresh.item()):
-            raise RuntimeError("distributed PCG did not converge in %d iterations" % maxit)
+        info["comm_per_iteration"] = {k: (self.comm[k] - c0[k]) / max(queued_all + 1, 1) for k in ("exchanges", "allreduces")}
+        if rr_h > 4.0 * thresh_h:
+            raise RuntimeError("distributed PCG did not converge in %d iterations (true relative residual %.3e)"
+                               % (maxit, np.sqrt(rr_h / bb_h)))
         return u, info
 
     def solve_timing(self):
@@ -1081,6 +1145,7 @@ def partition_model(elNodes, nocoord, material, fix, loads, device_index=0, devi
     else:
         ops = ops_factory(part, xyz_loc, material, fix_loc, lo)
     be = DistBackend(part, ops, device, pcg_check_every=pcg_check_every)
+    be.element_ids = np.asarray(sel, dtype=np.int64)    # crip (fcVM.py:2160 argmax over csr) in the caller's numbering
     if precond == "mg":
         be.enable_multigrid(xyz_loc, **(mg_options or {}))
     model = DistModel(part, be, xyz_loc, material, fix_loc, _local_loads(part, loads if loads is not None else Loads()),

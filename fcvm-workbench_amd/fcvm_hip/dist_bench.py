@@ -47,53 +47,60 @@ def build_rank_model(rank, world, cells, material, traction, device_index, backe
 
 def _shared_case(build, rank, world):
     """The global model of the weak-scaling run, built ONCE per node: rank 0 generates it (numpy, tens of seconds at 8 M tet10)
-    and parks the arrays in /dev/shm, the other ranks map them after a barrier (eight copies of the generator running side by side
-    took several times as long and eight times the memory).  Single node (bench.py's contract); FCVM_DIST_SHARED_MESH=0: every
-    rank builds its own."""
+    and parks the arrays in a PRIVATE directory under /dev/shm (tempfile.mkdtemp: mode 0700, unpredictable name -- nobody else on
+    a shared node can plant links there), the other ranks map them after the broadcast of its path (eight copies of the generator
+    running side by side took several times as long and eight times the memory).  A failure of rank 0's build travels in the same
+    broadcast, so the other ranks stop at once instead of sitting out the collective's time limit.  Single node (bench.py's
+    contract); FCVM_DIST_SHARED_MESH=0: every rank builds its own."""
     if world == 1 or os.environ.get("FCVM_DIST_SHARED_MESH", "1") == "0" or not os.path.isdir("/dev/shm"):
         return build()
-    base = "/dev/shm/fcvm_bench_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getuid())
+    import shutil
+    import tempfile
     keys = ("elNodes", "nocoord", "material", "ufaces", "uloads")
-    shared = [True]
+    msg = [None]            # rank 0 -> all: ("dir", path) | ("own", None) | ("error", text)
+    case, base = None, None
     if rank == 0:
-        case = build()
         try:
-            fd = np.fromiter(case["fix"].keys(), dtype=np.int64, count=len(case["fix"]))
-            fv = np.fromiter(case["fix"].values(), dtype=np.float64, count=len(case["fix"]))
-            for k in keys:
-                np.save(base + "_" + k + ".npy", np.ascontiguousarray(case[k]))
-            np.save(base + "_fixdof.npy", fd)
-            np.save(base + "_fixval.npy", fv)
-            with open(base + "_meta.json", "w") as fh:
-                json.dump({"ctl": case["ctl"], "name": case["name"]}, fh)
-        except OSError:       # /dev/shm not writable or full: every rank builds its own after all
-            shared = [False]
-    dist.broadcast_object_list(shared, src=0)     # (also the barrier behind which the files are complete)
-    def cleanup():
-        for k in keys + ("fixdof", "fixval"):
+            case = build()
+        except BaseException as ex:       # noqa: B902 -- reported to every rank, then raised again below
+            msg = [("error", "%s: %s" % (type(ex).__name__, ex))]
+            err = ex
+        else:
             try:
-                os.remove(base + "_" + k + ".npy")
-            except OSError:
-                pass
-        try:
-            os.remove(base + "_meta.json")
-        except OSError:
-            pass
-    if not shared[0]:
+                base = tempfile.mkdtemp(prefix="fcvm_bench_", dir="/dev/shm")
+                fd = np.fromiter(case["fix"].keys(), dtype=np.int64, count=len(case["fix"]))
+                fv = np.fromiter(case["fix"].values(), dtype=np.float64, count=len(case["fix"]))
+                for k in keys:
+                    np.save(os.path.join(base, k + ".npy"), np.ascontiguousarray(case[k]))
+                np.save(os.path.join(base, "fixdof.npy"), fd)
+                np.save(os.path.join(base, "fixval.npy"), fv)
+                with open(os.path.join(base, "meta.json"), "w") as fh:
+                    json.dump({"ctl": case["ctl"], "name": case["name"]}, fh)
+                msg = [("dir", base)]
+            except OSError:       # /dev/shm not writable or full: every rank builds its own after all
+                if base:
+                    shutil.rmtree(base, ignore_errors=True)
+                msg = [("own", None)]
+    dist.broadcast_object_list(msg, src=0)     # (also the barrier behind which the files are complete)
+    kind, val = msg[0]
+    if kind == "error":
         if rank == 0:
-            cleanup()
+            raise err
+        raise SystemExit("bench.py: rank 0 could not build the global mesh (%s)" % val)
+    if kind == "own":
         return case if rank == 0 else build()
     try:
         if rank != 0:
-            case = {k: np.load(base + "_" + k + ".npy", mmap_mode="r") for k in keys}
-            fd, fv = np.load(base + "_fixdof.npy"), np.load(base + "_fixval.npy")
+            case = {k: np.load(os.path.join(val, k + ".npy"), mmap_mode="r") for k in keys}
+            fd, fv = np.load(os.path.join(val, "fixdof.npy")), np.load(os.path.join(val, "fixval.npy"))
             case["fix"] = {int(d): float(v) for d, v in zip(fd, fv)}
-            case.update(json.load(open(base + "_meta.json")))
+            with open(os.path.join(val, "meta.json")) as fh:
+                case.update(json.load(fh))
             case["material"] = np.array(case["material"])
     finally:
         dist.barrier()     # everybody has mapped the files: the names can go (the mappings stay valid)
         if rank == 0:
-            cleanup()
+            shutil.rmtree(val, ignore_errors=True)
     return case
 
 

@@ -266,3 +266,184 @@ def test_two_rank_gnly_buckling_preanalysis_matches_oracle(orc, tmp_path):
         assert len(g["lout"]) == len(o["lout"])
         assert rel(g["lout"], o["lout"]) < 1e-5 and rel(g["un"], o["un"]) < 1e-5
         assert rel(g["disp"], o["displacements"].reshape(-1, 3)[g["gnodes"] - 1].reshape(-1)) < 1e-5
+
+
+def _crip_worker(rank, world, port, out, order_kind):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dist_helpers import OracleLocalOps
+        from fcvm_hip.dist import partition_model
+        from fcvm_hip.loads import Loads
+        from fcvm_hip.solver import calc_disp
+        case = small_case(3)
+        el = case["elNodes"]
+        order = None if order_kind == "default" else np.random.default_rng(11).permutation(len(el))
+        model = partition_model(el, case["nocoord"], case["material"], case["fix"],
+                                Loads(ufaces=case["ufaces"], uloads=case["uloads"]), device=torch.device("cpu"), precond="bj",
+                                order=order, pcg_check_every=10,
+                                ops_factory=lambda part, x, m, f, lo: OracleLocalOps(part, x, m, f, element_offset=lo))
+        res = calc_disp(model, CTL, rtol=1e-12)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, dict(crip=res["crip"], lout=res["lout"], elements=model.elements))
+        if rank == 0:
+            torch.save(gathered, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("order_kind", ["default", "random"])
+def test_crip_of_a_partitioned_model_is_the_callers_gauss_point_index(orc, tmp_path, order_kind):
+    """crip (the Gauss point with the largest csr, fcVM.py:2160: argmax = first occurrence in the GLOBAL numbering) through
+    partition_model, whose ranks hold ranges of a PERMUTATION of the element list (Morton order by default): the index
+    reported must be the caller's, not a position in the permuted list."""
+    out = str(tmp_path / "crip.pt")
+    world = 2
+    mp.spawn(_crip_worker, args=(world, _free_port(), out, order_kind), nprocs=world, join=True)
+    got = torch.load(out, weights_only=False)
+    case = small_case(3)
+    ref = orc.run_analysis(case["elNodes"], case["nocoord"], case["material"], case["fix"],
+                           orc.Loads(ufaces=case["ufaces"], uloads=case["uloads"]), CTL)
+    # the partition really is a permutation (not the identity ranges), or the test would not see the defect
+    allel = np.concatenate([g["elements"] for g in got])
+    assert sorted(allel.tolist()) == list(range(len(case["elNodes"]))) and not np.array_equal(allel, np.arange(len(allel)))
+    for g in got:
+        assert len(g["lout"]) == len(ref["lout"])
+        assert np.array_equal(g["crip"], ref["crip"])
+
+
+def _cg_guard_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dist_helpers import OracleLocalOps
+        from fcvm_hip.dist import TVec, partition_model
+        from fcvm_hip.loads import Loads
+        case = small_case(3, prescribed=False)
+        model = partition_model(case["elNodes"], case["nocoord"], case["material"], case["fix"],
+                                Loads(ufaces=case["ufaces"], uloads=case["uloads"]), device=torch.device("cpu"), precond="bj",
+                                pcg_check_every=4,
+                                ops_factory=lambda part, x, m, f, lo: OracleLocalOps(part, x, m, f, element_offset=lo))
+        be = model.ctx
+        glv, modf, V, _ = model.calc_gsm((0.0, 0.0, -9.81), want_x=False)
+        f = be.array(model.fixdof.get() * glv.get() + modf.get())
+        res = {}
+        # 1) what the loop reports is the TRUE residual f - K x
+        u, info = be.solve(f, rtol=1e-10, maxit=2000)
+        q = be.empty(f.n)
+        be.spmv(u, q)
+        rt = f.t - q.t
+        res["reported"] = info["rel_residual"]
+        res["true"] = float(np.sqrt(be.dot_t(rt, rt).item() / be.dot_t(f.t, f.t).item()))
+        res["refinements"] = info["refinements"]
+        # 2) a recurrence that drifts (the s = K p recurrence perturbed every iteration): the loop "converges" on its own r.r,
+        #    the true-residual check sees the gap and restarts from f - K x until the threshold holds
+        orig_spmv = be.spmv
+        calls = [0]
+
+        def drifting_spmv(x, y):
+            orig_spmv(x, y)
+            calls[0] += 1
+            if calls[0] % 7 == 3 and calls[0] < 60:
+                y.t.mul_(1.0 + 2e-5)
+            return y
+        be.spmv = drifting_spmv
+        u2, info2 = be.solve(f, rtol=1e-10, maxit=4000)
+        be.spmv = orig_spmv
+        be.spmv(u2, q)
+        rt = f.t - q.t
+        res["drift_true"] = float(np.sqrt(be.dot_t(rt, rt).item() / be.dot_t(f.t, f.t).item()))
+        res["drift_refinements"] = info2["refinements"]
+        res["drift_reported"] = info2["rel_residual"]
+        # 3) an indefinite preconditioner is a breakdown, not a silent run
+        orig_pre = be.precond
+
+        def negative_precond(r, z):
+            orig_pre(r, z)
+            z.t.mul_(-1.0)
+            return z
+        be.precond = negative_precond
+        try:
+            be.solve(f, rtol=1e-10, maxit=200)
+            res["breakdown"] = "no error"
+        except RuntimeError as ex:
+            res["breakdown"] = str(ex)
+        be.precond = orig_pre
+        gathered = [None] * world
+        dist.all_gather_object(gathered, res)
+        if rank == 0:
+            torch.save(gathered, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_single_reduction_cg_reports_the_true_residual_and_flags_breakdown(tmp_path):
+    """ADVICE round 3 on the Chronopoulos-Gear loop of the multi-GPU layer: convergence is judged on recurrences (r and
+    s = K p), so after convergence f - K x is formed once; a drifted recurrence restarts from it; p.Kp <= 0 or r.M^-1 r < 0
+    raise instead of going unnoticed."""
+    out = str(tmp_path / "cg.pt")
+    world = 2
+    mp.spawn(_cg_guard_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for g in torch.load(out, weights_only=False):
+        assert g["reported"] == pytest.approx(g["true"], rel=1e-6) and g["true"] <= 2e-10
+        assert g["drift_true"] <= 2e-10 and g["drift_reported"] == pytest.approx(g["drift_true"], rel=1e-6)
+        assert g["drift_refinements"] >= 1
+        assert "broke down" in g["breakdown"]
+
+
+def _shared_case_worker(rank, world, port, out, fail):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    res = dict(rank=rank)
+    try:
+        from fcvm_hip import dist_bench
+        import glob
+        import time
+        before = set(glob.glob("/dev/shm/fcvm_bench_*"))
+
+        def build():
+            if rank != 0:
+                raise AssertionError("only rank 0 builds the global mesh")
+            if fail:
+                raise ValueError("mesh generator failed")
+            c = small_case(2)
+            return dict(elNodes=c["elNodes"], nocoord=c["nocoord"], material=c["material"], ufaces=c["ufaces"], uloads=c["uloads"],
+                        fix=c["fix"], ctl={"nstep": 3}, name="tiny")
+        t0 = time.perf_counter()
+        try:
+            case = dist_bench._shared_case(build, rank, world)
+            res.update(ok=True, ne=len(case["elNodes"]), checksum=float(np.asarray(case["nocoord"]).sum()), nfix=len(case["fix"]),
+                       name=case["name"], nstep=case["ctl"]["nstep"])
+        except (SystemExit, ValueError) as ex:
+            res.update(ok=False, error="%s: %s" % (type(ex).__name__, ex))
+        res["seconds"] = time.perf_counter() - t0
+        res["left_behind"] = sorted(set(glob.glob("/dev/shm/fcvm_bench_*")) - before)
+    finally:
+        torch.save(res, out + ".%d" % rank)
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("fail", [False, True], ids=["built", "rank0-fails"])
+def test_shared_bench_mesh_uses_a_private_directory_and_reports_a_failed_build(tmp_path, fail):
+    """ADVICE round 3 (dist_bench._shared_case): the global mesh of `bench.py --gpus N` travels through a mkdtemp directory under
+    /dev/shm that is removed afterwards; when rank 0's generator raises, the other ranks leave at once with its message."""
+    out = str(tmp_path / "sc.pt")
+    world = 2
+    mp.spawn(_shared_case_worker, args=(world, _free_port(), out, fail), nprocs=world, join=True)
+    got = [torch.load(out + ".%d" % r, weights_only=False) for r in range(world)]
+    c = small_case(2)
+    for g in got:
+        assert g["left_behind"] == [] and g["seconds"] < 60
+        if fail:
+            assert not g["ok"] and "mesh generator failed" in g["error"]
+        else:
+            assert g["ok"] and g["ne"] == len(c["elNodes"]) and g["nfix"] == len(c["fix"]) and g["name"] == "tiny" and g["nstep"] == 3
+            assert g["checksum"] == float(np.asarray(c["nocoord"]).sum())

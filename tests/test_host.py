@@ -352,3 +352,45 @@ def test_spatial_element_order_bounds_the_interfaces_of_a_shuffled_mesh():
     assert max(s / h for s, h in zip(shared_s, held_s)) < 0.30          # Morton ranges: a surface-to-volume share
     assert sum(shared_s) == sum(shared_o) and sum(shared_o) < 1.3 * sum(shared_g)
     assert max(held_s) < 1.25 * len(xyz) / 8 + max(shared_s)
+
+
+def _bipyramid_fan(k):
+    """2k tet10 around one hub node: ring of k points, two apexes; the hub couples to 5k + 4 nodes"""
+    import itertools
+    ang = 2 * np.pi * np.arange(k) / k
+    corners = [(0.0, 0.0, 0.0)] + [(np.cos(a), np.sin(a), 0.0) for a in ang] + [(0.0, 0.0, 1.0), (0.0, 0.0, -1.0)]
+    top, bot = k + 1, k + 2
+    tets = []
+    for i in range(k):
+        a, b = 1 + i, 1 + (i + 1) % k
+        tets.append((0, a, b, top))
+        tets.append((0, b, a, bot))
+    xyz = [np.array(c) for c in corners]
+    mid = {}
+    el = []
+    pairs = [(0, 1), (1, 2), (0, 2), (0, 3), (1, 3), (2, 3)]
+    for t in tets:
+        row = list(t)
+        for a, b in pairs:
+            key = (min(t[a], t[b]), max(t[a], t[b]))
+            if key not in mid:
+                mid[key] = len(xyz)
+                xyz.append(0.5 * (xyz[key[0]] + xyz[key[1]]))
+            row.append(mid[key])
+        el.append(row)
+    return np.array(el, np.int64) + 1, np.array(xyz, np.float64)
+
+
+def test_symmetric_window_form_is_declined_where_a_row_would_receive_too_many_transposed_products():
+    """the 64-bit fixed-point sums of k_spmv_win_sym hold 85 transposed products per row without wrap-around
+    (fcvm_pattern.h SYM_MAX_RECEIVED); build_window_sym counts what every row receives and declines the form beyond that --
+    a hub node with 244 neighbours in one group receives about half of them -- and check_window_sym recounts it."""
+    from fcvm_hip import _lib
+    for k, built in ((20, 1), (48, 0)):
+        e, x = _bipyramid_fan(k)
+        assert np.bincount(e.ravel()).max() == 2 * k                   # the hub sits in every element
+        out = (C.c_int64 * 8)()
+        _lib.call("fcvm_host_window_sym_check", len(e), len(x), e.ctypes.data, x.ctypes.data, out)
+        assert out[0] == built, (k, list(out))
+        if built:
+            assert out[3] == 0 and out[2] > 0
