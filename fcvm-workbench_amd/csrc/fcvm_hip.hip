@@ -160,6 +160,7 @@ struct fcvm_ctx {
     bool repack_pending = false;
     bool wsym_use = false;      // the matrix being copied is an SPD stiffness matrix: also into the symmetric form
     bool wsym_lo = true;        // ... and its 16-bit copy (FCVM_WIN_SYM_LO=0: the smoother passes stay on the full form)
+    bool sym_pair = true;       // two right-hand sides share one pass over the symmetric form (FCVM_SYM_PAIR=0: the one-vector kernels twice)
     bool mg_fuse_prolong = false;  // FCVM_MG_FUSE_PROLONG=1: x + P e1 formed while the post-smoothing pass stages x instead of by k_prolong_add
                                    // (measured: 212 us against 177 + 29 -- every window node is staged by 2.9 groups -- so off)
     int spmv_win = 1, win_v2 = 1;   // win_v2: value components in 16-byte pairs (FCVM_WIN_V2=0: nine 8-byte runs)
@@ -370,14 +371,15 @@ static void launch_spmv_win(fcvm_ctx *c, bool dot, const double *x, double *y, c
     const WinDev &w = c->win;
     if (c->wsym.on && c->wsym.valid) {   // symmetric form: 0.70 x the blocks, transposed products through LDS in fixed point
         const WinSymDev &ws = c->wsym;
+        const SymVecs<1> V{{x}, {y}, {dot ? c->d_part_spmv : (double *)nullptr}, {done}};
         if (dot)
-            hipLaunchKernelGGL((k_spmv_win_sym<true, WIN_WAVES>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), ws.lds, c->stream,
+            hipLaunchKernelGGL((k_spmv_win_sym<true, WIN_WAVES, 1>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), ws.lds, c->stream,
                                w.pat.ngroups, w.pat.wmax, ws.pat.xmax, w.gptr, ws.gextra, w.wlist, ws.woff, ws.rowlen, ws.rownode, ws.seg, ws.own,
-                               ws.cols, ws.vals, w.lo_scale, x, y, c->d_part_spmv, done);
+                               ws.cols, ws.vals, w.lo_scale, V);
         else
-            hipLaunchKernelGGL((k_spmv_win_sym<false, WIN_WAVES>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), ws.lds, c->stream,
+            hipLaunchKernelGGL((k_spmv_win_sym<false, WIN_WAVES, 1>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), ws.lds, c->stream,
                                w.pat.ngroups, w.pat.wmax, ws.pat.xmax, w.gptr, ws.gextra, w.wlist, ws.woff, ws.rowlen, ws.rownode, ws.seg, ws.own,
-                               ws.cols, ws.vals, w.lo_scale, x, y, (double *)nullptr, done);
+                               ws.cols, ws.vals, w.lo_scale, V);
         return;
     }
     if (w.pat.waves == 4) {   // meshes whose 512-row windows do not fit the LDS: groups of 256 rows
@@ -411,9 +413,10 @@ static void launch_spmv_win_lo(fcvm_ctx *c, const double *x, const double *r, do
     if (c->wsym.on && c->wsym.lo_valid) {      // symmetric form of the 16-bit copy
         const WinSymDev &ws = c->wsym;
         const ProlongFuse pf{c->d_pa, c->d_pb, c->d_fixmask, fuse_e1};      // (fuse_e1: x + P e1 is formed while x is staged, EPI 2 only)
-        hipLaunchKernelGGL((k_spmv_win_lo_sym<EPI, WIN_WAVES>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), ws.lds_lo, c->stream, w.pat.ngroups,
+        const LoSymVecs<1> V{{x}, {r}, {out}, {part}, {done}};
+        hipLaunchKernelGGL((k_spmv_win_lo_sym<EPI, WIN_WAVES, 1>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), ws.lds_lo, c->stream, w.pat.ngroups,
                            w.pat.wmax, ws.pat.xmax, w.gptr, ws.gextra, w.wlist, ws.woff, ws.rowlen, ws.rownode, ws.seg, ws.own, ws.lo8,
-                           (const WinLoTail *)ws.lo2, w.lo_scale, x, r, out, c0, (const float *)c->d_dinv6f, part, done, pf);
+                           (const WinLoTail *)ws.lo2, w.lo_scale, V, c0, (const float *)c->d_dinv6f, pf);
         return;
     }
     if (w.pat.waves == 4)
@@ -430,15 +433,23 @@ static void launch_spmv_win2(fcvm_ctx *c, const double *xA, const double *xB, do
                              const double *doneA, const double *doneB) {
     const WinDev &w = c->win;
     if (c->wsym.on && c->wsym.valid) {
-        // the symmetric form has no two-vector kernel: two launches of the one-vector kernel (0.70 x the blocks each; the
-        // same arithmetic as a single solve, so paired and single solves stay bitwise equal)
+        // symmetric form, both vectors in one pass (round 4): per vector bitwise the one-vector kernel's result
         const WinSymDev &ws = c->wsym;
-        const double *xs2[2] = {xA, xB}, *dn[2] = {doneA, doneB};
-        double *ys2[2] = {yA, yB}, *pt[2] = {partA, partB};
-        for (int k = 0; k < 2; k++)
-            hipLaunchKernelGGL((k_spmv_win_sym<true, WIN_WAVES>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), ws.lds, c->stream,
+        if (c->sym_pair) {
+            const SymVecs<2> V{{xA, xB}, {yA, yB}, {partA, partB}, {doneA, doneB}};
+            hipLaunchKernelGGL((k_spmv_win_sym<true, WIN_WAVES, 2>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), 2 * ws.lds, c->stream,
                                w.pat.ngroups, w.pat.wmax, ws.pat.xmax, w.gptr, ws.gextra, w.wlist, ws.woff, ws.rowlen, ws.rownode, ws.seg, ws.own,
-                               ws.cols, ws.vals, w.lo_scale, xs2[k], ys2[k], pt[k], dn[k]);
+                               ws.cols, ws.vals, w.lo_scale, V);
+            return;
+        }
+        const double *xs2[2] = {xA, xB}, *dn[2] = {doneA, doneB};       // FCVM_SYM_PAIR=0: the one-vector kernel twice
+        double *ys2[2] = {yA, yB}, *pt[2] = {partA, partB};
+        for (int k = 0; k < 2; k++) {
+            const SymVecs<1> V{{xs2[k]}, {ys2[k]}, {pt[k]}, {dn[k]}};
+            hipLaunchKernelGGL((k_spmv_win_sym<true, WIN_WAVES, 1>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), ws.lds, c->stream,
+                               w.pat.ngroups, w.pat.wmax, ws.pat.xmax, w.gptr, ws.gextra, w.wlist, ws.woff, ws.rowlen, ws.rownode, ws.seg, ws.own,
+                               ws.cols, ws.vals, w.lo_scale, V);
+        }
         return;
     }
     if (w.pat.waves == 4)
@@ -454,7 +465,16 @@ template <int EPI>
 static void launch_spmv_win_lo2(fcvm_ctx *c, const double *xA, const double *xB, const double *rA, const double *rB, double *outA, double *outB,
                                 double c0, double *partA, double *partB, const double *doneA, const double *doneB) {
     const WinDev &w = c->win;
-    if (c->wsym.on && c->wsym.lo_valid) {      // no two-vector kernel on the symmetric form: the one-vector kernel twice (bitwise a single solve's)
+    if (c->wsym.on && c->wsym.lo_valid) {
+        if (c->sym_pair) {      // both vectors in one pass over the 16-bit copy (round 4), per vector bitwise the one-vector kernel's result
+            const WinSymDev &ws = c->wsym;
+            const ProlongFuse pf{c->d_pa, c->d_pb, c->d_fixmask, nullptr};
+            const LoSymVecs<2> V{{xA, xB}, {rA, rB}, {outA, outB}, {partA, partB}, {doneA, doneB}};
+            hipLaunchKernelGGL((k_spmv_win_lo_sym<EPI, WIN_WAVES, 2>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), 2 * ws.lds_lo, c->stream,
+                               w.pat.ngroups, w.pat.wmax, ws.pat.xmax, w.gptr, ws.gextra, w.wlist, ws.woff, ws.rowlen, ws.rownode, ws.seg, ws.own,
+                               ws.lo8, (const WinLoTail *)ws.lo2, w.lo_scale, V, c0, (const float *)c->d_dinv6f, pf);
+            return;
+        }
         launch_spmv_win_lo<EPI>(c, xA, rA, outA, c0, doneA, partA);
         launch_spmv_win_lo<EPI>(c, xB, rB, outB, c0, doneB, partB);
         return;
@@ -587,12 +607,15 @@ static int wsym_upload(fcvm_ctx *c) {
     HCHK(hipStreamSynchronize(s));
     size_t &lds_allowed = lds_allowed_dev[c->device & 63];
     lds_allowed = std::max(lds_allowed, d.lds);
-    if (win_allow_lds(k_spmv_win_sym<true, WIN_WAVES>, lds_allowed) || win_allow_lds(k_spmv_win_sym<false, WIN_WAVES>, lds_allowed)) return 1;
+    if (win_allow_lds(k_spmv_win_sym<true, WIN_WAVES, 1>, lds_allowed) || win_allow_lds(k_spmv_win_sym<false, WIN_WAVES, 1>, lds_allowed) ||
+        win_allow_lds(k_spmv_win_sym<true, WIN_WAVES, 2>, 2 * lds_allowed))      // (two workgroups of the form fit a CU: twice its LDS does)
+        return 1;
     d.lds = lds_allowed;
     // the 16-bit passes: FP32 window and segment results (even count: the 64-bit accumulators follow), accumulators
     d.lds_lo = sizeof(float) * (size_t)((3 * (c->win.pat.wmax + w.xmax) + 1) & ~(int64_t)1) + sizeof(unsigned long long) * 3 * 64 * WIN_WAVES;
-    if (win_allow_lds(k_spmv_win_lo_sym<0, WIN_WAVES>, d.lds) || win_allow_lds(k_spmv_win_lo_sym<1, WIN_WAVES>, d.lds) ||
-        win_allow_lds(k_spmv_win_lo_sym<2, WIN_WAVES>, d.lds))
+    if (win_allow_lds(k_spmv_win_lo_sym<0, WIN_WAVES, 1>, d.lds) || win_allow_lds(k_spmv_win_lo_sym<1, WIN_WAVES, 1>, d.lds) ||
+        win_allow_lds(k_spmv_win_lo_sym<2, WIN_WAVES, 1>, d.lds) || win_allow_lds(k_spmv_win_lo_sym<1, WIN_WAVES, 2>, 2 * d.lds) ||
+        win_allow_lds(k_spmv_win_lo_sym<2, WIN_WAVES, 2>, 2 * d.lds))
         return 1;
     d.pat.cols.clear(); d.pat.cols.shrink_to_fit();
     d.pat.jell.clear(); d.pat.jell.shrink_to_fit();
@@ -916,6 +939,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_MG_ADD_W")) c->mg_add_w = atof(v);
     if (const char *v = getenv("FCVM_WIN_SYM_LO")) c->wsym_lo = atoi(v) != 0;
     if (const char *v = getenv("FCVM_MG_FUSE_PROLONG")) c->mg_fuse_prolong = atoi(v) != 0;
+    if (const char *v = getenv("FCVM_SYM_PAIR")) c->sym_pair = atoi(v) != 0;
     HCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
     c->stream = c->own;
     if (dalloc(&c->d_S, S_COUNT) || dalloc(&c->d_out8, 16)) return 1;

@@ -1056,28 +1056,50 @@ __device__ __forceinline__ unsigned long long fixed62f(float t, int sh) {
     else q = 0ull;
     return b < 0 ? 0ull - q : q;
 }
-// y += K_ij x_j and, where wanted, the row of the column node += K_ij^T x_i in 64-bit fixed point (unit 2^-sh)
-__device__ __forceinline__ void win_fma_sym(const WinSlotS &t, bool active, const double *xs, double o0, double o1, double o2,
-                                            unsigned long long *yacc, int sh, bool tr_on, double &y0, double &y1, double &y2) {
-    const double *xa = xs + 3 * (int)(t.ct & 0xFFFFu);
-    const double a0 = active ? xa[0] : 0.0, a1 = active ? xa[1] : 0.0, a2 = active ? xa[2] : 0.0;
-    y0 += t.v[0] * a0 + t.v[1] * a1 + t.v[2] * a2;
-    y1 += t.v[3] * a0 + t.v[4] * a1 + t.v[5] * a2;
-    y2 += t.v[6] * a0 + t.v[7] * a1 + t.v[8] * a2;
+// y += K_ij x_j and, where wanted, the row of the column node += K_ij^T x_i in 64-bit fixed point (unit 2^-sh), for NRHS vectors
+// whose windows are interleaved per node in LDS ([node][rhs][3]).  Every product is spelled out as a chain of fused multiply-adds:
+// the one- and the two-vector kernels must produce bitwise the same numbers per vector (fcvm_solve2 against fcvm_solve), and the
+// compiler's own contraction of a * b + c * d + e * f differs between instantiations.
+template <int NRHS>
+__device__ __forceinline__ void win_fma_sym(const WinSlotS &t, bool active, const double *xs, const double (&o)[3 * NRHS],
+                                            unsigned long long *yacc, const int (&sh)[NRHS], const bool (&tr_on)[NRHS],
+                                            double (&y)[3 * NRHS]) {
+    const double *xa = xs + 3 * NRHS * (int)(t.ct & 0xFFFFu);
+#pragma unroll
+    for (int r = 0; r < NRHS; r++) {
+        const double a0 = active ? xa[3 * r] : 0.0, a1 = active ? xa[3 * r + 1] : 0.0, a2 = active ? xa[3 * r + 2] : 0.0;
+        y[3 * r] = __builtin_fma(t.v[2], a2, __builtin_fma(t.v[1], a1, __builtin_fma(t.v[0], a0, y[3 * r])));
+        y[3 * r + 1] = __builtin_fma(t.v[5], a2, __builtin_fma(t.v[4], a1, __builtin_fma(t.v[3], a0, y[3 * r + 1])));
+        y[3 * r + 2] = __builtin_fma(t.v[8], a2, __builtin_fma(t.v[7], a1, __builtin_fma(t.v[6], a0, y[3 * r + 2])));
+    }
     const uint32_t ts = t.ct >> 16;
-    if (active && tr_on && ts != 0xFFFFu) {
-        const double t0 = t.v[0] * o0 + t.v[3] * o1 + t.v[6] * o2;
-        const double t1 = t.v[1] * o0 + t.v[4] * o1 + t.v[7] * o2;
-        const double t2 = t.v[2] * o0 + t.v[5] * o1 + t.v[8] * o2;
-        unsigned long long *ya = yacc + 3 * ts;
-        atomicAdd(ya, fixed62(t0, sh));
-        atomicAdd(ya + 1, fixed62(t1, sh));
-        atomicAdd(ya + 2, fixed62(t2, sh));
+    if (active && ts != 0xFFFFu) {
+#pragma unroll
+        for (int r = 0; r < NRHS; r++)
+            if (tr_on[r]) {
+                const double o0 = o[3 * r], o1 = o[3 * r + 1], o2 = o[3 * r + 2];
+                const double t0 = __builtin_fma(t.v[6], o2, __builtin_fma(t.v[3], o1, t.v[0] * o0));
+                const double t1 = __builtin_fma(t.v[7], o2, __builtin_fma(t.v[4], o1, t.v[1] * o0));
+                const double t2 = __builtin_fma(t.v[8], o2, __builtin_fma(t.v[5], o1, t.v[2] * o0));
+                unsigned long long *ya = yacc + 3 * NRHS * ts + 3 * r;
+                atomicAdd(ya, fixed62(t0, sh[r]));
+                atomicAdd(ya + 1, fixed62(t1, sh[r]));
+                atomicAdd(ya + 2, fixed62(t2, sh[r]));
+            }
     }
 }
 
-// LDS: x of the window [3 wmax], partial results of later segments [3 xseg], fixed-point accumulators [3 * 64 * WAVES].
-// kexp[0] = exponent e0 with |K entries| < 2^e0 (k_lo_scale).  The unit of the accumulators is chosen per group from the largest
+// vectors of a launch: NRHS right-hand sides share one pass over the matrix (fcvm_solve2: the GNLY pair, the buckling block)
+template <int NRHS>
+struct SymVecs {
+    const double *x[NRHS];
+    double *y[NRHS];
+    double *partial[NRHS];
+    const double *done[NRHS];
+};
+
+// LDS: x of the window [3 NRHS wmax], partial results of later segments [3 NRHS xseg], fixed-point accumulators [3 NRHS * 64 * WAVES].
+// kexp[0] = exponent e0 with |K entries| < 2^e0 (k_lo_scale).  The unit of the accumulators is chosen per group (and vector) from the largest
 // |x| of its window: a row receives at most SYM_MAX_RECEIVED = 85 transposed products (counted by build_window_sym, which declines
 // the form beyond that; recounted by check_window_sym) of three terms below 2^e0 * xmax each, so the sums stay below
 // 3 * 85 * 2^(e0 + ex) < 2^(e0 + ex + 8) = 2^62 units of 2^(e0 + ex + 8 - 62): no wrap-around of the signed sums; one unit is
@@ -1086,78 +1108,103 @@ __device__ __forceinline__ void win_fma_sym(const WinSlotS &t, bool active, cons
 // kmax: on a mesh graded by a factor s in element size the transposed products of the region of smallest entries carry a relative
 // error of 2^-54 * kmax / K_local = 2^-54 * s (tet10 stiffness entries scale with h): 1e-13 at s = 1000 -- far below the PCG
 // tolerances in use (1e-10 .. 1e-12); a mesh graded beyond 1e4 should run with FCVM_WIN_SYM=0.
+// NRHS = 2 (round 4): both windows and both sets of accumulators in LDS -- one workgroup per CU instead of two, twice the
+// registers per lane -- and every number per vector bitwise what the one-vector kernel gives (same products, same accumulator
+// per block, integer sums).
 #ifndef FCVM_SYM_MINWAVES
 #define FCVM_SYM_MINWAVES 4
 #endif
-#ifndef FCVM_SYM_INFLIGHT
-#define FCVM_SYM_INFLIGHT 3
-#endif
-template <bool DOT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, FCVM_SYM_MINWAVES) void k_spmv_win_sym(int64_t ngroups, int64_t wmax, int64_t xseg, const int64_t *__restrict__ gptr,
+template <bool DOT, int WAVES, int NRHS>
+__global__ __launch_bounds__(64 * WAVES, NRHS == 1 ? FCVM_SYM_MINWAVES : 2) void k_spmv_win_sym(int64_t ngroups, int64_t wmax, int64_t xseg, const int64_t *__restrict__ gptr,
                                                                  const int32_t *__restrict__ gextra, const int32_t *__restrict__ wlist,
                                                                  const int64_t *__restrict__ woff, const uint16_t *__restrict__ rowlen,
                                                                  const int32_t *__restrict__ rownode, const uint32_t *__restrict__ seg,
                                                                  const uint16_t *__restrict__ own, const uint32_t *__restrict__ cols,
                                                                  const double *__restrict__ vals, const double *__restrict__ kexp,
-                                                                 const double *__restrict__ x, double *__restrict__ y,
-                                                                 double *__restrict__ partial, const double *__restrict__ done) {
+                                                                 SymVecs<NRHS> V) {
     extern __shared__ double xs[];
-    __shared__ double sh[WAVES];
+    __shared__ double sh[NRHS * WAVES];
     constexpr int WIN_THREADS = 64 * WAVES;
-    if (done && *done != 0.0) return;
+    {
+        bool all_done = true;
+#pragma unroll
+        for (int r = 0; r < NRHS; r++) all_done = all_done && V.done[r] && *V.done[r] != 0.0;
+        if (all_done) return;
+    }
     const int64_t b = blockIdx.x;
-    const int64_t q = ngroups >> 3, r = ngroups & 7, xcd = b & 7;
-    const int64_t g = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int64_t q = ngroups >> 3, r8 = ngroups & 7, xcd = b & 7;
+    const int64_t g = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wig = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t wave = g * WAVES + wig, row = wave * 64 + lane;
     const int len = rowlen[row];
     const int L = __builtin_amdgcn_readfirstlane(len);
     int64_t off = woff[wave];
-    unsigned long long *yacc = (unsigned long long *)(xs + 3 * (wmax + xseg));
-    double xm = 0.0;
+    unsigned long long *yacc = (unsigned long long *)(xs + 3 * NRHS * (wmax + xseg));
+    double xm[NRHS];
+#pragma unroll
+    for (int r = 0; r < NRHS; r++) xm[r] = 0.0;
     {
         const int64_t w0 = gptr[g];
         const int W = (int)(gptr[g + 1] - w0);
         for (int i = tid; i < W; i += WIN_THREADS) {
             const int32_t nd = wlist[w0 + i];
-            const double *xa = x + 3 * (int64_t)nd;
             const int o = nd & 1;
-            const double2 wv = *(const double2 *)(xa + o);
-            const double sv = xa[o ? 0 : 2];
-            const double v0 = o ? sv : wv.x, v1 = o ? wv.x : wv.y, v2 = o ? wv.y : sv;
-            xs[3 * i] = v0; xs[3 * i + 1] = v1; xs[3 * i + 2] = v2;
-            xm = fmax(xm, fmax(fabs(v0), fmax(fabs(v1), fabs(v2))));
-            if (!(fabs(v0) + fabs(v1) + fabs(v2) < 1e300)) xm = __builtin_huge_val();     // (fmax drops a NaN: carry it as Inf)
-        }
-        for (int i = tid; i < 3 * WIN_THREADS; i += WIN_THREADS) yacc[i] = 0ull;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) xm = fmax(xm, __shfl_xor(xm, o, 64));
-        if (lane == 0) sh[wig] = xm;
+            for (int r = 0; r < NRHS; r++) {
+                const double *xa = V.x[r] + 3 * (int64_t)nd;
+                const double2 wv = *(const double2 *)(xa + o);
+                const double sv = xa[o ? 0 : 2];
+                const double v0 = o ? sv : wv.x, v1 = o ? wv.x : wv.y, v2 = o ? wv.y : sv;
+                double *xd = xs + 3 * NRHS * i + 3 * r;
+                xd[0] = v0; xd[1] = v1; xd[2] = v2;
+                xm[r] = fmax(xm[r], fmax(fabs(v0), fmax(fabs(v1), fabs(v2))));
+                if (!(fabs(v0) + fabs(v1) + fabs(v2) < 1e300)) xm[r] = __builtin_huge_val();     // (fmax drops a NaN: carry it as Inf)
+            }
+        }
+        for (int i = tid; i < 3 * NRHS * WIN_THREADS; i += WIN_THREADS) yacc[i] = 0ull;
+#pragma unroll
+        for (int r = 0; r < NRHS; r++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) xm[r] = fmax(xm[r], __shfl_xor(xm[r], o, 64));
+            if (lane == 0) sh[r * WAVES + wig] = xm[r];
+        }
     }
     __syncthreads();
+    int shf[NRHS];
+    bool tr_on[NRHS], poison[NRHS];
 #pragma unroll
-    for (int i = 0; i < WAVES; i++) xm = fmax(xm, sh[i]);
-    int ex = 0;
-    // x of the window not finite or beyond 1e300: the fixed-point unit cannot be formed.  The transposed products are not
-    // silently left out (that would be the product with an unsymmetric matrix): the group's rows are written as NaN
-    const bool poison = !(xm < 1e300);
-    const bool tr_on = xm > 0.0 && !poison;
-    if (tr_on) (void)frexp(xm, &ex);
-    const int shf = 62 - ((int)kexp[0] + ex + 8);
+    for (int r = 0; r < NRHS; r++) {
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) xm[r] = fmax(xm[r], sh[r * WAVES + i]);
+        int ex = 0;
+        // x of the window not finite or beyond 1e300: the fixed-point unit cannot be formed.  The transposed products are not
+        // silently left out (that would be the product with an unsymmetric matrix): the group's rows are written as NaN
+        poison[r] = !(xm[r] < 1e300);
+        tr_on[r] = xm[r] > 0.0 && !poison[r];
+        if (tr_on[r]) (void)frexp(xm[r], &ex);
+        shf[r] = 62 - ((int)kexp[0] + ex + 8);
+    }
     const int32_t node = rownode[row];
-    double o0 = 0.0, o1 = 0.0, o2 = 0.0;
+    double o[3 * NRHS];
+#pragma unroll
+    for (int k = 0; k < 3 * NRHS; k++) o[k] = 0.0;
     if (node >= 0) {
-        const double *xo = xs + 3 * (int)own[row];
-        o0 = xo[0]; o1 = xo[1]; o2 = xo[2];
+        const double *xo = xs + 3 * NRHS * (int)own[row];
+#pragma unroll
+        for (int k = 0; k < 3 * NRHS; k++) o[k] = xo[k];
     }
     __syncthreads();       // (sh is used again below)
     WinSlotS a, bb, cc;
     int j = 0;
-    double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-    {   // three blocks in flight, two accumulator sets: the transposed products need registers too (four and four spilled)
-        double z0 = 0.0, z1 = 0.0, z2 = 0.0;
-#if FCVM_SYM_INFLIGHT == 3
+    double y[3 * NRHS];
+#pragma unroll
+    for (int k = 0; k < 3 * NRHS; k++) y[k] = 0.0;
+    {   // three blocks in flight, two accumulator sets (block j of a chunk of three goes to set j & 1; the rest to the first:
+        // the same assignment for every NRHS, so the sums per vector do not depend on it)
+        double z[3 * NRHS];
+#pragma unroll
+        for (int k = 0; k < 3 * NRHS; k++) z[k] = 0.0;
         for (; j + 3 <= L; j += 3) {
             const bool p0 = len > j, p1 = len > j + 1, p2 = len > j + 2;
             const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0)), n1 = __popcll(__builtin_amdgcn_ballot_w64(p1)),
@@ -1165,108 +1212,106 @@ __global__ __launch_bounds__(64 * WAVES, FCVM_SYM_MINWAVES) void k_spmv_win_sym(
             win_load_sym(a, cols, vals, off, n0, lane);
             win_load_sym(bb, cols, vals, off + n0, n1, lane);
             win_load_sym(cc, cols, vals, off + n0 + n1, n2, lane);
-            win_fma_sym(a, p0, xs, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
-            win_fma_sym(bb, p1, xs, o0, o1, o2, yacc, shf, tr_on, z0, z1, z2);
-            win_fma_sym(cc, p2, xs, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
+            win_fma_sym<NRHS>(a, p0, xs, o, yacc, shf, tr_on, y);
+            win_fma_sym<NRHS>(bb, p1, xs, o, yacc, shf, tr_on, z);
+            win_fma_sym<NRHS>(cc, p2, xs, o, yacc, shf, tr_on, y);
             off += n0 + n1 + n2;
         }
-#elif FCVM_SYM_INFLIGHT == 4
-        for (; j + 4 <= L; j += 4) {
-            const bool p0 = len > j, p1 = len > j + 1, p2 = len > j + 2, p3 = len > j + 3;
-            const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0)), n1 = __popcll(__builtin_amdgcn_ballot_w64(p1)),
-                      n2 = __popcll(__builtin_amdgcn_ballot_w64(p2)), n3 = __popcll(__builtin_amdgcn_ballot_w64(p3));
-            WinSlotS dd;
-            win_load_sym(a, cols, vals, off, n0, lane);
-            win_load_sym(bb, cols, vals, off + n0, n1, lane);
-            win_load_sym(cc, cols, vals, off + n0 + n1, n2, lane);
-            win_load_sym(dd, cols, vals, off + n0 + n1 + n2, n3, lane);
-            win_fma_sym(a, p0, xs, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
-            win_fma_sym(bb, p1, xs, o0, o1, o2, yacc, shf, tr_on, z0, z1, z2);
-            win_fma_sym(cc, p2, xs, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
-            win_fma_sym(dd, p3, xs, o0, o1, o2, yacc, shf, tr_on, z0, z1, z2);
-            off += n0 + n1 + n2 + n3;
-        }
-#else
-        for (; j + 2 <= L; j += 2) {
-            const bool p0 = len > j, p1 = len > j + 1;
-            const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0)), n1 = __popcll(__builtin_amdgcn_ballot_w64(p1));
-            win_load_sym(a, cols, vals, off, n0, lane);
-            win_load_sym(bb, cols, vals, off + n0, n1, lane);
-            win_fma_sym(a, p0, xs, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
-            win_fma_sym(bb, p1, xs, o0, o1, o2, yacc, shf, tr_on, z0, z1, z2);
-            off += n0 + n1;
-        }
-        (void)cc;
-#endif
-        y0 += z0; y1 += z1; y2 += z2;
+#pragma unroll
+        for (int k = 0; k < 3 * NRHS; k++) y[k] += z[k];
     }
     for (; j < L; j++) {
         const bool p0 = len > j;
         const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0));
         win_load_sym(a, cols, vals, off, n0, lane);
-        win_fma_sym(a, p0, xs, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
+        win_fma_sym<NRHS>(a, p0, xs, o, yacc, shf, tr_on, y);
         off += n0;
     }
     const uint32_t sc = seg[row];
     const int nseg = (int)(sc & 255u);
     __syncthreads();       // every transposed product of the group has arrived
-    if (node >= 0 && nseg > 0 && tr_on) {
-        const unsigned long long *ya = yacc + 3 * (wig * 64 + lane);
-        y0 += ldexp((double)(long long)ya[0], -shf);
-        y1 += ldexp((double)(long long)ya[1], -shf);
-        y2 += ldexp((double)(long long)ya[2], -shf);
+    if (node >= 0 && nseg > 0) {
+        const unsigned long long *ya = yacc + 3 * NRHS * (wig * 64 + lane);
+#pragma unroll
+        for (int r = 0; r < NRHS; r++)
+            if (tr_on[r]) {
+                y[3 * r] += ldexp((double)(long long)ya[3 * r], -shf[r]);
+                y[3 * r + 1] += ldexp((double)(long long)ya[3 * r + 1], -shf[r]);
+                y[3 * r + 2] += ldexp((double)(long long)ya[3 * r + 2], -shf[r]);
+            }
     }
     if (gextra[g] > 0) {
-        double *yp = xs + 3 * wmax + 3 * (int)(sc >> 8);
-        if (node >= 0 && nseg == 0) { yp[0] = y0; yp[1] = y1; yp[2] = y2; }
+        double *yp = xs + 3 * NRHS * wmax + 3 * NRHS * (int)(sc >> 8);
+        if (node >= 0 && nseg == 0) {
+#pragma unroll
+            for (int k = 0; k < 3 * NRHS; k++) yp[k] = y[k];
+        }
         __syncthreads();
-        for (int k = 0; k + 1 < nseg; k++) { y0 += yp[3 * k]; y1 += yp[3 * k + 1]; y2 += yp[3 * k + 2]; }
+        for (int k = 0; k + 1 < nseg; k++) {
+#pragma unroll
+            for (int m = 0; m < 3 * NRHS; m++) y[m] += yp[3 * NRHS * k + m];
+        }
     }
-    if (poison) y0 = y1 = y2 = __builtin_nan("");
+#pragma unroll
+    for (int r = 0; r < NRHS; r++)
+        if (poison[r]) y[3 * r] = y[3 * r + 1] = y[3 * r + 2] = __builtin_nan("");
     if (node >= 0 && nseg > 0) {
-        double *yo = y + 3 * (int64_t)node;
-        yo[0] = y0; yo[1] = y1; yo[2] = y2;
+#pragma unroll
+        for (int r = 0; r < NRHS; r++) {
+            double *yo = V.y[r] + 3 * (int64_t)node;
+            yo[0] = y[3 * r]; yo[1] = y[3 * r + 1]; yo[2] = y[3 * r + 2];
+        }
     }
     if (DOT) {
-        double d = 0.0;
-        if (node >= 0 && nseg > 0) d = y0 * o0 + y1 * o1 + y2 * o2;
-        d = wave_sum(d);
-        if (lane == 0) sh[wig] = d;
+        double d[NRHS];
+#pragma unroll
+        for (int r = 0; r < NRHS; r++) {
+            d[r] = 0.0;
+            if (node >= 0 && nseg > 0) d[r] = __builtin_fma(y[3 * r + 2], o[3 * r + 2], __builtin_fma(y[3 * r + 1], o[3 * r + 1], y[3 * r] * o[3 * r]));
+            d[r] = wave_sum(d[r]);
+            if (lane == 0) sh[r * WAVES + wig] = d[r];
+        }
         __syncthreads();
         if (tid == 0) {
-            double t = 0.0;
 #pragma unroll
-            for (int i = 0; i < WAVES; i++) t += sh[i];
-            partial[g] = t;
+            for (int r = 0; r < NRHS; r++) {
+                double t = 0.0;
+#pragma unroll
+                for (int i = 0; i < WAVES; i++) t += sh[r * WAVES + i];
+                V.partial[r][g] = t;
+            }
         }
     }
 }
 
-// direct product as win_fma_lo; K~_ij^T x_i of a stored in-group block goes to row j's accumulator in 64-bit fixed point
-__device__ __forceinline__ void win_fma_lo_sym(const WinSlotLo &t, bool active, const float *xs, float o0, float o1, float o2,
-                                               unsigned long long *yacc, int sh, bool tr_on, float &y0, float &y1, float &y2) {
-    const float *xa = xs + 3 * (int)t.t.col;
+// direct product as win_fma_lo; K~_ij^T x_i of a stored in-group block goes to row j's accumulator in 64-bit fixed point.
+// NRHS vectors: windows interleaved per node ([node][rhs][3] floats), the block's nine values converted once.
+template <int NRHS>
+__device__ __forceinline__ void win_fma_lo_sym(const WinSlotLo &t, bool active, const float *xs, const float (&o)[3 * NRHS],
+                                               unsigned long long *yacc, const int (&sh)[NRHS], const bool (&tr_on)[NRHS], float (&y)[3 * NRHS]) {
+    const float *xa = xs + 3 * NRHS * (int)t.t.col;
     const int e = (int)t.t.e;
     const float sc = active ? __builtin_bit_cast(float, (127 + (e < -126 ? -126 : e)) << 23) : 0.0f;
-    const float a0 = xa[0] * sc, a1 = xa[1] * sc, a2 = xa[2] * sc;
     const float q0 = (float)(int)t.a[0], q1 = (float)(int)t.a[1], q2 = (float)(int)t.a[2], q3 = (float)(int)t.a[3], q4 = (float)(int)t.a[4],
                 q5 = (float)(int)t.a[5], q6 = (float)(int)t.a[6], q7 = (float)(int)t.a[7], q8 = (float)(int)t.t.q8;
-    y0 += win_dot3(q0, q1, q2, a0, a1, a2);
-    y1 += win_dot3(q3, q4, q5, a0, a1, a2);
-    y2 += win_dot3(q6, q7, q8, a0, a1, a2);
+#pragma unroll
+    for (int r = 0; r < NRHS; r++) {
+        const float a0 = xa[3 * r] * sc, a1 = xa[3 * r + 1] * sc, a2 = xa[3 * r + 2] * sc;
+        y[3 * r] += win_dot3(q0, q1, q2, a0, a1, a2);
+        y[3 * r + 1] += win_dot3(q3, q4, q5, a0, a1, a2);
+        y[3 * r + 2] += win_dot3(q6, q7, q8, a0, a1, a2);
+    }
     const unsigned ts = (unsigned)__builtin_bit_cast(WinLoTailS, t.t).ts;
-    if (active && tr_on && ts != 0xFFFFu) {
-        const float b0 = o0 * sc, b1 = o1 * sc, b2 = o2 * sc;
-        unsigned long long *ya = yacc + 3 * ts;
-#ifdef FCVM_AB_LO_F64CONV      // (A/B build: the FP32 product widened and converted as a double)
-        atomicAdd(ya, fixed62((double)win_dot3(q0, q3, q6, b0, b1, b2), sh));
-        atomicAdd(ya + 1, fixed62((double)win_dot3(q1, q4, q7, b0, b1, b2), sh));
-        atomicAdd(ya + 2, fixed62((double)win_dot3(q2, q5, q8, b0, b1, b2), sh));
-#else
-        atomicAdd(ya, fixed62f(win_dot3(q0, q3, q6, b0, b1, b2), sh));
-        atomicAdd(ya + 1, fixed62f(win_dot3(q1, q4, q7, b0, b1, b2), sh));
-        atomicAdd(ya + 2, fixed62f(win_dot3(q2, q5, q8, b0, b1, b2), sh));
-#endif
+    if (active && ts != 0xFFFFu) {
+#pragma unroll
+        for (int r = 0; r < NRHS; r++)
+            if (tr_on[r]) {
+                const float b0 = o[3 * r] * sc, b1 = o[3 * r + 1] * sc, b2 = o[3 * r + 2] * sc;
+                unsigned long long *ya = yacc + 3 * NRHS * ts + 3 * r;
+                atomicAdd(ya, fixed62f(win_dot3(q0, q3, q6, b0, b1, b2), sh[r]));
+                atomicAdd(ya + 1, fixed62f(win_dot3(q1, q4, q7, b0, b1, b2), sh[r]));
+                atomicAdd(ya + 2, fixed62f(win_dot3(q2, q5, q8, b0, b1, b2), sh[r]));
+            }
     }
 }
 // the prolongation of the coarse correction fused into the staging of the post-smoothing pass: x := x + P e1 (k_prolong_add's
@@ -1286,26 +1331,69 @@ __device__ __forceinline__ void prolong_fuse_add(const ProlongFuse &pf, int32_t 
     v1 += (fm & 2) ? 0.0 : 0.5 * (ea[1] + eb[1]);
     v2 += (fm & 4) ? 0.0 : 0.5 * (ea[2] + eb[2]);
 }
+// vectors of a 16-bit pass: x (smoothed vector), r (right-hand side), out, partials of r.out and r.r (EPI 2), done flag
+template <int NRHS>
+struct LoSymVecs {
+    const double *x[NRHS];
+    const double *r[NRHS];
+    double *out[NRHS];
+    double *partial[NRHS];
+    const double *done[NRHS];
+};
+// one vector's share of the epilogue (one function for every NRHS: the same arithmetic in the same order)
+template <int EPI>
+__device__ __forceinline__ void win_lo_sym_epilogue(int64_t node, double is, double yd0, double yd1, double yd2, const double *__restrict__ x,
+                                                    const double *__restrict__ r, double *__restrict__ out, double c0,
+                                                    const float *__restrict__ dinv6, const ProlongFuse &pf, bool fuse, double &rz, double &rr) {
+    const int64_t o = 3 * node;
+    if (EPI == 0) {     // plain product out = K~ x (the host-driven cycle of the multi-GPU layer exchanges it before using it)
+        out[o] = is * yd0; out[o + 1] = is * yd1; out[o + 2] = is * yd2;
+        return;
+    }
+    const double r0 = r[o], r1 = r[o + 1], r2 = r[o + 2];
+    const double t0 = r0 - is * yd0, t1 = r1 - is * yd1, t2 = r2 - is * yd2;
+    if (EPI == 1) {
+        out[o] = t0; out[o + 1] = t1; out[o + 2] = t2;
+    } else {
+        const float2 *d2 = (const float2 *)(dinv6 + 6 * node);
+        const float2 u0 = d2[0], u1 = d2[1], u2 = d2[2];   // xx xy | xz yy | yz zz
+        const double *xo = x + o;      // the FP64 x of the row's own node (the window in LDS holds FP32 roundings)
+        double x0 = xo[0], x1 = xo[1], x2 = xo[2];
+        if (fuse) prolong_fuse_add(pf, (int32_t)node, x0, x1, x2);
+        const double z0 = x0 + c0 * ((double)u0.x * t0 + (double)u0.y * t1 + (double)u1.x * t2);
+        const double z1 = x1 + c0 * ((double)u0.y * t0 + (double)u1.y * t1 + (double)u2.x * t2);
+        const double z2 = x2 + c0 * ((double)u1.x * t0 + (double)u2.x * t1 + (double)u2.y * t2);
+        out[o] = z0; out[o + 1] = z1; out[o + 2] = z2;
+        rz = r0 * z0 + r1 * z1 + r2 * z2;
+        rr = r0 * r0 + r1 * r1 + r2 * r2;
+    }
+}
 #ifndef FCVM_LOSYM_MINWAVES
 #define FCVM_LOSYM_MINWAVES 8      // four workgroups per CU (31 KB of LDS, 58 registers) with two blocks in flight: 177 / 150 us; three with three: 181 / 152; two with six: 192 / 157
 #endif
 #ifndef FCVM_LOSYM_INFLIGHT
 #define FCVM_LOSYM_INFLIGHT 2
 #endif
-template <int EPI, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, FCVM_LOSYM_MINWAVES) void k_spmv_win_lo_sym(int64_t ngroups, int64_t wmax, int64_t xseg, const int64_t *__restrict__ gptr,
+// NRHS = 2 (round 4): both FP32 windows and both sets of accumulators in LDS (two workgroups per CU), per vector bitwise the
+// one-vector kernel's numbers.  The prolongation fused into the staging (pf) exists for one vector only.
+template <int EPI, int WAVES, int NRHS>
+__global__ __launch_bounds__(64 * WAVES, NRHS == 1 ? FCVM_LOSYM_MINWAVES : 4) void k_spmv_win_lo_sym(int64_t ngroups, int64_t wmax, int64_t xseg, const int64_t *__restrict__ gptr,
                                                                 const int32_t *__restrict__ gextra, const int32_t *__restrict__ wlist,
                                                                 const int64_t *__restrict__ woff, const uint16_t *__restrict__ rowlen,
                                                                 const int32_t *__restrict__ rownode, const uint32_t *__restrict__ seg, const uint16_t *__restrict__ own,
                                                                 const short8 *__restrict__ lo8, const WinLoTail *__restrict__ lo2,
-                                                                const double *__restrict__ lo_scale, const double *__restrict__ x,
-                                                                const double *__restrict__ r, double *__restrict__ out, double c0,
-                                                                const float *__restrict__ dinv6, double *__restrict__ partial,
-                                                                const double *__restrict__ done, ProlongFuse pf) {
-    extern __shared__ float xsf[];      // x of the window in FP32 (3 per window node), then the partial results of later segments
-    __shared__ double sh[2 * WAVES];
+                                                                const double *__restrict__ lo_scale, LoSymVecs<NRHS> V, double c0,
+                                                                const float *__restrict__ dinv6, ProlongFuse pf) {
+    extern __shared__ float xsf[];      // x of the window in FP32 (3 NRHS per window node), then the partial results of later segments
+    __shared__ double sh[2 * NRHS * WAVES];
     constexpr int WIN_THREADS = 64 * WAVES;
-    if (done && *done != 0.0) return;
+    {
+        bool all_done = true;
+#pragma unroll
+        for (int r = 0; r < NRHS; r++) all_done = all_done && V.done[r] && *V.done[r] != 0.0;
+        if (all_done) return;
+    }
+    const bool fuse = NRHS == 1 && EPI == 2 && pf.e1 != nullptr;
     const int64_t b = blockIdx.x;
     const int64_t q = ngroups >> 3, rr8 = ngroups & 7, xcd = b & 7;
     const int64_t g = (xcd < rr8 ? xcd * (q + 1) : rr8 * (q + 1) + (xcd - rr8) * q) + (b >> 3);
@@ -1316,50 +1404,72 @@ __global__ __launch_bounds__(64 * WAVES, FCVM_LOSYM_MINWAVES) void k_spmv_win_lo
     const int L = __builtin_amdgcn_readfirstlane(len);
     int64_t off = woff[wave];
     int j = 0;
-    unsigned long long *yacc = (unsigned long long *)(xsf + ((3 * (wmax + xseg) + 1) & ~(int64_t)1));
-    __shared__ float shx[WAVES];
-    float xm = 0.f;
+    unsigned long long *yacc = (unsigned long long *)(xsf + ((3 * NRHS * (wmax + xseg) + 1) & ~(int64_t)1));
+    __shared__ float shx[NRHS * WAVES];
+    float xm[NRHS];
+#pragma unroll
+    for (int r = 0; r < NRHS; r++) xm[r] = 0.f;
     {
         const int64_t w0 = gptr[g];
         const int W = (int)(gptr[g + 1] - w0);
         for (int i = tid; i < W; i += WIN_THREADS) {
             const int32_t nd = wlist[w0 + i];
-            const double *xa = x + 3 * (int64_t)nd;
             const int o = nd & 1;
-            const double2 wv = *(const double2 *)(xa + o);
-            const double sv = xa[o ? 0 : 2];
-            double d0 = o ? sv : wv.x, d1 = o ? wv.x : wv.y, d2 = o ? wv.y : sv;
-            if (EPI == 2 && pf.e1) prolong_fuse_add(pf, nd, d0, d1, d2);
-            const float v0 = (float)d0, v1 = (float)d1, v2 = (float)d2;
-            xsf[3 * i] = v0; xsf[3 * i + 1] = v1; xsf[3 * i + 2] = v2;
-            xm = fmaxf(xm, fmaxf(fabsf(v0), fmaxf(fabsf(v1), fabsf(v2))));
-            if (!(fabsf(v0) + fabsf(v1) + fabsf(v2) < 3e38f)) xm = __builtin_huge_valf();
-        }
-        for (int i = tid; i < 3 * WIN_THREADS; i += WIN_THREADS) yacc[i] = 0ull;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) xm = fmaxf(xm, __shfl_xor(xm, o, 64));
-        if (lane == 0) shx[wig] = xm;
+            for (int r = 0; r < NRHS; r++) {
+                const double *xa = V.x[r] + 3 * (int64_t)nd;
+                const double2 wv = *(const double2 *)(xa + o);
+                const double sv = xa[o ? 0 : 2];
+                double d0 = o ? sv : wv.x, d1 = o ? wv.x : wv.y, d2 = o ? wv.y : sv;
+                if (fuse) prolong_fuse_add(pf, nd, d0, d1, d2);
+                const float v0 = (float)d0, v1 = (float)d1, v2 = (float)d2;
+                float *xd = xsf + 3 * NRHS * i + 3 * r;
+                xd[0] = v0; xd[1] = v1; xd[2] = v2;
+                xm[r] = fmaxf(xm[r], fmaxf(fabsf(v0), fmaxf(fabsf(v1), fabsf(v2))));
+                if (!(fabsf(v0) + fabsf(v1) + fabsf(v2) < 3e38f)) xm[r] = __builtin_huge_valf();
+            }
+        }
+        for (int i = tid; i < 3 * NRHS * WIN_THREADS; i += WIN_THREADS) yacc[i] = 0ull;
+#pragma unroll
+        for (int r = 0; r < NRHS; r++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) xm[r] = fmaxf(xm[r], __shfl_xor(xm[r], o, 64));
+            if (lane == 0) shx[r * WAVES + wig] = xm[r];
+        }
     }
     __syncthreads();
+    int shf[NRHS];
+    bool tr_on[NRHS], poison[NRHS];
 #pragma unroll
-    for (int i = 0; i < WAVES; i++) xm = fmaxf(xm, shx[i]);
-    int ex = 0;
-    const bool poison = !(xm < 3e38f);          // as in k_spmv_win_sym: NaN out instead of a product without its transposed half
-    const bool tr_on = xm > 0.f && !poison;
-    if (tr_on) (void)frexpf(xm, &ex);
-    // products are in units of 2^(e0 - 15): |q 2^e| < 2^15, three terms, at most 64 transposed products per row (see k_spmv_win_sym)
-    const int shf = 62 - (15 + ex + 8);
-    const int32_t node = rownode[row];
-    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-    if (node >= 0) {
-        const float *xo = xsf + 3 * (int)own[row];
-        o0 = xo[0]; o1 = xo[1]; o2 = xo[2];
+    for (int r = 0; r < NRHS; r++) {
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) xm[r] = fmaxf(xm[r], shx[r * WAVES + i]);
+        int ex = 0;
+        poison[r] = !(xm[r] < 3e38f);          // as in k_spmv_win_sym: NaN out instead of a product without its transposed half
+        tr_on[r] = xm[r] > 0.f && !poison[r];
+        if (tr_on[r]) (void)frexpf(xm[r], &ex);
+        // products are in units of 2^(e0 - 15): |q 2^e| < 2^15, three terms, at most SYM_MAX_RECEIVED transposed products per row (see k_spmv_win_sym)
+        shf[r] = 62 - (15 + ex + 8);
     }
-    float y0 = 0.f, y1 = 0.f, y2 = 0.f;
+    const int32_t node = rownode[row];
+    float o[3 * NRHS];
+#pragma unroll
+    for (int k = 0; k < 3 * NRHS; k++) o[k] = 0.f;
+    if (node >= 0) {
+        const float *xo = xsf + 3 * NRHS * (int)own[row];
+#pragma unroll
+        for (int k = 0; k < 3 * NRHS; k++) o[k] = xo[k];
+    }
+    float y[3 * NRHS];
+#pragma unroll
+    for (int k = 0; k < 3 * NRHS; k++) y[k] = 0.f;
     {   // NB blocks in flight (24 bytes each)
         constexpr int NB = FCVM_LOSYM_INFLIGHT;      // (eight in flight spill beside the transposed products)
+        static_assert(NB >= 1 && NB <= 4, "accumulator sets: block k of a chunk goes to set k");
         WinSlotLo s[NB];
-        float z0 = 0.f, z1 = 0.f, z2 = 0.f, u0 = 0.f, u1 = 0.f, u2 = 0.f, w0 = 0.f, w1 = 0.f, w2 = 0.f;
+        float z[3 * NRHS], u[3 * NRHS], w[3 * NRHS];
+#pragma unroll
+        for (int k = 0; k < 3 * NRHS; k++) z[k] = u[k] = w[k] = 0.f;
         for (; j + NB <= L; j += NB) {
             bool p[NB];
             int n[NB];
@@ -1368,111 +1478,86 @@ __global__ __launch_bounds__(64 * WAVES, FCVM_LOSYM_MINWAVES) void k_spmv_win_lo
                 p[k] = len > j + k;
                 n[k] = __popcll(__builtin_amdgcn_ballot_w64(p[k]));
             }
-            int64_t o = off;
+            int64_t o2 = off;
 #pragma unroll
             for (int k = 0; k < NB; k++) {
-                win_load_lo(s[k], lo8, lo2, o, n[k], lane);
-                o += n[k];
+                win_load_lo(s[k], lo8, lo2, o2, n[k], lane);
+                o2 += n[k];
             }
 #pragma unroll
             for (int k = 0; k < NB; k++) {
-                if ((k & 3) == 0) win_fma_lo_sym(s[k], p[k], xsf, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
-                else if ((k & 3) == 1) win_fma_lo_sym(s[k], p[k], xsf, o0, o1, o2, yacc, shf, tr_on, z0, z1, z2);
-                else if ((k & 3) == 2) win_fma_lo_sym(s[k], p[k], xsf, o0, o1, o2, yacc, shf, tr_on, u0, u1, u2);
-                else win_fma_lo_sym(s[k], p[k], xsf, o0, o1, o2, yacc, shf, tr_on, w0, w1, w2);
+                if (k == 0) win_fma_lo_sym<NRHS>(s[k], p[k], xsf, o, yacc, shf, tr_on, y);
+                else if (k == 1) win_fma_lo_sym<NRHS>(s[k], p[k], xsf, o, yacc, shf, tr_on, z);
+                else if (k == 2) win_fma_lo_sym<NRHS>(s[k], p[k], xsf, o, yacc, shf, tr_on, u);
+                else win_fma_lo_sym<NRHS>(s[k], p[k], xsf, o, yacc, shf, tr_on, w);
             }
-            off = o;
+            off = o2;
         }
-        // the rest: block j always goes to accumulator set j & 3 (the chunk length is a multiple of 4), so the summation order
-        // does not depend on the number of blocks in flight -- k_spmv_win_lo2 keeps the same order: bitwise the same result
-#if FCVM_LOSYM_INFLIGHT >= 4
-        for (; j + 4 <= L; j += 4) {
-            const bool p0 = len > j, p1 = len > j + 1, p2 = len > j + 2, p3 = len > j + 3;
-            const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0)), n1 = __popcll(__builtin_amdgcn_ballot_w64(p1)),
-                      n2 = __popcll(__builtin_amdgcn_ballot_w64(p2)), n3 = __popcll(__builtin_amdgcn_ballot_w64(p3));
-            win_load_lo(s[0], lo8, lo2, off, n0, lane);
-            win_load_lo(s[1], lo8, lo2, off + n0, n1, lane);
-            win_load_lo(s[2], lo8, lo2, off + n0 + n1, n2, lane);
-            win_load_lo(s[3], lo8, lo2, off + n0 + n1 + n2, n3, lane);
-            win_fma_lo_sym(s[0], p0, xsf, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
-            win_fma_lo_sym(s[1], p1, xsf, o0, o1, o2, yacc, shf, tr_on, z0, z1, z2);
-            win_fma_lo_sym(s[2], p2, xsf, o0, o1, o2, yacc, shf, tr_on, u0, u1, u2);
-            win_fma_lo_sym(s[3], p3, xsf, o0, o1, o2, yacc, shf, tr_on, w0, w1, w2);
-            off += n0 + n1 + n2 + n3;
-        }
-#endif
+        // the rest: block j goes to accumulator set j & 3 -- a fixed function of j and the wave's longest row, the same for every
+        // NRHS, so the sums per vector do not depend on the number of vectors
         for (; j < L; j++) {
             const bool p0 = len > j;
             const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0));
             win_load_lo(s[0], lo8, lo2, off, n0, lane);
             const int a = j & 3;
-            if (a == 0) win_fma_lo_sym(s[0], p0, xsf, o0, o1, o2, yacc, shf, tr_on, y0, y1, y2);
-            else if (a == 1) win_fma_lo_sym(s[0], p0, xsf, o0, o1, o2, yacc, shf, tr_on, z0, z1, z2);
-            else if (a == 2) win_fma_lo_sym(s[0], p0, xsf, o0, o1, o2, yacc, shf, tr_on, u0, u1, u2);
-            else win_fma_lo_sym(s[0], p0, xsf, o0, o1, o2, yacc, shf, tr_on, w0, w1, w2);
+            if (a == 0) win_fma_lo_sym<NRHS>(s[0], p0, xsf, o, yacc, shf, tr_on, y);
+            else if (a == 1) win_fma_lo_sym<NRHS>(s[0], p0, xsf, o, yacc, shf, tr_on, z);
+            else if (a == 2) win_fma_lo_sym<NRHS>(s[0], p0, xsf, o, yacc, shf, tr_on, u);
+            else win_fma_lo_sym<NRHS>(s[0], p0, xsf, o, yacc, shf, tr_on, w);
             off += n0;
         }
-        y0 += z0 + u0 + w0; y1 += z1 + u1 + w1; y2 += z2 + u2 + w2;
+#pragma unroll
+        for (int k = 0; k < 3 * NRHS; k++) y[k] += z[k] + u[k] + w[k];
     }
     const uint32_t sc = seg[row];
     const int nseg = (int)(sc & 255u);
     __syncthreads();       // every transposed product of the group has arrived
     if (gextra[g] > 0) {
-        float *yp = xsf + 3 * wmax + 3 * (int)(sc >> 8);
-        if (node >= 0 && nseg == 0) { yp[0] = y0; yp[1] = y1; yp[2] = y2; }
-        __syncthreads();
-        for (int k = 0; k + 1 < nseg; k++) { y0 += yp[3 * k]; y1 += yp[3 * k + 1]; y2 += yp[3 * k + 2]; }
-    }
-    // the row's sum in FP64: its own FP32 sums + the fixed-point sum of the transposed products
-    double yd0 = (double)y0, yd1 = (double)y1, yd2 = (double)y2;
-    if (poison) yd0 = yd1 = yd2 = __builtin_nan("");
-    if (node >= 0 && nseg > 0 && tr_on) {
-        const unsigned long long *ya = yacc + 3 * (wig * 64 + lane);
-        yd0 += ldexp((double)(long long)ya[0], -shf);
-        yd1 += ldexp((double)(long long)ya[1], -shf);
-        yd2 += ldexp((double)(long long)ya[2], -shf);
-    }
-    double rz = 0.0, rr = 0.0;
-    if (EPI == 0) {     // plain product out = K~ x (the host-driven cycle of the multi-GPU layer exchanges it before using it)
-        if (node >= 0 && nseg > 0) {
-            const double is = lo_scale[1];
-            const int64_t o = 3 * (int64_t)node;
-            out[o] = is * yd0; out[o + 1] = is * yd1; out[o + 2] = is * yd2;
+        float *yp = xsf + 3 * NRHS * wmax + 3 * NRHS * (int)(sc >> 8);
+        if (node >= 0 && nseg == 0) {
+#pragma unroll
+            for (int k = 0; k < 3 * NRHS; k++) yp[k] = y[k];
         }
-        return;
+        __syncthreads();
+        for (int k = 0; k + 1 < nseg; k++) {
+#pragma unroll
+            for (int m = 0; m < 3 * NRHS; m++) y[m] += yp[3 * NRHS * k + m];
+        }
     }
-    if (node >= 0 && nseg > 0) {
-        const double is = lo_scale[1];
-        const int64_t o = 3 * (int64_t)node;
-        const double r0 = r[o], r1 = r[o + 1], r2 = r[o + 2];
-        const double t0 = r0 - is * yd0, t1 = r1 - is * yd1, t2 = r2 - is * yd2;
-        if (EPI == 1) {
-            out[o] = t0; out[o + 1] = t1; out[o + 2] = t2;
-        } else {
-            const float2 *d2 = (const float2 *)(dinv6 + 6 * (int64_t)node);
-            const float2 u0 = d2[0], u1 = d2[1], u2 = d2[2];   // xx xy | xz yy | yz zz
-            const double *xo = x + o;      // the FP64 x of the row's own node (the window in LDS holds FP32 roundings)
-            double x0 = xo[0], x1 = xo[1], x2 = xo[2];
-            if (pf.e1) prolong_fuse_add(pf, node, x0, x1, x2);
-            const double z0 = x0 + c0 * ((double)u0.x * t0 + (double)u0.y * t1 + (double)u1.x * t2);
-            const double z1 = x1 + c0 * ((double)u0.y * t0 + (double)u1.y * t1 + (double)u2.x * t2);
-            const double z2 = x2 + c0 * ((double)u1.x * t0 + (double)u2.x * t1 + (double)u2.y * t2);
-            out[o] = z0; out[o + 1] = z1; out[o + 2] = z2;
-            rz = r0 * z0 + r1 * z1 + r2 * z2;
-            rr = r0 * r0 + r1 * r1 + r2 * r2;
+    double rz[NRHS], rr[NRHS];
+#pragma unroll
+    for (int r = 0; r < NRHS; r++) {
+        rz[r] = rr[r] = 0.0;
+        // the row's sum in FP64: its own FP32 sums + the fixed-point sum of the transposed products
+        double yd0 = (double)y[3 * r], yd1 = (double)y[3 * r + 1], yd2 = (double)y[3 * r + 2];
+        if (poison[r]) yd0 = yd1 = yd2 = __builtin_nan("");
+        if (node >= 0 && nseg > 0) {
+            if (tr_on[r]) {
+                const unsigned long long *ya = yacc + 3 * NRHS * (wig * 64 + lane) + 3 * r;
+                yd0 += ldexp((double)(long long)ya[0], -shf[r]);
+                yd1 += ldexp((double)(long long)ya[1], -shf[r]);
+                yd2 += ldexp((double)(long long)ya[2], -shf[r]);
+            }
+            win_lo_sym_epilogue<EPI>((int64_t)node, lo_scale[1], yd0, yd1, yd2, V.x[r], V.r[r], V.out[r], c0, dinv6, pf, fuse, rz[r], rr[r]);
         }
     }
     if (EPI == 2) {
-        rz = wave_sum(rz);
-        rr = wave_sum(rr);
-        if (lane == 0) { sh[wig] = rz; sh[WAVES + wig] = rr; }
+#pragma unroll
+        for (int r = 0; r < NRHS; r++) {
+            rz[r] = wave_sum(rz[r]);
+            rr[r] = wave_sum(rr[r]);
+            if (lane == 0) { sh[2 * r * WAVES + wig] = rz[r]; sh[(2 * r + 1) * WAVES + wig] = rr[r]; }
+        }
         __syncthreads();
         if (tid == 0) {
-            double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-            for (int i = 0; i < WAVES; i++) { a0 += sh[i]; a1 += sh[WAVES + i]; }
-            partial[g] = a0;
-            partial[ngroups + g] = a1;
+            for (int r = 0; r < NRHS; r++) {
+                double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+                for (int i = 0; i < WAVES; i++) { a0 += sh[2 * r * WAVES + i]; a1 += sh[(2 * r + 1) * WAVES + i]; }
+                V.partial[r][g] = a0;
+                V.partial[r][ngroups + g] = a1;
+            }
         }
     }
 }
