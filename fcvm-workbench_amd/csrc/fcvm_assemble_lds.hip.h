@@ -18,6 +18,7 @@
 // What still goes through the scattered-access path are these inputs: 18 instead of 240 instructions per visit.
 #pragma once
 #include "fcvm_kernels.hip.h"
+#include "fcvm_spmv_win.hip.h"
 
 namespace fcvm {
 
@@ -66,7 +67,33 @@ __device__ __forceinline__ void load3(const double *__restrict__ base, int node,
     x = o ? s1 : w.x; y = o ? w.x : w.y; z = o ? w.y : s1;
 }
 
-template <bool TANGENT>
+// SYM (round 4): the work item is 16 consecutive lanes of a wave of the SYMMETRIC window form (WinSym, fcvm_pattern.h) instead of
+// a quarter slice of the sliced-ELL layout, the row image in LDS holds the row's KEPT blocks only (0.70 x the blocks: less LDS
+// per item, more items per CU), and the finished rows leave LDS straight into the SpMV's storage -- FP64 values of the symmetric
+// form, its 16-bit block-scaled copy and the diagonal blocks for the preconditioner -- so neither the sliced-ELL array nor the
+// copy kernel (k_repack_sym: 3.3 ms per assembly at 1 M elements) is involved.  A lane that holds a later segment of a cut row
+// idles here: the row is assembled once, by the item of its first segment, which writes every segment (consecutive first
+// segments have consecutive later segments -- the lanes of a group are sorted by length with ties in row order -- so those
+// stores coalesce as well).  All element blocks are still integrated (the boundary-condition terms need the blocks that are
+// not stored too); only the accumulation into LDS is skipped for a block whose transpose is the stored one.
+struct AsmSym {
+    const int32_t *rownode;     // [nwaves*64] node of a lane
+    const uint32_t *seg;        // [nwaves*64] low byte > 0: first segment (the lane that assembles the row)
+    const uint8_t *emap;        // [ne*100] kept number of element block (a, b) in the row of node a, 0xFF: not stored
+    const uint16_t *rowlen, *jfirst, *rowoff;
+    const int32_t *nextseg;
+    const int64_t *woff;
+    const uint32_t *cols;       // [nblocks] entry: window position | target lane << 16 (copied into the 16-bit tail)
+    const uint8_t *diagk;       // [nn]
+    double *vals;               // FP64 values of the symmetric form
+    short8 *lo8;                // 16-bit copy (null: not wanted)
+    WinLoTailS *lo2;
+    double *dblk;               // [nn*9] diagonal blocks
+    int maxl1;                  // row stride of rowoff (longest segment + 1)
+    int len;                    // kept blocks of the longest row of the launch's length class
+};
+
+template <bool TANGENT, bool SYM = false>
 __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__ items, const int64_t *__restrict__ sptr,
                                                      const int32_t *__restrict__ rownode, const int64_t *__restrict__ nptr,
                                                      const int32_t *__restrict__ nel, const int32_t *__restrict__ el,
@@ -75,7 +102,8 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                                                      const uint32_t *__restrict__ emap, const double *__restrict__ sig,
                                                      const uint8_t *__restrict__ pgp, MatConst mc, double gx, double gy, double gz,
                                                      double *__restrict__ vals, double *__restrict__ glv, double *__restrict__ modf,
-                                                     double *__restrict__ xgp, double *__restrict__ volume, int penalty_bc) {
+                                                     double *__restrict__ xgp, double *__restrict__ volume, int penalty_bc,
+                                                     AsmSym sy = AsmSym{}) {
     extern __shared__ double lds[];
     double *tab = lds, *jac = lds + ASM_TAB, *rowbuf = lds + ASM_TAB + ASM_JAC;
     // XCD-aware remap (as k_spmv): the workgroups of one XCD take a contiguous range of work items, whose rows share
@@ -86,7 +114,8 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
     const int64_t s = item >> 2;
     const int qd = item & 3;
     const int lane = threadIdx.x, rowl = lane >> 2, h = lane & 3;
-    const int64_t jb = sptr[s], len = sptr[s + 1] - jb;   // blocks of the slice's longest row = half chunks of the slice
+    // SYM: item = wave * 4 + quarter of the symmetric form; len = the launch's length class (kept blocks)
+    const int64_t jb = SYM ? 0 : sptr[s], len = SYM ? (int64_t)sy.len : sptr[s + 1] - jb;   // blocks of the slice's longest row = half chunks of the slice
     const int64_t S = asm_row_stride(len);
     for (int64_t i = lane; i < ASM_ROWS * S; i += 64) rowbuf[i] = 0.0;
     if (lane < 40) {   // shape-function tables (fcVM.py:365-424 at the Gauss points of fcVM.py:587-596)
@@ -98,7 +127,7 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
         tab[120 + lane] = shp_k(k, xi, et, ze);
     }
     const int64_t slot = s * 64 + qd * ASM_ROWS + rowl;
-    const int node = rownode[slot];
+    const int node = SYM ? ((sy.seg[slot] & 255u) ? sy.rownode[slot] : -1) : rownode[slot];
     const int64_t q0 = node >= 0 ? nptr[node] : 0;
     const int nvis = node >= 0 ? (int)(nptr[node + 1] - q0) : 0;
     int maxvis = nvis;
@@ -134,7 +163,7 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                 G.c[t][0] += u0; G.c[t][1] += u1; G.c[t][2] += u2;
             }
             G.ndb[t] = nd[t];
-            G.em[t] = emap[e * 100 + a * 10 + min(h + 4 * t, 9)];
+            G.em[t] = SYM ? (uint32_t)sy.emap[e * 100 + a * 10 + min(h + 4 * t, 9)] : emap[e * 100 + a * 10 + min(h + 4 * t, 9)];
             G.fb[t] = fixmask[nd[t]];
         }
     };
@@ -285,8 +314,9 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                 }
                 // boundary conditions folded in (fcVM.py:773-800) and accumulation into the row's LDS image
                 const uint32_t em = G0.em[t];
-                const int64_t jj = (int64_t)(em >> 2) - jb + (int64_t)((em >> 1) & 1u);   // block index inside the row
-                double *dst = myrow + jj * 9;
+                const int64_t jj = SYM ? (int64_t)em : (int64_t)(em >> 2) - jb + (int64_t)((em >> 1) & 1u);   // block index inside the row
+                const bool kept = !SYM || em != 0xFFu;     // SYM: the transpose of this block is the stored one -- nothing to add here
+                double *dst = myrow + (kept ? jj : 0) * 9;
                 const int fb = G0.fb[t];
                 const bool diag = (a == b);
                 if (penalty_bc) {   // linear-buckling matrices (fcVM.py:1051-1062): no elimination, fixed diagonal x 100
@@ -296,8 +326,10 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                         for (int c = 0; c < 3; c++)
                             lds_add(dst + r * 3 + c, (((fa >> r) & 1) && diag && r == c) ? 100.0 * K[r * 3 + c] : K[r * 3 + c]);
                 } else if ((fa | fb) == 0) {   // no supports at either node: the whole block
+                    if (kept) {
 #pragma unroll
-                    for (int k = 0; k < 9; k++) lds_add(dst + k, K[k]);
+                        for (int k = 0; k < 9; k++) lds_add(dst + k, K[k]);
+                    }
                 } else {
 #pragma unroll
                     for (int r = 0; r < 3; r++) {
@@ -306,7 +338,7 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                         for (int c = 0; c < 3; c++) {
                             const bool cfix = (fb >> c) & 1;
                             if (!rfix && !cfix) {
-                                lds_add(dst + r * 3 + c, K[r * 3 + c]);
+                                if (kept) lds_add(dst + r * 3 + c, K[r * 3 + c]);
                             } else if (!rfix && cfix) {
                                 racc[3 + r] -= K[r * 3 + c] * fixval[3 * (int64_t)G0.ndb[t] + c];
                             } else if (rfix && diag && r == c) {   // fcVM.py:773-778: unit diagonal per element occurrence
@@ -358,9 +390,78 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
         const double vsum = wave_sum(h == 0 ? racc[6] : 0.0);
         if (lane == 0) volume[wg] = vsum;
     }
+    __syncthreads();
+    if (SYM) {
+        // ---- the finished rows leave LDS in the symmetric window layout: thread (sub, r16) of row r16 stores the components
+        //      (2 sub, 2 sub + 1) of every kept block as one 16-byte word; sub 0 also component 8, sub 1 the eight 16-bit values, sub 2
+        //      the 8-byte tail {ninth 16-bit value, window column, block exponent, target lane}, sub 3 the diagonal block.
+        //      Segment after segment of a cut row; 16 consecutive lanes of a wave write 256 contiguous bytes per instruction ----
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const int sub = lane >> 4, r16 = lane & 15;
+        const double *src = rowbuf + r16 * S;
+        const int nd16 = __shfl(node, 4 * r16, 64);
+        int64_t cur = nd16 >= 0 ? s * 64 + qd * ASM_ROWS + r16 : -1;
+        if (sub == 3 && nd16 >= 0) {
+            const double *sd = src + 9 * (int)sy.diagk[nd16];
+            double *dd = sy.dblk + 9 * (int64_t)nd16;
+#pragma unroll
+            for (int k = 0; k < 9; k++) dd[k] = sd[k];
+        }
+        while (cur >= 0) {
+            const int64_t wv = cur >> 6;
+            const int ln = (int)(cur & 63);
+            const int L = sy.rowlen[cur], j0 = sy.jfirst[cur];
+            const int64_t wo = sy.woff[wv];
+            const uint16_t *ro = sy.rowoff + wv * sy.maxl1;
+            int o0 = ro[0];
+            for (int j = 0; j < L; j++) {
+                const int o1 = ro[j + 1];
+                const int n = o1 - o0;
+                const int64_t eoff = wo + o0;
+                const double *b9 = src + 9 * (j0 + j);
+                v2d d;
+                d.x = b9[2 * sub]; d.y = b9[2 * sub + 1];
+                __builtin_nontemporal_store(d, (v2d *)(sy.vals + 9 * eoff + (int64_t)2 * sub * n + 2 * ln));
+                if (sub == 0) __builtin_nontemporal_store(b9[8], sy.vals + 9 * eoff + (int64_t)8 * n + ln);
+                if (sy.lo8 && (sub == 1 || sub == 2)) {
+                    // 16-bit block-scaled copy: nine integers on the block's own power of two, the exponent stored absolutely
+                    // (frexp exponent of the block maximum; the kernels subtract the matrix exponent e0 when they read it)
+                    double m = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 9; c++) m = fmax(m, fabs(b9[c]));
+                    int eb = -1023;
+                    if (m > 0.0) (void)frexp(m, &eb);
+                    const int shq = 15 - eb;
+                    if (sub == 1) {
+                        short8 hq;
+#pragma unroll
+                        for (int c = 0; c < 8; c++) {
+                            double t = rint(ldexp(b9[c], shq));
+                            t = t > 32767.0 ? 32767.0 : (t < -32767.0 ? -32767.0 : t);
+                            hq[c] = (short)(int)t;
+                        }
+                        __builtin_nontemporal_store(hq, sy.lo8 + eoff + ln);
+                    } else {
+                        double t = rint(ldexp(b9[8], shq));
+                        t = t > 32767.0 ? 32767.0 : (t < -32767.0 ? -32767.0 : t);
+                        const uint32_t ct = sy.cols[eoff + ln];
+                        WinLoTailS tl;
+                        tl.q8 = (short)(int)t;
+                        tl.col = (unsigned short)(ct & 0xFFFFu);
+                        tl.eb = (short)eb;
+                        tl.ts = (unsigned short)(ct >> 16);
+                        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                        __builtin_nontemporal_store(__builtin_bit_cast(u32x2, tl), (u32x2 *)(sy.lo2 + eoff + ln));
+                    }
+                }
+                o0 = o1;
+            }
+            cur = sy.nextseg[cur];
+        }
+        return;
+    }
     // ---- the finished quarter slice leaves LDS: (pair p, component c) -> 16 lanes x 16 B, four segments per instruction;
     //      the single last block of an odd-length slice as 16 lanes x 8 B ----
-    __syncthreads();
     {
         typedef double v2d __attribute__((ext_vector_type(2)));
         const int sub = lane >> 4, r16 = lane & 15;

@@ -75,6 +75,17 @@ struct WinSymDev {
     WinLoTailS *lo2 = nullptr;
     size_t lds_lo = 0;
     bool lo_valid = false;
+    // assembly straight into this form (k_assemble_lds<.., SYM>, round 4): element map of kept block numbers, segment tables,
+    // work items (wave * 4 + quarter, only quarters with a first segment) grouped by the kept length of their longest row
+    bool asm_ok = false;
+    uint8_t *emap = nullptr, *diagk = nullptr;
+    uint16_t *jfirst = nullptr, *rowoff = nullptr;
+    int32_t *nextseg = nullptr, *asm_items = nullptr;
+    int maxl1 = 0;
+    static constexpr int ASM_BUCKETS = 6;
+    int64_t asm_count[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0}, asm_first[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0};
+    double *part_vol = nullptr;     // [items] volume partials
+    int64_t nitems = 0;
 };
 
 struct L2sDev {   // device state of the sparse aggregate level (owned by fcvm_ctx)
@@ -125,13 +136,13 @@ struct fcvm_ctx {
     int32_t *d_nel = nullptr, *d_nel1 = nullptr;
     int assemble_lds = 1;        // rows accumulated in LDS, one coalesced write per value (FCVM_ASSEMBLE_LDS=0: global read-modify-writes)
     // work items of k_assemble_lds (slice * 4 + quarter), grouped by the LDS a quarter slice needs
-    static constexpr int ASM_BUCKETS = 5;
+    static constexpr int ASM_BUCKETS = 6;
     int32_t *d_asm_items = nullptr;
-    int64_t asm_count[ASM_BUCKETS] = {0, 0, 0, 0, 0}, asm_first[ASM_BUCKETS] = {0, 0, 0, 0, 0};
+    int64_t asm_count[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0}, asm_first[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0};
     bool asm_lds_ok = false;
     // the length classes run side by side on streams of their own (a CU holds one long-row item next to two short-row ones)
-    hipStream_t asm_stream[ASM_BUCKETS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t asm_fork = nullptr, asm_join[ASM_BUCKETS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t asm_stream[ASM_BUCKETS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t asm_fork = nullptr, asm_join[ASM_BUCKETS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int asm_overlap = 1;         // FCVM_ASSEMBLE_OVERLAP=0: one stream, class after class
     int qin_atomic = 0;          // FCVM_QIN_ATOMIC=1: internal forces scattered with f64 atomics
     double *d_fe = nullptr;      // [ne][10][3] element nodal forces of the last stress update
@@ -160,6 +171,9 @@ struct fcvm_ctx {
     bool repack_pending = false;
     bool wsym_use = false;      // the matrix being copied is an SPD stiffness matrix: also into the symmetric form
     bool wsym_lo = true;        // ... and its 16-bit copy (FCVM_WIN_SYM_LO=0: the smoother passes stay on the full form)
+    int32_t *d_slotof = nullptr;   // [nn] sliced-ELL slot of a node, kept from fcvm_set_mesh's uploads until the symmetric form is set up
+    int asm_sym = 1;            // FCVM_ASSEMBLE_SYM=0: stiffness matrices go through the sliced-ELL array and the copy kernel (rounds 2-3)
+    bool sell_valid = false;    // d_vals holds the matrix of the last assembly (false after an assembly straight into the symmetric form)
     bool sym_pair = true;       // two right-hand sides share one pass over the symmetric form (FCVM_SYM_PAIR=0: the one-vector kernels twice)
     bool mg_fuse_prolong = false;  // FCVM_MG_FUSE_PROLONG=1: x + P e1 formed while the post-smoothing pass stages x instead of by k_prolong_add
                                    // (measured: 212 us against 177 + 29 -- every window node is staged by 2.9 groups -- so off)
@@ -511,6 +525,9 @@ static void alt_free(fcvm_ctx *c);
 static void wsym_free(WinSymDev &w) {
     dfree(w.woff); dfree(w.rownode); dfree(w.srcslot); dfree(w.gextra); dfree(w.seg); dfree(w.cols); dfree(w.rowlen); dfree(w.own);
     dfree(w.jell); dfree(w.vals); dfree(w.lo8); dfree(w.lo2);
+    dfree(w.emap); dfree(w.diagk); dfree(w.jfirst); dfree(w.rowoff); dfree(w.nextseg); dfree(w.asm_items); dfree(w.part_vol);
+    w.asm_ok = false;
+    w.nitems = 0;
     w.on = w.valid = w.lo_valid = false;
     w.pat = WinSym();
     w.lds = 0;
@@ -569,6 +586,89 @@ static int win_allow_lds(K kernel, size_t bytes) {
     HCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return 0;
 }
+// kept-length classes of the assembly into the symmetric form (blocks of the longest row of a work item's 16 lanes):
+// 22 / 30 / 39 / 53 / 68 / 160 KiB of LDS per item = 7 / 5 / 4 / 3 / 2 / 1 items per CU
+static const int64_t ASM_SYM_LIMIT[WinSymDev::ASM_BUCKETS] = {14, 20, 28, 40, 53, 133};
+// tables and work items of k_assemble_lds<.., SYM> (after wsym_upload; needs c->d_slotof, c->d_emap, c->d_sptr of fcvm_set_mesh).
+// Not available (asm_ok stays false, the sliced-ELL path + copy kernel remain): rows beyond the largest class, no LDS for it.
+static int wsym_asm_setup(fcvm_ctx *c) {
+    WinSymDev &d = c->wsym;
+    WinSym &w = d.pat;
+    d.asm_ok = false;
+    const int64_t nrows = w.nwaves * SLICE;
+    auto release_host = [&]() {
+        w.kmap.clear(); w.kmap.shrink_to_fit();
+        w.rowoff.clear(); w.rowoff.shrink_to_fit();
+    };
+    if (!c->asm_sym || !c->assemble_lds || !c->d_slotof || w.kmap.empty()) { release_host(); return 0; }
+    std::vector<int32_t> items[WinSymDev::ASM_BUCKETS];
+    bool fits = true;
+    for (int64_t wave = 0; wave < w.nwaves && fits; wave++)
+        for (int q = 0; q < 4; q++) {
+            int m = 0;
+            for (int l = 0; l < ASM_ROWS; l++) m = std::max<int>(m, w.rowtot[wave * SLICE + q * ASM_ROWS + l]);
+            if (m == 0) continue;       // later segments and empty lanes only: nothing to assemble
+            if (m > ASM_SYM_LIMIT[WinSymDev::ASM_BUCKETS - 1]) { fits = false; break; }
+            int b = 0;
+            while (m > ASM_SYM_LIMIT[b]) b++;
+            items[b].push_back((int32_t)(wave * 4 + q));
+        }
+    const int lds_cap = device_lds_cap(c->device);
+    for (int b = 0; b < WinSymDev::ASM_BUCKETS; b++)
+        if (!items[b].empty() && (int64_t)asm_lds_bytes(ASM_SYM_LIMIT[b]) > lds_cap) fits = false;
+    if (!fits || w.nwaves >= (int64_t(1) << 29)) { release_host(); return 0; }
+    std::vector<int32_t> all;
+    for (int b = 0; b < WinSymDev::ASM_BUCKETS; b++) {
+        d.asm_first[b] = (int64_t)all.size();
+        d.asm_count[b] = (int64_t)items[b].size();
+        all.insert(all.end(), items[b].begin(), items[b].end());
+    }
+    d.nitems = (int64_t)all.size();
+    d.maxl1 = w.maxl + 1;
+    uint8_t *d_kmap = nullptr;
+    int64_t *d_rowptr = nullptr;
+    if (dalloc(&d.emap, c->ne * 100) || dalloc(&d.diagk, c->nn) || dalloc(&d.jfirst, nrows) || dalloc(&d.rowoff, (int64_t)w.rowoff.size()) ||
+        dalloc(&d.nextseg, nrows) || dalloc(&d.asm_items, d.nitems) || dalloc(&d.part_vol, d.nitems) || dalloc(&d_kmap, (int64_t)w.kmap.size()) ||
+        dalloc(&d_rowptr, c->nn + 1)) {
+        (void)hipGetLastError();
+        dfree(d_kmap); dfree(d_rowptr);
+        dfree(d.emap); dfree(d.diagk); dfree(d.jfirst); dfree(d.rowoff); dfree(d.nextseg); dfree(d.asm_items); dfree(d.part_vol);
+        release_host();
+        return 0;       // (no memory for the tables: the copy-kernel path stays)
+    }
+    hipStream_t s = c->stream;
+    HCHK(hipMemcpyAsync(d.diagk, w.diagk.data(), sizeof(uint8_t) * c->nn, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.jfirst, w.jfirst.data(), sizeof(uint16_t) * nrows, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.rowoff, w.rowoff.data(), sizeof(uint16_t) * w.rowoff.size(), hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.nextseg, w.nextseg.data(), sizeof(int32_t) * nrows, hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d.asm_items, all.data(), sizeof(int32_t) * all.size(), hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d_kmap, w.kmap.data(), sizeof(uint8_t) * w.kmap.size(), hipMemcpyHostToDevice, s));
+    HCHK(hipMemcpyAsync(d_rowptr, c->pat.rowptr.data(), sizeof(int64_t) * (c->nn + 1), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_build_emap_sym, dim3((unsigned)cdiv(c->ne * 10, 256)), dim3(256), 0, s, c->ne, c->d_el, c->d_slotof, c->d_sptr, d_rowptr,
+                       c->d_emap, d_kmap, d.emap);
+    HCHK(hipGetLastError());
+    HCHK(hipStreamSynchronize(s));
+    dfree(d_kmap); dfree(d_rowptr);
+    release_host();
+    static int asm_sym_lds_allowed_dev[64] = {0};
+    int &allowed = asm_sym_lds_allowed_dev[c->device & 63];
+    if (allowed == 0) allowed = 64 * 1024;
+    for (int b = 0; b < WinSymDev::ASM_BUCKETS; b++) {
+        const int bytes = (int)asm_lds_bytes(ASM_SYM_LIMIT[b]);
+        if (bytes <= allowed || !d.asm_count[b]) continue;
+        HCHK(hipFuncSetAttribute((const void *)k_assemble_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HCHK(hipFuncSetAttribute((const void *)k_assemble_lds<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        allowed = bytes;
+    }
+    d.asm_ok = true;
+    if (getenv("FCVM_VERBOSE")) {
+        fprintf(stderr, "fcvm: assembly into the symmetric form: %lld work items, by kept length", (long long)d.nitems);
+        for (int b = 0; b < WinSymDev::ASM_BUCKETS; b++) fprintf(stderr, " <=%lld: %lld", (long long)ASM_SYM_LIMIT[b], (long long)d.asm_count[b]);
+        fprintf(stderr, "\n");
+    }
+    return 0;
+}
+
 // device copy of the symmetric form built by win_build_host (nothing to do when it was not built); used only where two
 // workgroups of it fit the LDS of a CU
 static int wsym_upload(fcvm_ctx *c) {
@@ -621,6 +721,7 @@ static int wsym_upload(fcvm_ctx *c) {
     d.pat.jell.clear(); d.pat.jell.shrink_to_fit();
     d.on = true;
     d.valid = false;
+    if (wsym_asm_setup(c)) return 1;
     if (getenv("FCVM_VERBOSE"))
         fprintf(stderr, "fcvm: symmetric window form: %lld entries (%.3f of the full form), %zu B LDS\n", (long long)w.nblocks,
                 (double)w.nblocks / (double)c->win.pat.nblocks, d.lds);
@@ -825,7 +926,7 @@ static int tune_matrix_placement(fcvm_ctx *c) {
 }
 
 // slice-length classes of k_assemble_lds (blocks of the longest row): a quarter slice needs asm_lds_bytes() of LDS
-static const int64_t ASM_LEN_LIMIT[fcvm_ctx::ASM_BUCKETS] = {19, 27, 41, 65, 133};   // 28 / 37 / 54 / 81 / 160 KiB: 5 / 4 / 3 / 2 / 1 per CU
+static const int64_t ASM_LEN_LIMIT[fcvm_ctx::ASM_BUCKETS] = {19, 27, 41, 65, 98, 133};   // 28 / 37 / 54 / 81 / 119 / 160 KiB: 5 / 4 / 3 / 2 / 1 / 1 per CU
 
 static int build_asm_items(fcvm_ctx *c) {
     const Pattern &p = c->pat;
@@ -901,6 +1002,47 @@ static int launch_assemble_lds(fcvm_ctx *c, const double *disp, const double *si
     return 0;
 }
 
+// the same kernel on the work items of the symmetric window form: rows leave LDS straight into the SpMV's storage
+template <bool TANGENT>
+static int launch_assemble_sym(fcvm_ctx *c, const double *disp, const double *sig, const uint8_t *pgp, const MatConst &mc,
+                               const double grav[3], double *glv, double *modf, double *xgp, bool want_lo) {
+    static_assert(WinSymDev::ASM_BUCKETS <= fcvm_ctx::ASM_BUCKETS, "one stream per length class");
+    WinSymDev &d = c->wsym;
+    int nb = 0;
+    for (int b = 0; b < WinSymDev::ASM_BUCKETS; b++) nb += d.asm_count[b] ? 1 : 0;
+    const bool overlap = c->asm_overlap && nb > 1;
+    if (overlap) {
+        if (!c->asm_fork) {
+            HCHK(hipEventCreateWithFlags(&c->asm_fork, hipEventDisableTiming));
+            for (int b = 0; b < fcvm_ctx::ASM_BUCKETS; b++) {
+                HCHK(hipStreamCreateWithFlags(&c->asm_stream[b], hipStreamNonBlocking));
+                HCHK(hipEventCreateWithFlags(&c->asm_join[b], hipEventDisableTiming));
+            }
+        }
+        HCHK(hipEventRecord(c->asm_fork, c->stream));
+    }
+    AsmSym sy;
+    sy.rownode = d.rownode; sy.seg = d.seg; sy.emap = d.emap; sy.rowlen = d.rowlen; sy.jfirst = d.jfirst; sy.rowoff = d.rowoff;
+    sy.nextseg = d.nextseg; sy.woff = d.woff; sy.cols = d.cols; sy.diagk = d.diagk; sy.vals = d.vals;
+    sy.lo8 = want_lo ? d.lo8 : nullptr; sy.lo2 = want_lo ? d.lo2 : nullptr; sy.dblk = c->d_dblk; sy.maxl1 = d.maxl1; sy.len = 0;
+    for (int b = WinSymDev::ASM_BUCKETS - 1; b >= 0; b--) {   // longest rows first: their items run longest
+        if (!d.asm_count[b]) continue;
+        hipStream_t st = overlap ? c->asm_stream[b] : c->stream;
+        if (overlap) HCHK(hipStreamWaitEvent(st, c->asm_fork, 0));
+        sy.len = (int)ASM_SYM_LIMIT[b];
+        hipLaunchKernelGGL((k_assemble_lds<TANGENT, true>), dim3((unsigned)d.asm_count[b]), dim3(64), (size_t)asm_lds_bytes(ASM_SYM_LIMIT[b]), st,
+                           d.asm_items + d.asm_first[b], c->d_sptr, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord, disp, c->d_fixmask,
+                           c->d_fixval, c->d_emap, sig, pgp, mc, grav[0], grav[1], grav[2], (double *)nullptr, glv, modf, xgp,
+                           d.part_vol + d.asm_first[b], 0, sy);
+        if (overlap) {
+            HCHK(hipEventRecord(c->asm_join[b], st));
+            HCHK(hipStreamWaitEvent(c->stream, c->asm_join[b], 0));
+        }
+    }
+    HCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" {
 
 const char *fcvm_last_error(void) { return g_err.c_str(); }
@@ -940,6 +1082,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_WIN_SYM_LO")) c->wsym_lo = atoi(v) != 0;
     if (const char *v = getenv("FCVM_MG_FUSE_PROLONG")) c->mg_fuse_prolong = atoi(v) != 0;
     if (const char *v = getenv("FCVM_SYM_PAIR")) c->sym_pair = atoi(v) != 0;
+    if (const char *v = getenv("FCVM_ASSEMBLE_SYM")) c->asm_sym = atoi(v);
     HCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
     c->stream = c->own;
     if (dalloc(&c->d_S, S_COUNT) || dalloc(&c->d_out8, 16)) return 1;
@@ -962,7 +1105,8 @@ static void free_mesh(fcvm_ctx *c) {
     if (c->sym_thread.joinable()) c->sym_thread.join();
     dfree(c->d_el); dfree(c->d_cols); dfree(c->d_rownode); dfree(c->d_noce); dfree(c->d_sptr);
     dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
-    dfree(c->d_nptr); dfree(c->d_nel); dfree(c->d_fe); dfree(c->d_part_vol); dfree(c->d_asm_items);
+    dfree(c->d_nptr); dfree(c->d_nel); dfree(c->d_fe); dfree(c->d_part_vol); dfree(c->d_asm_items); dfree(c->d_slotof);
+    c->sell_valid = false;
     win_free(c->win);
     wsym_free(c->wsym);
     dfree(c->d_vals); dfree(c->d_vals_g); dfree(c->d_dblk); dfree(c->d_dinv); dfree(c->d_dinv6f); dfree(c->d_r); dfree(c->d_z); dfree(c->d_p);
@@ -1128,13 +1272,13 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     HCHK(hipMemcpyAsync(c->d_rownode, p.rownode.data(), sizeof(int32_t) * p.nslices * SLICE, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_noce, noce.data(), sizeof(int32_t) * nn, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(c->d_sptr, p.sptr.data(), sizeof(int64_t) * (p.nslices + 1), hipMemcpyHostToDevice, s));
-    int32_t *d_slotof = nullptr;
+    dfree(c->d_slotof);
+    if (dalloc(&c->d_slotof, nn)) return 1;      // (kept until the symmetric window form has built its own element map)
+    HCHK(hipMemcpyAsync(c->d_slotof, p.slotof.data(), sizeof(int32_t) * nn, hipMemcpyHostToDevice, s));
     if (emap_host) {
         HCHK(hipMemcpyAsync(c->d_emap, p.emap.data(), sizeof(uint32_t) * ne * 100, hipMemcpyHostToDevice, s));
     } else {   // (after d_el, d_cols and d_sptr above, in stream order)
-        if (dalloc(&d_slotof, nn)) return 1;
-        HCHK(hipMemcpyAsync(d_slotof, p.slotof.data(), sizeof(int32_t) * nn, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_build_emap, dim3((unsigned)cdiv(ne * 10, 256)), dim3(256), 0, s, ne, c->d_el, d_slotof, c->d_sptr, c->d_cols, c->d_emap);
+        hipLaunchKernelGGL(k_build_emap, dim3((unsigned)cdiv(ne * 10, 256)), dim3(256), 0, s, ne, c->d_el, c->d_slotof, c->d_sptr, c->d_cols, c->d_emap);
         HCHK(hipGetLastError());
     }
     HCHK(hipMemcpyAsync(c->d_diagoff, p.diagoff.data(), sizeof(uint64_t) * nn, hipMemcpyHostToDevice, s));
@@ -1145,7 +1289,6 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     HCHK(hipMemsetAsync(c->d_fixval, 0, sizeof(double) * nn * 3, s));
     HCHK(hipMemsetAsync(c->d_vals, 0, sizeof(double) * p.value_count(), s));
     HCHK(hipStreamSynchronize(s));
-    dfree(d_slotof);
     lap("allocation, upload");
     c->ne = ne;
     c->nn = nn;
@@ -1154,6 +1297,7 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     winthread.join();
     if (setup_window_format(c, winres)) return 1;
     lap("window format (rest of the build + upload)");
+    dfree(c->d_slotof);
     c->h_morton.clear();
     c->h_morton.shrink_to_fit();
     if (!c->win.on && tune_matrix_placement(c)) return 1;
@@ -1225,7 +1369,8 @@ int fcvm_spmv_info(fcvm_ctx *c, int64_t out[8]) {
 
 /* the symmetric form of the window format (the PCG's FP64 SpMV): out[0] = 1 if built for this mesh, out[1] = stored entries,
  * out[2] = blocks of the matrix not stored (their transposes are), out[3] = bytes one launch streams from the format, out[4] =
- * LDS bytes per workgroup, out[5] = 1 if the values of the last assembly are in it (fcvm_spmv / fcvm_solve then use it) */
+ * LDS bytes per workgroup, out[5] = 1 if the values of the last assembly are in it (fcvm_spmv / fcvm_solve then use it), out[6] = 1
+ * if the assembly kernels can write the form themselves, out[7] = 1 if the last assembly did (no sliced-ELL array, no copy) */
 int fcvm_spmv_sym_info(fcvm_ctx *c, int64_t out[8]) {
     NEED(c && c->have_mesh && out, "fcvm_spmv_sym_info: no mesh");
     for (int k = 0; k < 8; k++) out[k] = 0;
@@ -1235,11 +1380,74 @@ int fcvm_spmv_sym_info(fcvm_ctx *c, int64_t out[8]) {
     out[0] = 1; out[1] = w.nblocks; out[2] = w.dropped;
     out[3] = w.nblocks * 76 + f.gptr[f.ngroups] * 4 + w.nwaves * SLICE * 16 + (w.nwaves + w.ngroups) * 8;
     out[4] = (int64_t)c->wsym.lds; out[5] = c->wsym.valid ? 1 : 0;
+    out[6] = c->wsym.asm_ok ? 1 : 0;                            // the assembly can write this form itself (k_assemble_lds<.., SYM>)
+    out[7] = (c->wsym.valid && !c->sell_valid) ? 1 : 0;         // ... and the last one did
+    return 0;
+}
+
+// the matrix of the last assembly read back from the SYMMETRIC window form (an assembly straight into it leaves the sliced-ELL
+// array untouched): every stored entry gives block (i, j) and, where it carries a transposed product, block (j, i) = its transpose
+static int matrix_to_coo_sym(fcvm_ctx *c, int64_t *row, int64_t *col, double *val) {
+    const Pattern &p = c->pat;
+    const WinSymDev &d = c->wsym;
+    const WinDev &f = c->win;
+    const int64_t nrows = d.pat.nwaves * SLICE, nb = d.pat.nblocks, ng = f.pat.ngroups;
+    std::vector<double> v(9 * nb);
+    std::vector<uint32_t> cols(nb);
+    std::vector<int64_t> woff(d.pat.nwaves + 1), gptr(ng + 1);
+    std::vector<uint16_t> rowlen(nrows);
+    std::vector<int32_t> rownode(nrows);
+    HCHK(hipStreamSynchronize(c->stream));
+    HCHK(hipMemcpy(v.data(), d.vals, sizeof(double) * 9 * nb, hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(cols.data(), d.cols, sizeof(uint32_t) * nb, hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(woff.data(), d.woff, sizeof(int64_t) * (d.pat.nwaves + 1), hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(gptr.data(), f.gptr, sizeof(int64_t) * (ng + 1), hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(rowlen.data(), d.rowlen, sizeof(uint16_t) * nrows, hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(rownode.data(), d.rownode, sizeof(int32_t) * nrows, hipMemcpyDeviceToHost));
+    std::vector<int32_t> wlist(gptr[ng]);
+    HCHK(hipMemcpy(wlist.data(), f.wlist, sizeof(int32_t) * wlist.size(), hipMemcpyDeviceToHost));
+    int64_t k = 0;
+    for (int64_t i = 0; i < p.nn; i++)
+        for (int64_t q = p.rowptr[i]; q < p.rowptr[i + 1]; q++)
+            for (int r = 0; r < 3; r++)
+                for (int cc = 0; cc < 3; cc++) {
+                    row[k] = 3 * i + r;
+                    col[k] = 3 * (int64_t)p.colidx[q] + cc;
+                    val[k] = 0.0;
+                    k++;
+                }
+    auto put = [&](int32_t i, int32_t j, const double *b9, bool transposed) {
+        const int32_t *rb = p.colidx.data() + p.rowptr[i], *re = p.colidx.data() + p.rowptr[i + 1];
+        const int64_t q = std::lower_bound(rb, re, j) - p.colidx.data();
+        for (int r = 0; r < 3; r++)
+            for (int cc = 0; cc < 3; cc++) val[9 * q + 3 * r + cc] = transposed ? b9[3 * cc + r] : b9[3 * r + cc];
+    };
+    const int64_t R = (int64_t)d.pat.waves * SLICE;
+    for (int64_t wave = 0; wave < d.pat.nwaves; wave++) {
+        const int64_t g = wave / d.pat.waves;
+        const uint16_t *len = &rowlen[wave * SLICE];
+        int64_t off = woff[wave];
+        for (int64_t j = 0; j < len[0]; j++) {
+            int64_t n = 0;
+            while (n < SLICE && len[n] > j) n++;
+            for (int64_t l = 0; l < n; l++) {
+                const uint32_t en = cols[off + l];
+                const int32_t i = rownode[wave * SLICE + l], jn = wlist[gptr[g] + (en & 0xFFFFu)];
+                double b9[9];
+                for (int cmp = 0; cmp < 9; cmp++)       // V2 component layout, see win_value_at
+                    b9[cmp] = v[9 * off + (cmp < 8 ? (cmp >> 1) * 2 * n + 2 * l + (cmp & 1) : 8 * n + l)];
+                put(i, jn, b9, false);
+                if ((en >> 16) != 0xFFFFu) put(rownode[g * R + (en >> 16)], i, b9, true);
+            }
+            off += n;
+        }
+    }
     return 0;
 }
 
 int fcvm_matrix_to_coo(fcvm_ctx *c, int64_t *row, int64_t *col, double *val) {
     NEED(c && c->have_mesh, "fcvm_matrix_to_coo: no mesh");
+    if (!c->sell_valid && c->wsym.on && c->wsym.valid) return matrix_to_coo_sym(c, row, col, val);
     const Pattern &p = c->pat;
     std::vector<double> v(p.value_count());
     HCHK(hipMemcpyAsync(v.data(), c->d_vals, sizeof(double) * v.size(), hipMemcpyDeviceToHost, c->stream));
@@ -1266,6 +1474,23 @@ static int win_join(fcvm_ctx *c) {
         HCHK(hipStreamWaitEvent(c->stream, c->repack_done, 0));
         c->repack_pending = false;
     }
+    return 0;
+}
+
+// after an assembly straight into the symmetric window form (k_assemble_lds<.., SYM> wrote the FP64 values, the 16-bit copy and
+// the diagonal blocks): the matrix exponent for the fixed-point sums / the 16-bit copy, and the diagonal inverses
+static int refresh_precond_direct(fcvm_ctx *c, bool lo) {
+    WinDev &w = c->win;
+    WinSymDev &ws = c->wsym;
+    if (!w.lo_scale && dalloc(&w.lo_scale, 2)) return 1;
+    hipLaunchKernelGGL(k_absmax_partial, dim3(1024), dim3(256), 0, c->stream, 9 * c->nn, c->d_dblk, c->d_part_misc);
+    hipLaunchKernelGGL(k_lo_scale, dim3(1), dim3(256), 0, c->stream, c->d_part_misc, (int64_t)1024, w.lo_scale);
+    ws.valid = true;
+    ws.lo_valid = lo;
+    w.lo_valid = false;
+    hipLaunchKernelGGL(k_diag_invert, dim3(cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_dblk, c->d_dinv);
+    hipLaunchKernelGGL(k_dinv_pack6f, dim3(cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_dinv, c->d_dinv6f);
+    HCHK(hipGetLastError());
     return 0;
 }
 
@@ -1344,7 +1569,23 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
     const int64_t nslots = c->pat.nslices * SLICE;
     dim3 rgrid((unsigned)cdiv(nslots, 256));
     const bool level1_early = mg_level1_early(c, sig ? disp : nullptr, sig, pgp, Et_E);   // a refresh: beside the fine assembly
-    if (use_lds) {  // quarter slices accumulated in LDS, written once (fcvm_assemble_lds.hip.h)
+    // round 4: straight into the SpMV's storage (symmetric window form + its 16-bit copy + diagonal blocks) where that form is
+    // in charge -- no sliced-ELL array, no copy kernel
+    const bool lo = c->precond_mode >= 1 && c->mg_additive == 2;
+    // (cycle form 0 smooths with Chebyshev steps fused into the sliced-ELL SpMV: it needs that array)
+    const bool direct = use_lds && c->asm_sym && c->win.on && c->wsym.on && c->wsym.asm_ok && (!lo || c->wsym_lo) &&
+                        !(c->precond_mode >= 1 && c->mg_additive == 0);
+    if (direct) {
+        WinSymDev &ws = c->wsym;
+        if (lo && !c->win.part_lo && dalloc(&c->win.part_lo, 2 * c->win.pat.ngroups)) return 1;
+        if (lo && !ws.lo8 && (dalloc(&ws.lo8, ws.pat.nblocks) || dalloc(&ws.lo2, ws.pat.nblocks))) return 1;
+        if (sig ? launch_assemble_sym<true>(c, disp, sig, pgp, mc, grav, glv_grav, modf, xgp, lo)
+                : launch_assemble_sym<false>(c, disp, nullptr, nullptr, mc, grav, glv_grav, modf, xgp, lo))
+            return 1;
+        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, s, ws.part_vol, ws.nitems, c->d_out8);
+        HCHK(hipGetLastError());
+        c->sell_valid = false;
+    } else if (use_lds) {  // quarter slices accumulated in LDS, written once (fcvm_assemble_lds.hip.h)
         if (sig ? launch_assemble_lds<true>(c, disp, sig, pgp, mc, grav, glv_grav, modf, xgp, c->d_part_vol, 0)
                 : launch_assemble_lds<false>(c, disp, nullptr, nullptr, mc, grav, glv_grav, modf, xgp, c->d_part_vol, 0))
             return 1;
@@ -1364,7 +1605,12 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
     SetupLap lap(s);
     lap("assemble: kernels");
     c->wsym_use = true;
-    if (refresh_precond(c)) return 1;
+    if (direct) {
+        if (refresh_precond_direct(c, lo)) return 1;
+    } else {
+        c->sell_valid = true;
+        if (refresh_precond(c)) return 1;
+    }
     lap("assemble: diagonal blocks, window-format copy");
     if (c->precond_mode >= 1) {
         HCHK(hipStreamSynchronize(s));
@@ -1475,6 +1721,10 @@ int fcvm_precond(fcvm_ctx *c, const double *r, double *z) {
 
 int fcvm_get_diag_blocks(fcvm_ctx *c, double *dblk) {
     NEED(c && c->have_mesh, "fcvm_get_diag_blocks: no mesh");
+    if (!c->sell_valid && c->wsym.on && c->wsym.valid) {      // assembled straight into the symmetric form: the kernel left the blocks in d_dblk
+        HCHK(hipMemcpyAsync(dblk, c->d_dblk, sizeof(double) * 9 * c->nn, hipMemcpyDeviceToDevice, c->stream));
+        return 0;
+    }
     hipLaunchKernelGGL(k_diag_get, dim3((unsigned)c->nb_vec), dim3(256), 0, c->stream, c->nn, c->d_diagoff, c->d_vals, dblk);
     HCHK(hipGetLastError());
     return 0;
@@ -2035,7 +2285,8 @@ int fcvm_mg_coarse_map(fcvm_ctx *c, int32_t *c2f) {
 int fcvm_spmv_level(fcvm_ctx *c, int level, const double *x, double *y) {
     MatView A; const double *dinv; int64_t n;
     if (mg_level(c, level, &A, &dinv, &n)) return 1;
-    launch_spmv_t<false>(c, A, x, y, nullptr, nullptr);
+    if (level == 0) launch_spmv(c, false, x, y, nullptr);      // (window format where it is in charge: the sliced-ELL array may be stale)
+    else launch_spmv_t<false>(c, A, x, y, nullptr, nullptr);
     HCHK(hipGetLastError());
     return 0;
 }
@@ -2215,6 +2466,7 @@ int fcvm_assemble_buckling(fcvm_ctx *c, const double *sig, double shift) {
         hipLaunchKernelGGL(k_axpby, dim3((unsigned)cdiv(nv, 256)), dim3(256), 0, s, nv, 1.0, c->d_vals, shift, c->d_vals_g, c->d_vals);
     HCHK(hipGetLastError());
     c->wsym_use = false;      // K_b + sigma K_g is not positive definite in general: the bound behind the fixed-point sums does not hold
+    c->sell_valid = true;
     if (refresh_precond(c)) return 1;
     if (c->precond_mode >= 1) {
         HCHK(hipStreamSynchronize(s));

@@ -141,6 +141,28 @@ __global__ __launch_bounds__(256) void k_build_emap(int64_t ne, const int32_t *_
     for (int b = 0; b < 10; b++) emap[t * 10 + b] = out[b];
 }
 
+// Element map of the assembly into the symmetric window form (k_assemble_lds<.., SYM>): one byte per element block (a, b), the
+// KEPT number of the block in the row of node a (WinSym::kmap, fcvm_pattern.h) or 0xFF when its transpose is the stored one.
+// From the sliced-ELL map: its entry gives the block's number in the row (both layouts keep a row's blocks in column order).
+__global__ __launch_bounds__(256) void k_build_emap_sym(int64_t ne, const int32_t *__restrict__ el, const int32_t *__restrict__ slotof,
+                                                        const int64_t *__restrict__ sptr, const int64_t *__restrict__ rowptr,
+                                                        const uint32_t *__restrict__ emap, const uint8_t *__restrict__ kmap,
+                                                        uint8_t *__restrict__ emap_sym) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ne * 10) return;
+    const int32_t i = el[t];
+    const int64_t jb = sptr[slotof[i] >> 6], base = rowptr[i];
+    uint8_t out[10];
+#pragma unroll
+    for (int b = 0; b < 10; b++) {
+        const uint32_t em = emap[t * 10 + b];
+        const int64_t jj = (int64_t)(em >> 2) - jb + (int64_t)((em >> 1) & 1u);
+        out[b] = kmap[base + jj];
+    }
+#pragma unroll
+    for (int b = 0; b < 10; b++) emap_sym[t * 10 + b] = out[b];
+}
+
 // the 64-bit form (Pattern::abs_offset: offset << 1 | single) of tables that are read without knowing the lane
 __device__ __forceinline__ int64_t unpack_abs(uint64_t loc, int &stride) {
     stride = (loc & 1ull) ? 64 : 128;

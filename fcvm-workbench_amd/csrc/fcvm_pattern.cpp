@@ -485,9 +485,12 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
     const bool flagged_first = !(getenv("FCVM_SYM_FLAGGED_FIRST") && atoi(getenv("FCVM_SYM_FLAGGED_FIRST")) == 0);
     const std::vector<int32_t> grp = window_group_of(p, w);
     lap("group of every node");
-    std::vector<uint16_t> jfirst(s.nwaves * SLICE, 0);      // first kept block of the segment (index into the row's kept list)
+    std::vector<uint16_t> &jfirst = s.jfirst;               // first kept block of the segment (index into the row's kept list)
+    jfirst.assign(s.nwaves * SLICE, 0);
+    s.rowtot.assign(s.nwaves * SLICE, 0);
+    s.nextseg.assign(s.nwaves * SLICE, -1);
     std::vector<int64_t> drop(nthreads > 0 ? nthreads : 1, 0);
-    struct VRow { int64_t len; int32_t nd; int32_t j0; uint32_t seg; };
+    struct VRow { int64_t len; int32_t nd; int32_t j0; uint32_t seg; int32_t tt; int32_t tot; };
     // kept blocks of row i of group g, in column order: calls f(block number in the row, column node, transposed product wanted)
     auto for_kept = [&](int32_t i, int32_t g, auto &&f) {
         for (int64_t q = p.rowptr[i]; q < p.rowptr[i + 1]; q++) {
@@ -505,6 +508,7 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
     // pass 1: new lengths, segments, lanes, entries per wave
     parallel_for(ng, nthreads, [&](int64_t b, int64_t e, int t) {
         std::vector<VRow> rows;
+        std::vector<std::pair<int64_t, int64_t>> chain;
         for (int64_t g = b; g < e; g++) {
             rows.clear();
             int32_t extra = 0;
@@ -524,7 +528,7 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
                 for (int tt = 0; tt < k; tt++) {
                     const int64_t l = len / k + (tt < len % k ? 1 : 0);
                     const uint32_t code = tt == 0 ? ((uint32_t)extra << 8) | (uint32_t)k : ((uint32_t)(extra + tt - 1) << 8);
-                    rows.push_back({l, nd, (int32_t)j0, code});
+                    rows.push_back({l, nd, (int32_t)j0, code, tt, (int32_t)len});
                     j0 += l;
                 }
                 extra += k - 1;
@@ -534,6 +538,7 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
             // on one or two sliced-ELL slices and the copy kernel at 2.6 instead of 3.3 ms per assembly, but the 16-bit passes
             // lose 4 % to the ragged block rows (gpurun_out/r03bi, r03bj): the passes run 80 times per Newton iteration
             std::stable_sort(rows.begin(), rows.end(), [](const VRow &x, const VRow &y) { return x.len > y.len; });
+            chain.clear();
             for (size_t k = 0; k < rows.size(); k++) {
                 const int64_t wave = g * WV + (int64_t)k / SLICE, at = wave * SLICE + (int64_t)k % SLICE;
                 s.rownode[at] = rows[k].nd;
@@ -542,7 +547,13 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
                 jfirst[at] = (uint16_t)rows[k].j0;
                 s.seg[at] = rows[k].seg;
                 s.woff[wave + 1] += rows[k].len;
+                if (rows[k].tt == 0) s.rowtot[at] = (uint8_t)rows[k].tot;
+                if ((rows[k].seg & 255u) != 1u) chain.push_back({((int64_t)rows[k].nd << 8) | rows[k].tt, at});   // a cut row
             }
+            // the segments of a cut row, linked in order (the assembly owns whole rows and writes every segment)
+            std::sort(chain.begin(), chain.end());
+            for (size_t k = 0; k + 1 < chain.size(); k++)
+                if ((chain[k].first >> 8) == (chain[k + 1].first >> 8)) s.nextseg[chain[k].second] = (int32_t)chain[k + 1].second;
         }
     }, 16);
     lap("pass 1 (lengths, lanes)");
@@ -557,6 +568,11 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
     s.nblocks = s.woff[s.nwaves];
     s.cols.resize(s.nblocks);
     s.jell.resize(s.nblocks);
+    s.kmap.resize(p.nnzb);
+    s.diagk.assign(nn, 0);
+    s.maxl = 0;
+    for (int64_t i = 0; i < s.nwaves; i++) s.maxl = std::max<int>(s.maxl, s.rowlen[i * SLICE]);
+    s.rowoff.assign(s.nwaves * (s.maxl + 1), 0);
     lap("offsets, allocation");
     // pass 2: entries in the prefix layout
     parallel_for(ng, nthreads, [&](int64_t b, int64_t e, int) {
@@ -566,7 +582,11 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
             const int64_t W = w.gptr[g + 1] - w.gptr[g];
             for (int64_t i = 0; i < W; i++) pos[wl[i]] = (uint16_t)i;
             for (int64_t at = g * R; at < (g + 1) * R; at++)
-                if (s.rownode[at] >= 0 && (s.seg[at] & 255u) > 0) slot[s.rownode[at]] = (uint16_t)(at - g * R);
+                if (s.rownode[at] >= 0 && (s.seg[at] & 255u) > 0) {
+                    const int32_t nd = s.rownode[at];
+                    slot[nd] = (uint16_t)(at - g * R);
+                    std::fill(s.kmap.begin() + p.rowptr[nd], s.kmap.begin() + p.rowptr[nd + 1], (uint8_t)0xFF);
+                }
             for (int64_t wave = g * WV; wave < (g + 1) * WV; wave++) {
                 // pad entries of the wave (alignment) are never read as blocks; fill them harmlessly
                 for (int64_t q = s.woff[wave]; q < s.woff[wave + 1]; q++) { s.cols[q] = 0xFFFF0000u; s.jell[q] = 0; }
@@ -579,8 +599,10 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
                     for (int64_t jj = 0; jj < len[0]; jj++) {
                         while (n > 0 && len[n - 1] <= jj) n--;
                         rowoff[jj] = off;
+                        s.rowoff[wave * (s.maxl + 1) + jj] = (uint16_t)(off - s.woff[wave]);
                         off += n;
                     }
+                    s.rowoff[wave * (s.maxl + 1) + len[0]] = (uint16_t)(off - s.woff[wave]);
                 }
                 for (int64_t l = 0; l < SLICE; l++) {
                     const int32_t nd = s.rownode[wave * SLICE + l];
@@ -598,6 +620,8 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
                         if (k >= j0 && k < j1) {
                             s.cols[rowoff[k - j0] + l] = (uint32_t)pos[col] | ((tr ? (uint32_t)slot[col] : 0xFFFFu) << 16);
                             s.jell[rowoff[k - j0] + l] = (uint8_t)jq;
+                            s.kmap[p.rowptr[nd] + jq] = (uint8_t)k;
+                            if (col == nd) s.diagk[nd] = (uint8_t)k;
                         }
                     });
                 }
@@ -644,6 +668,9 @@ int64_t check_window_sym(const Pattern &p, const WinPattern &w, const WinSym &s)
                 const int32_t jn = wl[cp];
                 mark(i, jn);
                 if (p.colidx[p.rowptr[i] + s.jell[off + l]] != jn) bad++;           // the copy kernel's source is this block
+                // the assembly's tables: kept number of the block, position of the block row in the wave
+                if (s.kmap[p.rowptr[i] + s.jell[off + l]] != (uint8_t)(s.jfirst[wave * SLICE + l] + j)) bad++;
+                if (l == 0 && s.rowoff[wave * (s.maxl + 1) + j] != (uint16_t)(off - s.woff[wave])) bad++;
                 if (ts != 0xFFFFu) {
                     const int64_t tat = g * R + ts;
                     if ((int64_t)ts >= R || s.rownode[tat] != jn || (s.seg[tat] & 255u) == 0 || jn == i) bad++;
@@ -656,6 +683,31 @@ int64_t check_window_sym(const Pattern &p, const WinPattern &w, const WinSym &s)
     }
     for (int64_t q = 0; q < p.nnzb; q++)
         if (hit[q] != 1) bad++;
+    // segment chains of cut rows: same node, kept numbers follow on, total = rowtot; diagonal blocks; blocks not stored
+    std::vector<uint8_t> seen(p.nn, 0);
+    for (int64_t at = 0; at < s.nwaves * SLICE; at++) {
+        const int32_t i = s.rownode[at];
+        if (i < 0 || (s.seg[at] & 255u) == 0) { if (s.rowtot[at]) bad++; continue; }
+        if (seen[i]++) bad++;
+        int64_t tot = 0, cur = at, nseg = 0;
+        while (cur >= 0) {
+            if (s.rownode[cur] != i || s.jfirst[cur] != tot || (cur != at && (s.seg[cur] & 255u) != 0)) bad++;
+            if (cur / R != at / R) bad++;                       // all segments in the row's group
+            tot += s.rowlen[cur];
+            nseg++;
+            cur = s.nextseg[cur];
+            if (nseg > 256) { bad++; break; }
+        }
+        if (tot != s.rowtot[at] || nseg != (int64_t)(s.seg[at] & 255u)) bad++;
+        int64_t kept = 0;
+        for (int64_t q = p.rowptr[i]; q < p.rowptr[i + 1]; q++) {
+            if (s.kmap[q] != 0xFF) kept++;
+            if (p.colidx[q] == i && s.kmap[q] != s.diagk[i]) bad++;
+        }
+        if (kept != tot) bad++;
+    }
+    for (int64_t i = 0; i < p.nn; i++)
+        if (!seen[i]) bad++;
     int64_t most = 0;
     for (int64_t i = 0; i < p.nn; i++) most = std::max<int64_t>(most, recv[i]);
     if (most != s.trmax || most > SYM_MAX_RECEIVED) bad++;

@@ -162,6 +162,16 @@ struct WinSym {
     std::vector<int32_t> gextra;                // [ngroups]
     RawVec<uint32_t> cols;                      // [nblocks]
     RawVec<uint8_t> jell;                       // [nblocks]
+    // --- what the assembly needs to write this layout itself (round 4: k_assemble_sym, no sliced-ELL detour, no copy kernel) ---
+    // A row's KEPT blocks are numbered 0 .. rowtot-1 in the order its segments store them (the ones that want a transposed
+    // product first, each class in column order); segment t holds the kept blocks jfirst .. jfirst + rowlen - 1.
+    RawVec<uint8_t> kmap;                       // [p.nnzb] kept number of block q of the matrix (CSR order of Pattern), 0xFF: not stored
+    std::vector<uint8_t> diagk;                 // [nn] kept number of the diagonal block of a node's row
+    std::vector<uint16_t> jfirst;               // [nwaves*64] first kept block of the segment
+    std::vector<uint8_t> rowtot;                // [nwaves*64] kept blocks of the whole row at its first segment's lane, 0 elsewhere
+    std::vector<int32_t> nextseg;               // [nwaves*64] lane (wave*64+lane) of the row's next segment, -1: none
+    int maxl = 0;                               // longest segment of the mesh (<= split)
+    std::vector<uint16_t> rowoff;               // [nwaves*(maxl+1)] entry of block row j of a wave, relative to woff[wave]
 };
 // false: not applicable (a row with more than 255 blocks, or one that would receive more than SYM_MAX_RECEIVED transposed products)
 bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSym &s);

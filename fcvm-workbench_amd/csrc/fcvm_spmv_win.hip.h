@@ -42,11 +42,13 @@ struct __attribute__((aligned(8))) WinLoTail {
 };
 static_assert(sizeof(WinLoTail) == 8, "WinLoTail must be 8 bytes");
 // the same eight bytes in the symmetric form (WinSym layout): the spare bytes carry the position of the column node's row
+// and the block exponent is stored ABSOLUTELY (frexp exponent of the block maximum, 16 bits; round 4): whoever writes a block
+// needs nothing global -- the assembly kernel writes this layout itself, before the matrix exponent e0 is known -- and the
+// kernels form e = eb - e0 when they read it
 struct __attribute__((aligned(8))) WinLoTailS {
     short q8;
     unsigned short col;
-    signed char e;
-    signed char pad;
+    short eb;
     unsigned short ts;      // position in the group of the first segment of the column node's row, 0xFFFF: no transposed product
 };
 static_assert(sizeof(WinLoTailS) == 8, "WinLoTailS must be 8 bytes");
@@ -976,19 +978,13 @@ __global__ __launch_bounds__(256) void k_repack_sym(int64_t nrows, const int32_t
             for (int c = 0; c < 9; c++) v[c] = sp[c * cs];
 #pragma unroll
             for (int c = 0; c < 9; c++) dp[win_value_at(c, n, lane, 1)] = v[c];
-            if (lo8) {      // 16-bit block-scaled copy, quantised exactly as in k_repack_win
-                const int e0 = (int)lo_scale[0];
+            if (lo8) {      // 16-bit block-scaled copy, quantised exactly as in k_repack_win (the exponent stored absolutely)
                 double m = 0.0;
 #pragma unroll
                 for (int c = 0; c < 9; c++) m = fmax(m, fabs(v[c]));
-                int e = -127;
-                if (m > 0.0) {
-                    int eb;
-                    (void)frexp(m, &eb);
-                    e = eb - e0;
-                    e = e < -127 ? -127 : (e > 127 ? 127 : e);
-                }
-                const int sh = 15 - (e0 + e);
+                int eb = -1023;
+                if (m > 0.0) (void)frexp(m, &eb);
+                const int sh = 15 - eb;
                 short8 h;
                 int q[9];
 #pragma unroll
@@ -1004,8 +1000,7 @@ __global__ __launch_bounds__(256) void k_repack_sym(int64_t nrows, const int32_t
                 WinLoTailS tl;
                 tl.q8 = (short)q[8];
                 tl.col = (unsigned short)(ct & 0xFFFFu);
-                tl.e = (signed char)e;
-                tl.pad = 0;
+                tl.eb = (short)eb;
                 tl.ts = (unsigned short)(ct >> 16);
                 lo2[off + lane] = tl;
             }
@@ -1288,10 +1283,12 @@ __global__ __launch_bounds__(64 * WAVES, NRHS == 1 ? FCVM_SYM_MINWAVES : 2) void
 // NRHS vectors: windows interleaved per node ([node][rhs][3] floats), the block's nine values converted once.
 template <int NRHS>
 __device__ __forceinline__ void win_fma_lo_sym(const WinSlotLo &t, bool active, const float *xs, const float (&o)[3 * NRHS],
-                                               unsigned long long *yacc, const int (&sh)[NRHS], const bool (&tr_on)[NRHS], float (&y)[3 * NRHS]) {
+                                               unsigned long long *yacc, const int (&sh)[NRHS], const bool (&tr_on)[NRHS], int e0,
+                                               float (&y)[3 * NRHS]) {
     const float *xa = xs + 3 * NRHS * (int)t.t.col;
-    const int e = (int)t.t.e;
-    const float sc = active ? __builtin_bit_cast(float, (127 + (e < -126 ? -126 : e)) << 23) : 0.0f;
+    const WinLoTailS ts8 = __builtin_bit_cast(WinLoTailS, t.t);
+    const int e = (int)ts8.eb - e0;       // <= 0 for an SPD matrix (every entry below its largest diagonal entry)
+    const float sc = active ? __builtin_bit_cast(float, (127 + (e < -126 ? -126 : (e > 127 ? 127 : e))) << 23) : 0.0f;
     const float q0 = (float)(int)t.a[0], q1 = (float)(int)t.a[1], q2 = (float)(int)t.a[2], q3 = (float)(int)t.a[3], q4 = (float)(int)t.a[4],
                 q5 = (float)(int)t.a[5], q6 = (float)(int)t.a[6], q7 = (float)(int)t.a[7], q8 = (float)(int)t.t.q8;
 #pragma unroll
@@ -1301,7 +1298,7 @@ __device__ __forceinline__ void win_fma_lo_sym(const WinSlotLo &t, bool active, 
         y[3 * r + 1] += win_dot3(q3, q4, q5, a0, a1, a2);
         y[3 * r + 2] += win_dot3(q6, q7, q8, a0, a1, a2);
     }
-    const unsigned ts = (unsigned)__builtin_bit_cast(WinLoTailS, t.t).ts;
+    const unsigned ts = (unsigned)ts8.ts;
     if (active && ts != 0xFFFFu) {
 #pragma unroll
         for (int r = 0; r < NRHS; r++)
@@ -1394,6 +1391,7 @@ __global__ __launch_bounds__(64 * WAVES, NRHS == 1 ? FCVM_LOSYM_MINWAVES : 4) vo
         if (all_done) return;
     }
     const bool fuse = NRHS == 1 && EPI == 2 && pf.e1 != nullptr;
+    const int e0 = (int)lo_scale[0];      // matrix exponent: block exponents are stored absolutely (WinLoTailS)
     const int64_t b = blockIdx.x;
     const int64_t q = ngroups >> 3, rr8 = ngroups & 7, xcd = b & 7;
     const int64_t g = (xcd < rr8 ? xcd * (q + 1) : rr8 * (q + 1) + (xcd - rr8) * q) + (b >> 3);
@@ -1486,10 +1484,10 @@ __global__ __launch_bounds__(64 * WAVES, NRHS == 1 ? FCVM_LOSYM_MINWAVES : 4) vo
             }
 #pragma unroll
             for (int k = 0; k < NB; k++) {
-                if (k == 0) win_fma_lo_sym<NRHS>(s[k], p[k], xsf, o, yacc, shf, tr_on, y);
-                else if (k == 1) win_fma_lo_sym<NRHS>(s[k], p[k], xsf, o, yacc, shf, tr_on, z);
-                else if (k == 2) win_fma_lo_sym<NRHS>(s[k], p[k], xsf, o, yacc, shf, tr_on, u);
-                else win_fma_lo_sym<NRHS>(s[k], p[k], xsf, o, yacc, shf, tr_on, w);
+                if (k == 0) win_fma_lo_sym<NRHS>(s[k], p[k], xsf, o, yacc, shf, tr_on, e0, y);
+                else if (k == 1) win_fma_lo_sym<NRHS>(s[k], p[k], xsf, o, yacc, shf, tr_on, e0, z);
+                else if (k == 2) win_fma_lo_sym<NRHS>(s[k], p[k], xsf, o, yacc, shf, tr_on, e0, u);
+                else win_fma_lo_sym<NRHS>(s[k], p[k], xsf, o, yacc, shf, tr_on, e0, w);
             }
             off = o2;
         }
@@ -1500,10 +1498,10 @@ __global__ __launch_bounds__(64 * WAVES, NRHS == 1 ? FCVM_LOSYM_MINWAVES : 4) vo
             const int n0 = __popcll(__builtin_amdgcn_ballot_w64(p0));
             win_load_lo(s[0], lo8, lo2, off, n0, lane);
             const int a = j & 3;
-            if (a == 0) win_fma_lo_sym<NRHS>(s[0], p0, xsf, o, yacc, shf, tr_on, y);
-            else if (a == 1) win_fma_lo_sym<NRHS>(s[0], p0, xsf, o, yacc, shf, tr_on, z);
-            else if (a == 2) win_fma_lo_sym<NRHS>(s[0], p0, xsf, o, yacc, shf, tr_on, u);
-            else win_fma_lo_sym<NRHS>(s[0], p0, xsf, o, yacc, shf, tr_on, w);
+            if (a == 0) win_fma_lo_sym<NRHS>(s[0], p0, xsf, o, yacc, shf, tr_on, e0, y);
+            else if (a == 1) win_fma_lo_sym<NRHS>(s[0], p0, xsf, o, yacc, shf, tr_on, e0, z);
+            else if (a == 2) win_fma_lo_sym<NRHS>(s[0], p0, xsf, o, yacc, shf, tr_on, e0, u);
+            else win_fma_lo_sym<NRHS>(s[0], p0, xsf, o, yacc, shf, tr_on, e0, w);
             off += n0;
         }
 #pragma unroll

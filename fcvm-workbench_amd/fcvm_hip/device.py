@@ -194,7 +194,8 @@ class Context:
         launch / LDS bytes / in use"""
         out = (C.c_int64 * 8)()
         call("fcvm_spmv_sym_info", self.h, out)
-        return dict(built=bool(out[0]), blocks=out[1], dropped=out[2], bytes=out[3], lds_bytes=out[4], in_use=bool(out[5]))
+        return dict(built=bool(out[0]), blocks=out[1], dropped=out[2], bytes=out[3], lds_bytes=out[4], in_use=bool(out[5]),
+                    assembly_writes_it=bool(out[6]), assembled_directly=bool(out[7]))
 
     def matrix_coo(self):
         nnz = 9 * self.pattern_info()["nnz_blocks"]
@@ -377,6 +378,17 @@ class Context:
     def spmv(self, x, y):
         call("fcvm_spmv", self.h, x.ptr, y.ptr)
         return y
+
+    def spmv_lo(self, x, y):
+        """y = K~ x with the 16-bit block-scaled copy of the matrix (the smoother's operator in cycle form 2)"""
+        call("fcvm_spmv_lo", self.h, x.ptr, y.ptr)
+        return y
+
+    def get_diag_blocks(self, out=None):
+        """the 3x3 diagonal blocks of the assembled matrix, [nn][9]"""
+        out = out if out is not None else self.empty(3 * self.pattern_info()["ndof"])
+        call("fcvm_get_diag_blocks", self.h, out.ptr)
+        return out
 
     def mg_apply(self, r, z):
         """z = M^-1 r with the multigrid preconditioner of solve()"""

@@ -262,7 +262,9 @@ int fcvm_membench(fcvm_ctx *c, int64_t nbytes, double out[2]);
 /* The symmetric form of the window format that fcvm_spmv / the PCG use for an assembled stiffness matrix (round 3: one block
  * per pair K_ij, K_ji inside a group, the transposed product through LDS in 64-bit fixed point): out[0] = 1 if built for this
  * mesh, out[1] = stored entries, out[2] = blocks not stored, out[3] = bytes one launch streams, out[4] = LDS bytes per
- * workgroup, out[5] = 1 if it holds the values of the last assembly.  No reference counterpart (CHOLMOD, fcVM.py:1121). */
+ * workgroup, out[5] = 1 if it holds the values of the last assembly, out[6] = 1 if fcvm_assemble can write the form itself
+ * (round 4: rows leave the assembly kernel's LDS straight into this storage, its 16-bit copy and the diagonal blocks), out[7] = 1
+ * if the last assembly did.  No reference counterpart (CHOLMOD, fcVM.py:1121). */
 int fcvm_spmv_sym_info(fcvm_ctx *c, int64_t out[8]);
 
 /* host-only self check of the symmetric form of the window format (the PCG's FP64 SpMV stores one block of every pair

@@ -139,6 +139,73 @@ def test_tangent_assemble_matches_calcTSM(orc):
     assert rel(glv.get(), glv_o) < KTOL
 
 
+@pytest.mark.parametrize("mesh", ["cube", "embankment"])
+def test_assembly_straight_into_the_symmetric_window_form(orc, monkeypatch, mesh):
+    """Round 4: on meshes that run the symmetric window form, calcGSM / calcTSM (fcVM.py:729-800, 940-1050) leave the assembly
+    kernel's LDS straight in the SpMV's storage (FP64 values of the stored blocks, their 16-bit copy, the diagonal blocks) --
+    no sliced-ELL array, no copy kernel.  The matrix read back from that storage (stored blocks + transposes) must be the
+    oracle's, elastic and tangent form; load vectors, Gauss point coordinates and volume as before; and everything the solver
+    sees -- FP64 product, 16-bit product, cycle, solution -- must be BITWISE what the sliced-ELL + copy path of rounds 2-3
+    gives (same sums in the same order, only the route of the values differs).  Cube: structured, prescribed displacements,
+    corner rows cut into segments; Embankment refined once: unstructured, gravity."""
+    from fcvm_hip import examples
+    from fcvm_hip.device import Context
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import GpuModel
+    if mesh == "cube":
+        case = small_case(7)
+        grav = (0.3, -0.2, -9.81)
+    else:
+        case = examples.embankment(refine=1)
+        case["material"] = np.asarray(case["material"], dtype=np.float64)
+        grav = (0.0, 0.0, -10.0)
+    if "ufaces" not in case:
+        case["ufaces"], case["uloads"] = np.zeros((0, 6), np.int64), np.zeros((0, 3))
+    rng = np.random.default_rng(3)
+    du, disp, sig, sy = _random_state(case, rng, 1e-3)
+    ne, n = len(case["elNodes"]), 3 * len(case["nocoord"])
+    pgp = (rng.random(4 * ne) < 0.4).astype(np.uint8)
+    x = rng.standard_normal(n)
+    res = {}
+    for route in ("direct", "copy"):
+        monkeypatch.setenv("FCVM_ASSEMBLE_SYM", "1" if route == "direct" else "0")
+        m = GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"], Loads(ufaces=case["ufaces"], uloads=case["uloads"]),
+                     ctx=Context(0))
+        c = m.ctx
+        out = {}
+        for form in ("elastic", "tangent"):
+            kw = {} if form == "elastic" else dict(disp=c.array(disp), sig=c.array(sig), pgp=c.array(pgp, np.uint8), Et_E=0.1)
+            glv, modf, V, xgp = m.calc_gsm(grav, **kw)
+            info = c.spmv_sym_info()
+            assert info["built"] and info["in_use"] and info["assembly_writes_it"] == (route == "direct")
+            assert info["assembled_directly"] == (route == "direct")
+            xd = c.array(m.fixdof_h * x)
+            f = c.mul(m.fixdof, glv)
+            u, it = c.solve(f, rtol=1e-11)
+            out[form] = dict(K=gpu_matrix(m), glv=glv.get(), modf=modf.get(), V=V, xgp=xgp.get(), y=c.spmv(xd, c.empty(n)).get(),
+                             ylo=c.spmv_lo(xd, c.empty(n)).get(), z=c.mg_apply(xd, c.empty(n)).get(), u=u.get(), it=it["iterations"],
+                             dblk=c.get_diag_blocks().get())
+        res[route] = out
+        c.close()
+    for form in ("elastic", "tangent"):
+        kw = {} if form == "elastic" else dict(disp=disp, sig=sig, pgp=pgp, Et_E=0.1)
+        Ko, glv_o, modf_o, V_o, x_o = oracle_full_matrix(orc, case, grav, **kw)
+        d, cp = res["direct"][form], res["copy"][form]
+        assert abs(d["K"] - Ko).max() <= KTOL * abs(Ko).max()
+        assert abs(d["K"] - d["K"].T).max() == 0.0                      # one stored block serves both halves
+        assert rel(d["glv"], glv_o) < KTOL and rel(d["modf"], modf_o) < KTOL and rel(d["xgp"], x_o.reshape(-1)) < KTOL
+        assert abs(d["V"] - V_o) < 1e-11 * abs(V_o)
+        xm = x.copy()
+        xm[list(case["fix"])] = 0.0
+        assert rel(d["y"], Ko @ xm) < 1e-12
+        diag = np.stack([Ko[3 * i:3 * i + 3, 3 * i:3 * i + 3].toarray().reshape(9) for i in range(n // 3)]).reshape(-1)
+        assert rel(d["dblk"], diag) < KTOL
+        for k in ("glv", "modf", "xgp", "y", "ylo", "z", "u", "dblk"):
+            assert np.array_equal(d[k], cp[k]), (form, k)
+        assert abs(d["V"] - cp["V"]) <= 1e-13 * abs(V_o) and d["it"] == cp["it"]      # (volume partials are summed per work item)
+        assert abs(d["K"] - cp["K"]).max() <= 1e-15 * abs(Ko).max()    # (the copy route reads the sliced-ELL array: both halves stored)
+
+
 def test_update_peeq_csr_matches(orc, gpu_ctx):
     case = small_case(2)
     rng = np.random.default_rng(11)
