@@ -67,14 +67,14 @@ __device__ __forceinline__ void load3(const double *__restrict__ base, int node,
     x = o ? s1 : w.x; y = o ? w.x : w.y; z = o ? w.y : s1;
 }
 
-// SYM (round 4): the work item is 16 consecutive lanes of a wave of the SYMMETRIC window form (WinSym, fcvm_pattern.h) instead of
+// SYM (round 4): the work item is 16 rows of one group of the SYMMETRIC window form (WinSym, fcvm_pattern.h) instead of
 // a quarter slice of the sliced-ELL layout, the row image in LDS holds the row's KEPT blocks only (0.70 x the blocks: less LDS
 // per item, more items per CU), and the finished rows leave LDS straight into the SpMV's storage -- FP64 values of the symmetric
 // form, its 16-bit block-scaled copy and the diagonal blocks for the preconditioner -- so neither the sliced-ELL array nor the
-// copy kernel (k_repack_sym: 3.3 ms per assembly at 1 M elements) is involved.  A lane that holds a later segment of a cut row
-// idles here: the row is assembled once, by the item of its first segment, which writes every segment (consecutive first
-// segments have consecutive later segments -- the lanes of a group are sorted by length with ties in row order -- so those
-// stores coalesce as well).  All element blocks are still integrated (the boundary-condition terms need the blocks that are
+// copy kernel (k_repack_sym: 3.3 ms per assembly at 1 M elements) is involved.  A cut row is assembled once and written
+// segment by segment to the lanes of its segments.  The item's rows are the group's rows in the order of their kept length, 16
+// at a time (every quad busy, one length class per item); their lanes are near each other in the group's waves, so the
+// 16-byte stores of a block row fall into a few 128-byte lines that the L2 completes with the neighbouring items'.  All element blocks are still integrated (the boundary-condition terms need the blocks that are
 // not stored too); only the accumulation into LDS is skipped for a block whose transpose is the stored one.
 struct AsmSym {
     const int32_t *rownode;     // [nwaves*64] node of a lane
@@ -90,6 +90,7 @@ struct AsmSym {
     WinLoTailS *lo2;
     double *dblk;               // [nn*9] diagonal blocks
     int maxl1;                  // row stride of rowoff (longest segment + 1)
+    int waves;                  // waves per group
     int len;                    // kept blocks of the longest row of the launch's length class
 };
 
@@ -110,10 +111,11 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
     // elements and nodes, so that their gathers meet in one L2
     const int64_t nb = gridDim.x, bq = nb >> 3, br = nb & 7, xcd = blockIdx.x & 7;
     const int64_t wg = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + (blockIdx.x >> 3);
-    const int item = items[wg];
-    const int64_t s = item >> 2;
-    const int qd = item & 3;
     const int lane = threadIdx.x, rowl = lane >> 2, h = lane & 3;
+    // SYM: the item lists the lane (wave * 64 + lane) of each of its 16 rows in the window layout, -1: none
+    const int item = SYM ? items[wg * ASM_ROWS] : items[wg];
+    const int64_t s = SYM ? (int64_t)(item >> 6) : (int64_t)(item >> 2);     // SYM: a wave of the item's group
+    const int qd = item & 3;
     // SYM: item = wave * 4 + quarter of the symmetric form; len = the launch's length class (kept blocks)
     const int64_t jb = SYM ? 0 : sptr[s], len = SYM ? (int64_t)sy.len : sptr[s + 1] - jb;   // blocks of the slice's longest row = half chunks of the slice
     const int64_t S = asm_row_stride(len);
@@ -126,8 +128,8 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
         tab[3 * lane] = d0; tab[3 * lane + 1] = d1; tab[3 * lane + 2] = d2;
         tab[120 + lane] = shp_k(k, xi, et, ze);
     }
-    const int64_t slot = s * 64 + qd * ASM_ROWS + rowl;
-    const int node = SYM ? ((sy.seg[slot] & 255u) ? sy.rownode[slot] : -1) : rownode[slot];
+    const int64_t slot = SYM ? (int64_t)items[wg * ASM_ROWS + rowl] : s * 64 + qd * ASM_ROWS + rowl;
+    const int node = SYM ? (slot >= 0 ? sy.rownode[slot] : -1) : rownode[slot];
     const int64_t q0 = node >= 0 ? nptr[node] : 0;
     const int nvis = node >= 0 ? (int)(nptr[node + 1] - q0) : 0;
     int maxvis = nvis;
@@ -400,7 +402,18 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
         const int sub = lane >> 4, r16 = lane & 15;
         const double *src = rowbuf + r16 * S;
         const int nd16 = __shfl(node, 4 * r16, 64);
-        int64_t cur = nd16 >= 0 ? s * 64 + qd * ASM_ROWS + r16 : -1;
+        int64_t cur = nd16 >= 0 ? (int64_t)items[wg * ASM_ROWS + r16] : -1;
+        // the block-row offsets of the waves of this group (every segment of the item's rows lives in one of them) staged in the
+        // free Jacobian area: a dependent global load per block row otherwise, with one wavefront per item to hide it
+        const int64_t wave0 = s - s % sy.waves;
+        uint16_t *ros = (uint16_t *)jac;
+        int64_t *wos = (int64_t *)(jac + ASM_JAC - 16);
+        const bool staged = sy.waves * sy.maxl1 <= (ASM_JAC - 16) * 4 && sy.waves <= 16;
+        if (staged) {
+            for (int i = lane; i < sy.waves * sy.maxl1; i += 64) ros[i] = sy.rowoff[wave0 * sy.maxl1 + i];
+            if (lane < sy.waves) wos[lane] = sy.woff[wave0 + lane];
+        }
+        __syncthreads();
         if (sub == 3 && nd16 >= 0) {
             const double *sd = src + 9 * (int)sy.diagk[nd16];
             double *dd = sy.dblk + 9 * (int64_t)nd16;
@@ -411,8 +424,8 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
             const int64_t wv = cur >> 6;
             const int ln = (int)(cur & 63);
             const int L = sy.rowlen[cur], j0 = sy.jfirst[cur];
-            const int64_t wo = sy.woff[wv];
-            const uint16_t *ro = sy.rowoff + wv * sy.maxl1;
+            const int64_t wo = staged ? wos[wv - wave0] : sy.woff[wv];
+            const uint16_t *ro = staged ? ros + (wv - wave0) * sy.maxl1 : sy.rowoff + wv * sy.maxl1;
             int o0 = ro[0];
             for (int j = 0; j < L; j++) {
                 const int o1 = ro[j + 1];
@@ -444,14 +457,10 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                     } else {
                         double t = rint(ldexp(b9[8], shq));
                         t = t > 32767.0 ? 32767.0 : (t < -32767.0 ? -32767.0 : t);
-                        const uint32_t ct = sy.cols[eoff + ln];
-                        WinLoTailS tl;
-                        tl.q8 = (short)(int)t;
-                        tl.col = (unsigned short)(ct & 0xFFFFu);
-                        tl.eb = (short)eb;
-                        tl.ts = (unsigned short)(ct >> 16);
-                        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                        __builtin_nontemporal_store(__builtin_bit_cast(u32x2, tl), (u32x2 *)(sy.lo2 + eoff + ln));
+                        // {q8, eb}: the first four bytes of the tail; the other four (window column, target lane) belong to the
+                        // pattern and were written when the copy was allocated (k_lo2_static) -- nothing is read here
+                        const uint32_t w4 = (uint32_t)(uint16_t)(short)(int)t | ((uint32_t)(uint16_t)(short)eb << 16);
+                        __builtin_nontemporal_store(w4, (uint32_t *)(sy.lo2 + eoff + ln));
                     }
                 }
                 o0 = o1;

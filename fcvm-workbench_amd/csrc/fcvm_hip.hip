@@ -82,8 +82,8 @@ struct WinSymDev {
     uint16_t *jfirst = nullptr, *rowoff = nullptr;
     int32_t *nextseg = nullptr, *asm_items = nullptr;
     int maxl1 = 0;
-    static constexpr int ASM_BUCKETS = 6;
-    int64_t asm_count[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0}, asm_first[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0};
+    static constexpr int ASM_BUCKETS = 7;
+    int64_t asm_count[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0, 0}, asm_first[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0, 0};
     double *part_vol = nullptr;     // [items] volume partials
     int64_t nitems = 0;
 };
@@ -136,13 +136,13 @@ struct fcvm_ctx {
     int32_t *d_nel = nullptr, *d_nel1 = nullptr;
     int assemble_lds = 1;        // rows accumulated in LDS, one coalesced write per value (FCVM_ASSEMBLE_LDS=0: global read-modify-writes)
     // work items of k_assemble_lds (slice * 4 + quarter), grouped by the LDS a quarter slice needs
-    static constexpr int ASM_BUCKETS = 6;
+    static constexpr int ASM_BUCKETS = 7;
     int32_t *d_asm_items = nullptr;
-    int64_t asm_count[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0}, asm_first[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0};
+    int64_t asm_count[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0, 0}, asm_first[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0, 0};
     bool asm_lds_ok = false;
     // the length classes run side by side on streams of their own (a CU holds one long-row item next to two short-row ones)
-    hipStream_t asm_stream[ASM_BUCKETS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t asm_fork = nullptr, asm_join[ASM_BUCKETS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipStream_t asm_stream[ASM_BUCKETS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t asm_fork = nullptr, asm_join[ASM_BUCKETS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int asm_overlap = 1;         // FCVM_ASSEMBLE_OVERLAP=0: one stream, class after class
     int qin_atomic = 0;          // FCVM_QIN_ATOMIC=1: internal forces scattered with f64 atomics
     double *d_fe = nullptr;      // [ne][10][3] element nodal forces of the last stress update
@@ -587,8 +587,8 @@ static int win_allow_lds(K kernel, size_t bytes) {
     return 0;
 }
 // kept-length classes of the assembly into the symmetric form (blocks of the longest row of a work item's 16 lanes):
-// 22 / 30 / 39 / 53 / 68 / 160 KiB of LDS per item = 7 / 5 / 4 / 3 / 2 / 1 items per CU
-static const int64_t ASM_SYM_LIMIT[WinSymDev::ASM_BUCKETS] = {14, 20, 28, 40, 53, 133};
+// 22 / 30 / 39 / 53 / 68 / 80 / 160 KiB of LDS per item = 7 / 5 / 4 / 3 / 2 / 2 / 1 items per CU
+static const int64_t ASM_SYM_LIMIT[WinSymDev::ASM_BUCKETS] = {14, 20, 28, 40, 53, 64, 133};
 // tables and work items of k_assemble_lds<.., SYM> (after wsym_upload; needs c->d_slotof, c->d_emap, c->d_sptr of fcvm_set_mesh).
 // Not available (asm_ok stays false, the sliced-ELL path + copy kernel remain): rows beyond the largest class, no LDS for it.
 static int wsym_asm_setup(fcvm_ctx *c) {
@@ -601,34 +601,47 @@ static int wsym_asm_setup(fcvm_ctx *c) {
         w.rowoff.clear(); w.rowoff.shrink_to_fit();
     };
     if (!c->asm_sym || !c->assemble_lds || !c->d_slotof || w.kmap.empty()) { release_host(); return 0; }
+    // A work item = 16 rows of ONE group, taken from the group's rows sorted by their kept length (longest first): rows of one
+    // length class together (the LDS of an item is sized by its longest row), every quad busy.  Their lanes in the window layout
+    // are near each other but not consecutive -- the lanes of a group are sorted by SEGMENT length, later segments of cut rows
+    // in between -- so the write-out's 16-byte stores of a block row land in one or two 1 KiB stretches, which the L2 merges
+    // with the neighbouring items' (first version: item = 16 consecutive lanes; 38 % of the items then held a long row, most
+    // of them with half their quads idle on later segments: 12.2 ms per assembly against 10.0 of the copy route).
     std::vector<int32_t> items[WinSymDev::ASM_BUCKETS];
     bool fits = true;
-    for (int64_t wave = 0; wave < w.nwaves && fits; wave++)
-        for (int q = 0; q < 4; q++) {
-            int m = 0;
-            for (int l = 0; l < ASM_ROWS; l++) m = std::max<int>(m, w.rowtot[wave * SLICE + q * ASM_ROWS + l]);
-            if (m == 0) continue;       // later segments and empty lanes only: nothing to assemble
-            if (m > ASM_SYM_LIMIT[WinSymDev::ASM_BUCKETS - 1]) { fits = false; break; }
-            int b = 0;
-            while (m > ASM_SYM_LIMIT[b]) b++;
-            items[b].push_back((int32_t)(wave * 4 + q));
+    {
+        const int64_t R = (int64_t)w.waves * SLICE;
+        std::vector<int32_t> rows;
+        for (int64_t g = 0; g < w.ngroups && fits; g++) {
+            rows.clear();
+            for (int64_t at = g * R; at < (g + 1) * R; at++)
+                if (w.rownode[at] >= 0 && (w.seg[at] & 255u) > 0) rows.push_back((int32_t)at);
+            std::stable_sort(rows.begin(), rows.end(), [&](int32_t x, int32_t y) { return w.rowtot[x] > w.rowtot[y]; });
+            for (size_t k = 0; k < rows.size(); k += ASM_ROWS) {
+                const int m = w.rowtot[rows[k]];
+                if (m > ASM_SYM_LIMIT[WinSymDev::ASM_BUCKETS - 1]) { fits = false; break; }
+                int b = 0;
+                while (m > ASM_SYM_LIMIT[b]) b++;
+                for (int l = 0; l < ASM_ROWS; l++) items[b].push_back(k + l < rows.size() ? rows[k + l] : -1);
+            }
         }
+    }
     const int lds_cap = device_lds_cap(c->device);
     for (int b = 0; b < WinSymDev::ASM_BUCKETS; b++)
         if (!items[b].empty() && (int64_t)asm_lds_bytes(ASM_SYM_LIMIT[b]) > lds_cap) fits = false;
-    if (!fits || w.nwaves >= (int64_t(1) << 29)) { release_host(); return 0; }
-    std::vector<int32_t> all;
+    if (!fits || w.nwaves >= (int64_t(1) << 25)) { release_host(); return 0; }
+    std::vector<int32_t> all;      // [item][16] lane (wave * 64 + lane) of each of the item's rows, -1: none
     for (int b = 0; b < WinSymDev::ASM_BUCKETS; b++) {
-        d.asm_first[b] = (int64_t)all.size();
-        d.asm_count[b] = (int64_t)items[b].size();
+        d.asm_first[b] = (int64_t)all.size() / ASM_ROWS;
+        d.asm_count[b] = (int64_t)items[b].size() / ASM_ROWS;
         all.insert(all.end(), items[b].begin(), items[b].end());
     }
-    d.nitems = (int64_t)all.size();
+    d.nitems = (int64_t)all.size() / ASM_ROWS;
     d.maxl1 = w.maxl + 1;
     uint8_t *d_kmap = nullptr;
     int64_t *d_rowptr = nullptr;
     if (dalloc(&d.emap, c->ne * 100) || dalloc(&d.diagk, c->nn) || dalloc(&d.jfirst, nrows) || dalloc(&d.rowoff, (int64_t)w.rowoff.size()) ||
-        dalloc(&d.nextseg, nrows) || dalloc(&d.asm_items, d.nitems) || dalloc(&d.part_vol, d.nitems) || dalloc(&d_kmap, (int64_t)w.kmap.size()) ||
+        dalloc(&d.nextseg, nrows) || dalloc(&d.asm_items, d.nitems * ASM_ROWS) || dalloc(&d.part_vol, d.nitems) || dalloc(&d_kmap, (int64_t)w.kmap.size()) ||
         dalloc(&d_rowptr, c->nn + 1)) {
         (void)hipGetLastError();
         dfree(d_kmap); dfree(d_rowptr);
@@ -926,7 +939,7 @@ static int tune_matrix_placement(fcvm_ctx *c) {
 }
 
 // slice-length classes of k_assemble_lds (blocks of the longest row): a quarter slice needs asm_lds_bytes() of LDS
-static const int64_t ASM_LEN_LIMIT[fcvm_ctx::ASM_BUCKETS] = {19, 27, 41, 65, 98, 133};   // 28 / 37 / 54 / 81 / 119 / 160 KiB: 5 / 4 / 3 / 2 / 1 / 1 per CU
+static const int64_t ASM_LEN_LIMIT[fcvm_ctx::ASM_BUCKETS] = {19, 27, 41, 65, 82, 98, 133};   // 28 / 37 / 54 / 81 / 100 / 119 / 160 KiB: 5 / 4 / 3 / 2 / 1 / 1 / 1 per CU
 
 static int build_asm_items(fcvm_ctx *c) {
     const Pattern &p = c->pat;
@@ -1024,14 +1037,14 @@ static int launch_assemble_sym(fcvm_ctx *c, const double *disp, const double *si
     AsmSym sy;
     sy.rownode = d.rownode; sy.seg = d.seg; sy.emap = d.emap; sy.rowlen = d.rowlen; sy.jfirst = d.jfirst; sy.rowoff = d.rowoff;
     sy.nextseg = d.nextseg; sy.woff = d.woff; sy.cols = d.cols; sy.diagk = d.diagk; sy.vals = d.vals;
-    sy.lo8 = want_lo ? d.lo8 : nullptr; sy.lo2 = want_lo ? d.lo2 : nullptr; sy.dblk = c->d_dblk; sy.maxl1 = d.maxl1; sy.len = 0;
+    sy.lo8 = want_lo ? d.lo8 : nullptr; sy.lo2 = want_lo ? d.lo2 : nullptr; sy.dblk = c->d_dblk; sy.maxl1 = d.maxl1; sy.waves = d.pat.waves; sy.len = 0;
     for (int b = WinSymDev::ASM_BUCKETS - 1; b >= 0; b--) {   // longest rows first: their items run longest
         if (!d.asm_count[b]) continue;
         hipStream_t st = overlap ? c->asm_stream[b] : c->stream;
         if (overlap) HCHK(hipStreamWaitEvent(st, c->asm_fork, 0));
         sy.len = (int)ASM_SYM_LIMIT[b];
         hipLaunchKernelGGL((k_assemble_lds<TANGENT, true>), dim3((unsigned)d.asm_count[b]), dim3(64), (size_t)asm_lds_bytes(ASM_SYM_LIMIT[b]), st,
-                           d.asm_items + d.asm_first[b], c->d_sptr, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord, disp, c->d_fixmask,
+                           d.asm_items + d.asm_first[b] * ASM_ROWS, c->d_sptr, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord, disp, c->d_fixmask,
                            c->d_fixval, c->d_emap, sig, pgp, mc, grav[0], grav[1], grav[2], (double *)nullptr, glv, modf, xgp,
                            d.part_vol + d.asm_first[b], 0, sy);
         if (overlap) {
@@ -1578,7 +1591,10 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
     if (direct) {
         WinSymDev &ws = c->wsym;
         if (lo && !c->win.part_lo && dalloc(&c->win.part_lo, 2 * c->win.pat.ngroups)) return 1;
-        if (lo && !ws.lo8 && (dalloc(&ws.lo8, ws.pat.nblocks) || dalloc(&ws.lo2, ws.pat.nblocks))) return 1;
+        if (lo && !ws.lo8) {
+            if (dalloc(&ws.lo8, ws.pat.nblocks) || dalloc(&ws.lo2, ws.pat.nblocks)) return 1;
+            hipLaunchKernelGGL(k_lo2_static, dim3((unsigned)cdiv(ws.pat.nblocks, 256)), dim3(256), 0, s, ws.pat.nblocks, ws.cols, ws.lo2);
+        }
         if (sig ? launch_assemble_sym<true>(c, disp, sig, pgp, mc, grav, glv_grav, modf, xgp, lo)
                 : launch_assemble_sym<false>(c, disp, nullptr, nullptr, mc, grav, glv_grav, modf, xgp, lo))
             return 1;

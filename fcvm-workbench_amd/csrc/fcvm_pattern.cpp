@@ -629,6 +629,31 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
         }
     }, 16);
     lap("pass 2 (entries)");
+    if (getenv("FCVM_SYM_STATS")) {      // what the assembly's work items (16 lanes of a wave) look like: kept blocks of their rows
+        int64_t hist[9] = {0}, items = 0, sum_max = 0, sum_tot = 0, first = 0, later = 0, empty = 0;
+        const int lim[9] = {14, 20, 28, 34, 40, 46, 53, 64, 255};
+        for (int64_t it = 0; it < s.nwaves * 4; it++) {
+            int m = 0, nf = 0;
+            for (int l = 0; l < 16; l++) {
+                const int64_t at = it * 16 + l;
+                if (s.rownode[at] < 0) { empty++; continue; }
+                if ((s.seg[at] & 255u) == 0) { later++; continue; }
+                first++; nf++;
+                m = std::max<int>(m, s.rowtot[at]);
+                sum_tot += s.rowtot[at];
+            }
+            if (!nf) continue;
+            items++;
+            sum_max += 16 * m;
+            int b = 0;
+            while (m > lim[b]) b++;
+            hist[b]++;
+        }
+        fprintf(stderr, "fcvm symmetric form: %lld items; lanes: %lld rows, %lld later segments, %lld empty; kept blocks %lld, 16 x item maximum %lld (%.2f x)\n   items by longest row:",
+                (long long)items, (long long)first, (long long)later, (long long)empty, (long long)sum_tot, (long long)sum_max, (double)sum_max / (double)sum_tot);
+        for (int b = 0; b < 9; b++) fprintf(stderr, " <=%d: %lld", lim[b], (long long)hist[b]);
+        fprintf(stderr, "\n");
+    }
     return true;
 }
 

@@ -45,10 +45,12 @@ static_assert(sizeof(WinLoTail) == 8, "WinLoTail must be 8 bytes");
 // and the block exponent is stored ABSOLUTELY (frexp exponent of the block maximum, 16 bits; round 4): whoever writes a block
 // needs nothing global -- the assembly kernel writes this layout itself, before the matrix exponent e0 is known -- and the
 // kernels form e = eb - e0 when they read it
+// kernels form e = eb - e0 when they read it.  The first four bytes change with every assembly, the last four are the pattern's
+// (written once, k_lo2_static): the assembly kernel stores {q8, eb} as one 4-byte word without reading the entry
 struct __attribute__((aligned(8))) WinLoTailS {
     short q8;
-    unsigned short col;
     short eb;
+    unsigned short col;
     unsigned short ts;      // position in the group of the first segment of the column node's row, 0xFFFF: no transposed product
 };
 static_assert(sizeof(WinLoTailS) == 8, "WinLoTailS must be 8 bytes");
@@ -931,6 +933,19 @@ __global__ __launch_bounds__(64) void k_spmv_l1_i16(int64_t nslices, const int64
     epi.x[o] += a0; epi.x[o + 1] += a1; epi.x[o + 2] += a2;
 }
 
+// the pattern's half of the 16-bit tails of the symmetric form (window column, target lane), written once when the copy is allocated
+__global__ __launch_bounds__(256) void k_lo2_static(int64_t n, const uint32_t *__restrict__ cols, WinLoTailS *__restrict__ lo2) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t ct = cols[i];
+    WinLoTailS tl;
+    tl.q8 = 0;
+    tl.eb = -1023;
+    tl.col = (unsigned short)(ct & 0xFFFFu);
+    tl.ts = (unsigned short)(ct >> 16);
+    lo2[i] = tl;
+}
+
 // ---- symmetric form of the window format (WinSym, fcvm_pattern.h): the PCG's FP64 SpMV on 0.70 x the blocks --------------------
 // values of the sliced-ELL array -> symmetric window storage (V2 component layout); thread = vrow, source block from jell
 __global__ __launch_bounds__(256) void k_repack_sym(int64_t nrows, const int32_t *__restrict__ srcslot, const uint16_t *__restrict__ rowlen,
@@ -1285,8 +1300,8 @@ template <int NRHS>
 __device__ __forceinline__ void win_fma_lo_sym(const WinSlotLo &t, bool active, const float *xs, const float (&o)[3 * NRHS],
                                                unsigned long long *yacc, const int (&sh)[NRHS], const bool (&tr_on)[NRHS], int e0,
                                                float (&y)[3 * NRHS]) {
-    const float *xa = xs + 3 * NRHS * (int)t.t.col;
     const WinLoTailS ts8 = __builtin_bit_cast(WinLoTailS, t.t);
+    const float *xa = xs + 3 * NRHS * (int)ts8.col;
     const int e = (int)ts8.eb - e0;       // <= 0 for an SPD matrix (every entry below its largest diagonal entry)
     const float sc = active ? __builtin_bit_cast(float, (127 + (e < -126 ? -126 : (e > 127 ? 127 : e))) << 23) : 0.0f;
     const float q0 = (float)(int)t.a[0], q1 = (float)(int)t.a[1], q2 = (float)(int)t.a[2], q3 = (float)(int)t.a[3], q4 = (float)(int)t.a[4],
