@@ -35,7 +35,12 @@ constexpr int ASM_JREC = 10;                       // doubles per (row, Gauss po
 constexpr int ASM_JAC = ASM_ROWS * 4 * ASM_JREC;   // doubles
 // len = blocks of the longest row of the slice; row stride in doubles, odd so that the 16 rows spread over the LDS banks
 __host__ __device__ inline int64_t asm_row_stride(int64_t len) { return len * 9 + ((len & 1) ? 0 : 1); }
-__host__ __device__ inline int64_t asm_lds_bytes(int64_t len) { return (ASM_TAB + ASM_JAC + ASM_ROWS * asm_row_stride(len)) * 8; }
+// tangent form: deviatoric stress and plastic factor of the visited elements' Gauss points, one record per (row, Gauss point)
+constexpr int ASM_PREC = 8;                        // doubles: pf, s[6], unused
+constexpr int ASM_PL = ASM_ROWS * 4 * ASM_PREC;    // doubles
+__host__ __device__ inline int64_t asm_lds_bytes(int64_t len, bool tangent = true) {
+    return (ASM_TAB + ASM_JAC + (tangent ? ASM_PL : 0) + ASM_ROWS * asm_row_stride(len)) * 8;
+}
 
 // Hides where a pointer came from, so that loads through it are not hoisted out of the visit loop: every lane always
 // uses the same table entries (its Gauss point, its three local columns: 66 doubles), and keeping all of them in
@@ -56,6 +61,8 @@ struct AsmGeom {      // what lane h of a quad fetches for one visit: its local 
     uint32_t em[3];   // packed block location of (row node, b)
     int ndb[3];       // node b
     int fb[3];        // its support flags
+    uint32_t pg;      // tangent form: the element's four plastic flags (pgp[4 e .. 4 e + 3])
+    double sg[6];     // ... and the stress of Gauss point h of the element
 };
 
 // three doubles at a 24-byte stride: one 8-byte and one 16-byte load (even nodes are 16-byte aligned, odd ones 8 off)
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                                                      double *__restrict__ xgp, double *__restrict__ volume, int penalty_bc,
                                                      AsmSym sy = AsmSym{}) {
     extern __shared__ double lds[];
-    double *tab = lds, *jac = lds + ASM_TAB, *rowbuf = lds + ASM_TAB + ASM_JAC;
+    double *tab = lds, *jac = lds + ASM_TAB, *pl = lds + ASM_TAB + ASM_JAC, *rowbuf = lds + ASM_TAB + ASM_JAC + (TANGENT ? ASM_PL : 0);
     // XCD-aware remap (as k_spmv): the workgroups of one XCD take a contiguous range of work items, whose rows share
     // elements and nodes, so that their gathers meet in one L2
     const int64_t nb = gridDim.x, bq = nb >> 3, br = nb & 7, xcd = blockIdx.x & 7;
@@ -168,6 +175,13 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
             G.em[t] = SYM ? (uint32_t)sy.emap[e * 100 + a * 10 + min(h + 4 * t, 9)] : emap[e * 100 + a * 10 + min(h + 4 * t, 9)];
             G.fb[t] = fixmask[nd[t]];
         }
+        if (TANGENT) {   // with the other inputs of the visit, one visit ahead (round 4: these loads used to sit inside the Gauss
+                         // point loop, four dependent round trips to memory per visit with one or two wavefronts per CU to hide them)
+            G.pg = *(const uint32_t *)(pgp + 4 * e);
+            const double2 *s2 = (const double2 *)(sig + 24 * e + 6 * h);
+            const double2 q0 = s2[0], q1 = s2[1], q2 = s2[2];
+            G.sg[0] = q0.x; G.sg[1] = q0.y; G.sg[2] = q1.x; G.sg[3] = q1.y; G.sg[4] = q2.x; G.sg[5] = q2.y;
+        }
     };
 
     double racc[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};   // gravity (3), modf (3), volume
@@ -211,6 +225,20 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
             j2[0] = double2{mine[0], mine[1]}; j2[1] = double2{mine[2], mine[3]}; j2[2] = double2{mine[4], mine[5]};
             j2[3] = double2{mine[6], mine[7]}; j2[4] = double2{mine[8], xsj * FCVM_GPW};
         }
+        if (TANGENT) {   // deviatoric stress and plastic factor of Gauss point h (fcVM.py:983-998), once per quad -> LDS record of (row, h)
+            double pf = 0.0, Sg[6] = {0, 0, 0, 0, 0, 0};
+            if (active && ((G0.pg >> (8 * h)) & 0xFFu)) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) Sg[j] = G0.sg[j];
+                const double p = (Sg[0] + Sg[1] + Sg[2]) / 3.0;
+                Sg[0] -= p; Sg[1] -= p; Sg[2] -= p;
+                double svm = sqrt(1.5 * (Sg[0] * Sg[0] + Sg[1] * Sg[1] + Sg[2] * Sg[2]) + 3.0 * (Sg[3] * Sg[3] + Sg[4] * Sg[4] + Sg[5] * Sg[5]));
+                if (svm == 0.0) svm = 1.0;
+                pf = 3.0 * mc.G / (1.0 + mc.H / 3.0 / mc.G) / (svm * svm);
+            }
+            double2 *p2 = (double2 *)(pl + (rowl * 4 + h) * ASM_PREC);
+            p2[0] = double2{pf, Sg[0]}; p2[1] = double2{Sg[1], Sg[2]}; p2[2] = double2{Sg[3], Sg[4]}; p2[3] = double2{Sg[5], 0.0};
+        }
         // Gauss point coordinates (fcVM.py:761): lane 3 of the quad (it integrates one block less)
         if (xgp && active && a < 4 && h == 3) {
             const double *nsa = tab + 120 + 10 * a;
@@ -247,17 +275,10 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
             to_global(xsi, da[0], da[1], da[2], ga[0], ga[1], ga[2]);
             gam += wg_ * tab[120 + 10 * g + a];
             double pf = 0.0, Sg[6] = {0, 0, 0, 0, 0, 0}, ta[3];
-            if (TANGENT) {   // deviatoric stress and plastic factor of Gauss point g (fcVM.py:983-998); same address in the quad
-                if (active && pgp[4 * e + g]) {
-                    const double *s0 = sig + 24 * e + 6 * g;
-#pragma unroll
-                    for (int j = 0; j < 6; j++) Sg[j] = s0[j];
-                    const double p = (Sg[0] + Sg[1] + Sg[2]) / 3.0;
-                    Sg[0] -= p; Sg[1] -= p; Sg[2] -= p;
-                    double svm = sqrt(1.5 * (Sg[0] * Sg[0] + Sg[1] * Sg[1] + Sg[2] * Sg[2]) + 3.0 * (Sg[3] * Sg[3] + Sg[4] * Sg[4] + Sg[5] * Sg[5]));
-                    if (svm == 0.0) svm = 1.0;
-                    pf = 3.0 * mc.G / (1.0 + mc.H / 3.0 / mc.G) / (svm * svm);
-                }
+            if (TANGENT) {   // the record lane g of the quad left for Gauss point g
+                const double2 *P2 = (const double2 *)(pl + (rowl * 4 + g) * ASM_PREC);
+                const double2 r0 = P2[0], r1 = P2[1], r2 = P2[2], r3 = P2[3];
+                pf = r0.x; Sg[0] = r0.y; Sg[1] = r1.x; Sg[2] = r1.y; Sg[3] = r2.x; Sg[4] = r2.y; Sg[5] = r3.x;
                 ta[0] = ga[0] * Sg[0] + ga[1] * Sg[3] + ga[2] * Sg[4];
                 ta[1] = ga[1] * Sg[1] + ga[0] * Sg[3] + ga[2] * Sg[5];
                 ta[2] = ga[2] * Sg[2] + ga[0] * Sg[4] + ga[1] * Sg[5];

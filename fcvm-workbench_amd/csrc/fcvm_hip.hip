@@ -1002,7 +1002,7 @@ static int launch_assemble_lds(fcvm_ctx *c, const double *disp, const double *si
         if (!c->asm_count[b]) continue;
         hipStream_t st = overlap ? c->asm_stream[b] : c->stream;
         if (overlap) HCHK(hipStreamWaitEvent(st, c->asm_fork, 0));
-        hipLaunchKernelGGL(k_assemble_lds<TANGENT>, dim3((unsigned)c->asm_count[b]), dim3(64), (size_t)asm_lds_bytes(ASM_LEN_LIMIT[b]), st,
+        hipLaunchKernelGGL(k_assemble_lds<TANGENT>, dim3((unsigned)c->asm_count[b]), dim3(64), (size_t)asm_lds_bytes(ASM_LEN_LIMIT[b], TANGENT), st,
                            c->d_asm_items + c->asm_first[b], c->d_sptr, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord, disp, c->d_fixmask,
                            c->d_fixval, c->d_emap, sig, pgp, mc, grav[0], grav[1], grav[2], c->d_vals, glv, modf, xgp,
                            vol_part ? vol_part + c->asm_first[b] : nullptr, penalty_bc);
@@ -1043,7 +1043,7 @@ static int launch_assemble_sym(fcvm_ctx *c, const double *disp, const double *si
         hipStream_t st = overlap ? c->asm_stream[b] : c->stream;
         if (overlap) HCHK(hipStreamWaitEvent(st, c->asm_fork, 0));
         sy.len = (int)ASM_SYM_LIMIT[b];
-        hipLaunchKernelGGL((k_assemble_lds<TANGENT, true>), dim3((unsigned)d.asm_count[b]), dim3(64), (size_t)asm_lds_bytes(ASM_SYM_LIMIT[b]), st,
+        hipLaunchKernelGGL((k_assemble_lds<TANGENT, true>), dim3((unsigned)d.asm_count[b]), dim3(64), (size_t)asm_lds_bytes(ASM_SYM_LIMIT[b], TANGENT), st,
                            d.asm_items + d.asm_first[b] * ASM_ROWS, c->d_sptr, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord, disp, c->d_fixmask,
                            c->d_fixval, c->d_emap, sig, pgp, mc, grav[0], grav[1], grav[2], (double *)nullptr, glv, modf, xgp,
                            d.part_vol + d.asm_first[b], 0, sy);
