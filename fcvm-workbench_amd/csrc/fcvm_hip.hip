@@ -174,6 +174,7 @@ struct fcvm_ctx {
     int32_t *d_slotof = nullptr;   // [nn] sliced-ELL slot of a node, kept from fcvm_set_mesh's uploads until the symmetric form is set up
     int asm_sym = 1;            // FCVM_ASSEMBLE_SYM=0: stiffness matrices go through the sliced-ELL array and the copy kernel (rounds 2-3)
     bool sell_valid = false;    // d_vals holds the matrix of the last assembly (false after an assembly straight into the symmetric form)
+    bool wsym_pending = false;  // the symmetric form's host build may still be running; its device half is done by wsym_finish
     bool sym_pair = true;       // two right-hand sides share one pass over the symmetric form (FCVM_SYM_PAIR=0: the one-vector kernels twice)
     bool mg_fuse_prolong = false;  // FCVM_MG_FUSE_PROLONG=1: x + P e1 formed while the post-smoothing pass stages x instead of by k_prolong_add
                                    // (measured: 212 us against 177 + 29 -- every window node is staged by 2.9 groups -- so off)
@@ -591,10 +592,23 @@ static int win_allow_lds(K kernel, size_t bytes) {
 static const int64_t ASM_SYM_LIMIT[WinSymDev::ASM_BUCKETS] = {14, 20, 28, 40, 53, 64, 133};
 // tables and work items of k_assemble_lds<.., SYM> (after wsym_upload; needs c->d_slotof, c->d_emap, c->d_sptr of fcvm_set_mesh).
 // Not available (asm_ok stays false, the sliced-ELL path + copy kernel remain): rows beyond the largest class, no LDS for it.
+struct StageLap {      // FCVM_PATTERN_TIMING=1: wall time of the stages of a set-up function on stderr
+    const char *who;
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    explicit StageLap(const char *w) : who(w), on(getenv("FCVM_PATTERN_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void operator()(const char *what) {
+        if (!on) return;
+        auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "fcvm %s: %-28s %.3f s\n", who, what, std::chrono::duration<double>(n - t).count());
+        t = n;
+    }
+};
 static int wsym_asm_setup(fcvm_ctx *c) {
     WinSymDev &d = c->wsym;
     WinSym &w = d.pat;
     d.asm_ok = false;
+    StageLap lap("assembly into the symmetric form");
     const int64_t nrows = w.nwaves * SLICE;
     auto release_host = [&]() {
         w.kmap.clear(); w.kmap.shrink_to_fit();
@@ -611,21 +625,36 @@ static int wsym_asm_setup(fcvm_ctx *c) {
     bool fits = true;
     {
         const int64_t R = (int64_t)w.waves * SLICE;
-        std::vector<int32_t> rows;
-        for (int64_t g = 0; g < w.ngroups && fits; g++) {
-            rows.clear();
-            for (int64_t at = g * R; at < (g + 1) * R; at++)
-                if (w.rownode[at] >= 0 && (w.seg[at] & 255u) > 0) rows.push_back((int32_t)at);
-            std::stable_sort(rows.begin(), rows.end(), [&](int32_t x, int32_t y) { return w.rowtot[x] > w.rowtot[y]; });
-            for (size_t k = 0; k < rows.size(); k += ASM_ROWS) {
-                const int m = w.rowtot[rows[k]];
-                if (m > ASM_SYM_LIMIT[WinSymDev::ASM_BUCKETS - 1]) { fits = false; break; }
-                int b = 0;
-                while (m > ASM_SYM_LIMIT[b]) b++;
-                for (int l = 0; l < ASM_ROWS; l++) items[b].push_back(k + l < rows.size() ? rows[k + l] : -1);
+        int nt = (int)std::thread::hardware_concurrency();
+        nt = std::min(std::max(nt, 1), 32);
+        std::vector<std::vector<int32_t>> part(nt * WinSymDev::ASM_BUCKETS);      // per thread (= contiguous range of groups) and class
+        std::vector<char> bad(nt, 0);
+        parallel_for(w.ngroups, nt, [&](int64_t gb, int64_t ge, int t) {
+            std::vector<int32_t> rows;
+            for (int64_t g = gb; g < ge; g++) {
+                rows.clear();
+                for (int64_t at = g * R; at < (g + 1) * R; at++)
+                    if (w.rownode[at] >= 0 && (w.seg[at] & 255u) > 0) rows.push_back((int32_t)at);
+                std::stable_sort(rows.begin(), rows.end(), [&](int32_t x, int32_t y) { return w.rowtot[x] > w.rowtot[y]; });
+                for (size_t k = 0; k < rows.size(); k += ASM_ROWS) {
+                    const int m = w.rowtot[rows[k]];
+                    if (m > ASM_SYM_LIMIT[WinSymDev::ASM_BUCKETS - 1]) { bad[t] = 1; return; }
+                    int b = 0;
+                    while (m > ASM_SYM_LIMIT[b]) b++;
+                    std::vector<int32_t> &dst = part[t * WinSymDev::ASM_BUCKETS + b];
+                    for (int l = 0; l < ASM_ROWS; l++) dst.push_back(k + l < rows.size() ? rows[k + l] : -1);
+                }
+            }
+        }, 16);
+        for (int t = 0; t < nt; t++) {      // (threads in order: the same item lists whatever the thread count)
+            if (bad[t]) fits = false;
+            for (int b = 0; b < WinSymDev::ASM_BUCKETS; b++) {
+                const std::vector<int32_t> &src = part[t * WinSymDev::ASM_BUCKETS + b];
+                items[b].insert(items[b].end(), src.begin(), src.end());
             }
         }
     }
+    lap("work items (host)");
     const int lds_cap = device_lds_cap(c->device);
     for (int b = 0; b < WinSymDev::ASM_BUCKETS; b++)
         if (!items[b].empty() && (int64_t)asm_lds_bytes(ASM_SYM_LIMIT[b]) > lds_cap) fits = false;
@@ -649,6 +678,7 @@ static int wsym_asm_setup(fcvm_ctx *c) {
         release_host();
         return 0;       // (no memory for the tables: the copy-kernel path stays)
     }
+    lap("allocations");
     hipStream_t s = c->stream;
     HCHK(hipMemcpyAsync(d.diagk, w.diagk.data(), sizeof(uint8_t) * c->nn, hipMemcpyHostToDevice, s));
     HCHK(hipMemcpyAsync(d.jfirst, w.jfirst.data(), sizeof(uint16_t) * nrows, hipMemcpyHostToDevice, s));
@@ -661,8 +691,10 @@ static int wsym_asm_setup(fcvm_ctx *c) {
                        c->d_emap, d_kmap, d.emap);
     HCHK(hipGetLastError());
     HCHK(hipStreamSynchronize(s));
+    lap("uploads, element map kernel");
     dfree(d_kmap); dfree(d_rowptr);
     release_host();
+    lap("release");
     static int asm_sym_lds_allowed_dev[64] = {0};
     int &allowed = asm_sym_lds_allowed_dev[c->device & 63];
     if (allowed == 0) allowed = 64 * 1024;
@@ -685,7 +717,9 @@ static int wsym_asm_setup(fcvm_ctx *c) {
 // device copy of the symmetric form built by win_build_host (nothing to do when it was not built); used only where two
 // workgroups of it fit the LDS of a CU
 static int wsym_upload(fcvm_ctx *c) {
+    StageLap lap("symmetric form (device)");
     if (c->sym_thread.joinable()) c->sym_thread.join();
+    lap("wait for the host build");
     WinSymDev &d = c->wsym;
     const WinSym &w = d.pat;
     if (w.nblocks <= 0 || !c->win.on) { d.pat = WinSym(); return 0; }
@@ -718,6 +752,7 @@ static int wsym_upload(fcvm_ctx *c) {
     HCHK(hipMemcpyAsync(d.jell, w.jell.data(), sizeof(uint8_t) * w.nblocks, hipMemcpyHostToDevice, s));
     HCHK(hipMemsetAsync(d.vals, 0, sizeof(double) * 9 * w.nblocks, s));
     HCHK(hipStreamSynchronize(s));
+    lap("allocations, uploads");
     size_t &lds_allowed = lds_allowed_dev[c->device & 63];
     lds_allowed = std::max(lds_allowed, d.lds);
     if (win_allow_lds(k_spmv_win_sym<true, WIN_WAVES, 1>, lds_allowed) || win_allow_lds(k_spmv_win_sym<false, WIN_WAVES, 1>, lds_allowed) ||
@@ -794,8 +829,28 @@ static int setup_window_format_body(fcvm_ctx *c, const WinBuild &res);
 // (a failed fcvm_set_mesh followed by another one on the same context)
 static int setup_window_format(fcvm_ctx *c, const WinBuild &res) {
     const int rc = setup_window_format_body(c, res);
-    if (c->sym_thread.joinable()) c->sym_thread.join();
+    if (rc || !c->wsym_pending) {
+        if (c->sym_thread.joinable()) c->sym_thread.join();
+        c->wsym_pending = false;
+    }
     if (rc) { wsym_free(c->wsym); }
+    return rc;
+}
+// The symmetric form's host build (0.05-0.09 s at 1 M elements) can only start when the full form's is done, so fcvm_set_mesh
+// would sit waiting for it; it returns instead and the device half (upload, the assembly's element map and work items) happens
+// here, at the first call that needs the form -- the caller's own set-up work (supports, load vectors) runs beside the thread.
+static int wsym_finish(fcvm_ctx *c) {
+    if (!c->wsym_pending) return 0;
+    c->wsym_pending = false;
+    HCHK(hipSetDevice(c->device));
+    const int rc = wsym_upload(c);      // (joins the builder)
+    if (c->sym_thread.joinable()) c->sym_thread.join();
+    WinPattern &w = c->win.pat;
+    // the host copies of the big tables are not needed again (the symmetric form's builder has read them)
+    w.wlist.clear(); w.wlist.shrink_to_fit();
+    w.cols.clear(); w.cols.shrink_to_fit();
+    dfree(c->d_slotof);
+    if (rc) wsym_free(c->wsym);
     return rc;
 }
 static int setup_window_format_body(fcvm_ctx *c, const WinBuild &res) {
@@ -837,10 +892,8 @@ static int setup_window_format_body(fcvm_ctx *c, const WinBuild &res) {
     // other otherwise)
     c->win2_ok = 2 * lds <= (size_t)lds_cap;
     if (c->win2_ok && (win_allow_lds(k_spmv_win2<true, WIN_WAVES>, 2 * lds) || win_allow_lds(k_spmv_win2<true, 4>, 2 * lds))) return 1;
-    if (wsym_upload(c)) return 1;
-    // the host copies of the big tables are not needed again (the symmetric form's builder has read them)
-    w.wlist.clear(); w.wlist.shrink_to_fit();
-    w.cols.clear(); w.cols.shrink_to_fit();
+    c->wsym_pending = true;      // (wsym_finish: at the first assembly)
+    if (getenv("FCVM_WSYM_EAGER") && atoi(getenv("FCVM_WSYM_EAGER")) != 0 && wsym_finish(c)) return 1;
     if (getenv("FCVM_VERBOSE"))
         fprintf(stderr, "fcvm: window format: %lld groups of %d waves, windows mean %.0f / max %lld nodes (%zu B LDS of %d), %lld entries\n",
                 (long long)w.ngroups, w.waves, w.wmean, (long long)w.wmax, lds, lds_cap, (long long)w.nblocks);
@@ -1116,6 +1169,7 @@ static void mg_topology_start(fcvm_ctx *c);
 static void free_mesh(fcvm_ctx *c) {
     mg_topology_join(c, true);
     if (c->sym_thread.joinable()) c->sym_thread.join();
+    c->wsym_pending = false;
     dfree(c->d_el); dfree(c->d_cols); dfree(c->d_rownode); dfree(c->d_noce); dfree(c->d_sptr);
     dfree(c->d_emap); dfree(c->d_diagoff); dfree(c->d_fixmask); dfree(c->d_coord); dfree(c->d_fixval);
     dfree(c->d_nptr); dfree(c->d_nel); dfree(c->d_fe); dfree(c->d_part_vol); dfree(c->d_asm_items); dfree(c->d_slotof);
@@ -1257,7 +1311,10 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     WinBuild winres;
     std::thread winthread(win_build_host, c, nocoord, &winres);
     // joined on every return path, the symmetric form's builder (started by winthread) after it
-    struct Joiner { std::thread &t; std::thread &t2; ~Joiner() { if (t.joinable()) t.join(); if (t2.joinable()) t2.join(); } } joiner{winthread, c->sym_thread};
+    struct Joiner {
+        std::thread &t; std::thread &t2; bool keep_second = false;
+        ~Joiner() { if (t.joinable()) t.join(); if (!keep_second && t2.joinable()) t2.join(); }
+    } joiner{winthread, c->sym_thread};
     c->h_el = el;
     c->h_coord.assign(nocoord, nocoord + 3 * nn);
     c->h_fixmask.assign(nn, 0);
@@ -1310,7 +1367,8 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     winthread.join();
     if (setup_window_format(c, winres)) return 1;
     lap("window format (rest of the build + upload)");
-    dfree(c->d_slotof);
+    if (!c->wsym_pending) dfree(c->d_slotof);
+    joiner.keep_second = c->wsym_pending;      // (the symmetric form's builder may run on: wsym_finish joins it)
     c->h_morton.clear();
     c->h_morton.shrink_to_fit();
     if (!c->win.on && tune_matrix_placement(c)) return 1;
@@ -1319,6 +1377,13 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     c->pat.emap.shrink_to_fit();
     c->have_mesh = true;
     return 0;
+}
+
+/* completes what fcvm_set_mesh left running in the background (the symmetric window form's host build and its device half);
+ * called implicitly by the first fcvm_assemble -- a caller with host work of its own between the two calls it after that work */
+int fcvm_finish_setup(fcvm_ctx *c) {
+    NEED(c && c->have_mesh, "fcvm_finish_setup: no mesh");
+    return wsym_finish(c);
 }
 
 int fcvm_set_coords(fcvm_ctx *c, const double *nocoord) {
@@ -1386,6 +1451,7 @@ int fcvm_spmv_info(fcvm_ctx *c, int64_t out[8]) {
  * if the assembly kernels can write the form themselves, out[7] = 1 if the last assembly did (no sliced-ELL array, no copy) */
 int fcvm_spmv_sym_info(fcvm_ctx *c, int64_t out[8]) {
     NEED(c && c->have_mesh && out, "fcvm_spmv_sym_info: no mesh");
+    if (wsym_finish(c)) return 1;
     for (int k = 0; k < 8; k++) out[k] = 0;
     if (!c->wsym.on) return 0;
     const WinSym &w = c->wsym.pat;
@@ -1571,6 +1637,7 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
     NEED(c && c->have_mesh && c->have_mat, "fcvm_assemble: mesh and material must be set");
     NEED(glv_grav && modf, "fcvm_assemble: glv_grav and modf are required");
     NEED((sig == nullptr) == (pgp == nullptr), "fcvm_assemble: sig and pgp go together");
+    if (wsym_finish(c)) return 1;
     hipStream_t s = c->stream;
     const bool use_lds = c->assemble_lds && c->asm_lds_ok;
     if (!use_lds) HCHK(hipMemsetAsync(c->d_vals, 0, sizeof(double) * c->pat.value_count(), s));   // the LDS kernel writes every value once
@@ -2456,6 +2523,7 @@ int fcvm_get_mg_cycle(fcvm_ctx *c, int *form, double *weight, int *fp16_copy_in_
  */
 int fcvm_assemble_buckling(fcvm_ctx *c, const double *sig, double shift) {
     NEED(c && c->have_mesh && c->have_mat && sig, "fcvm_assemble_buckling: mesh, material and stresses are required");
+    if (wsym_finish(c)) return 1;
     hipStream_t s = c->stream;
     const int64_t nv = c->pat.value_count();
     if (!c->d_vals_g && dalloc(&c->d_vals_g, nv)) return 1;

@@ -62,6 +62,7 @@ SIGNATURES = {
     "fcvm_host_pattern_check": [_i64, _i64, _vp, _pi64],
     "fcvm_check_device_emap": [_vp, _pi64],
     "fcvm_host_window_sym_check": [_i64, _i64, _vp, _vp, _pi64],
+    "fcvm_finish_setup": [_vp],
     "fcvm_spmv_sym_info": [_vp, _pi64],
     "fcvm_spmv_info": [_vp, _pi64],
     "fcvm_mem_info": [_vp, _pi64],

@@ -379,6 +379,10 @@ class Context:
         call("fcvm_spmv", self.h, x.ptr, y.ptr)
         return y
 
+    def finish_setup(self):
+        """wait for / upload what set_mesh left building in the background (otherwise the first assemble does)"""
+        call("fcvm_finish_setup", self.h)
+
     def spmv_lo(self, x, y):
         """y = K~ x with the 16-bit block-scaled copy of the matrix (the smoother's operator in cycle form 2)"""
         call("fcvm_spmv_lo", self.h, x.ptr, y.ptr)

@@ -1176,6 +1176,7 @@ class HipLocalOps:
         self.c.set_mesh(part.elNodes, nocoord_local)
         self.c.set_material(*material)
         self.c.set_fix(fix_local)
+        self.c.finish_setup()
         self.element_offset = element_offset
         self.local_mg = False
 

@@ -45,6 +45,7 @@ class GpuModel:
         self.movdof = self.ctx.array(movdof)
         self.moving = bool(movdof.max() == 1.0) if len(movdof) else False
         self._ext = None   # device copy of the external load vector (None: not built yet, False: no such loads)
+        self.ctx.finish_setup()   # (the symmetric window form was building beside the lines above)
 
     def calc_gsm(self, grav, disp=None, sig=None, pgp=None, Et_E=0.0, want_x=True):
         """calcGSM (fcVM.py:621-816) / calcTSM material part: assembles K on the GPU, returns

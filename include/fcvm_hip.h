@@ -57,6 +57,11 @@ int fcvm_memset0(fcvm_ctx *c, void *dev, uint64_t bytes);
 int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, const double *nocoord);
 int fcvm_set_material(fcvm_ctx *c, double E, double nu, double density);
 int fcvm_set_fix(fcvm_ctx *c, int64_t nfix, const int64_t *dofs, const double *vals);
+/* fcvm_set_mesh returns while a background thread still builds the symmetric form of the window format (round 4); the first
+ * fcvm_assemble waits for it and uploads it.  A caller with host work of its own after fcvm_set_mesh (supports, load vectors)
+ * calls this when that work is done, so that the wait does not fall into the analysis.  No reference counterpart. */
+int fcvm_finish_setup(fcvm_ctx *c);
+
 /* nodal coordinate update (imperfections, fcVM.py:1240) */
 int fcvm_set_coords(fcvm_ctx *c, const double *nocoord);
 
