@@ -257,7 +257,9 @@ def run_single(args):
         "pcg_iterations_per_step": pcg_its / args.steps,
         "pcg_iterations_per_solve": pcg_its / max(solves, 1),
         "fine_spmv_per_step": (s1.get("spmv_total", 0) - s0.get("spmv_total", 0)) / args.steps,
-        "assembly": {"ms": t_asm * 1e3, "elements_gp_per_s": ne * 4 / t_asm},
+        "assembly": {"ms": t_asm * 1e3, "elements_gp_per_s": ne * 4 / t_asm,
+                     "route": ("k_assemble_lds<SYM>: rows leave LDS straight into the SpMV's storage (symmetric window form, its 16-bit copy, "
+                               "diagonal blocks)" if sinfo.get("assembled_directly") else "sliced-ELL array + copy into the SpMV's storage")},
         "setup_s": {"mesh": t_mesh, "pattern_and_upload": run["pattern_and_upload_s"], "pattern_host": t_pat,
                     "assembly_plus_preconditioner_hierarchy": t_asm_setup},
         "roofline": {"bound": "hbm",

@@ -672,7 +672,11 @@ __global__ void k_dist_pcg_scalars(int phase, double *__restrict__ S, const doub
         const double den = delta - beta * gn / (S[5] != 0.0 ? S[5] : 1.0);
         // p.Kp (= den) <= 0 or r.M^-1 r (= gn) < 0: operator or preconditioner not positive definite -- S[3] = 2 stops the loop
         // as a breakdown (the host raises) instead of iterating on
-        if (go && (den <= 0.0 || gn < 0.0)) { S[3] = 2.0; go = false; beta = 0.0; }
+        if (go && (den <= 0.0 || gn < 0.0)) {      // (S[5], S[6] = the offending p.Kp and r.M^-1 r for the host's message; the loop is over)
+            S[3] = 2.0; S[5] = den; S[6] = gn;
+            return;
+        }
+        if (S[3] == 2.0) return;
         const double alpha = (go && S[5] != 0.0) ? gn / den : 0.0;
         if (go) S[0] = gn;
         S[5] = alpha;

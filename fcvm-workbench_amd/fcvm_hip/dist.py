@@ -600,6 +600,7 @@ class DistBackend:
                     self.comm["host_syncs"] += 1
                 Sh = S.cpu()
                 rr_h, it, flag = float(Sh[1]), int(Sh[4]), float(Sh[3])
+                detail = " (p.Kp = %.3e, r.M^-1 r = %.3e, r.r / threshold = %.3e)" % (float(Sh[5]), float(Sh[6]), rr_h / thresh_h) if flag == 2.0 else ""
             else:
                 zero, one = torch.zeros(1, dtype=torch.float64, device=dev), torch.ones(1, dtype=torch.float64, device=dev)
                 done = torch.zeros(1, dtype=torch.bool, device=dev)
@@ -643,13 +644,14 @@ class DistBackend:
                     finished = bool(done.item())
                     self.comm["host_syncs"] += 1
                 rr_h, it, flag = float(rr.item()), int(it_t.item()), 2.0 if bool(broke.item()) else float(done.item())
+                detail = ""
             total_it += it
             queued_all += queued
             if not np.isfinite(rr_h):
                 raise RuntimeError("distributed PCG broke down (non-finite residual)")
             if flag == 2.0:
                 raise RuntimeError("distributed PCG broke down: p.Kp <= 0 or r.M^-1 r < 0 (operator or preconditioner not positive "
-                                   "definite) after %d iterations" % total_it)
+                                   "definite) after %d iterations%s" % (total_it, detail))
             if rr_h > thresh_h:
                 break           # iteration budget used up: reported below
             # the true residual of what the recurrences converged to
@@ -682,6 +684,9 @@ class DistBackend:
 
     def solve_timing(self):
         return self._timing
+
+
+LMAX_SAFETY = 1.02     # on the Lanczos estimate of lambda_max(Dinv A): MG_LMAX_SAFETY of csrc/fcvm_mg.inc, see the comment there
 
 
 class _Cheb:
@@ -762,23 +767,50 @@ class DistMG:
         self.topo = True
 
     def _lmax(self, level, n, wdot):
-        """power iteration on Dinv*A of a level with distributed SpMV; start vector is a fixed function
-        of the global node numbers so that it is consistent across ranks"""
+        """largest eigenvalue of Dinv*A: Lanczos for the pencil (A, D) with D-orthonormal vectors v_j = Dinv p_j carried beside
+        p_j = D v_j (the recurrences of mg_estimate_lmax, csrc/fcvm_mg.inc, with the products summed over the shared nodes and
+        owner-weighted dots).  Rounds 1-3 ran 15 power iterations from a smooth function of the global node number: 87 % of the
+        eigenvalue on the plate, and with the 1.1 safety factor a Jacobi weight of c0 * lambda_max = 2.02 on two ranks -- cycle
+        form 2 was indefinite there (r.M^-1 r < 0 after seven PCG iterations; three ranks sat at 1.97 and took 43 instead of 33
+        iterations per solve)."""
         dev = self.be.device
         g = torch.as_tensor(self.part.gnodes if level == 0 else self.part.gnodes[self.c2f], dtype=torch.float64, device=dev)
-        v = TVec(torch.stack([torch.sin(0.7 * g + 0.1), torch.cos(1.3 * g), torch.sin(2.9 * g + 1.0)], 1).reshape(-1).contiguous())
-        w, z, tmp1, tmp2 = (TVec(torch.zeros(n, dtype=torch.float64, device=dev)) for _ in range(4))
+        # start vector: a fixed pseudo-random function of the GLOBAL node number (the same vector on every partition), rich
+        # in short wavelengths whatever the numbering
+        ph = torch.remainder(g * 0.6180339887498949 + 0.31, 1.0)
+        P = TVec((torch.stack([torch.remainder(ph * 7919.0, 1.0), torch.remainder(ph * 104729.0 + 0.17, 1.0),
+                               torch.remainder(ph * 1299709.0 + 0.71, 1.0)], 1) - 0.5).reshape(-1).contiguous())
+        V, Q, U, tmp1, tmp2 = (TVec(torch.zeros(n, dtype=torch.float64, device=dev)) for _ in range(5))
         ex = self.be.ex if level == 0 else self.ex1
-        nv = float(wdot(v.t, v.t).item())
-        lam = 0.0
-        for _ in range(15):
-            self.ops.mg_spmv(level, v, w)
-            ex.interface_sum(w.t, 3)
-            self.ops.mg_cheb_init(level, w, tmp1, tmp2, z, 1.0)  # z = Dinv w
-            nz = float(wdot(z.t, z.t).item())
-            lam = float(np.sqrt(nz / nv))
-            v.t.copy_(z.t / np.sqrt(nz))
-            nv = 1.0
+        dinv = lambda x, y: self.ops.mg_cheb_init(level, x, tmp1, tmp2, y, 1.0)      # noqa: E731  y = Dinv x
+        dinv(P, V)
+        nrm = float(wdot(P.t, V.t).item())
+        P.t.mul_(1.0 / np.sqrt(nrm)); V.t.mul_(1.0 / np.sqrt(nrm))
+        kmax = int(os.environ.get("FCVM_DIST_LMAX_ITERS", "40"))
+        al, be_, lam, hist, beta_prev = [], [], 0.0, [], 0.0
+        for j in range(kmax):
+            self.ops.mg_spmv(level, V, U)
+            ex.interface_sum(U.t, 3)
+            alpha = float(wdot(V.t, U.t).item())
+            al.append(alpha)
+            T = np.diag(al) + (np.diag(be_, 1) + np.diag(be_, -1) if be_ else 0.0)
+            lam = float(np.linalg.eigvalsh(T)[-1])
+            hist.append(lam)
+            if (j + 1 >= 8 and abs(lam - hist[-3]) <= 1e-3 * abs(lam)) or j + 1 == kmax:
+                break
+            Q.t.mul_(-beta_prev).add_(U.t).add_(P.t, alpha=-alpha)      # p~ = u - alpha p_j - beta_{j-1} p_{j-1}
+            dinv(Q, U)                                                  # v~
+            b2 = float(wdot(Q.t, U.t).item())
+            if b2 <= 1e-28 * alpha * alpha:
+                break
+            beta = float(np.sqrt(b2))
+            Q.t.mul_(1.0 / beta); U.t.mul_(1.0 / beta)
+            be_.append(beta)
+            beta_prev = beta
+            V, U = U, V
+            P, Q = Q, P
+        if not np.isfinite(lam) or lam <= 0.0:
+            raise RuntimeError("DistMG: eigenvalue estimate broke down")
         return lam
 
     def setup(self):
@@ -794,8 +826,10 @@ class DistMG:
         wdot1 = lambda a, b: be._allreduce(torch.sum(self.own1 * a * b).reshape(1))  # noqa: E731
         self.lmax0 = self._lmax(0, 3 * self.part.nn, wdot0)
         self.lmax1 = self._lmax(1, 3 * self.nc, wdot1)
-        self.ch0 = _Cheb(1.1 * self.lmax0, self.alpha0, self.k0)
-        self.ch1 = _Cheb(1.1 * self.lmax1, self.alpha1s, self.k1s)
+        if os.environ.get("FCVM_VERBOSE") and self.part.rank == 0:
+            print("fcvm dist: smoother bounds lmax0 %.6f lmax1 %.6f (alpha0 %.3g, weight %.3g)" % (self.lmax0, self.lmax1, self.alpha0, self.weight), flush=True)
+        self.ch0 = _Cheb(LMAX_SAFETY * self.lmax0, self.alpha0, self.k0)
+        self.ch1 = _Cheb(LMAX_SAFETY * self.lmax1, self.alpha1s, self.k1s)
         if not getattr(self, "nagg", 0):
             self._level2()   # once per mesh; tangent re-assemblies keep the aggregate level
         self.ready = True

@@ -424,6 +424,7 @@ def _shared_case_worker(rank, world, port, out, fail):
         except (SystemExit, ValueError) as ex:
             res.update(ok=False, error="%s: %s" % (type(ex).__name__, ex))
         res["seconds"] = time.perf_counter() - t0
+        dist.barrier()      # (rank 0 removes the directory after the helper's own barrier: look only when it has returned there too)
         res["left_behind"] = sorted(set(glob.glob("/dev/shm/fcvm_bench_*")) - before)
     finally:
         torch.save(res, out + ".%d" % rank)
