@@ -50,7 +50,7 @@ def spmv_traffic(cells, variant):
         t = json.load(open(SPMV_TRAFFIC_FILE))
     except (OSError, ValueError):
         return None, None
-    for e in t.get("measurements", []):
+    for e in reversed(t.get("measurements", [])):      # (the latest measurement of a layout)
         if e.get("workload", e.get("cells")) == cells and e.get("variant") == variant:
             return float(e["traffic_bytes_per_launch"]), "%s (commit %s, %s)" % (e.get("source", SPMV_TRAFFIC_FILE), e.get("commit", "?"), e.get("method", ""))
     return None, None

@@ -98,6 +98,7 @@ struct AsmSym {
     double *dblk;               // [nn*9] diagonal blocks
     int maxl1;                  // row stride of rowoff (longest segment + 1)
     int waves;                  // waves per group
+    int nt;                     // nontemporal stores of the finished rows (FCVM_ASM_NT)
     int len;                    // kept blocks of the longest row of the launch's length class
 };
 
@@ -455,8 +456,12 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                 const double *b9 = src + 9 * (j0 + j);
                 v2d d;
                 d.x = b9[2 * sub]; d.y = b9[2 * sub + 1];
-                __builtin_nontemporal_store(d, (v2d *)(sy.vals + 9 * eoff + (int64_t)2 * sub * n + 2 * ln));
-                if (sub == 0) __builtin_nontemporal_store(b9[8], sy.vals + 9 * eoff + (int64_t)8 * n + ln);
+                v2d *dv = (v2d *)(sy.vals + 9 * eoff + (int64_t)2 * sub * n + 2 * ln);
+                if (sy.nt) __builtin_nontemporal_store(d, dv); else *dv = d;
+                if (sub == 0) {
+                    double *d8 = sy.vals + 9 * eoff + (int64_t)8 * n + ln;
+                    if (sy.nt) __builtin_nontemporal_store(b9[8], d8); else *d8 = b9[8];
+                }
                 if (sy.lo8 && (sub == 1 || sub == 2)) {
                     // 16-bit block-scaled copy: nine integers on the block's own power of two, the exponent stored absolutely
                     // (frexp exponent of the block maximum; the kernels subtract the matrix exponent e0 when they read it)
@@ -474,14 +479,14 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                             t = t > 32767.0 ? 32767.0 : (t < -32767.0 ? -32767.0 : t);
                             hq[c] = (short)(int)t;
                         }
-                        __builtin_nontemporal_store(hq, sy.lo8 + eoff + ln);
+                        if (sy.nt) __builtin_nontemporal_store(hq, sy.lo8 + eoff + ln); else sy.lo8[eoff + ln] = hq;
                     } else {
                         double t = rint(ldexp(b9[8], shq));
                         t = t > 32767.0 ? 32767.0 : (t < -32767.0 ? -32767.0 : t);
                         // {q8, eb}: the first four bytes of the tail; the other four (window column, target lane) belong to the
                         // pattern and were written when the copy was allocated (k_lo2_static) -- nothing is read here
                         const uint32_t w4 = (uint32_t)(uint16_t)(short)(int)t | ((uint32_t)(uint16_t)(short)eb << 16);
-                        __builtin_nontemporal_store(w4, (uint32_t *)(sy.lo2 + eoff + ln));
+                        if (sy.nt) __builtin_nontemporal_store(w4, (uint32_t *)(sy.lo2 + eoff + ln)); else *(uint32_t *)(sy.lo2 + eoff + ln) = w4;
                     }
                 }
                 o0 = o1;

@@ -172,6 +172,7 @@ struct fcvm_ctx {
     bool wsym_use = false;      // the matrix being copied is an SPD stiffness matrix: also into the symmetric form
     bool wsym_lo = true;        // ... and its 16-bit copy (FCVM_WIN_SYM_LO=0: the smoother passes stay on the full form)
     int32_t *d_slotof = nullptr;   // [nn] sliced-ELL slot of a node, kept from fcvm_set_mesh's uploads until the symmetric form is set up
+    int asm_nt = 1;             // FCVM_ASM_NT=0: plain instead of nontemporal stores when the assembly writes the symmetric window form
     int asm_sym = 1;            // FCVM_ASSEMBLE_SYM=0: stiffness matrices go through the sliced-ELL array and the copy kernel (rounds 2-3)
     bool sell_valid = false;    // d_vals holds the matrix of the last assembly (false after an assembly straight into the symmetric form)
     bool wsym_pending = false;  // the symmetric form's host build may still be running; its device half is done by wsym_finish
@@ -1091,6 +1092,7 @@ static int launch_assemble_sym(fcvm_ctx *c, const double *disp, const double *si
     sy.rownode = d.rownode; sy.seg = d.seg; sy.emap = d.emap; sy.rowlen = d.rowlen; sy.jfirst = d.jfirst; sy.rowoff = d.rowoff;
     sy.nextseg = d.nextseg; sy.woff = d.woff; sy.cols = d.cols; sy.diagk = d.diagk; sy.vals = d.vals;
     sy.lo8 = want_lo ? d.lo8 : nullptr; sy.lo2 = want_lo ? d.lo2 : nullptr; sy.dblk = c->d_dblk; sy.maxl1 = d.maxl1; sy.waves = d.pat.waves; sy.len = 0;
+    sy.nt = c->asm_nt;
     for (int b = WinSymDev::ASM_BUCKETS - 1; b >= 0; b--) {   // longest rows first: their items run longest
         if (!d.asm_count[b]) continue;
         hipStream_t st = overlap ? c->asm_stream[b] : c->stream;
@@ -1149,6 +1151,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_MG_FUSE_PROLONG")) c->mg_fuse_prolong = atoi(v) != 0;
     if (const char *v = getenv("FCVM_SYM_PAIR")) c->sym_pair = atoi(v) != 0;
     if (const char *v = getenv("FCVM_ASSEMBLE_SYM")) c->asm_sym = atoi(v);
+    if (const char *v = getenv("FCVM_ASM_NT")) c->asm_nt = atoi(v);
     HCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
     c->stream = c->own;
     if (dalloc(&c->d_S, S_COUNT) || dalloc(&c->d_out8, 16)) return 1;
