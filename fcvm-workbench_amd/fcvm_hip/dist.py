@@ -993,10 +993,15 @@ class DistMG:
             else:
                 self.ops.mg_cheb_step(level, None, x, r, d, 0.0, 0.0, False)
 
-    def _coarse(self, r):
-        """x1 = M1^-1 P^T (w0 r): weighted restriction of a consistent fine vector, level-1 / aggregate cycle"""
+    def _coarse(self, r, partial=False):
+        """x1 = M1^-1 P^T (w0 r): weighted restriction of a consistent fine vector, level-1 / aggregate cycle.
+        partial: r is already a per-rank PART of the fine vector (its sum over the ranks is the vector): restricted as it stands,
+        the level-1 exchange then completes fine and coarse sums at once"""
         be = self.be
-        self.ops.mg_restrict_weighted(r, TVec(self.w0), self.r1)
+        if partial:
+            self.ops.mg_restrict(r, self.r1)
+        else:
+            self.ops.mg_restrict_weighted(r, TVec(self.w0), self.r1)
         self.ex1.interface_sum(self.r1.t, 3)
         self._from_zero(1, self.ch1, self.k1s, self.r1, self.x1, self.rr1, self.d1, self.t1)
         torch.mul(self.rr1.t, self.own1, out=self.t1.t)       # owner-weighted: shared nodes count once
@@ -1011,12 +1016,15 @@ class DistMG:
 
     def _cycle_lo(self, b, x):
         """form 2 from x1 = c0 Dinv b in self.d0:  x2 = x1 + P M1^-1 P^T (b - K~ x1);  x = x2 + c0 Dinv (b - K~ x2), K~ = the sum
-        over the ranks of the 16-bit copies of their local matrices (two fine-level exchanges)"""
+        over the ranks of the 16-bit copies of their local matrices (one fine-level exchange: the second product's)"""
         be, c0 = self.be, self.weight * self.ch0.c0
         self.ops.spmv_lo(self.d0, self.t0)
-        be.ex.interface_sum(self.t0.t, 3)
-        torch.sub(b.t, self.t0.t, out=self.r0.t)
-        self._coarse(self.r0)
+        # round 4: the residual after pre-smoothing is only ever restricted, and the restriction is linear -- so the rank's
+        # UNSUMMED product goes into it (b enters weighted by 1 / holders: a part of b) and the level-1 exchange that follows
+        # the restriction anyway completes the sum over the ranks: one fine-level exchange less per cycle (mid-side nodes
+        # interpolate from corners of their own element, so every part lands on coarse nodes of the rank that formed it)
+        torch.addcmul(-self.t0.t, b.t, self.w0, out=self.r0.t)          # w0 b - K~_local x1
+        self._coarse(self.r0, partial=True)
         self.ops.mg_prolong_add(self.x1, self.d0, self.x2)
         self.ops.spmv_lo(self.x2, self.t0)
         be.ex.interface_sum(self.t0.t, 3)
