@@ -32,14 +32,16 @@ constexpr int ASM_ROWS = 16;                       // rows per wavefront (4 lane
 // LDS of a work item: shape-function tables | Jacobians of the visited elements (one per row and Gauss point) | rows
 constexpr int ASM_TAB = 160;                       // doubles: dN/dxi at the 4 Gauss points [4][10][3], then N [4][10]
 constexpr int ASM_JREC = 10;                       // doubles per (row, Gauss point): xsi[9], GPW * det J (signed)
-constexpr int ASM_JAC = ASM_ROWS * 4 * ASM_JREC;   // doubles
+constexpr int ASM_JAC = ASM_ROWS * 4 * ASM_JREC;   // doubles (16 rows per wavefront; `rows` rows: rows * 4 * ASM_JREC)
 // len = blocks of the longest row of the slice; row stride in doubles, odd so that the 16 rows spread over the LDS banks
 __host__ __device__ inline int64_t asm_row_stride(int64_t len) { return len * 9 + ((len & 1) ? 0 : 1); }
 // tangent form: deviatoric stress and plastic factor of the visited elements' Gauss points, one record per (row, Gauss point)
 constexpr int ASM_PREC = 8;                        // doubles: pf, s[6], unused
 constexpr int ASM_PL = ASM_ROWS * 4 * ASM_PREC;    // doubles
-__host__ __device__ inline int64_t asm_lds_bytes(int64_t len, bool tangent = true) {
-    return (ASM_TAB + ASM_JAC + (tangent ? ASM_PL : 0) + ASM_ROWS * asm_row_stride(len)) * 8;
+// rows: rows per wavefront = 64 / lanes per row (16 with four lanes per row; round 4: 8 or 4 where the assembly writes the symmetric
+// window form -- half / a quarter of the LDS per wavefront, so twice / four times the wavefronts on the same rows)
+__host__ __device__ inline int64_t asm_lds_bytes(int64_t len, bool tangent = true, int rows = ASM_ROWS) {
+    return (ASM_TAB + rows * 4 * ASM_JREC + (tangent ? rows * 4 * ASM_PREC : 0) + rows * asm_row_stride(len)) * 8;
 }
 
 // Hides where a pointer came from, so that loads through it are not hoisted out of the visit loop: every lane always
@@ -56,11 +58,12 @@ __device__ __forceinline__ T *reload_each_time(T *p) {
 // program order: the sums are formed in a fixed order, the atomic is only the cheaper encoding of read-add-write.
 __device__ __forceinline__ void lds_add(double *dst, double v) { __hip_atomic_fetch_add(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-struct AsmGeom {      // what lane h of a quad fetches for one visit: its local columns b = h + 4 t
-    double c[3][3];   // (updated) coordinates of node b
-    uint32_t em[3];   // packed block location of (row node, b)
-    int ndb[3];       // node b
-    int fb[3];        // its support flags
+template <int NT>
+struct AsmGeomT {     // what lane h of a row's lanes fetches for one visit: its local columns b = h + LPR t, t < NT
+    double c[NT][3];  // (updated) coordinates of node b
+    uint32_t em[NT];  // packed block location of (row node, b)
+    int ndb[NT];      // node b
+    int fb[NT];       // its support flags
     uint32_t pg;      // tangent form: the element's four plastic flags (pgp[4 e .. 4 e + 3])
     double sg[6];     // ... and the stress of Gauss point h of the element
 };
@@ -102,7 +105,11 @@ struct AsmSym {
     int len;                    // kept blocks of the longest row of the launch's length class
 };
 
-template <bool TANGENT, bool SYM = false>
+// LPR = lanes per row (round 4, SYM only: 8 or 16).  The kernel is bound by the latency of the dependent chain of an element visit
+// and the LDS capacity fixes how many ROWS a CU holds, so what is left is the length of that chain: with LPR lanes per row a lane
+// integrates ceil(10 / LPR) blocks per visit instead of three and a wavefront holds 64 / LPR rows -- more wavefronts on the same LDS
+// (measured first: forcing the short-row classes down to two wavefronts per CU made them 2.3-3.6 x slower).
+template <bool TANGENT, bool SYM = false, int LPR = 4>
 __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__ items, const int64_t *__restrict__ sptr,
                                                      const int32_t *__restrict__ rownode, const int64_t *__restrict__ nptr,
                                                      const int32_t *__restrict__ nel, const int32_t *__restrict__ el,
@@ -113,21 +120,26 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                                                      double *__restrict__ vals, double *__restrict__ glv, double *__restrict__ modf,
                                                      double *__restrict__ xgp, double *__restrict__ volume, int penalty_bc,
                                                      AsmSym sy = AsmSym{}) {
+    static_assert(LPR == 4 || (SYM && (LPR == 8 || LPR == 16)), "lanes per row: 4, or 8 / 16 for the symmetric window form");
+    constexpr int R = 64 / LPR;                 // rows per wavefront
+    constexpr int NT = (10 + LPR - 1) / LPR;    // local columns per lane
+    constexpr int JAC = R * 4 * ASM_JREC, PLD = R * 4 * ASM_PREC;
+    typedef AsmGeomT<NT> AsmGeom;
     extern __shared__ double lds[];
-    double *tab = lds, *jac = lds + ASM_TAB, *pl = lds + ASM_TAB + ASM_JAC, *rowbuf = lds + ASM_TAB + ASM_JAC + (TANGENT ? ASM_PL : 0);
+    double *tab = lds, *jac = lds + ASM_TAB, *pl = lds + ASM_TAB + JAC, *rowbuf = lds + ASM_TAB + JAC + (TANGENT ? PLD : 0);
     // XCD-aware remap (as k_spmv): the workgroups of one XCD take a contiguous range of work items, whose rows share
     // elements and nodes, so that their gathers meet in one L2
     const int64_t nb = gridDim.x, bq = nb >> 3, br = nb & 7, xcd = blockIdx.x & 7;
     const int64_t wg = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + (blockIdx.x >> 3);
-    const int lane = threadIdx.x, rowl = lane >> 2, h = lane & 3;
-    // SYM: the item lists the lane (wave * 64 + lane) of each of its 16 rows in the window layout, -1: none
-    const int item = SYM ? items[wg * ASM_ROWS] : items[wg];
+    const int lane = threadIdx.x, rowl = lane / LPR, h = lane % LPR;
+    // SYM: the item lists the lane (wave * 64 + lane) of each of its R rows in the window layout, -1: none
+    const int item = SYM ? items[wg * R] : items[wg];
     const int64_t s = SYM ? (int64_t)(item >> 6) : (int64_t)(item >> 2);     // SYM: a wave of the item's group
     const int qd = item & 3;
     // SYM: item = wave * 4 + quarter of the symmetric form; len = the launch's length class (kept blocks)
     const int64_t jb = SYM ? 0 : sptr[s], len = SYM ? (int64_t)sy.len : sptr[s + 1] - jb;   // blocks of the slice's longest row = half chunks of the slice
     const int64_t S = asm_row_stride(len);
-    for (int64_t i = lane; i < ASM_ROWS * S; i += 64) rowbuf[i] = 0.0;
+    for (int64_t i = lane; i < R * S; i += 64) rowbuf[i] = 0.0;
     if (lane < 40) {   // shape-function tables (fcVM.py:365-424 at the Gauss points of fcVM.py:587-596)
         const int g = lane / 10, k = lane - 10 * g;
         double xi, et, ze, d0, d1, d2;
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
         tab[3 * lane] = d0; tab[3 * lane + 1] = d1; tab[3 * lane + 2] = d2;
         tab[120 + lane] = shp_k(k, xi, et, ze);
     }
-    const int64_t slot = SYM ? (int64_t)items[wg * ASM_ROWS + rowl] : s * 64 + qd * ASM_ROWS + rowl;
+    const int64_t slot = SYM ? (int64_t)items[wg * R + rowl] : s * 64 + qd * ASM_ROWS + rowl;
     const int node = SYM ? (slot >= 0 ? sy.rownode[slot] : -1) : rownode[slot];
     const int64_t q0 = node >= 0 ? nptr[node] : 0;
     const int nvis = node >= 0 ? (int)(nptr[node + 1] - q0) : 0;
@@ -145,9 +157,10 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
     for (int o = 32; o > 0; o >>= 1) maxvis = max(maxvis, __shfl_xor(maxvis, o, 64));
     const int fa = node >= 0 ? fixmask[node] : 0;
     double *myrow = rowbuf + rowl * S;
-    double *myjac = jac + (rowl * 4 + h) * ASM_JREC;         // this lane's Gauss point of this row's visited element
+    const int hg = h & 3;                                    // Gauss point of this lane (lanes h >= 4 of a row idle in that stage)
+    double *myjac = jac + (rowl * 4 + hg) * ASM_JREC;        // this lane's Gauss point of this row's visited element
     const double *rowjac = jac + rowl * 4 * ASM_JREC;        // all four
-    const double *mydn = tab + 30 * h;                       // dN/dxi at Gauss point h
+    const double *mydn = tab + 30 * hg;                      // dN/dxi at Gauss point h
     __syncthreads();
 
     // packed visit: element << 4 | local index of the row node, -1: no visit (lanes of shorter rows)
@@ -155,17 +168,17 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
     // The four lanes of a quad visit the same element: lane h fetches the nodes b = h, h + 4, h + 8 -- the columns whose
     // blocks it integrates -- and their coordinates; the quad exchanges the coordinates through LDS (the Jacobian needs all
     // ten).  12 + 6 vector-memory instructions per visit instead of 44 with every lane loading everything.
-    int nd[3];        // nodes b of the visit whose coordinates are fetched next
+    int nd[NT];       // nodes b of the visit whose coordinates are fetched next
     auto load_nodes = [&](int32_t packed) {
         const int64_t e = packed >= 0 ? (int64_t)(packed >> 4) : 0;   // idle lanes read element 0 (valid memory), results unused
 #pragma unroll
-        for (int t = 0; t < 3; t++) nd[t] = el[e * 10 + min(h + 4 * t, 9)];
+        for (int t = 0; t < NT; t++) nd[t] = el[e * 10 + min(h + LPR * t, 9)];
     };
     auto load_geom = [&](int32_t packed, AsmGeom &G) {
         const int64_t e = packed >= 0 ? (int64_t)(packed >> 4) : 0;
         const int a = packed >= 0 ? (packed & 15) : 0;
 #pragma unroll
-        for (int t = 0; t < 3; t++) {
+        for (int t = 0; t < NT; t++) {
             load3(coord, nd[t], G.c[t][0], G.c[t][1], G.c[t][2]);
             if (disp) {
                 double u0, u1, u2;
@@ -173,13 +186,13 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                 G.c[t][0] += u0; G.c[t][1] += u1; G.c[t][2] += u2;
             }
             G.ndb[t] = nd[t];
-            G.em[t] = SYM ? (uint32_t)sy.emap[e * 100 + a * 10 + min(h + 4 * t, 9)] : emap[e * 100 + a * 10 + min(h + 4 * t, 9)];
+            G.em[t] = SYM ? (uint32_t)sy.emap[e * 100 + a * 10 + min(h + LPR * t, 9)] : emap[e * 100 + a * 10 + min(h + LPR * t, 9)];
             G.fb[t] = fixmask[nd[t]];
         }
         if (TANGENT) {   // with the other inputs of the visit, one visit ahead (round 4: these loads used to sit inside the Gauss
                          // point loop, four dependent round trips to memory per visit with one or two wavefronts per CU to hide them)
             G.pg = *(const uint32_t *)(pgp + 4 * e);
-            const double2 *s2 = (const double2 *)(sig + 24 * e + 6 * h);
+            const double2 *s2 = (const double2 *)(sig + 24 * e + 6 * hg);
             const double2 q0 = s2[0], q1 = s2[1], q2 = s2[2];
             G.sg[0] = q0.x; G.sg[1] = q0.y; G.sg[2] = q1.x; G.sg[3] = q1.y; G.sg[4] = q2.x; G.sg[5] = q2.y;
         }
@@ -193,9 +206,9 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
         // ---- coordinates of the element's ten nodes: every lane contributes its three, the row's image is [node][3] ----
         double *crd = jac + rowl * 4 * ASM_JREC;   // the row's Jacobian records double as the exchange area (30 of 40 doubles)
 #pragma unroll
-        for (int t = 0; t < 3; t++)
-            if (h + 4 * t < 10) {
-                double *o = crd + 3 * (h + 4 * t);
+        for (int t = 0; t < NT; t++)
+            if (h + LPR * t < 10) {
+                double *o = crd + 3 * (h + LPR * t);
                 o[0] = G0.c[t][0]; o[1] = G0.c[t][1]; o[2] = G0.c[t][2];
             }
         __syncthreads();
@@ -222,13 +235,15 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
             }
             double mine[9];
             const double xsj = jac_inverse(xs, mine);
-            double2 *j2 = (double2 *)myjac;   // 10 doubles = five 16-byte LDS writes
-            j2[0] = double2{mine[0], mine[1]}; j2[1] = double2{mine[2], mine[3]}; j2[2] = double2{mine[4], mine[5]};
-            j2[3] = double2{mine[6], mine[7]}; j2[4] = double2{mine[8], xsj * FCVM_GPW};
+            if (LPR == 4 || h < 4) {      // (more than four lanes per row: the others would write the same records)
+                double2 *j2 = (double2 *)myjac;   // 10 doubles = five 16-byte LDS writes
+                j2[0] = double2{mine[0], mine[1]}; j2[1] = double2{mine[2], mine[3]}; j2[2] = double2{mine[4], mine[5]};
+                j2[3] = double2{mine[6], mine[7]}; j2[4] = double2{mine[8], xsj * FCVM_GPW};
+            }
         }
         if (TANGENT) {   // deviatoric stress and plastic factor of Gauss point h (fcVM.py:983-998), once per quad -> LDS record of (row, h)
             double pf = 0.0, Sg[6] = {0, 0, 0, 0, 0, 0};
-            if (active && ((G0.pg >> (8 * h)) & 0xFFu)) {
+            if (active && ((G0.pg >> (8 * hg)) & 0xFFu)) {
 #pragma unroll
                 for (int j = 0; j < 6; j++) Sg[j] = G0.sg[j];
                 const double p = (Sg[0] + Sg[1] + Sg[2]) / 3.0;
@@ -237,8 +252,10 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                 if (svm == 0.0) svm = 1.0;
                 pf = 3.0 * mc.G / (1.0 + mc.H / 3.0 / mc.G) / (svm * svm);
             }
-            double2 *p2 = (double2 *)(pl + (rowl * 4 + h) * ASM_PREC);
-            p2[0] = double2{pf, Sg[0]}; p2[1] = double2{Sg[1], Sg[2]}; p2[2] = double2{Sg[3], Sg[4]}; p2[3] = double2{Sg[5], 0.0};
+            if (LPR == 4 || h < 4) {
+                double2 *p2 = (double2 *)(pl + (rowl * 4 + hg) * ASM_PREC);
+                p2[0] = double2{pf, Sg[0]}; p2[1] = double2{Sg[1], Sg[2]}; p2[2] = double2{Sg[3], Sg[4]}; p2[3] = double2{Sg[5], 0.0};
+            }
         }
         // Gauss point coordinates (fcVM.py:761): lane 3 of the quad (it integrates one block less)
         if (xgp && active && a < 4 && h == 3) {
@@ -253,14 +270,14 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
             o[0] = px; o[1] = py; o[2] = pz;
         }
         __syncthreads();   // one wavefront: orders the LDS records of the quad before they are read
-        // ---- blocks K_ab, b = h, h + 4, h + 8, Gauss points outermost ----
-        double M[3][9], Pl[TANGENT ? 3 : 1][9];   // Pl: plastic part of the tangent blocks
+        // ---- blocks K_ab, b = h + LPR t (h, h + 4, h + 8 with four lanes per row), Gauss points outermost ----
+        double M[NT][9], Pl[TANGENT ? NT : 1][9];   // Pl: plastic part of the tangent blocks
 #pragma unroll
-        for (int t = 0; t < 3; t++)
+        for (int t = 0; t < NT; t++)
 #pragma unroll
             for (int k = 0; k < 9; k++) M[t][k] = 0.0;
 #pragma unroll
-        for (int t = 0; t < (TANGENT ? 3 : 1); t++)
+        for (int t = 0; t < (TANGENT ? NT : 1); t++)
 #pragma unroll
             for (int k = 0; k < 9; k++) Pl[t][k] = 0.0;
         double gam = 0.0, vol = 0.0;
@@ -285,8 +302,8 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                 ta[2] = ga[2] * Sg[2] + ga[0] * Sg[4] + ga[1] * Sg[5];
             }
 #pragma unroll
-            for (int t = 0; t < 3; t++) {
-                const int b = min(h + 4 * t, 9);
+            for (int t = 0; t < NT; t++) {
+                const int b = min(h + LPR * t, 9);
                 const double *db = reload_each_time<ASM_RELOAD_DB>(tab + 30 * g + 3 * b);
                 double gb[3];
                 to_global(xsi, db[0], db[1], db[2], gb[0], gb[1], gb[2]);
@@ -319,8 +336,8 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
             if (a == 0) racc[6] += vol;
         }
 #pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const int b = h + 4 * t;
+        for (int t = 0; t < NT; t++) {
+            const int b = h + LPR * t;
             if (active && b < 10) {
                 double K[9];
                 {   // K = D12 M + D44 M^T + (D11 - D12 - D44) diag(M) + D44 tr(M) I (fcVM.py:769-771 regrouped)
@@ -402,9 +419,14 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
     // ---- per-row sums: quad reduction in a fixed order, lane 0 of the quad writes ----
 #pragma unroll
     for (int k = 3; k < 6; k++) {
-        const int qb = lane & 60;
-        const double v0 = __shfl(racc[k], qb, 64), v1 = __shfl(racc[k], qb + 1, 64), v2 = __shfl(racc[k], qb + 2, 64), v3 = __shfl(racc[k], qb + 3, 64);
-        racc[k] = (v0 + v1) + (v2 + v3);
+        if (LPR == 4) {
+            const int qb = lane & 60;
+            const double v0 = __shfl(racc[k], qb, 64), v1 = __shfl(racc[k], qb + 1, 64), v2 = __shfl(racc[k], qb + 2, 64), v3 = __shfl(racc[k], qb + 3, 64);
+            racc[k] = (v0 + v1) + (v2 + v3);
+        } else {      // the same pairwise tree over the row's LPR lanes
+#pragma unroll
+            for (int o = 1; o < LPR; o <<= 1) racc[k] += __shfl_xor(racc[k], o, 64);
+        }
     }
     if (node >= 0 && h == 0) {
         glv[3 * (int64_t)node] = racc[0]; glv[3 * (int64_t)node + 1] = racc[1]; glv[3 * (int64_t)node + 2] = racc[2];
@@ -421,22 +443,24 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
         //      the 8-byte tail {ninth 16-bit value, window column, block exponent, target lane}, sub 3 the diagonal block.
         //      Segment after segment of a cut row; 16 consecutive lanes of a wave write 256 contiguous bytes per instruction ----
         typedef double v2d __attribute__((ext_vector_type(2)));
-        const int sub = lane >> 4, r16 = lane & 15;
+        // thread (sub, r16): row r16 of the item's R rows, sub = 0 .. LPR - 1 (the names keep the four-lanes-per-row case's)
+        const int sub = lane / R, r16 = lane % R;
+        constexpr int SUB8 = LPR == 4 ? 0 : 4, SUBLO8 = LPR == 4 ? 1 : 5, SUBLO2 = LPR == 4 ? 2 : 6, SUBDIAG = LPR == 4 ? 3 : 7;
         const double *src = rowbuf + r16 * S;
-        const int nd16 = __shfl(node, 4 * r16, 64);
-        int64_t cur = nd16 >= 0 ? (int64_t)items[wg * ASM_ROWS + r16] : -1;
+        const int nd16 = __shfl(node, LPR * r16, 64);
+        int64_t cur = nd16 >= 0 ? (int64_t)items[wg * R + r16] : -1;
         // the block-row offsets of the waves of this group (every segment of the item's rows lives in one of them) staged in the
         // free Jacobian area: a dependent global load per block row otherwise, with one wavefront per item to hide it
         const int64_t wave0 = s - s % sy.waves;
         uint16_t *ros = (uint16_t *)jac;
-        int64_t *wos = (int64_t *)(jac + ASM_JAC - 16);
-        const bool staged = sy.waves * sy.maxl1 <= (ASM_JAC - 16) * 4 && sy.waves <= 16;
+        int64_t *wos = (int64_t *)(jac + JAC - 16);
+        const bool staged = sy.waves * sy.maxl1 <= (JAC - 16) * 4 && sy.waves <= 16;
         if (staged) {
             for (int i = lane; i < sy.waves * sy.maxl1; i += 64) ros[i] = sy.rowoff[wave0 * sy.maxl1 + i];
             if (lane < sy.waves) wos[lane] = sy.woff[wave0 + lane];
         }
         __syncthreads();
-        if (sub == 3 && nd16 >= 0) {
+        if (sub == SUBDIAG && nd16 >= 0) {
             const double *sd = src + 9 * (int)sy.diagk[nd16];
             double *dd = sy.dblk + 9 * (int64_t)nd16;
 #pragma unroll
@@ -454,15 +478,17 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                 const int n = o1 - o0;
                 const int64_t eoff = wo + o0;
                 const double *b9 = src + 9 * (j0 + j);
-                v2d d;
-                d.x = b9[2 * sub]; d.y = b9[2 * sub + 1];
-                v2d *dv = (v2d *)(sy.vals + 9 * eoff + (int64_t)2 * sub * n + 2 * ln);
-                if (sy.nt) __builtin_nontemporal_store(d, dv); else *dv = d;
-                if (sub == 0) {
+                if (sub < 4) {
+                    v2d d;
+                    d.x = b9[2 * sub]; d.y = b9[2 * sub + 1];
+                    v2d *dv = (v2d *)(sy.vals + 9 * eoff + (int64_t)2 * sub * n + 2 * ln);
+                    if (sy.nt) __builtin_nontemporal_store(d, dv); else *dv = d;
+                }
+                if (sub == SUB8) {
                     double *d8 = sy.vals + 9 * eoff + (int64_t)8 * n + ln;
                     if (sy.nt) __builtin_nontemporal_store(b9[8], d8); else *d8 = b9[8];
                 }
-                if (sy.lo8 && (sub == 1 || sub == 2)) {
+                if (sy.lo8 && (sub == SUBLO8 || sub == SUBLO2)) {
                     // 16-bit block-scaled copy: nine integers on the block's own power of two, the exponent stored absolutely
                     // (frexp exponent of the block maximum; the kernels subtract the matrix exponent e0 when they read it)
                     double m = 0.0;
@@ -471,7 +497,7 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
                     int eb = -1023;
                     if (m > 0.0) (void)frexp(m, &eb);
                     const int shq = 15 - eb;
-                    if (sub == 1) {
+                    if (sub == SUBLO8) {
                         short8 hq;
 #pragma unroll
                         for (int c = 0; c < 8; c++) {

@@ -82,8 +82,9 @@ struct WinSymDev {
     uint16_t *jfirst = nullptr, *rowoff = nullptr;
     int32_t *nextseg = nullptr, *asm_items = nullptr;
     int maxl1 = 0;
+    int asm_rows[7] = {ASM_ROWS, ASM_ROWS, ASM_ROWS, ASM_ROWS, ASM_ROWS, ASM_ROWS, ASM_ROWS};   // rows per work item of a class = 64 / its lanes per row
     static constexpr int ASM_BUCKETS = 7;
-    int64_t asm_count[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0, 0}, asm_first[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0, 0};
+    int64_t asm_count[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0, 0}, asm_first[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0, 0}, asm_off[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0, 0};
     double *part_vol = nullptr;     // [items] volume partials
     int64_t nitems = 0;
 };
@@ -172,6 +173,9 @@ struct fcvm_ctx {
     bool wsym_use = false;      // the matrix being copied is an SPD stiffness matrix: also into the symmetric form
     bool wsym_lo = true;        // ... and its 16-bit copy (FCVM_WIN_SYM_LO=0: the smoother passes stay on the full form)
     int32_t *d_slotof = nullptr;   // [nn] sliced-ELL slot of a node, kept from fcvm_set_mesh's uploads until the symmetric form is set up
+    int asm_lpr = 4;            // lanes per row of the assembly into the symmetric window form (FCVM_ASM_LPR = 4, 8 or 16) ...
+    int asm_lpr_long = 8;       // ... and in its long-row classes (FCVM_ASM_LPR_LONG), kept length above asm_lpr_from (FCVM_ASM_LPR_FROM)
+    int asm_lpr_from = 28;
     int asm_nt = 1;             // FCVM_ASM_NT=0: plain instead of nontemporal stores when the assembly writes the symmetric window form
     int asm_sym = 1;            // FCVM_ASSEMBLE_SYM=0: stiffness matrices go through the sliced-ELL array and the copy kernel (rounds 2-3)
     bool sell_valid = false;    // d_vals holds the matrix of the last assembly (false after an assembly straight into the symmetric form)
@@ -626,6 +630,8 @@ static int wsym_asm_setup(fcvm_ctx *c) {
     bool fits = true;
     {
         const int64_t R = (int64_t)w.waves * SLICE;
+        for (int b = 0; b < WinSymDev::ASM_BUCKETS; b++)      // rows per work item: the long-row classes get more lanes per row
+            d.asm_rows[b] = 64 / (ASM_SYM_LIMIT[b] > c->asm_lpr_from ? c->asm_lpr_long : c->asm_lpr);
         int nt = (int)std::thread::hardware_concurrency();
         nt = std::min(std::max(nt, 1), 32);
         std::vector<std::vector<int32_t>> part(nt * WinSymDev::ASM_BUCKETS);      // per thread (= contiguous range of groups) and class
@@ -637,13 +643,15 @@ static int wsym_asm_setup(fcvm_ctx *c) {
                 for (int64_t at = g * R; at < (g + 1) * R; at++)
                     if (w.rownode[at] >= 0 && (w.seg[at] & 255u) > 0) rows.push_back((int32_t)at);
                 std::stable_sort(rows.begin(), rows.end(), [&](int32_t x, int32_t y) { return w.rowtot[x] > w.rowtot[y]; });
-                for (size_t k = 0; k < rows.size(); k += ASM_ROWS) {
+                for (size_t k = 0; k < rows.size();) {
                     const int m = w.rowtot[rows[k]];
                     if (m > ASM_SYM_LIMIT[WinSymDev::ASM_BUCKETS - 1]) { bad[t] = 1; return; }
                     int b = 0;
                     while (m > ASM_SYM_LIMIT[b]) b++;
+                    const int RW = d.asm_rows[b];
                     std::vector<int32_t> &dst = part[t * WinSymDev::ASM_BUCKETS + b];
-                    for (int l = 0; l < ASM_ROWS; l++) dst.push_back(k + l < rows.size() ? rows[k + l] : -1);
+                    for (int l = 0; l < RW; l++) dst.push_back(k + l < rows.size() ? rows[k + l] : -1);
+                    k += RW;
                 }
             }
         }, 16);
@@ -658,20 +666,22 @@ static int wsym_asm_setup(fcvm_ctx *c) {
     lap("work items (host)");
     const int lds_cap = device_lds_cap(c->device);
     for (int b = 0; b < WinSymDev::ASM_BUCKETS; b++)
-        if (!items[b].empty() && (int64_t)asm_lds_bytes(ASM_SYM_LIMIT[b]) > lds_cap) fits = false;
+        if (!items[b].empty() && (int64_t)asm_lds_bytes(ASM_SYM_LIMIT[b], true, d.asm_rows[b]) > lds_cap) fits = false;
     if (!fits || w.nwaves >= (int64_t(1) << 25)) { release_host(); return 0; }
-    std::vector<int32_t> all;      // [item][16] lane (wave * 64 + lane) of each of the item's rows, -1: none
+    std::vector<int32_t> all;      // per class: [item][rows of the class] lane (wave * 64 + lane) of each of the item's rows, -1: none
+    d.nitems = 0;
     for (int b = 0; b < WinSymDev::ASM_BUCKETS; b++) {
-        d.asm_first[b] = (int64_t)all.size() / ASM_ROWS;
-        d.asm_count[b] = (int64_t)items[b].size() / ASM_ROWS;
+        d.asm_first[b] = d.nitems;                     // first volume partial of the class
+        d.asm_off[b] = (int64_t)all.size();            // first entry of the class in asm_items
+        d.asm_count[b] = (int64_t)items[b].size() / d.asm_rows[b];
+        d.nitems += d.asm_count[b];
         all.insert(all.end(), items[b].begin(), items[b].end());
     }
-    d.nitems = (int64_t)all.size() / ASM_ROWS;
     d.maxl1 = w.maxl + 1;
     uint8_t *d_kmap = nullptr;
     int64_t *d_rowptr = nullptr;
     if (dalloc(&d.emap, c->ne * 100) || dalloc(&d.diagk, c->nn) || dalloc(&d.jfirst, nrows) || dalloc(&d.rowoff, (int64_t)w.rowoff.size()) ||
-        dalloc(&d.nextseg, nrows) || dalloc(&d.asm_items, d.nitems * ASM_ROWS) || dalloc(&d.part_vol, d.nitems) || dalloc(&d_kmap, (int64_t)w.kmap.size()) ||
+        dalloc(&d.nextseg, nrows) || dalloc(&d.asm_items, (int64_t)all.size()) || dalloc(&d.part_vol, d.nitems) || dalloc(&d_kmap, (int64_t)w.kmap.size()) ||
         dalloc(&d_rowptr, c->nn + 1)) {
         (void)hipGetLastError();
         dfree(d_kmap); dfree(d_rowptr);
@@ -700,16 +710,20 @@ static int wsym_asm_setup(fcvm_ctx *c) {
     int &allowed = asm_sym_lds_allowed_dev[c->device & 63];
     if (allowed == 0) allowed = 64 * 1024;
     for (int b = 0; b < WinSymDev::ASM_BUCKETS; b++) {
-        const int bytes = (int)asm_lds_bytes(ASM_SYM_LIMIT[b]);
+        const int bytes = (int)asm_lds_bytes(ASM_SYM_LIMIT[b], true, d.asm_rows[b]);
         if (bytes <= allowed || !d.asm_count[b]) continue;
-        HCHK(hipFuncSetAttribute((const void *)k_assemble_lds<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HCHK(hipFuncSetAttribute((const void *)k_assemble_lds<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HCHK(hipFuncSetAttribute((const void *)k_assemble_lds<false, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HCHK(hipFuncSetAttribute((const void *)k_assemble_lds<true, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HCHK(hipFuncSetAttribute((const void *)k_assemble_lds<false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HCHK(hipFuncSetAttribute((const void *)k_assemble_lds<true, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HCHK(hipFuncSetAttribute((const void *)k_assemble_lds<false, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HCHK(hipFuncSetAttribute((const void *)k_assemble_lds<true, true, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         allowed = bytes;
     }
     d.asm_ok = true;
     if (getenv("FCVM_VERBOSE")) {
-        fprintf(stderr, "fcvm: assembly into the symmetric form: %lld work items, by kept length", (long long)d.nitems);
-        for (int b = 0; b < WinSymDev::ASM_BUCKETS; b++) fprintf(stderr, " <=%lld: %lld", (long long)ASM_SYM_LIMIT[b], (long long)d.asm_count[b]);
+        fprintf(stderr, "fcvm: assembly into the symmetric form: %lld work items, by kept length (x rows per item)", (long long)d.nitems);
+        for (int b = 0; b < WinSymDev::ASM_BUCKETS; b++) fprintf(stderr, " <=%lld: %lld x %d", (long long)ASM_SYM_LIMIT[b], (long long)d.asm_count[b], d.asm_rows[b]);
         fprintf(stderr, "\n");
     }
     return 0;
@@ -1098,10 +1112,17 @@ static int launch_assemble_sym(fcvm_ctx *c, const double *disp, const double *si
         hipStream_t st = overlap ? c->asm_stream[b] : c->stream;
         if (overlap) HCHK(hipStreamWaitEvent(st, c->asm_fork, 0));
         sy.len = (int)ASM_SYM_LIMIT[b];
-        hipLaunchKernelGGL((k_assemble_lds<TANGENT, true>), dim3((unsigned)d.asm_count[b]), dim3(64), (size_t)asm_lds_bytes(ASM_SYM_LIMIT[b], TANGENT), st,
-                           d.asm_items + d.asm_first[b] * ASM_ROWS, c->d_sptr, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord, disp, c->d_fixmask,
-                           c->d_fixval, c->d_emap, sig, pgp, mc, grav[0], grav[1], grav[2], (double *)nullptr, glv, modf, xgp,
-                           d.part_vol + d.asm_first[b], 0, sy);
+        size_t lds_b = (size_t)asm_lds_bytes(ASM_SYM_LIMIT[b], TANGENT, d.asm_rows[b]);
+        if (const char *v = getenv("FCVM_ASM_LDS_MIN")) lds_b = std::min<size_t>(std::max<size_t>(lds_b, (size_t)atol(v)), 64 * 1024);   // (experiment: fewer items per CU)
+#define FCVM_LAUNCH_ASM_SYM(LPR_)                                                                                                              \
+        hipLaunchKernelGGL((k_assemble_lds<TANGENT, true, LPR_>), dim3((unsigned)d.asm_count[b]), dim3(64), lds_b, st,                         \
+                           d.asm_items + d.asm_off[b], c->d_sptr, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord, disp, \
+                           c->d_fixmask, c->d_fixval, c->d_emap, sig, pgp, mc, grav[0], grav[1], grav[2], (double *)nullptr, glv, modf, xgp,  \
+                           d.part_vol + d.asm_first[b], 0, sy)
+        if (d.asm_rows[b] == 16) FCVM_LAUNCH_ASM_SYM(4);
+        else if (d.asm_rows[b] == 8) FCVM_LAUNCH_ASM_SYM(8);
+        else FCVM_LAUNCH_ASM_SYM(16);
+#undef FCVM_LAUNCH_ASM_SYM
         if (overlap) {
             HCHK(hipEventRecord(c->asm_join[b], st));
             HCHK(hipStreamWaitEvent(c->stream, c->asm_join[b], 0));
@@ -1152,6 +1173,9 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_SYM_PAIR")) c->sym_pair = atoi(v) != 0;
     if (const char *v = getenv("FCVM_ASSEMBLE_SYM")) c->asm_sym = atoi(v);
     if (const char *v = getenv("FCVM_ASM_NT")) c->asm_nt = atoi(v);
+    if (const char *v = getenv("FCVM_ASM_LPR")) { const int l = atoi(v); if (l == 4 || l == 8 || l == 16) c->asm_lpr = l; }
+    if (const char *v = getenv("FCVM_ASM_LPR_LONG")) { const int l = atoi(v); if (l == 4 || l == 8 || l == 16) c->asm_lpr_long = l; }
+    if (const char *v = getenv("FCVM_ASM_LPR_FROM")) c->asm_lpr_from = atoi(v);
     HCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
     c->stream = c->own;
     if (dalloc(&c->d_S, S_COUNT) || dalloc(&c->d_out8, 16)) return 1;

@@ -200,9 +200,12 @@ def test_assembly_straight_into_the_symmetric_window_form(orc, monkeypatch, mesh
         assert rel(d["y"], Ko @ xm) < 1e-12
         diag = np.stack([Ko[3 * i:3 * i + 3, 3 * i:3 * i + 3].toarray().reshape(9) for i in range(n // 3)]).reshape(-1)
         assert rel(d["dblk"], diag) < KTOL
-        for k in ("glv", "modf", "xgp", "y", "ylo", "z", "u", "dblk"):
+        for k in ("glv", "xgp", "y", "ylo", "z", "dblk"):
             assert np.array_equal(d[k], cp[k]), (form, k)
-        assert abs(d["V"] - cp["V"]) <= 1e-13 * abs(V_o) and d["it"] == cp["it"]      # (volume partials are summed per work item)
+        # modf = - sum over the row's blocks of K_ab u_b(prescribed): the lanes of a row sum their own columns first (eight lanes
+        # per row on this route, four on the copy route), so its rounding -- and through the right-hand side the solution's -- differs
+        assert rel(d["modf"], cp["modf"]) < 1e-14 and rel(d["u"], cp["u"]) < 1e-9
+        assert abs(d["V"] - cp["V"]) <= 1e-13 * abs(V_o) and abs(d["it"] - cp["it"]) <= 1      # (volume partials are summed per work item)
         assert abs(d["K"] - cp["K"]).max() <= 1e-15 * abs(Ko).max()    # (the copy route reads the sliced-ELL array: both halves stored)
 
 
