@@ -120,6 +120,42 @@ def main(h):
     variants = [("jacobi V(1,1) (library)", B_mult), ("chebyshev(2) jacobi", make_mult(cheb2, cheb2))]
     pre, post = gs_pair(node_rank, 1.0)
     variants.append(("block Gauss-Seidel over nodes (Morton order)", make_mult(pre, post)))
+    # round 4: "hybrid" block Gauss-Seidel -- Gauss-Seidel over the nodes INSIDE a group of consecutive Morton nodes (what a workgroup of
+    # the window format could do in LDS, its rows colour by colour), damped Jacobi BETWEEN the groups (no dependency between
+    # workgroups): splitting matrix Q = D / w + (couplings to earlier nodes of the same group); pre forward, post its adjoint
+    def hybrid_pair(gsize, damp):
+        grp = np.arange(nn) // gsize                 # (nodes are in Morton order after the permutation)
+        cd = np.repeat(grp, 3)
+        nd3 = np.repeat(np.arange(nn), 3)
+        coo = Kp.tocoo()
+        m = (cd[coo.row] == cd[coo.col]) & (nd3[coo.row] > nd3[coo.col])
+        Lm = sp.coo_matrix((coo.data * m, (coo.row, coo.col)), shape=Kp.shape).tocsr(); Lm.eliminate_zeros()
+        Fw = spla.splu((Dp / damp + Lm).tocsc()); Bw = spla.splu((Dp / damp + Lm.T).tocsc())
+        def pre(r, z): return unperm(Fw.solve(r[perm]))
+        def post(r, z): return z + unperm(Bw.solve((r - K @ z)[perm]))
+        return pre, post
+    # ... and its GPU-shaped form: the rows of a group dealt to `nclass` classes (the waves of a workgroup, no spatial meaning),
+    # Gauss-Seidel from class to class, Jacobi inside a class
+    def class_pair(gsize, nclass, damp):
+        grp = np.arange(nn) // gsize
+        cls = np.random.default_rng(1).integers(0, nclass, nn)
+        cd, cl3 = np.repeat(grp, 3), np.repeat(cls, 3)
+        coo = Kp.tocoo()
+        m = (cd[coo.row] == cd[coo.col]) & (cl3[coo.row] > cl3[coo.col])
+        Lm = sp.coo_matrix((coo.data * m, (coo.row, coo.col)), shape=Kp.shape).tocsr(); Lm.eliminate_zeros()
+        Fw = spla.splu((Dp / damp + Lm).tocsc()); Bw = spla.splu((Dp / damp + Lm.T).tocsc())
+        def pre(r, z): return unperm(Fw.solve(r[perm]))
+        def post(r, z): return z + unperm(Bw.solve((r - K @ z)[perm]))
+        return pre, post
+    if os.environ.get("CYCLE_FORMS_HYBRID"):
+        for nclass in (2, 4, 8):
+            for damp in (0.8, 0.7):
+                pre, post = class_pair(512, nclass, damp)
+                variants.append(("class GS, groups of 512, %d classes, damping %.2f" % (nclass, damp), make_mult(pre, post)))
+        for gsize in (512,):
+            for damp in (1.0, 0.8, 0.65):
+                pre, post = hybrid_pair(gsize, damp)
+                variants.append(("hybrid GS, groups of %d nodes, damping %.2f" % (gsize, damp), make_mult(pre, post)))
     for name, B in variants:
         t0 = time.time(); it = pcg(K, f, B); print("  mult, smoother %-40s %4d iterations  (%.1f s)" % (name, it, time.time() - t0), flush=True)
     if os.environ.get("CYCLE_FORMS_DAMPING"):
