@@ -547,4 +547,155 @@ __global__ __launch_bounds__(64) void k_assemble_lds(const int32_t *__restrict__
     }
 }
 
+// ---- level 1 of the multigrid hierarchy (linear tets on the corner nodes) with the same scheme (round 4) -------------------------
+// k_assemble_tet4_rows (round 1) adds every block with read-modify-writes in global memory: PMC in round 4 (1 M plate, 186 k
+// coarse nodes) 5.35 GB fetched + 2.25 GB written for a 0.1 GB matrix, 95 % of the wave cycles waiting, 1.3-1.5 ms.  Here a wavefront
+// owns 16 rows of a level-1 slice, four lanes per row: lane h integrates block (a, h) of every element at the row's corner (the
+// element's four gradients are cheap enough to be formed by each lane), the rows are summed in LDS and leave in one coalesced
+// pass -- each value written once, no memset, every entry summed in the order of the old kernel (bitwise the same matrix).
+template <bool TANGENT>
+__global__ __launch_bounds__(64) void k_assemble_tet4_lds(int64_t nitems, const int64_t *__restrict__ sptr1, const int32_t *__restrict__ rownode1,
+                                                          const int64_t *__restrict__ nptr1, const int32_t *__restrict__ nel1,
+                                                          const int32_t *__restrict__ el4, const double *__restrict__ coord1,
+                                                          const uint8_t *__restrict__ fixmask1, const uint32_t *__restrict__ emap4, MatConst mc,
+                                                          double *__restrict__ vals, const int32_t *__restrict__ c2f,
+                                                          const double *__restrict__ disp, const double *__restrict__ sig,
+                                                          const uint8_t *__restrict__ pgp) {
+    extern __shared__ double rowbuf[];
+    const int64_t nb = gridDim.x, bq = nb >> 3, br = nb & 7, xcd = blockIdx.x & 7;
+    const int64_t wg = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + (blockIdx.x >> 3);
+    if (wg >= nitems) return;
+    const int64_t s = wg >> 2;
+    const int qd = (int)(wg & 3);
+    const int lane = threadIdx.x, rowl = lane >> 2, h = lane & 3;
+    const int64_t jb = sptr1[s], len = sptr1[s + 1] - jb;
+    const int64_t S = asm_row_stride(len);
+    for (int64_t i = lane; i < ASM_ROWS * S; i += 64) rowbuf[i] = 0.0;
+    const int64_t slot = s * 64 + qd * ASM_ROWS + rowl;
+    const int node = rownode1[slot];
+    const int64_t q0 = node >= 0 ? nptr1[node] : 0;
+    const int nvis = node >= 0 ? (int)(nptr1[node + 1] - q0) : 0;
+    int maxvis = nvis;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxvis = max(maxvis, __shfl_xor(maxvis, o, 64));
+    const int fa = node >= 0 ? fixmask1[node] : 0;
+    double *myrow = rowbuf + rowl * S;
+    __syncthreads();
+    for (int v = 0; v < maxvis; v++) {
+        const int32_t packed = v < nvis ? nel1[q0 + v] : -1;
+        const bool active = packed >= 0;
+        const int64_t e = active ? (int64_t)(packed >> 4) : 0;
+        const int a = active ? (packed & 15) : 0;
+        int nd[4];
+        double x[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            nd[k] = el4[e * 4 + k];
+            load3(coord1, nd[k], x[k][0], x[k][1], x[k][2]);
+            if (TANGENT && disp) {
+                double u0, u1, u2;
+                load3(disp, c2f[nd[k]], u0, u1, u2);
+                x[k][0] += u0; x[k][1] += u1; x[k][2] += u2;
+            }
+        }
+        // gradients of the four linear shape functions (the arithmetic of tet4_element_row, fcvm_mg_kernels.hip.h)
+        double e1[3], e2[3], e3[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            e1[c] = x[1][c] - x[0][c];
+            e2[c] = x[2][c] - x[0][c];
+            e3[c] = x[3][c] - x[0][c];
+        }
+        double g[4][3];
+        g[1][0] = e2[1] * e3[2] - e2[2] * e3[1]; g[1][1] = e2[2] * e3[0] - e2[0] * e3[2]; g[1][2] = e2[0] * e3[1] - e2[1] * e3[0];
+        g[2][0] = e3[1] * e1[2] - e3[2] * e1[1]; g[2][1] = e3[2] * e1[0] - e3[0] * e1[2]; g[2][2] = e3[0] * e1[1] - e3[1] * e1[0];
+        g[3][0] = e1[1] * e2[2] - e1[2] * e2[1]; g[3][1] = e1[2] * e2[0] - e1[0] * e2[2]; g[3][2] = e1[0] * e2[1] - e1[1] * e2[0];
+        const double det = e1[0] * g[1][0] + e1[1] * g[1][1] + e1[2] * g[1][2];
+        const double inv = 1.0 / det;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            g[1][c] *= inv; g[2][c] *= inv; g[3][c] *= inv;
+            g[0][c] = -(g[1][c] + g[2][c] + g[3][c]);
+        }
+        const double vol = fabs(det) / 6.0;
+        double ga[3] = {0, 0, 0}, gb[3] = {0, 0, 0};
+        int ndb = nd[0];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k == a) { ga[0] = g[k][0]; ga[1] = g[k][1]; ga[2] = g[k][2]; }
+            if (k == h) { gb[0] = g[k][0]; gb[1] = g[k][1]; gb[2] = g[k][2]; ndb = nd[k]; }
+        }
+        const double dot = ga[0] * gb[0] + ga[1] * gb[1] + ga[2] * gb[2];
+        double sub[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (TANGENT) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (active && pgp[4 * e + q]) {
+                    const double *s0 = sig + 24 * e + 6 * q;
+                    double sd[6] = {s0[0], s0[1], s0[2], s0[3], s0[4], s0[5]};
+                    const double p = (sd[0] + sd[1] + sd[2]) / 3.0;
+                    sd[0] -= p; sd[1] -= p; sd[2] -= p;
+                    double svm = sqrt(1.5 * (sd[0] * sd[0] + sd[1] * sd[1] + sd[2] * sd[2]) + 3.0 * (sd[3] * sd[3] + sd[4] * sd[4] + sd[5] * sd[5]));
+                    if (svm == 0.0) svm = 1.0;
+                    const double pf = 0.25 * 3.0 * mc.G / (1.0 + mc.H / 3.0 / mc.G) / (svm * svm);   // 0.25: four equal Gauss weights
+                    double ta[3], tb[3];
+                    ta[0] = ga[0] * sd[0] + ga[1] * sd[3] + ga[2] * sd[4];
+                    ta[1] = ga[1] * sd[1] + ga[0] * sd[3] + ga[2] * sd[5];
+                    ta[2] = ga[2] * sd[2] + ga[0] * sd[4] + ga[1] * sd[5];
+                    tb[0] = gb[0] * sd[0] + gb[1] * sd[3] + gb[2] * sd[4];
+                    tb[1] = gb[1] * sd[1] + gb[0] * sd[3] + gb[2] * sd[5];
+                    tb[2] = gb[2] * sd[2] + gb[0] * sd[4] + gb[1] * sd[5];
+#pragma unroll
+                    for (int r = 0; r < 3; r++)
+#pragma unroll
+                        for (int c = 0; c < 3; c++) sub[r * 3 + c] += pf * ta[r] * tb[c];
+                }
+            }
+        }
+        if (active) {
+            const int fb = fixmask1[ndb];
+            const uint32_t em = emap4[(e * 4 + a) * 4 + h];
+            const int64_t jj = (int64_t)(em >> 2) - jb + (int64_t)((em >> 1) & 1u);
+            double *dst = myrow + 9 * jj;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const bool rfix = (fa >> r) & 1;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const bool cfix = (fb >> c) & 1;
+                    double vv;
+                    if (r == c) vv = mc.D11 * ga[r] * gb[r] + mc.D44 * (dot - ga[r] * gb[r]);
+                    else vv = mc.D12 * ga[r] * gb[c] + mc.D44 * ga[c] * gb[r];
+                    if (TANGENT) vv -= sub[r * 3 + c];
+                    if (!rfix && !cfix) dst[r * 3 + c] += vol * vv;
+                    else if (rfix && a == h && r == c) dst[r * 3 + c] += 1.0;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {   // the finished quarter slice: as the fine kernel's sliced-ELL write-out
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const int sub4 = lane >> 4, r16 = lane & 15;
+        const double *src = rowbuf + r16 * S;
+        double *base = vals + jb * (9 * 64);
+        v2d *out = (v2d *)base + qd * ASM_ROWS + r16;
+        const int64_t npairs = len >> 1;
+        int64_t p = 0;
+        int c = sub4;
+        while (p < npairs) {
+            v2d d;
+            d.x = src[(2 * p) * 9 + c];
+            d.y = src[(2 * p + 1) * 9 + c];
+            out[(p * 9 + c) * 64] = d;
+            c += 4;
+            if (c >= 9) { c -= 9; p++; }
+        }
+        if (len & 1) {
+            double *o1 = base + 2 * npairs * (9 * 64) + qd * ASM_ROWS + r16;
+            for (int cc = sub4; cc < 9; cc += 4) o1[cc * 64] = src[(len - 1) * 9 + cc];
+        }
+    }
+}
+
 }  // namespace fcvm

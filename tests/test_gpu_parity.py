@@ -578,14 +578,14 @@ def test_aggregate_level_product_from_the_lower_triangle_equals_the_row_kernel(m
 
 @pytest.mark.parametrize("switch", ["FCVM_TOPO_EARLY=0", "FCVM_TRINV_ROWS=1", "FCVM_EMAP_HOST=1", "FCVM_L1_NT=1", "FCVM_MORTON_THREADS=1",
                                     "FCVM_WIN_SYM=0", "FCVM_WIN_SYM_LO=0", "FCVM_MORTON_AXIS_SCALE=1", "FCVM_ASSEMBLE_SYM=0", "FCVM_SYM_PAIR=0",
-                                    "FCVM_ASM_LPR=8", "FCVM_ASM_LPR_LONG=16", "FCVM_ASM_LPR_LONG=4", "FCVM_WSYM_EAGER=1"])
+                                    "FCVM_ASM_LPR=8", "FCVM_ASM_LPR_LONG=16", "FCVM_ASM_LPR_LONG=4", "FCVM_WSYM_EAGER=1", "FCVM_TET4_LDS=0"])
 def test_set_up_switches_do_not_change_the_solution(monkeypatch, switch):
     """The round-3 set-up paths against the ones they replaced: level-1 topology on the background thread / at the first
     assembly, triangular inverse by recursive doubling / block row by block row, element map from the device kernel / the host
     builder, plain / nontemporal loads of the level-1 matrix, Morton sort on all threads / one, the symmetric form of the window
     format / the full form (all three passes, the 16-bit passes only), Morton keys with one scale / per-axis scales; round 4: assembly
     through the sliced-ELL array and the copy kernel, lanes per row of the assembly into the symmetric form, its device half at
-    fcvm_set_mesh.  Same matrix bitwise, same PCG iteration count (+-1 where the inverse is formed in another order), same solution."""
+    fcvm_set_mesh, level-1 operator by the round-1 kernel.  Same matrix bitwise, same PCG iteration count (+-1 where the inverse is formed in another order), same solution."""
     from fcvm_hip import examples
     from fcvm_hip.device import Context
     from fcvm_hip.loads import Loads
