@@ -1083,7 +1083,11 @@ __device__ __forceinline__ void win_fma_sym(const WinSlotS &t, bool active, cons
         y[3 * r + 2] = __builtin_fma(t.v[8], a2, __builtin_fma(t.v[7], a1, __builtin_fma(t.v[6], a0, y[3 * r + 2])));
     }
     const uint32_t ts = t.ct >> 16;
+#ifdef FCVM_AB_NO_TR      // (timing experiment only: results are wrong without the transposed products)
+    if (false) {
+#else
     if (active && ts != 0xFFFFu) {
+#endif
 #pragma unroll
         for (int r = 0; r < NRHS; r++)
             if (tr_on[r]) {
