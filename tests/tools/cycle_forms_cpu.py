@@ -12,7 +12,7 @@ Chebyshev(2) 29, Gauss-Seidel 31 at 3840 tet10 -- with the library's approximate
 """
 import sys, os, time
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "fcvm-workbench_amd"))
 from fcvm_hip import examples, meshgen
 from oracle import oracle as orc
