@@ -363,7 +363,7 @@ class DistBackend:
         """p-multigrid V-cycle as PCG preconditioner on all ranks (needs LocalOps with the mg_* methods).  A single
         rank has nothing to exchange: it runs the library's own V-cycle PCG (fcvm_solve), i.e. exactly the one-GPU
         solver, instead of the host-sequenced cycle."""
-        if self.part.world == 1 and hasattr(self.ops, "enable_local_multigrid"):
+        if self.part.world == 1 and hasattr(self.ops, "enable_local_multigrid") and os.environ.get("FCVM_DIST_FORCE_HOST") != "1":
             self.ops.enable_local_multigrid()
             self.local_solver = True
             return
