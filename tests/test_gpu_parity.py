@@ -615,6 +615,33 @@ def test_set_up_switches_do_not_change_the_solution(monkeypatch, switch):
     assert rel(out[1][2], out[0][2]) < 1e-9
 
 
+def test_a_second_mesh_on_one_context_while_the_background_builders_still_run(orc):
+    """fcvm_set_mesh leaves two host threads behind (level-1 topology, symmetric window form); a second
+    fcvm_set_mesh on the same context -- before anything waited for them -- must join them, drop their results and build the new
+    mesh's; so must closing the context.  The second model then assembles (straight into the new symmetric form) and solves."""
+    from fcvm_hip import examples
+    from fcvm_hip.device import Context
+    a, b = small_case(7), examples.embankment(refine=1)
+    c = Context(0)
+    c.set_mesh(np.asarray(a["elNodes"]), np.asarray(a["nocoord"], dtype=np.float64))
+    c.set_mesh(np.asarray(b["elNodes"]), np.asarray(b["nocoord"], dtype=np.float64))      # (no finish_setup in between)
+    c.set_material(*[float(v) for v in np.asarray(b["material"]).reshape(-1)[:3]])
+    c.set_fix(b["fix"])
+    n = 3 * len(b["nocoord"])
+    glv, modf, V = c.assemble((0.0, 0.0, -10.0))
+    info = c.spmv_sym_info()
+    assert info["built"] and info["assembled_directly"]
+    fixdof = np.ones(n); fixdof[list(b["fix"])] = 0.0
+    f = c.array(fixdof * glv.get() + modf.get())
+    u, it = c.solve(f, rtol=1e-10)
+    r = c.axpby(1.0, f, -1.0, c.spmv(u, c.empty(n)))
+    assert c.norm(r) <= 5e-10 * c.norm(f)
+    c.close()
+    c2 = Context(0)                     # closed right after set_mesh: the threads are joined by fcvm_destroy
+    c2.set_mesh(np.asarray(a["elNodes"]), np.asarray(a["nocoord"], dtype=np.float64))
+    c2.close()
+
+
 def test_smoother_bounds_are_the_largest_eigenvalue_within_two_percent():
     """Round 4: every smoother interval / weight of the multigrid cycle comes from lambda_max(D^-1 A) of its level (D = the 3x3
     diagonal blocks).  Rounds 1-3 took 1.1 x fifteen power iterations, which reached 87-90 % of it -- the damped Jacobi step of cycle
