@@ -698,4 +698,117 @@ __global__ __launch_bounds__(64) void k_assemble_tet4_lds(int64_t nitems, const 
     }
 }
 
+// ---- geometric stiffness of the buckling pre-analysis (calcTSM with nstep = 1, fcVM.py:1002-1006) with rows in LDS (round 4) ------
+// Kg_ab = (sum_gp w ga . sigma . gb) I3: one scalar per block.  k_assemble_geometric (round 1) adds it to three components of every
+// block with read-modify-writes in global memory; here a wavefront owns 16 rows of a slice, four lanes per row, keeps ONE double per
+// block in LDS (lane h forms Gauss point h's Jacobian and sigma . ga once per visit and leaves them in an LDS record for the quad,
+// then sums the blocks of the local columns h, h + 4, h + 8) and writes the three diagonal components of the finished rows once
+// (the array is zeroed before, as for the old kernel; every entry is summed in the old kernel's order).
+constexpr int ASM_GREC = 14;      // doubles per (row, Gauss point): xsi[9], w, sigma . ga [3], unused
+__host__ __device__ inline int64_t asm_geom_lds_bytes(int64_t len) { return (ASM_ROWS * 4 * ASM_GREC + ASM_ROWS * (len | 1)) * 8; }
+__global__ __launch_bounds__(64) void k_assemble_geometric_lds(int64_t nitems, const int64_t *__restrict__ sptr, const int32_t *__restrict__ rownode,
+                                                               const int64_t *__restrict__ nptr, const int32_t *__restrict__ nel,
+                                                               const int32_t *__restrict__ el, const double *__restrict__ coord,
+                                                               const uint32_t *__restrict__ emap, const double *__restrict__ sig,
+                                                               double *__restrict__ vals_g) {
+    extern __shared__ double glds[];
+    double *rec = glds, *rowbuf = glds + ASM_ROWS * 4 * ASM_GREC;
+    const int64_t nb = gridDim.x, bq = nb >> 3, br = nb & 7, xcd = blockIdx.x & 7;
+    const int64_t wg = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + (blockIdx.x >> 3);
+    if (wg >= nitems) return;
+    const int64_t s = wg >> 2;
+    const int qd = (int)(wg & 3);
+    const int lane = threadIdx.x, rowl = lane >> 2, h = lane & 3;
+    const int64_t jb = sptr[s], len = sptr[s + 1] - jb;
+    const int64_t S = len | 1;
+    for (int64_t i = lane; i < ASM_ROWS * S; i += 64) rowbuf[i] = 0.0;
+    const int64_t slot = s * 64 + qd * ASM_ROWS + rowl;
+    const int node = rownode[slot];
+    const int64_t q0 = node >= 0 ? nptr[node] : 0;
+    const int nvis = node >= 0 ? (int)(nptr[node + 1] - q0) : 0;
+    int maxvis = nvis;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxvis = max(maxvis, __shfl_xor(maxvis, o, 64));
+    double *myrow = rowbuf + rowl * S;
+    double *myrec = rec + (rowl * 4 + h) * ASM_GREC;
+    const double *rowrec = rec + rowl * 4 * ASM_GREC;
+    __syncthreads();
+    for (int v = 0; v < maxvis; v++) {
+        const int32_t packed = v < nvis ? nel[q0 + v] : -1;
+        const bool active = packed >= 0;
+        const int64_t e = active ? (int64_t)(packed >> 4) : 0;
+        const int a = active ? (packed & 15) : 0;
+        {   // Gauss point h: Jacobian, weight, sigma . ga  (the arithmetic of geometric_element_row)
+            double xi, et, ze;
+            gp_point(h, xi, et, ze);
+            double xs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 10; k++) {
+                const int ndk = el[e * 10 + k];
+                double cx, cy, cz, d0, d1, d2;
+                load3(coord, ndk, cx, cy, cz);
+                dshp_k(k, xi, et, ze, d0, d1, d2);
+                xs[0] += cx * d0; xs[1] += cx * d1; xs[2] += cx * d2;
+                xs[3] += cy * d0; xs[4] += cy * d1; xs[5] += cy * d2;
+                xs[6] += cz * d0; xs[7] += cz * d1; xs[8] += cz * d2;
+            }
+            double xsi[9];
+            const double xsj = jac_inverse(xs, xsi);
+            double d0, d1, d2, g0, g1, g2;
+            dshp_k(a, xi, et, ze, d0, d1, d2);
+            to_global(xsi, d0, d1, d2, g0, g1, g2);
+            const double *sg = sig + 24 * e + 6 * h;  // (xx, yy, zz, xy, zx, yz)
+#pragma unroll
+            for (int k = 0; k < 9; k++) myrec[k] = xsi[k];
+            myrec[9] = FCVM_GPW * fabs(xsj);
+            myrec[10] = g0 * sg[0] + g1 * sg[3] + g2 * sg[4];
+            myrec[11] = g0 * sg[3] + g1 * sg[1] + g2 * sg[5];
+            myrec[12] = g0 * sg[4] + g1 * sg[5] + g2 * sg[2];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int b = h + 4 * t;
+            if (active && b < 10) {
+                double vsum = 0.0;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const double *rg = rowrec + g * ASM_GREC;
+                    double xi, et, ze, d0, d1, d2, g0, g1, g2;
+                    gp_point(g, xi, et, ze);
+                    dshp_k(b, xi, et, ze, d0, d1, d2);
+                    to_global(rg, d0, d1, d2, g0, g1, g2);
+                    vsum += rg[9] * (rg[10] * g0 + rg[11] * g1 + rg[12] * g2);
+                }
+                const uint32_t em = emap[e * 100 + a * 10 + b];
+                const int64_t jj = (int64_t)(em >> 2) - jb + (int64_t)((em >> 1) & 1u);
+                myrow[jj] += vsum;
+            }
+        }
+        __syncthreads();   // the records are rewritten by the next visit
+    }
+    __syncthreads();
+    {   // components 0, 4, 8 of every block of the quarter slice (pairs as 16-byte words, a single last block as 8-byte words)
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const int sub4 = lane >> 4, r16 = lane & 15;
+        const double *src = rowbuf + r16 * S;
+        double *base = vals_g + jb * (9 * 64);
+        v2d *out = (v2d *)base + qd * ASM_ROWS + r16;
+        const int64_t npairs = len >> 1;
+        if (sub4 < 3) {
+            const int c = 4 * sub4;
+            for (int64_t p = 0; p < npairs; p++) {
+                v2d d;
+                d.x = src[2 * p];
+                d.y = src[2 * p + 1];
+                out[(p * 9 + c) * 64] = d;
+            }
+            if (len & 1) {
+                double *o1 = base + 2 * npairs * (9 * 64) + qd * ASM_ROWS + r16;
+                o1[c * 64] = src[len - 1];
+            }
+        }
+    }
+}
+
 }  // namespace fcvm

@@ -2569,9 +2569,18 @@ int fcvm_assemble_buckling(fcvm_ctx *c, const double *sig, double shift) {
                            (const uint8_t *)nullptr, mc, 0.0, 0.0, 0.0, c->d_vals, c->d_r, c->d_z, (double *)nullptr, (double *)nullptr, 1);
     }
     {
+        // round 4: one double per block summed in LDS, written once (k_assemble_geometric_lds); FCVM_GEOM_LDS=0: the round-1 kernel
+        const size_t gl = (size_t)asm_geom_lds_bytes(c->pat.maxlen);
+        const bool geom_lds = !(getenv("FCVM_GEOM_LDS") && atoi(getenv("FCVM_GEOM_LDS")) == 0) && gl <= (size_t)64 * 1024;
         const int64_t nslots = c->pat.nslices * SLICE;
-        hipLaunchKernelGGL(k_assemble_geometric, dim3((unsigned)cdiv(nslots, 256)), block, 0, s, nslots, c->d_rownode, c->d_nptr, c->d_nel,
-                           c->d_el, c->d_coord, c->d_emap, sig, c->d_vals_g);
+        if (geom_lds) {
+            const int64_t nitems = 4 * c->pat.nslices;
+            hipLaunchKernelGGL(k_assemble_geometric_lds, dim3((unsigned)nitems), dim3(64), gl, s, nitems, c->d_sptr, c->d_rownode, c->d_nptr, c->d_nel,
+                               c->d_el, c->d_coord, c->d_emap, sig, c->d_vals_g);
+        } else {
+            hipLaunchKernelGGL(k_assemble_geometric, dim3((unsigned)cdiv(nslots, 256)), block, 0, s, nslots, c->d_rownode, c->d_nptr, c->d_nel,
+                               c->d_el, c->d_coord, c->d_emap, sig, c->d_vals_g);
+        }
     }
     if (shift != 0.0)
         hipLaunchKernelGGL(k_axpby, dim3((unsigned)cdiv(nv, 256)), dim3(256), 0, s, nv, 1.0, c->d_vals, shift, c->d_vals_g, c->d_vals);

@@ -1056,6 +1056,40 @@ def test_buckling_factors_on_gpu(orc):
         assert cos > 1 - 1e-6
 
 
+def test_geometric_stiffness_rows_in_lds_equal_the_read_modify_write_kernel(monkeypatch):
+    """K_g of the buckling pre-analysis (fcVM.py:1002-1006): the kernel that sums each row's blocks in LDS and writes them once
+    against the round-1 kernel that adds every element's share to global memory (FCVM_GEOM_LDS=0), through K_g x on a mesh with
+    odd and even slice lengths and a stress field that differs in every Gauss point."""
+    import time
+    from fcvm_hip import meshgen
+    from fcvm_hip.device import Context
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import GpuModel
+    el, xyz = meshgen.cube_tet10(9, 7, 5, 9.0, 7.0, 5.0)
+    fixed = {3 * int(n) + k: 0.0 for n in meshgen.nodes_on_plane(xyz, 0, 0.0) for k in range(3)}
+    xyz = xyz + 0.03 * np.random.default_rng(5).standard_normal(xyz.shape)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FCVM_GEOM_LDS", flag)
+        m = GpuModel(el, xyz, np.array([210000.0, 0.3, 7.8e-6]), fixed, Loads(), ctx=Context(0))
+        c = m.ctx
+        m.calc_gsm((0.0, 0.0, -10.0), want_x=False)
+        sig = c.array(np.random.default_rng(6).standard_normal(24 * len(el)))
+        c.assemble_buckling(sig, 0.1)
+        c.sync()
+        t0 = time.perf_counter()
+        c.assemble_buckling(sig, 0.1)
+        c.sync()
+        dt = time.perf_counter() - t0
+        x = c.array(np.random.default_rng(7).standard_normal(3 * len(xyz)))
+        out[flag] = (c.spmv_geometric(x, c.empty(3 * len(xyz))).get(), dt)
+        c.close()
+    a, b = out["1"][0], out["0"][0]
+    print("K_b and K_g assembly: rows in lds %.3f ms, global adds %.3f ms" % (1e3 * out["1"][1], 1e3 * out["0"][1]))
+    assert np.linalg.norm(b) > 0
+    assert np.abs(a - b).max() <= 1e-13 * np.abs(b).max()
+
+
 def test_gnly_with_buckling_imperfection_full_flow(orc, tmp_path):
     """The complete GNLY flow on the GPU -- elastic solution, buckling factors, imperfection from the
     buckling shapes, restart on the imperfect geometry, non-linear run, .out / .vtk with the buckling
