@@ -109,6 +109,8 @@ struct MgAlt {
     double *r = nullptr, *z = nullptr, *p = nullptr, *q = nullptr, *S = nullptr, *part_vec = nullptr, *part_spmv = nullptr, *part_lo = nullptr;
     double *md = nullptr, *mr = nullptr, *mt = nullptr, *x1 = nullptr, *rr1 = nullptr, *d1 = nullptr, *t1 = nullptr, *r2 = nullptr, *e2 = nullptr;
     double *sx = nullptr, *sr = nullptr, *sd = nullptr, *st = nullptr, *sr3 = nullptr, *se3 = nullptr;   // sparse aggregate level
+    double *symv_part = nullptr;   // its own partial buffer of k_symv_tiles: the two coarse parts of a pair run side by side
+    bool symv = false;
 };
 
 // host half of the level-1 (tet4) topology, see mg_topology_host in fcvm_mg.inc
@@ -166,6 +168,9 @@ struct fcvm_ctx {
     int level1_overlap = 1;         // FCVM_LEVEL1_OVERLAP=0: the level-1 operator of a tangent refresh after the fine assembly, on the main stream
     hipStream_t level1_stream = nullptr;
     hipEvent_t level1_fork = nullptr, level1_done = nullptr;
+    int pair_overlap = 1;           // FCVM_PAIR_OVERLAP=0: the coarse parts of a pair of solves one after the other on the main stream
+    hipStream_t pair_stream = nullptr;
+    hipEvent_t pair_fork = nullptr, pair_done = nullptr;
     int repack_overlap = 1;         // FCVM_REPACK_OVERLAP=0: the copy into the window storage on the main stream
     hipStream_t repack_stream = nullptr;
     hipEvent_t repack_fork = nullptr, repack_done = nullptr;
@@ -1171,6 +1176,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_WIN_SYM_LO")) c->wsym_lo = atoi(v) != 0;
     if (const char *v = getenv("FCVM_MG_FUSE_PROLONG")) c->mg_fuse_prolong = atoi(v) != 0;
     if (const char *v = getenv("FCVM_SYM_PAIR")) c->sym_pair = atoi(v) != 0;
+    if (const char *v = getenv("FCVM_PAIR_OVERLAP")) c->pair_overlap = atoi(v) != 0;
     if (const char *v = getenv("FCVM_ASSEMBLE_SYM")) c->asm_sym = atoi(v);
     if (const char *v = getenv("FCVM_ASM_NT")) c->asm_nt = atoi(v);
     if (const char *v = getenv("FCVM_ASM_LPR")) { const int l = atoi(v); if (l == 4 || l == 8 || l == 16) c->asm_lpr = l; }
@@ -1187,7 +1193,7 @@ static void alt_free(fcvm_ctx *c) {
     MgAlt &a = c->alt;
     dfree(a.r); dfree(a.z); dfree(a.p); dfree(a.q); dfree(a.S); dfree(a.part_vec); dfree(a.part_spmv); dfree(a.part_lo);
     dfree(a.md); dfree(a.mr); dfree(a.mt); dfree(a.x1); dfree(a.rr1); dfree(a.d1); dfree(a.t1); dfree(a.r2); dfree(a.e2);
-    dfree(a.sx); dfree(a.sr); dfree(a.sd); dfree(a.st); dfree(a.sr3); dfree(a.se3);
+    dfree(a.sx); dfree(a.sr); dfree(a.sd); dfree(a.st); dfree(a.sr3); dfree(a.se3); dfree(a.symv_part);
     a = MgAlt();
 }
 
@@ -1222,6 +1228,9 @@ int fcvm_destroy(fcvm_ctx *c) {
     if (c->level1_fork) (void)hipEventDestroy(c->level1_fork);
     if (c->level1_done) (void)hipEventDestroy(c->level1_done);
     if (c->level1_stream) (void)hipStreamDestroy(c->level1_stream);
+    if (c->pair_fork) (void)hipEventDestroy(c->pair_fork);
+    if (c->pair_done) (void)hipEventDestroy(c->pair_done);
+    if (c->pair_stream) (void)hipStreamDestroy(c->pair_stream);
     if (c->repack_fork) (void)hipEventDestroy(c->repack_fork);
     if (c->repack_done) (void)hipEventDestroy(c->repack_done);
     if (c->repack_stream) (void)hipStreamDestroy(c->repack_stream);

@@ -47,6 +47,6 @@ for k in range(a.steps):
     drv.iteration()
     c.sync()
     dt = time.perf_counter() - t0
-    print("iteration %d: %.1f ms total, assembly + hierarchy refresh %.1f ms, solves %d, PCG iterations %d, solve %.1f ms" %
+    print("iteration %d: %.1f ms total, assembly + hierarchy refresh %.1f ms, solves %d, PCG iterations %d (in lockstep: %d), solve %.1f ms" %
           (k, dt * 1e3, t_asm[0] * 1e3, st["solves"] - s0["solves"], st["pcg_iterations"] - s0["pcg_iterations"],
-           (st["solve_s"] - s0["solve_s"]) * 1e3))
+           st.get("paired_iterations", 0) - s0.get("paired_iterations", 0), (st["solve_s"] - s0["solve_s"]) * 1e3))
