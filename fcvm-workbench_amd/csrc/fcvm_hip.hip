@@ -2460,6 +2460,43 @@ int fcvm_mg_restrict_weighted(fcvm_ctx *c, const double *r0, const double *wgt, 
     return 0;
 }
 
+int fcvm_mg_restrict_diff(fcvm_ctx *c, const double *r0, const double *wgt, const double *sub, double *r1) {
+    NEED(c && c->mg_topo && wgt && sub, "fcvm_mg_restrict_diff: no multigrid hierarchy / weights / second vector");
+    hipLaunchKernelGGL(k_restrict, dim3((unsigned)cdiv(c->nc, 256)), dim3(256), 0, c->stream, c->nc, c->d_c2f, c->d_mptr, c->d_mids,
+                       c->d_fixmask, r0, r1, (const double *)nullptr, wgt, sub);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_jacobi6f(fcvm_ctx *c, const double *r, double weight, double *z) {
+    NEED(c && c->have_mesh && c->d_dinv6f && r && z, "fcvm_jacobi6f: no mesh / diagonal blocks");
+    hipLaunchKernelGGL(k_jacobi6f, dim3((unsigned)cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, (const float *)c->d_dinv6f, r, weight, z);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_dist_post_smooth(fcvm_ctx *c, const double *x2, const double *b, const double *t, double c0, const double *ow, double *z,
+                          double *bz_dev, double *bb_dev) {
+    NEED(c && c->have_mesh && c->d_dinv6f && c->d_part_misc, "fcvm_dist_post_smooth: no mesh / diagonal blocks");
+    NEED(x2 && b && t && ow && z && bz_dev && bb_dev, "fcvm_dist_post_smooth: null argument");
+    const int64_t nb = std::min<int64_t>(std::max<int64_t>(cdiv(c->nn, 256), 1), 1024);     // d_part_misc holds 2048 partials
+    hipLaunchKernelGGL(k_dist_post_smooth, dim3((unsigned)nb), dim3(256), 0, c->stream, c->nn, (const float *)c->d_dinv6f, x2, b, t, c0, ow, z,
+                       c->d_part_misc);
+    hipLaunchKernelGGL(k_sum_final2, dim3(1), dim3(256), 0, c->stream, c->d_part_misc, nb, bz_dev, bb_dev);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_spmv_dot(fcvm_ctx *c, const double *x, double *y, double *xy_dev) {
+    NEED(c && c->have_mesh && xy_dev, "fcvm_spmv_dot: no mesh");
+    NEED(x != y, "fcvm_spmv_dot: x and y must not alias");
+    NEED(aligned16(x) && aligned16(y), "fcvm_spmv_dot: device vectors must be 16-byte aligned");
+    launch_spmv(c, true, x, y, nullptr);
+    hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, c->stream, c->d_part_spmv, spmv_partials(c), xy_dev);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
 int fcvm_mg_prolong_add(fcvm_ctx *c, const double *e1, const double *z0, double *z) {
     NEED(c && c->mg_topo, "fcvm_mg_prolong_add: no multigrid hierarchy");
     hipLaunchKernelGGL(k_prolong_add, dim3((unsigned)cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, c->d_pa, c->d_pb, c->d_fixmask, e1,
@@ -2473,6 +2510,15 @@ int fcvm_pcg_update_xr_z0(fcvm_ctx *c, const double *alpha_dev, const double *p,
     NEED(c && c->have_mesh && alpha_dev, "fcvm_pcg_update_xr_z0: no mesh");
     hipLaunchKernelGGL(k_update_xr_z0_ext, dim3((unsigned)cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, alpha_dev, p, q, x, r, c->d_dinv,
                        z0, weight);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_pcg_update_xr_z0_f32(fcvm_ctx *c, const double *alpha_dev, const double *p, const double *q, double *x, double *r, double *z0,
+                              double weight) {
+    NEED(c && c->have_mesh && alpha_dev && c->d_dinv6f, "fcvm_pcg_update_xr_z0_f32: no mesh / diagonal blocks");
+    hipLaunchKernelGGL(k_update_xr_z0_ext, dim3((unsigned)cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, alpha_dev, p, q, x, r, c->d_dinv,
+                       z0, weight, (const float *)c->d_dinv6f);
     HCHK(hipGetLastError());
     return 0;
 }

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_restrict(int64_t nc, const int32_t *__r
                                                   const int64_t *__restrict__ mptr, const int32_t *__restrict__ mids,
                                                   const uint8_t *__restrict__ fixmask0, const double *__restrict__ r0,
                                                   double *__restrict__ r1, const double *__restrict__ done,
-                                                  const double *__restrict__ wgt = nullptr) {
+                                                  const double *__restrict__ wgt = nullptr, const double *__restrict__ sub = nullptr) {
     if (done && *done != 0.0) return;
     int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= nc) return;
@@ -153,13 +153,16 @@ __global__ __launch_bounds__(256) void k_restrict(int64_t nc, const int32_t *__r
     const int fm = fixmask0[f];
     double a0 = r0[3 * f], a1 = r0[3 * f + 1], a2 = r0[3 * f + 2];
     if (wgt) { a0 *= wgt[3 * f]; a1 *= wgt[3 * f + 1]; a2 *= wgt[3 * f + 2]; }
+    // sub (round 4, with wgt): the restricted vector is wgt * r0 - sub, formed on the fly (the multi-GPU cycle's w0 b - K~_local x1)
+    if (sub) { a0 -= sub[3 * f]; a1 -= sub[3 * f + 1]; a2 -= sub[3 * f + 2]; }
     for (int64_t q = mptr[c]; q < mptr[c + 1]; q++) {
         const int64_t m = mids[q];
         const int mm = fixmask0[m];
         const double w0 = wgt ? wgt[3 * m] : 1.0, w1 = wgt ? wgt[3 * m + 1] : 1.0, w2 = wgt ? wgt[3 * m + 2] : 1.0;
-        if (!(mm & 1)) a0 += 0.5 * w0 * r0[3 * m];
-        if (!(mm & 2)) a1 += 0.5 * w1 * r0[3 * m + 1];
-        if (!(mm & 4)) a2 += 0.5 * w2 * r0[3 * m + 2];
+        const double s0 = sub ? sub[3 * m] : 0.0, s1 = sub ? sub[3 * m + 1] : 0.0, s2 = sub ? sub[3 * m + 2] : 0.0;
+        if (!(mm & 1)) a0 += 0.5 * (w0 * r0[3 * m] - s0);
+        if (!(mm & 2)) a1 += 0.5 * (w1 * r0[3 * m + 1] - s1);
+        if (!(mm & 4)) a2 += 0.5 * (w2 * r0[3 * m + 2] - s2);
     }
     r1[3 * c] = (fm & 1) ? 0.0 : a0;
     r1[3 * c + 1] = (fm & 2) ? 0.0 : a1;
@@ -242,9 +245,18 @@ __global__ __launch_bounds__(256) void k_prolong_add(int64_t nn, const int32_t *
 }
 
 // x += alpha p ; r -= alpha q ; z0 = w * Dinv r, alpha read from device memory (multi-GPU host code)
+// z = Dinv r with the six distinct entries of the symmetric inverse diagonal block in FP32 (xx xy | xz yy | yz zz)
+__device__ __forceinline__ void apply_dinv6f(const float *__restrict__ d6, double r0, double r1, double r2, double &a0, double &a1, double &a2) {
+    const float2 *d2 = (const float2 *)d6;
+    const float2 u0 = d2[0], u1 = d2[1], u2 = d2[2];
+    a0 = (double)u0.x * r0 + (double)u0.y * r1 + (double)u1.x * r2;
+    a1 = (double)u0.y * r0 + (double)u1.y * r1 + (double)u2.x * r2;
+    a2 = (double)u1.x * r0 + (double)u2.x * r1 + (double)u2.y * r2;
+}
 __global__ __launch_bounds__(256) void k_update_xr_z0_ext(int64_t nn, const double *__restrict__ alpha_ptr, const double *__restrict__ p,
                                                           const double *__restrict__ q, double *__restrict__ x, double *__restrict__ r,
-                                                          const double *__restrict__ dinv, double *__restrict__ z0, double w) {
+                                                          const double *__restrict__ dinv, double *__restrict__ z0, double w,
+                                                          const float *__restrict__ dinv6 = nullptr) {
     const double alpha = *alpha_ptr;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nn) return;
@@ -256,8 +268,42 @@ __global__ __launch_bounds__(256) void k_update_xr_z0_ext(int64_t nn, const doub
         r[3 * i + c] = rn[c];
     }
     double a0, a1, a2;
-    apply_dinv(dinv + i * 9, rn[0], rn[1], rn[2], a0, a1, a2);
+    if (dinv6) apply_dinv6f(dinv6 + 6 * i, rn[0], rn[1], rn[2], a0, a1, a2);
+    else apply_dinv(dinv + i * 9, rn[0], rn[1], rn[2], a0, a1, a2);
     z0[3 * i] = w * a0; z0[3 * i + 1] = w * a1; z0[3 * i + 2] = w * a2;
+}
+
+// end of the multi-GPU cycle (form 2) once the second 16-bit product t = K~ x2 has been summed over the ranks (round 4):
+// z = x2 + c0 Dinv (b - t) with the six-entry FP32 form of Dinv (the S of k_jacobi6f and k_update_xr_z0_ext: pre- and
+// post-smoothing must be one operator), and on the way the rank's owner-weighted shares of b.z and b.b, which the
+// single-reduction CG wants next (b is its residual r): per-workgroup partials [2][gridDim.x], summed by k_sum_final2.
+// Replaces a subtraction, k_cheb_init, an addition and two of the three inner-product passes.
+__global__ __launch_bounds__(256) void k_dist_post_smooth(int64_t nn, const float *__restrict__ dinv6, const double *__restrict__ x2,
+                                                          const double *__restrict__ b, const double *__restrict__ t, double c0,
+                                                          const double *__restrict__ ow, double *__restrict__ z, double *__restrict__ part) {
+    __shared__ double sh[4];
+    double bz = 0.0, bb = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nn; i += (int64_t)gridDim.x * 256) {
+        const double b0 = b[3 * i], b1 = b[3 * i + 1], b2 = b[3 * i + 2];
+        double a0, a1, a2;
+        apply_dinv6f(dinv6 + 6 * i, b0 - t[3 * i], b1 - t[3 * i + 1], b2 - t[3 * i + 2], a0, a1, a2);
+        const double z0 = x2[3 * i] + c0 * a0, z1 = x2[3 * i + 1] + c0 * a1, z2 = x2[3 * i + 2] + c0 * a2;
+        z[3 * i] = z0; z[3 * i + 1] = z1; z[3 * i + 2] = z2;
+        const double w0 = ow[3 * i], w1 = ow[3 * i + 1], w2 = ow[3 * i + 2];
+        bz += w0 * b0 * z0 + w1 * b1 * z1 + w2 * b2 * z2;
+        bb += w0 * b0 * b0 + w1 * b1 * b1 + w2 * b2 * b2;
+    }
+    bz = block_sum(bz, sh);
+    __syncthreads();
+    bb = block_sum(bb, sh);
+    if (threadIdx.x == 0) { part[blockIdx.x] = bz; part[gridDim.x + blockIdx.x] = bb; }
+}
+__global__ __launch_bounds__(256) void k_sum_final2(const double *__restrict__ part, int64_t n, double *__restrict__ out0, double *__restrict__ out1) {
+    __shared__ double sh[4];
+    const double a = sum_partials(part, n, sh);
+    __syncthreads();
+    const double b = sum_partials(part + n, n, sh);
+    if (threadIdx.x == 0) { *out0 = a; *out1 = b; }
 }
 
 // start of a Chebyshev sweep from the zero vector: x = 0, r = b, d = c0 * Dinv b

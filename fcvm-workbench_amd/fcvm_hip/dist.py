@@ -415,8 +415,14 @@ class DistBackend:
         best["peeq_max"] = max(d["peeq_max"] for d in allo)
         return best
 
-    def spmv(self, x, y):
-        self.ops.spmv(x, y)
+    def spmv(self, x, y, xkx=None):
+        """y = K x (consistent);  xkx (1-element device tensor, optional): the rank's share of x^T K x = x_local . (K_local x_local),
+        from the SpMV kernel's own inner product -- taken BEFORE the shared-node sum (x consistent, product unsummed: the shares
+        add up to x^T K x without owner weights)"""
+        if xkx is not None:
+            self.ops.spmv_dot(x, y, xkx)
+        else:
+            self.ops.spmv(x, y)
         self.ex.interface_sum(y.t, 3)
         return y
 
@@ -553,13 +559,26 @@ class DistBackend:
         info = dict(iterations=0, rel_residual=0.0, spmv=0, refinements=0)
         fused = self.mg is not None and self.mg.ready and self.mg.fused
         dev_scalars = hasattr(self.ops, "pcg_scalars")
+        # round 4: with the fused end of the cycle (DistMG.fused_lo) the rank's shares of r.z and r.r come out of the cycle's last
+        # kernel and z^T K z out of the SpMV kernel (its own inner product over the rank's rows, before the shared-node sum): no
+        # separate inner-product passes, still ONE all-reduce of three numbers per iteration
+        fused_lo = fused and getattr(self.mg, "fused_lo", False)
+
+        def spmv_zw():
+            if fused_lo:
+                self.spmv(z, w, xkx=self.mg._dots[1:2])
+            else:
+                self.spmv(z, w)
+
+        def dots():
+            return self._allreduce(self.mg._dots) if fused_lo else self.dot3_t(r, z.t, w.t)
         total_it, spmvs, queued_all = 0, 0, 0
         bb_h = thresh_h = prev_true = None
         for attempt in range(1 + max_refine):
             self.precond(TVec(r), z)
-            self.spmv(z, w)
+            spmv_zw()
             spmvs += 1
-            g3 = self.dot3_t(r, z.t, w.t)
+            g3 = dots()
             gamma, delta = g3[0:1].clone(), g3[1:2].clone()
             if attempt == 0:
                 bb_h = float(g3[2].item())
@@ -590,9 +609,9 @@ class DistBackend:
                             x.addcmul_(p.t, alpha)
                             r.addcmul_(sv.t, -alpha)
                             self.precond(TVec(r), z)
-                        self.spmv(z, w)
+                        spmv_zw()
                         spmvs += 1
-                        self.ops.pcg_scalars(2, S, self.dot3_t(r, z.t, w.t))
+                        self.ops.pcg_scalars(2, S, dots())
                         torch.addcmul(z.t, p.t, beta, out=p.t)       # p = z + beta p
                         torch.addcmul(w.t, sv.t, beta, out=sv.t)     # s = w + beta s   (= K p)
                     queued += n
@@ -620,9 +639,9 @@ class DistBackend:
                             x.addcmul_(p.t, alpha)
                             r.addcmul_(sv.t, -alpha)
                             self.precond(TVec(r), z)
-                        self.spmv(z, w)
+                        spmv_zw()
                         spmvs += 1
-                        g3 = self.dot3_t(r, z.t, w.t)
+                        g3 = dots()
                         live = ~done
                         it_t += live
                         rr = torch.where(live, g3[2:3], rr)
@@ -738,6 +757,13 @@ class DistMG:
         self.check_every = check_every
         self.additive, self.weight = self.form == 1, weight
         self.fused = self.form in (1, 2)             # the PCG update x, r and the start of the cycle in one kernel
+        # round 4 (form 2 on the HIP kernels): the residual after pre-smoothing formed inside the restriction, the end of the cycle
+        # (subtraction, Dinv, addition) in one kernel that also leaves the rank's shares of r.z and r.r, z^T K z from the SpMV
+        # kernel's own inner product: per PCG iteration eight vector passes and four launches fewer.  FCVM_DIST_FUSED_LO=0: off.
+        self.fused_lo = (self.form == 2 and all(hasattr(be.ops, m) for m in ("post_smooth", "mg_restrict_diff", "jacobi6f", "spmv_dot",
+                                                                              "pcg_update_xr_z0_f32"))
+                         and os.environ.get("FCVM_DIST_FUSED_LO", "1") != "0")
+        self.rz_rr = None                            # (r.z, r.r) shares of the last cycle (device, 2 one-element views), fused_lo only
         self.ready = False
         self.topo = False
 
@@ -994,12 +1020,14 @@ class DistMG:
             else:
                 self.ops.mg_cheb_step(level, None, x, r, d, 0.0, 0.0, False)
 
-    def _coarse(self, r, partial=False):
+    def _coarse(self, r, partial=False, restricted=False):
         """x1 = M1^-1 P^T (w0 r): weighted restriction of a consistent fine vector, level-1 / aggregate cycle.
         partial: r is already a per-rank PART of the fine vector (its sum over the ranks is the vector): restricted as it stands,
-        the level-1 exchange then completes fine and coarse sums at once"""
+        the level-1 exchange then completes fine and coarse sums at once.  restricted: self.r1 already holds the rank's part."""
         be = self.be
-        if partial:
+        if restricted:
+            pass
+        elif partial:
             self.ops.mg_restrict(r, self.r1)
         else:
             self.ops.mg_restrict_weighted(r, TVec(self.w0), self.r1)
@@ -1020,6 +1048,17 @@ class DistMG:
         over the ranks of the 16-bit copies of their local matrices (one fine-level exchange: the second product's)"""
         be, c0 = self.be, self.weight * self.ch0.c0
         self.ops.spmv_lo(self.d0, self.t0)
+        if self.fused_lo:
+            self.ops.mg_restrict_diff(b, TVec(self.w0), self.t0, self.r1)        # P^T (w0 b - K~_local x1), never written out
+            self._coarse(None, restricted=True)
+            self.ops.mg_prolong_add(self.x1, self.d0, self.x2)
+            self.ops.spmv_lo(self.x2, self.t0)
+            be.ex.interface_sum(self.t0.t, 3)
+            if self.rz_rr is None:
+                self._dots = torch.zeros(3, dtype=torch.float64, device=be.device)
+                self.rz_rr = (self._dots[0:1], self._dots[2:3])
+            self.ops.post_smooth(self.x2, b, self.t0, c0, be.w, x, self.rz_rr[0], self.rz_rr[1])
+            return
         # round 4: the residual after pre-smoothing is only ever restricted, and the restriction is linear -- so the rank's
         # UNSUMMED product goes into it (b enters weighted by 1 / holders: a part of b) and the level-1 exchange that follows
         # the restriction anyway completes the sum over the ranks: one fine-level exchange less per cycle (mid-side nodes
@@ -1036,7 +1075,10 @@ class DistMG:
     def vcycle(self, b, x):
         """x = M^-1 b (consistent fine vectors)"""
         if self.form == 2:
-            self.ops.mg_cheb_init(0, b, self.z0, b, self.d0, self.weight * self.ch0.c0)   # x1 = c0 Dinv b
+            if self.fused_lo:
+                self.ops.jacobi6f(b, self.weight * self.ch0.c0, self.d0)                  # x1 = c0 Dinv b (FP32 Dinv, as the other two uses)
+            else:
+                self.ops.mg_cheb_init(0, b, self.z0, b, self.d0, self.weight * self.ch0.c0)   # x1 = c0 Dinv b
             self._cycle_lo(b, x)
             return
         if self.additive:   # x = w c0 Dinv b + P M1^-1 P^T b : no fine-level SpMV / exchange in the preconditioner
@@ -1052,6 +1094,10 @@ class DistMG:
     def update_and_vcycle(self, alpha, p, q, x, r, z):
         """additive cycle fused with the PCG update: x += alpha p, r -= alpha q, z = w c0 Dinv r + P M1^-1 P^T r
         (alpha: 1-element device tensor)"""
+        if self.fused_lo:
+            self.ops.pcg_update_xr_z0_f32(alpha, p, q, x, r, self.d0, self.weight * self.ch0.c0)
+            self._cycle_lo(r, z)
+            return
         self.ops.pcg_update_xr_z0(alpha, p, q, x, r, self.d0, self.weight * self.ch0.c0)
         if self.form == 2:      # d0 = x1 = c0 Dinv r is the pre-smoothing step
             self._cycle_lo(r, z)
@@ -1378,6 +1424,31 @@ class HipLocalOps:
     def pcg_update_xr_z0(self, alpha, p, q, x, r, z0, weight):
         from ._lib import call
         call("fcvm_pcg_update_xr_z0", self.c.h, alpha.data_ptr(), p.ptr, q.ptr, x.ptr, r.ptr, z0.ptr, float(weight))
+
+    # round 4: fused forms for the cycle of form 2, all with the six-entry FP32 inverse diagonal blocks (one smoother S before
+    # and after the coarse correction); DistMG uses them together or not at all (`fused_lo`)
+    def pcg_update_xr_z0_f32(self, alpha, p, q, x, r, z0, weight):
+        from ._lib import call
+        call("fcvm_pcg_update_xr_z0_f32", self.c.h, alpha.data_ptr(), p.ptr, q.ptr, x.ptr, r.ptr, z0.ptr, float(weight))
+
+    def jacobi6f(self, r, weight, z):
+        from ._lib import call
+        call("fcvm_jacobi6f", self.c.h, r.ptr, float(weight), z.ptr)
+
+    def mg_restrict_diff(self, r0, w, sub, r1):
+        """r1 = P^T (w * r0 - sub)"""
+        from ._lib import call
+        call("fcvm_mg_restrict_diff", self.c.h, r0.ptr, w.ptr, sub.ptr, r1.ptr)
+
+    def post_smooth(self, x2, b, t, c0, ow, z, bz, bb):
+        """z = x2 + c0 Dinv (b - t);  bz[0] = sum ow b z,  bb[0] = sum ow b b  (ow, bz, bb: torch tensors)"""
+        from ._lib import call
+        call("fcvm_dist_post_smooth", self.c.h, x2.ptr, b.ptr, t.ptr, float(c0), ow.data_ptr(), z.ptr, bz.data_ptr(), bb.data_ptr())
+
+    def spmv_dot(self, x, y, out):
+        """y = K_local x and out[0] = x . y over the local rows (the rank's share of x^T K x for a consistent x)"""
+        from ._lib import call
+        call("fcvm_spmv_dot", self.c.h, x.ptr, y.ptr, out.data_ptr())
 
     def mg_set_level2(self, nagg, agg, Z, rows):
         """rows: this rank's row block [m, 6 nagg] of the aggregate-level inverse (torch f64 on the device);

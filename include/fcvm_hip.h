@@ -323,6 +323,21 @@ int fcvm_mg_restrict_weighted(fcvm_ctx *c, const double *r0, const double *wgt, 
 int fcvm_mg_prolong_add(fcvm_ctx *c, const double *e1, const double *z0, double *z);
 int fcvm_pcg_update_xr_z0(fcvm_ctx *c, const double *alpha_dev, const double *p, const double *q, double *x, double *r,
                           double *z0, double weight);
+/* round 4 -- fused forms for the host-driven cycle of form 2 (16-bit smoother passes), all with the six-entry FP32 form of
+ * the inverse diagonal blocks, which pre- and post-smoothing must share:
+ *   fcvm_pcg_update_xr_z0_f32: as fcvm_pcg_update_xr_z0;   fcvm_jacobi6f: z = weight * Dinv r;
+ *   fcvm_mg_restrict_diff: r1 = P^T (wgt * r0 - sub) (the residual after pre-smoothing, formed on the fly);
+ *   fcvm_dist_post_smooth: z = x2 + c0 * Dinv (b - t), and *bz_dev = sum ow b z, *bb_dev = sum ow b b over this rank's dofs
+ *     (ow: owner weights; the two sums the single-reduction CG needs next, fixed summation order);
+ *   fcvm_spmv_dot: y = K x and *xy_dev = x . y over this rank's rows (with consistent x and the rank's UNSUMMED product this
+ *     is the rank's share of x^T K x: no owner weights, no exchange needed before it). */
+int fcvm_pcg_update_xr_z0_f32(fcvm_ctx *c, const double *alpha_dev, const double *p, const double *q, double *x, double *r,
+                              double *z0, double weight);
+int fcvm_jacobi6f(fcvm_ctx *c, const double *r, double weight, double *z);
+int fcvm_mg_restrict_diff(fcvm_ctx *c, const double *r0, const double *wgt, const double *sub, double *r1);
+int fcvm_dist_post_smooth(fcvm_ctx *c, const double *x2, const double *b, const double *t, double c0, const double *ow, double *z,
+                          double *bz_dev, double *bb_dev);
+int fcvm_spmv_dot(fcvm_ctx *c, const double *x, double *y, double *xy_dev);
 /* aggregate level after fcvm_mg_set_level2: r2 = Z^T r1 (f64[n2]), e2 = A2inv r2, d1 = Z e2 */
 int fcvm_mg_l2_restrict(fcvm_ctx *c, const double *r1, double *r2);
 int fcvm_mg_l2_solve(fcvm_ctx *c, const double *r2, double *e2);

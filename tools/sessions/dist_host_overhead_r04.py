@@ -13,7 +13,7 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER
 dist.init_process_group("gloo", rank=0, world_size=1)
 case = examples.plate_with_hole(float(os.environ.get("PLATE_H", "1.45")))
 torch.cuda.set_device(0)
-for force in ("0", "1"):
+for force in os.environ.get("FORCE_MODES", "0,1").split(","):
     os.environ["FCVM_DIST_FORCE_HOST"] = force
     model = partition_model(case["elNodes"], case["nocoord"], case["material"], case["fix"], Loads(ufaces=case["ufaces"], uloads=case["uloads"]),
                             device_index=0, device=torch.device("cuda", 0))
