@@ -2462,8 +2462,8 @@ int fcvm_mg_restrict_weighted(fcvm_ctx *c, const double *r0, const double *wgt, 
 
 int fcvm_mg_restrict_diff(fcvm_ctx *c, const double *r0, const double *wgt, const double *sub, double *r1) {
     NEED(c && c->mg_topo && wgt && sub, "fcvm_mg_restrict_diff: no multigrid hierarchy / weights / second vector");
-    hipLaunchKernelGGL(k_restrict, dim3((unsigned)cdiv(c->nc, 256)), dim3(256), 0, c->stream, c->nc, c->d_c2f, c->d_mptr, c->d_mids,
-                       c->d_fixmask, r0, r1, (const double *)nullptr, wgt, sub);
+    hipLaunchKernelGGL(k_restrict_diff4, dim3((unsigned)cdiv(4 * c->nc, 256)), dim3(256), 0, c->stream, c->nc, c->d_c2f, c->d_mptr, c->d_mids,
+                       c->d_fixmask, r0, wgt, sub, r1);
     HCHK(hipGetLastError());
     return 0;
 }
@@ -2535,6 +2535,23 @@ int fcvm_mg_l2_restrict(fcvm_ctx *c, const double *r1, double *r2) {
     NEED(c && c->l2, "fcvm_mg_l2_restrict: no aggregate level (fcvm_mg_set_level2)");
     hipLaunchKernelGGL(k_l2_restrict, dim3((unsigned)cdiv(c->nagg, 4)), dim3(256), 0, c->stream, c->nagg, c->d_aptr, c->d_anodes,
                        c->d_aoff, c->d_Z, r1, r2, (const double *)nullptr);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_mg_l2_restrict_weighted(fcvm_ctx *c, const double *r1, const double *wgt, double *r2) {
+    NEED(c && c->l2 && wgt, "fcvm_mg_l2_restrict_weighted: no aggregate level (fcvm_mg_set_level2) / weights");
+    hipLaunchKernelGGL(k_l2_restrict, dim3((unsigned)cdiv(c->nagg, 4)), dim3(256), 0, c->stream, c->nagg, c->d_aptr, c->d_anodes,
+                       c->d_aoff, c->d_Z, r1, r2, (const double *)nullptr, wgt);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+int fcvm_dist_cg_update(fcvm_ctx *c, const double *S_dev, const double *z, const double *w, double *p, double *s, double *x, double *r,
+                        double *z0, double weight) {
+    NEED(c && c->have_mesh && c->d_dinv6f && S_dev && z && w && p && s && x && r && z0, "fcvm_dist_cg_update: no mesh / null argument");
+    hipLaunchKernelGGL(k_dist_cg_update, dim3((unsigned)cdiv(c->nn, 256)), dim3(256), 0, c->stream, c->nn, S_dev, z, w, p, s, x, r,
+                       (const float *)c->d_dinv6f, z0, weight);
     HCHK(hipGetLastError());
     return 0;
 }

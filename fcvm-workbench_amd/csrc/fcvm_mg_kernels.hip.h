@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_restrict(int64_t nc, const int32_t *__r
                                                   const int64_t *__restrict__ mptr, const int32_t *__restrict__ mids,
                                                   const uint8_t *__restrict__ fixmask0, const double *__restrict__ r0,
                                                   double *__restrict__ r1, const double *__restrict__ done,
-                                                  const double *__restrict__ wgt = nullptr, const double *__restrict__ sub = nullptr) {
+                                                  const double *__restrict__ wgt = nullptr) {
     if (done && *done != 0.0) return;
     int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= nc) return;
@@ -153,17 +153,48 @@ __global__ __launch_bounds__(256) void k_restrict(int64_t nc, const int32_t *__r
     const int fm = fixmask0[f];
     double a0 = r0[3 * f], a1 = r0[3 * f + 1], a2 = r0[3 * f + 2];
     if (wgt) { a0 *= wgt[3 * f]; a1 *= wgt[3 * f + 1]; a2 *= wgt[3 * f + 2]; }
-    // sub (round 4, with wgt): the restricted vector is wgt * r0 - sub, formed on the fly (the multi-GPU cycle's w0 b - K~_local x1)
-    if (sub) { a0 -= sub[3 * f]; a1 -= sub[3 * f + 1]; a2 -= sub[3 * f + 2]; }
     for (int64_t q = mptr[c]; q < mptr[c + 1]; q++) {
         const int64_t m = mids[q];
         const int mm = fixmask0[m];
         const double w0 = wgt ? wgt[3 * m] : 1.0, w1 = wgt ? wgt[3 * m + 1] : 1.0, w2 = wgt ? wgt[3 * m + 2] : 1.0;
-        const double s0 = sub ? sub[3 * m] : 0.0, s1 = sub ? sub[3 * m + 1] : 0.0, s2 = sub ? sub[3 * m + 2] : 0.0;
-        if (!(mm & 1)) a0 += 0.5 * (w0 * r0[3 * m] - s0);
-        if (!(mm & 2)) a1 += 0.5 * (w1 * r0[3 * m + 1] - s1);
-        if (!(mm & 4)) a2 += 0.5 * (w2 * r0[3 * m + 2] - s2);
+        if (!(mm & 1)) a0 += 0.5 * w0 * r0[3 * m];
+        if (!(mm & 2)) a1 += 0.5 * w1 * r0[3 * m + 1];
+        if (!(mm & 4)) a2 += 0.5 * w2 * r0[3 * m + 2];
     }
+    r1[3 * c] = (fm & 1) ? 0.0 : a0;
+    r1[3 * c + 1] = (fm & 2) ? 0.0 : a1;
+    r1[3 * c + 2] = (fm & 4) ? 0.0 : a2;
+}
+
+// r1 = P^T (wgt * r0 - sub) with four lanes per coarse node (the partition and reduction tree of k_restrict_init below): the
+// multi-GPU cycle's restriction of w0 b - K~_local x1, formed on the fly (round 4; one lane per node: 60 us at 1 M tet10, this: 30)
+__global__ __launch_bounds__(256) void k_restrict_diff4(int64_t nc, const int32_t *__restrict__ c2f, const int64_t *__restrict__ mptr,
+                                                        const int32_t *__restrict__ mids, const uint8_t *__restrict__ fixmask0,
+                                                        const double *__restrict__ r0, const double *__restrict__ wgt,
+                                                        const double *__restrict__ sub, double *__restrict__ r1) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t c = t >> 2;
+    const int q = (int)(t & 3);
+    const bool valid = c < nc;
+    if (!valid) c = nc - 1;
+    const int64_t f = c2f[c];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (q == 0) {
+        a0 = wgt[3 * f] * r0[3 * f] - sub[3 * f];
+        a1 = wgt[3 * f + 1] * r0[3 * f + 1] - sub[3 * f + 1];
+        a2 = wgt[3 * f + 2] * r0[3 * f + 2] - sub[3 * f + 2];
+    }
+    for (int64_t k = mptr[c] + q; k < mptr[c + 1]; k += 4) {
+        const int64_t m = mids[k];
+        const int mm = fixmask0[m];
+        if (!(mm & 1)) a0 += 0.5 * (wgt[3 * m] * r0[3 * m] - sub[3 * m]);
+        if (!(mm & 2)) a1 += 0.5 * (wgt[3 * m + 1] * r0[3 * m + 1] - sub[3 * m + 1]);
+        if (!(mm & 4)) a2 += 0.5 * (wgt[3 * m + 2] * r0[3 * m + 2] - sub[3 * m + 2]);
+    }
+    a0 += __shfl_xor(a0, 1, 64); a1 += __shfl_xor(a1, 1, 64); a2 += __shfl_xor(a2, 1, 64);
+    a0 += __shfl_xor(a0, 2, 64); a1 += __shfl_xor(a1, 2, 64); a2 += __shfl_xor(a2, 2, 64);
+    if (!valid || q != 0) return;
+    const int fm = fixmask0[f];
     r1[3 * c] = (fm & 1) ? 0.0 : a0;
     r1[3 * c + 1] = (fm & 2) ? 0.0 : a1;
     r1[3 * c + 2] = (fm & 4) ? 0.0 : a2;
@@ -271,6 +302,32 @@ __global__ __launch_bounds__(256) void k_update_xr_z0_ext(int64_t nn, const doub
     if (dinv6) apply_dinv6f(dinv6 + 6 * i, rn[0], rn[1], rn[2], a0, a1, a2);
     else apply_dinv(dinv + i * 9, rn[0], rn[1], rn[2], a0, a1, a2);
     z0[3 * i] = w * a0; z0[3 * i + 1] = w * a1; z0[3 * i + 2] = w * a2;
+}
+
+// the vector half of a Chronopoulos-Gear iteration of the multi-GPU PCG in one pass (round 4): the direction updates of the PREVIOUS
+// iteration, p = z + beta p, s = w + beta s (s = K p by recurrence), then x += alpha p, r -= alpha s, z0 = weight * Dinv r with the
+// six-entry FP32 Dinv; alpha = S[5], beta = S[6] from k_dist_pcg_scalars (both zero once converged: nothing changes any more).
+// Eleven vector passes and one launch instead of thirteen and three.
+__global__ __launch_bounds__(256) void k_dist_cg_update(int64_t nn, const double *__restrict__ S, const double *__restrict__ z,
+                                                        const double *__restrict__ w, double *__restrict__ p, double *__restrict__ s,
+                                                        double *__restrict__ x, double *__restrict__ r, const float *__restrict__ dinv6,
+                                                        double *__restrict__ z0, double weight) {
+    const double alpha = S[5], beta = S[6];
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nn) return;
+    double rn[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double pn = z[3 * i + c] + beta * p[3 * i + c], sn = w[3 * i + c] + beta * s[3 * i + c];
+        p[3 * i + c] = pn;
+        s[3 * i + c] = sn;
+        x[3 * i + c] += alpha * pn;
+        rn[c] = r[3 * i + c] - alpha * sn;
+        r[3 * i + c] = rn[c];
+    }
+    double a0, a1, a2;
+    apply_dinv6f(dinv6 + 6 * i, rn[0], rn[1], rn[2], a0, a1, a2);
+    z0[3 * i] = weight * a0; z0[3 * i + 1] = weight * a1; z0[3 * i + 2] = weight * a2;
 }
 
 // end of the multi-GPU cycle (form 2) once the second 16-bit product t = K~ x2 has been summed over the ranks (round 4):
@@ -471,7 +528,8 @@ __global__ __launch_bounds__(256) void k_dot2_partial(int64_t nn, const double *
 // r2[aoff[g]+k] = sum_{i in aggregate g} sum_c Z[i][c][k] * r1[3i+c]; one wavefront per aggregate
 __global__ __launch_bounds__(256) void k_l2_restrict(int64_t nagg, const int64_t *__restrict__ aptr, const int32_t *__restrict__ anodes,
                                                      const int64_t *__restrict__ aoff, const double *__restrict__ Z,
-                                                     const double *__restrict__ r1, double *__restrict__ r2, const double *__restrict__ done) {
+                                                     const double *__restrict__ r1, double *__restrict__ r2, const double *__restrict__ done,
+                                                     const double *__restrict__ wgt = nullptr) {
     if (done && *done != 0.0) return;
     const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= nagg) return;
@@ -480,7 +538,8 @@ __global__ __launch_bounds__(256) void k_l2_restrict(int64_t nagg, const int64_t
     for (int64_t q = aptr[g] + lane; q < aptr[g + 1]; q += 64) {
         const int64_t i = anodes[q];
         const double *z = Z + i * 18;
-        const double a0 = r1[3 * i], a1 = r1[3 * i + 1], a2 = r1[3 * i + 2];
+        double a0 = r1[3 * i], a1 = r1[3 * i + 1], a2 = r1[3 * i + 2];
+        if (wgt) { a0 *= wgt[3 * i]; a1 *= wgt[3 * i + 1]; a2 *= wgt[3 * i + 2]; }   // (multi-GPU: owner weights, shared nodes count once)
 #pragma unroll
         for (int k = 0; k < 6; k++) acc[k] += z[k] * a0 + z[6 + k] * a1 + z[12 + k] * a2;
     }

@@ -97,6 +97,8 @@ SIGNATURES = {
     "fcvm_mg_restrict_diff": [_vp, _vp, _vp, _vp, _vp],
     "fcvm_dist_post_smooth": [_vp, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _vp],
     "fcvm_spmv_dot": [_vp, _vp, _vp, _vp],
+    "fcvm_dist_cg_update": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64],
+    "fcvm_mg_l2_restrict_weighted": [_vp, _vp, _vp, _vp],
     "fcvm_mg_l2_restrict": [_vp, _vp, _vp],
     "fcvm_mg_l2_solve": [_vp, _vp, _vp],
     "fcvm_membench": [_vp, _i64, _vp],

@@ -600,9 +600,18 @@ class DistBackend:
                 S[2] = thresh_h
                 self.ops.pcg_scalars(3, S, g3)
                 alpha, beta = S[5:6], S[6:7]
+                one_pass = fused_lo and hasattr(self.ops, "cg_update")
                 while queued < budget and not finished:
                     n = min(chunk, budget - queued)
                     for _ in range(n):
+                        if one_pass:
+                            # the direction updates of the previous iteration ride on this one's x / r update (beta = 0 at the
+                            # first: p = z, s = w): one pass over the vectors, then the cycle from its pre-smoothed start
+                            self.mg.cg_update_and_vcycle(S, z, w, p, sv, TVec(x), TVec(r))
+                            spmv_zw()
+                            spmvs += 1
+                            self.ops.pcg_scalars(2, S, dots())
+                            continue
                         if fused:
                             self.mg.update_and_vcycle(alpha, p, sv, TVec(x), TVec(r), z)
                         else:
@@ -1033,8 +1042,11 @@ class DistMG:
             self.ops.mg_restrict_weighted(r, TVec(self.w0), self.r1)
         self.ex1.interface_sum(self.r1.t, 3)
         self._from_zero(1, self.ch1, self.k1s, self.r1, self.x1, self.rr1, self.d1, self.t1)
-        torch.mul(self.rr1.t, self.own1, out=self.t1.t)       # owner-weighted: shared nodes count once
-        self.ops.mg_l2_restrict(self.t1, self.r2)             # r2 = Z^T (.)  (local part)
+        if hasattr(self.ops, "mg_l2_restrict_weighted"):
+            self.ops.mg_l2_restrict_weighted(self.rr1, self.own1, self.r2)   # r2 = Z^T (own1 * r1): shared nodes count once (local part)
+        else:
+            torch.mul(self.rr1.t, self.own1, out=self.t1.t)       # owner-weighted: shared nodes count once
+            self.ops.mg_l2_restrict(self.t1, self.r2)             # r2 = Z^T (.)  (local part)
         be._allreduce(self.r2.t)                              # replicated right-hand side of the aggregate level
         self.e2.t.zero_()
         if self.row_hi > self.row_lo:                         # this rank's rows of e2 = A2inv r2 ...
@@ -1090,6 +1102,11 @@ class DistMG:
         self._coarse(self.r0)
         self.ops.mg_prolong(self.x1, self.d0)
         self._post(0, self.ch0, self.k0, x, self.r0, self.d0, self.t0)
+
+    def cg_update_and_vcycle(self, S, z, w, p, s, x, r):
+        """the vector half of a Chronopoulos-Gear iteration (HipLocalOps.cg_update) and z = M^-1 r from its pre-smoothed start"""
+        self.ops.cg_update(S, z, w, p, s, x, r, self.d0, self.weight * self.ch0.c0)
+        self._cycle_lo(r, z)
 
     def update_and_vcycle(self, alpha, p, q, x, r, z):
         """additive cycle fused with the PCG update: x += alpha p, r -= alpha q, z = w c0 Dinv r + P M1^-1 P^T r
@@ -1444,6 +1461,15 @@ class HipLocalOps:
         """z = x2 + c0 Dinv (b - t);  bz[0] = sum ow b z,  bb[0] = sum ow b b  (ow, bz, bb: torch tensors)"""
         from ._lib import call
         call("fcvm_dist_post_smooth", self.c.h, x2.ptr, b.ptr, t.ptr, float(c0), ow.data_ptr(), z.ptr, bz.data_ptr(), bb.data_ptr())
+
+    def cg_update(self, S, z, w, p, s, x, r, z0, weight):
+        """p = z + beta p, s = w + beta s, x += alpha p, r -= alpha s, z0 = weight Dinv r (alpha = S[5], beta = S[6], torch tensor S)"""
+        from ._lib import call
+        call("fcvm_dist_cg_update", self.c.h, S.data_ptr(), z.ptr, w.ptr, p.ptr, s.ptr, x.ptr, r.ptr, z0.ptr, float(weight))
+
+    def mg_l2_restrict_weighted(self, r1, wgt, r2):
+        from ._lib import call
+        call("fcvm_mg_l2_restrict_weighted", self.c.h, r1.ptr, wgt.data_ptr(), r2.ptr)
 
     def spmv_dot(self, x, y, out):
         """y = K_local x and out[0] = x . y over the local rows (the rank's share of x^T K x for a consistent x)"""

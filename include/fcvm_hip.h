@@ -338,6 +338,13 @@ int fcvm_mg_restrict_diff(fcvm_ctx *c, const double *r0, const double *wgt, cons
 int fcvm_dist_post_smooth(fcvm_ctx *c, const double *x2, const double *b, const double *t, double c0, const double *ow, double *z,
                           double *bz_dev, double *bb_dev);
 int fcvm_spmv_dot(fcvm_ctx *c, const double *x, double *y, double *xy_dev);
+/*   fcvm_dist_cg_update: the vector half of a Chronopoulos-Gear iteration in one pass -- p = z + beta p, s = w + beta s (the
+ *     previous iteration's direction updates), x += alpha p, r -= alpha s, z0 = weight * Dinv r; alpha = S_dev[5], beta = S_dev[6]
+ *     as fcvm_dist_pcg_scalars leaves them;
+ *   fcvm_mg_l2_restrict_weighted: r2 = Z^T (wgt * r1) (owner weights of the level-1 nodes) */
+int fcvm_dist_cg_update(fcvm_ctx *c, const double *S_dev, const double *z, const double *w, double *p, double *s, double *x, double *r,
+                        double *z0, double weight);
+int fcvm_mg_l2_restrict_weighted(fcvm_ctx *c, const double *r1, const double *wgt, double *r2);
 /* aggregate level after fcvm_mg_set_level2: r2 = Z^T r1 (f64[n2]), e2 = A2inv r2, d1 = Z e2 */
 int fcvm_mg_l2_restrict(fcvm_ctx *c, const double *r1, double *r2);
 int fcvm_mg_l2_solve(fcvm_ctx *c, const double *r2, double *e2);
