@@ -86,6 +86,8 @@ class RiksDriver:
         self.rtol, self.maxit = rtol, maxit
         self.proj_depth = int(os.environ.get("FCVM_RHS_PROJECTION", "6"))  # previous solutions kept for the start vector
         self._hist, self._gram = [], None
+        self._carry = []            # GNLY: solutions of the previous tangent kept as directions for the next start vector
+        self.carry_depth = int(os.environ.get("FCVM_GNLY_CARRY", "2"))
         self.nstep, self.iterat_max, self.error_max = int(ctl["nstep"]), int(ctl["iterat_max"]), float(ctl["error_max"])
         self.relax, self.scale_re, self.scale_up, self.scale_dn = (
             float(ctl[k]) for k in ("relax", "scale_re", "scale_up", "scale_dn"))
@@ -188,22 +190,7 @@ class RiksDriver:
         x0, r0 = None, rhs
         nf = n0 = 1.0
         if hist and self.proj_depth > 0:
-            U = [h[0] for h in hist]
-            bn = self.dots(U + [rhs], rhs)          # projections and ||rhs||^2 in one pass over rhs
-            b, nf2 = np.array(bn[:-1]), bn[-1]
-            # least squares with a cut-off: a start vector that is (nearly) a combination of older ones makes the
-            # Gram matrix (nearly) singular; np.linalg.solve would answer with huge coefficients instead of failing
-            a = np.linalg.lstsq(self._gram, b, rcond=1e-12)[0]
-            if np.all(np.isfinite(a)) and np.any(a != 0.0):
-                x0 = c.axpby(a[0], U[0], 0.0, None)
-                for ai, ui in zip(a[1:], U[1:]):
-                    c.axpby(1.0, x0, ai, ui, out=x0)
-                r0 = c.spmv(x0, c.empty(rhs.n))             # true residual of the start vector
-                c.axpby(1.0, rhs, -1.0, r0, out=r0)
-                st["projection_spmv"] = st.get("projection_spmv", 0) + 1
-                nf, n0 = float(np.sqrt(nf2)), c.norm(r0)
-                if not np.isfinite(n0) or n0 >= nf:         # projection did not help: plain solve
-                    x0, r0, n0 = None, rhs, nf
+            x0, r0, nf, n0 = self._project(rhs)
         elif guess is not None and self.proj_depth > 0:
             x0 = guess.clone()
             r0 = c.spmv(x0, c.empty(rhs.n))                 # true residual of the start vector
@@ -246,6 +233,55 @@ class RiksDriver:
         st["spmv_total"] = st.get("spmv_total", 0) + info["spmv"]    # incl. the SpMVs inside V-cycles
         return u
 
+    def _project(self, rhs):
+        """Start vector for K x = rhs from the history: x0 = U a with (U^T K U) a = U^T rhs, and its TRUE residual (one SpMV).
+        Returns (x0, r0, ||rhs||, ||r0||); (None, rhs, nf, nf) when the projection does not help."""
+        c, st = self.c, self.st
+        U = [h[0] for h in self._hist]
+        bn = self.dots(U + [rhs], rhs)          # projections and ||rhs||^2 in one pass over rhs
+        b, nf = np.array(bn[:-1]), float(np.sqrt(bn[-1]))
+        # least squares with a cut-off: a start vector that is (nearly) a combination of older ones makes the
+        # Gram matrix (nearly) singular; np.linalg.solve would answer with huge coefficients instead of failing
+        a = np.linalg.lstsq(self._gram, b, rcond=1e-12)[0]
+        if not (np.all(np.isfinite(a)) and np.any(a != 0.0)):
+            return None, rhs, nf, nf
+        x0 = c.axpby(a[0], U[0], 0.0, None)
+        for ai, ui in zip(a[1:], U[1:]):
+            c.axpby(1.0, x0, ai, ui, out=x0)
+        r0 = c.spmv(x0, c.empty(rhs.n))             # true residual of the start vector
+        c.axpby(1.0, rhs, -1.0, r0, out=r0)
+        st["projection_spmv"] = st.get("projection_spmv", 0) + 1
+        n0 = c.norm(r0)
+        if not np.isfinite(n0) or n0 >= nf:         # projection did not help: plain solve
+            return None, rhs, nf, nf
+        return x0, r0, nf, n0
+
+    def _adopt_carry(self, known):
+        """History for the first solve with a new tangent: `known` = (u, K u) pairs whose product is at hand, plus the carried
+        solutions of the previous tangent with their products formed now (one SpMV each).  Sets _hist / _gram."""
+        c = self.c
+        carry, self._carry = self._carry, []
+        if self.proj_depth <= 0 or not carry:
+            return
+        hist = [(u, f.clone()) for u, f in known]
+        while len(carry) >= 2 and hasattr(c, "spmv2"):      # two products per pass over the matrix
+            ua, ub = carry.pop(0), carry.pop(0)
+            fa, fb = c.spmv2(ua, ub, c.empty(ua.n), c.empty(ub.n))
+            hist += [(ua, fa), (ub, fb)]
+            self.st["projection_spmv"] = self.st.get("projection_spmv", 0) + 1
+        for u in carry:
+            hist.append((u, c.spmv(u, c.empty(u.n))))
+            self.st["projection_spmv"] = self.st.get("projection_spmv", 0) + 1
+        hist = hist[-self.proj_depth:]
+        m = len(hist)
+        g = np.zeros((m, m))
+        U = [h[0] for h in hist]
+        for j in range(m):
+            col = self.dots(U, hist[j][1])
+            for i in range(m):
+                g[i, j] = col[i]
+        self._hist, self._gram = hist, 0.5 * (g + g.T)
+
     def solve_pair(self, rhs_a, guess_a, rhs_b):
         """The two back substitutions of a GNLY Newton iteration with its new tangent matrix (fcVM.py:1351-1401: ue = factor(f),
         due = factor(relax * r)) as ONE lockstep solve: every pass over the matrix serves both systems (Context.solve2).
@@ -264,12 +300,21 @@ class RiksDriver:
         if not np.isfinite(n0) or n0 >= nf:
             x0, r0, n0 = None, rhs_a, nf
         if x0 is not None and n0 <= self.rtol * nf:        # the old ue still solves the new system: only due is left
+            self._adopt_carry([(x0, rhs_a)])               # ... from the projection onto ue (product known: rhs_a) and the carried solutions
             st["solve_s"] += time.perf_counter() - t0
             st["solves"] += 1
             return x0, self.solve(rhs_b)
         rt_a = min(1.0, self.rtol * nf / n0) if x0 is not None else self.rtol
-        da, ub, ia, ib = c.solve2(r0, rhs_b, rtol=(rt_a, self.rtol), maxit=self.maxit)
+        # due: from the projection onto the carried solutions of the previous tangent (products formed now), if that helps
+        xb0, rb0, rt_b = None, rhs_b, self.rtol
+        self._adopt_carry([])
+        if self._hist:
+            xb0, rb0, nfb, n0b = self._project(rhs_b)
+            if xb0 is not None:
+                rt_b = min(1.0, self.rtol * nfb / max(n0b, 1e-300))
+        da, db, ia, ib = c.solve2(r0, rb0, rtol=(rt_a, rt_b), maxit=self.maxit)
         ua = da if x0 is None else c.axpby(1.0, x0, 1.0, da, out=da)
+        ub = db if xb0 is None else c.axpby(1.0, xb0, 1.0, db, out=db)
         # history for the start vectors of later solves with this matrix (none in GNLY once Gauss points are plastic: the
         # next iteration assembles a new tangent)
         self._hist = [(ua, rhs_a.clone()), (ub, rhs_b.clone())]
@@ -336,7 +381,11 @@ class RiksDriver:
         if self.LD and (self.iterat == 1 or c.any_nonzero(self.pgp)):  # fcVM.py:1351-1396
             self.glv, self.modf, _, _ = self.model.calc_gsm(self.grav, disp=self.disp_new, sig=self.sig_old,
                                                             pgp=self.pgp, Et_E=self.Et_E, want_x=False)
-            self._hist, self._gram = [], None   # new tangent matrix: the stored K U products are stale
+            # new tangent matrix: the stored K U products are stale.  The last solutions themselves still point the way (the
+            # right-hand side of the next due is close to the last one's): they are kept, without products -- solve_pair forms
+            # K_new u for them (one SpMV each) where that pays (FCVM_GNLY_CARRY vectors, default 2; 0: start every due from zero)
+            self._carry = [h[0] for h in self._hist][-self.carry_depth:] if self.carry_depth > 0 else []
+            self._hist, self._gram = [], None
             c.mul(self.model.fixdof, self.glv, out=self.f)
             c.axpby(1.0, self.f, 1.0, self.modf, out=self.f)
             f2 = c.axpby(self.relax, self.r, 0.0, None)
