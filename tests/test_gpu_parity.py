@@ -869,6 +869,30 @@ def test_gnly_updated_lagrange_analysis_matches_oracle(orc):
     assert rel(res["peeq"], o["peeq"]) < 1e-6
 
 
+def test_gnly_start_directions_carried_over_a_tangent_refresh_save_iterations_not_accuracy(monkeypatch):
+    """GNLY: the solutions of the previous tangent carried over as start directions (FCVM_GNLY_CARRY, products with the new matrix
+    formed by fcvm_spmv2) against starting every first solve with a new tangent from zero: the same analysis (the PCG works on
+    the true residual either way), fewer PCG iterations."""
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import run_analysis
+    case = small_case(6, prescribed=False)
+    ctl = dict(sig_yield=30.0, grav_x=0.0, grav_y=0.0, grav_z=-9.81, nstep=4, iterat_max=20, error_max=1e-5, relax=1.2,
+               scale_re=2.0, scale_up=1.2, scale_dn=1.2, disp_output="total", ultimate_strain=0.25, Et_E=0.05, target_LF=10.0,
+               csr_option="PEEQ", averaged_option="unaveraged", gnl="GNLY", maxImp="0.0", ev1="1.0", ev2="0.0")
+    case["uloads"] = case["uloads"] * 4.0
+    out = {}
+    for carry in ("0", "2"):
+        monkeypatch.setenv("FCVM_GNLY_CARRY", carry)
+        out[carry] = run_analysis(case["elNodes"], case["nocoord"], case["material"], case["fix"],
+                                  Loads(ufaces=case["ufaces"], uloads=case["uloads"]), ctl, rtol=1e-12)
+    a, b = out["2"], out["0"]
+    assert b["peeq"].max() > 0 and len(a["lout"]) == len(b["lout"])
+    assert rel(a["lout"], b["lout"]) < 1e-8 and rel(a["displacements"], b["displacements"]) < 1e-8 and rel(a["peeq"], b["peeq"]) < 1e-7
+    ia, ib = a["stats"]["pcg_iterations"], b["stats"]["pcg_iterations"]
+    print("PCG iterations of the analysis: carried directions %d, from zero %d" % (ia, ib))
+    assert ia < ib
+
+
 def test_embankment_document_in_reference_out_file_out(tmp_path):
     """Drop-in at file level: the reference's Embankment_with_Ditch_Example document (mesh, BREP, constraints) and its
     control file go in, the GPU path writes a .out file that is the reference's shipped one byte for byte and a .vtk
