@@ -106,7 +106,10 @@ void build_pattern(int64_t ne, int64_t nn, const int32_t *elnodes0, Pattern &p, 
 //     adds them in segment order (fixed order: bitwise reproducible) and writes y.
 // The values are copied from the sliced-ELL array by k_repack_win after every assembly (src: SELL slot of the row; both
 // layouts keep a row's blocks in ascending column order, so block j of a segment is block jstart + j of the row).
-constexpr int WIN_WAVES = 8;      // waves per group (default; WinPattern::waves holds the value a pattern was built with)
+#ifndef FCVM_WIN_WAVES
+#define FCVM_WIN_WAVES 8           // (experiment builds: -DFCVM_WIN_WAVES=16, tools/sessions/gpu_r04zd.sh)
+#endif
+constexpr int WIN_WAVES = FCVM_WIN_WAVES;      // waves per group (default; WinPattern::waves holds the value a pattern was built with)
 constexpr int WIN_SPLIT = 32;     // longest row segment (default; WinPattern::split)
 struct WinPattern {
     int64_t ngroups = 0, nwaves = 0, nblocks = 0;
