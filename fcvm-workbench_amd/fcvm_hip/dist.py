@@ -1134,7 +1134,7 @@ class DistModel:
         self.fix = dict(fix_local)
         self.loads = loads_local
         self._ext_fn = external_loads_fn
-        self._ext = None   # (solver.GpuModel keeps a cached load vector under this name; not cached here)
+        self._ext = None   # cached external load vector (device, exchanged), as solver.GpuModel; None: build it at the next calc_gsm
         self.ne, self.nn = len(part.elNodes), part.nn
         self.ndof = 3 * self.nn
         fixdof, movdof = np.ones(self.ndof), np.zeros(self.ndof)
@@ -1146,17 +1146,29 @@ class DistModel:
         mv = torch.tensor([movdof.max() if len(movdof) else 0.0], dtype=torch.float64, device=backend.device)
         backend._allreduce(mv, dist.ReduceOp.MAX)
         self.moving = bool(mv.item() == 1.0)
+        # does ANY rank hold a pressure load?  Only pressure follows the deformed geometry (fcVM.py:858-883): without one the
+        # external load vector is built once and kept on the device, as solver.GpuModel does -- no displacements back to the
+        # host, no upload, no exchange per GNLY tangent.  The answer must be the same on every rank (the exchange is collective).
+        hp = torch.tensor([1.0 if getattr(loads_local, "has_pressure", True) else 0.0], dtype=torch.float64, device=backend.device)
+        backend._allreduce(hp, dist.ReduceOp.MAX)
+        self.follower_loads = bool(hp.item() == 1.0)
         self.t_pattern = 0.0
 
     def calc_gsm(self, grav, disp=None, sig=None, pgp=None, Et_E=0.0, want_x=True):
         c = self.ctx
         xgp = c.empty(12 * self.ne) if want_x else None
-        ext = self._ext_fn(self.nocoord, self.loads, None if disp is None else disp.get())
         glv, modf, V = c.assemble(grav, disp=disp, sig=sig, pgp=pgp, Et_E=Et_E, xgp=xgp)
-        # every rank takes part in the exchange, loaded or not (a rank-local "any load?" test would
-        # leave the neighbours waiting)
-        e = c.array(ext)
-        c.ex.interface_sum(e.t, 3)
+        follower = disp is not None and self.follower_loads
+        if follower or self._ext is None:
+            ext = self._ext_fn(self.nocoord, self.loads, disp.get() if follower else None)
+            # every rank takes part in the exchange, loaded or not (a rank-local "any load?" test would
+            # leave the neighbours waiting)
+            e = c.array(ext)
+            c.ex.interface_sum(e.t, 3)
+            if not follower:
+                self._ext = e          # (the driver resets it when the coordinates change: imperfection, set_coords)
+        else:
+            e = self._ext
         glv.t.add_(e.t)
         return glv, modf, V, xgp
 
