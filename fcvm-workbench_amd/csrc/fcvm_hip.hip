@@ -2547,6 +2547,14 @@ int fcvm_mg_l2_restrict_weighted(fcvm_ctx *c, const double *r1, const double *wg
     return 0;
 }
 
+int fcvm_mg_l2_restrict_diff(fcvm_ctx *c, const double *r1, const double *wgt, const double *sub, double *r2) {
+    NEED(c && c->l2 && wgt && sub, "fcvm_mg_l2_restrict_diff: no aggregate level (fcvm_mg_set_level2) / weights / second vector");
+    hipLaunchKernelGGL(k_l2_restrict, dim3((unsigned)cdiv(c->nagg, 4)), dim3(256), 0, c->stream, c->nagg, c->d_aptr, c->d_anodes,
+                       c->d_aoff, c->d_Z, r1, r2, (const double *)nullptr, wgt, sub);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
 int fcvm_dist_cg_update(fcvm_ctx *c, const double *S_dev, const double *z, const double *w, double *p, double *s, double *x, double *r,
                         double *z0, double weight) {
     NEED(c && c->have_mesh && c->d_dinv6f && S_dev && z && w && p && s && x && r && z0, "fcvm_dist_cg_update: no mesh / null argument");

@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void k_dot2_partial(int64_t nn, const double *
 __global__ __launch_bounds__(256) void k_l2_restrict(int64_t nagg, const int64_t *__restrict__ aptr, const int32_t *__restrict__ anodes,
                                                      const int64_t *__restrict__ aoff, const double *__restrict__ Z,
                                                      const double *__restrict__ r1, double *__restrict__ r2, const double *__restrict__ done,
-                                                     const double *__restrict__ wgt = nullptr) {
+                                                     const double *__restrict__ wgt = nullptr, const double *__restrict__ sub = nullptr) {
     if (done && *done != 0.0) return;
     const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= nagg) return;
@@ -540,6 +540,7 @@ __global__ __launch_bounds__(256) void k_l2_restrict(int64_t nagg, const int64_t
         const double *z = Z + i * 18;
         double a0 = r1[3 * i], a1 = r1[3 * i + 1], a2 = r1[3 * i + 2];
         if (wgt) { a0 *= wgt[3 * i]; a1 *= wgt[3 * i + 1]; a2 *= wgt[3 * i + 2]; }   // (multi-GPU: owner weights, shared nodes count once)
+        if (sub) { a0 -= sub[3 * i]; a1 -= sub[3 * i + 1]; a2 -= sub[3 * i + 2]; }     // (... minus the rank's unsummed last product, see DistMG._coarse)
 #pragma unroll
         for (int k = 0; k < 6; k++) acc[k] += z[k] * a0 + z[6 + k] * a1 + z[12 + k] * a2;
     }

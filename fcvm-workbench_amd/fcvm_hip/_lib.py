@@ -99,6 +99,7 @@ SIGNATURES = {
     "fcvm_spmv_dot": [_vp, _vp, _vp, _vp],
     "fcvm_dist_cg_update": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64],
     "fcvm_mg_l2_restrict_weighted": [_vp, _vp, _vp, _vp],
+    "fcvm_mg_l2_restrict_diff": [_vp, _vp, _vp, _vp, _vp],
     "fcvm_mg_l2_restrict": [_vp, _vp, _vp],
     "fcvm_mg_l2_solve": [_vp, _vp, _vp],
     "fcvm_membench": [_vp, _i64, _vp],

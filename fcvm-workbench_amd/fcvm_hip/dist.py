@@ -773,6 +773,12 @@ class DistMG:
                                                                               "pcg_update_xr_z0_f32"))
                          and os.environ.get("FCVM_DIST_FUSED_LO", "1") != "0")
         self.rz_rr = None                            # (r.z, r.r) shares of the last cycle (device, 2 one-element views), fused_lo only
+        # round 4: the last product of the level-1 pre-smoothing only ever enters (a) the residual the aggregate level restricts --
+        # whose sum over the ranks the all-reduce of r2 completes anyway -- and (b) the residual the post-smoothing starts from, where
+        # it rides on the exchange of the FIRST post-smoothing product (both are subtracted from the same vector): one shared-node
+        # exchange less per cycle (8 instead of 9 exchange points per PCG iteration), the same numbers up to rounding.
+        # FCVM_DIST_MERGE_L1=0: every product exchanged on its own.
+        self.merge_l1 = os.environ.get("FCVM_DIST_MERGE_L1", "1") != "0"
         self.ready = False
         self.topo = False
 
@@ -800,6 +806,7 @@ class DistMG:
         self.r0, self.d0, self.t0 = mk(n0), mk(n0), mk(n0)
         self.x2, self.z0 = mk(n0), mk(n0)       # form 2: x after the coarse correction; a scratch vector
         self.r1, self.x1, self.rr1, self.d1, self.t1 = mk(n1), mk(n1), mk(n1), mk(n1), mk(n1)
+        self.tk1 = mk(n1)      # the last pre-smoothing product of level 1, unsummed (merge_l1)
         self.topo = True
 
     def _lmax(self, level, n, wdot):
@@ -1041,19 +1048,49 @@ class DistMG:
         else:
             self.ops.mg_restrict_weighted(r, TVec(self.w0), self.r1)
         self.ex1.interface_sum(self.r1.t, 3)
-        self._from_zero(1, self.ch1, self.k1s, self.r1, self.x1, self.rr1, self.d1, self.t1)
-        if hasattr(self.ops, "mg_l2_restrict_weighted"):
-            self.ops.mg_l2_restrict_weighted(self.rr1, self.own1, self.r2)   # r2 = Z^T (own1 * r1): shared nodes count once (local part)
+        merge = self.merge_l1
+        if merge:
+            # k1s Chebyshev steps from zero, the last one's product A1 d left UNSUMMED in tk1: x is complete, rr1 still lacks it
+            ch, k = self.ch1, self.k1s
+            self.ops.mg_cheb_init(1, self.r1, self.x1, self.rr1, self.d1, ch.c0)
+            for j in range(1, k):
+                self._spmv(1, self.d1, self.t1)
+                self.ops.mg_cheb_step(1, self.t1, self.x1, self.rr1, self.d1, ch.cdd[j], ch.cdr[j], True)
+            self.ops.mg_spmv(1, self.d1, self.tk1)                                        # this rank's part of the last product
+            self.ops.mg_cheb_step(1, None, self.x1, self.rr1, self.d1, 0.0, 0.0, False)   # x += d
+            if hasattr(self.ops, "mg_l2_restrict_diff"):
+                self.ops.mg_l2_restrict_diff(self.rr1, self.own1, self.tk1, self.r2)      # Z^T (own1 * rr1 - tk1): summed by the all-reduce
+            else:
+                torch.addcmul(-self.tk1.t, self.rr1.t, self.own1, out=self.t1.t)
+                self.ops.mg_l2_restrict(self.t1, self.r2)
         else:
-            torch.mul(self.rr1.t, self.own1, out=self.t1.t)       # owner-weighted: shared nodes count once
-            self.ops.mg_l2_restrict(self.t1, self.r2)             # r2 = Z^T (.)  (local part)
+            self._from_zero(1, self.ch1, self.k1s, self.r1, self.x1, self.rr1, self.d1, self.t1)
+            if hasattr(self.ops, "mg_l2_restrict_weighted"):
+                self.ops.mg_l2_restrict_weighted(self.rr1, self.own1, self.r2)   # r2 = Z^T (own1 * r1): shared nodes count once (local part)
+            else:
+                torch.mul(self.rr1.t, self.own1, out=self.t1.t)       # owner-weighted: shared nodes count once
+                self.ops.mg_l2_restrict(self.t1, self.r2)             # r2 = Z^T (.)  (local part)
         be._allreduce(self.r2.t)                              # replicated right-hand side of the aggregate level
         self.e2.t.zero_()
         if self.row_hi > self.row_lo:                         # this rank's rows of e2 = A2inv r2 ...
             self.ops.mg_l2_solve(self.r2, TVec(self.e2.t[self.row_lo:self.row_hi]))
         be._allreduce(self.e2.t)                              # ... gathered (sum with zeros: bit-identical on every rank)
         self.ops.mg_l2_prolong(self.e2, self.d1)
-        self._post(1, self.ch1, self.k1s, self.x1, self.rr1, self.d1, self.t1)
+        if merge:
+            # first post-smoothing product + the pending one, ONE exchange for both: rr1 -= sum over the ranks of (A1 d + tk1)
+            ch, k = self.ch1, self.k1s
+            self.ops.mg_spmv(1, self.d1, self.t1)
+            self.t1.t.add_(self.tk1.t)
+            self.ex1.interface_sum(self.t1.t, 3)
+            self.ops.mg_cheb_step(1, self.t1, self.x1, self.rr1, self.d1, 0.0, ch.c0, True)
+            for j in range(1, k + 1):
+                if j < k:
+                    self._spmv(1, self.d1, self.t1)
+                    self.ops.mg_cheb_step(1, self.t1, self.x1, self.rr1, self.d1, ch.cdd[j], ch.cdr[j], True)
+                else:
+                    self.ops.mg_cheb_step(1, None, self.x1, self.rr1, self.d1, 0.0, 0.0, False)
+        else:
+            self._post(1, self.ch1, self.k1s, self.x1, self.rr1, self.d1, self.t1)
 
     def _cycle_lo(self, b, x):
         """form 2 from x1 = c0 Dinv b in self.d0:  x2 = x1 + P M1^-1 P^T (b - K~ x1);  x = x2 + c0 Dinv (b - K~ x2), K~ = the sum
@@ -1482,6 +1519,11 @@ class HipLocalOps:
     def mg_l2_restrict_weighted(self, r1, wgt, r2):
         from ._lib import call
         call("fcvm_mg_l2_restrict_weighted", self.c.h, r1.ptr, wgt.data_ptr(), r2.ptr)
+
+    def mg_l2_restrict_diff(self, r1, wgt, sub, r2):
+        """r2 = Z^T (wgt * r1 - sub)"""
+        from ._lib import call
+        call("fcvm_mg_l2_restrict_diff", self.c.h, r1.ptr, wgt.data_ptr(), sub.ptr, r2.ptr)
 
     def spmv_dot(self, x, y, out):
         """y = K_local x and out[0] = x . y over the local rows (the rank's share of x^T K x for a consistent x)"""

@@ -345,6 +345,9 @@ int fcvm_spmv_dot(fcvm_ctx *c, const double *x, double *y, double *xy_dev);
 int fcvm_dist_cg_update(fcvm_ctx *c, const double *S_dev, const double *z, const double *w, double *p, double *s, double *x, double *r,
                         double *z0, double weight);
 int fcvm_mg_l2_restrict_weighted(fcvm_ctx *c, const double *r1, const double *wgt, double *r2);
+/*   fcvm_mg_l2_restrict_diff: r2 = Z^T (wgt * r1 - sub): the level-1 residual whose last product (sub: this rank's UNSUMMED A1 d)
+ *     has not been exchanged -- the all-reduce of r2 completes the sum over the ranks */
+int fcvm_mg_l2_restrict_diff(fcvm_ctx *c, const double *r1, const double *wgt, const double *sub, double *r2);
 /* aggregate level after fcvm_mg_set_level2: r2 = Z^T r1 (f64[n2]), e2 = A2inv r2, d1 = Z e2 */
 int fcvm_mg_l2_restrict(fcvm_ctx *c, const double *r1, double *r2);
 int fcvm_mg_l2_solve(fcvm_ctx *c, const double *r2, double *e2);

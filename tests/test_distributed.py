@@ -171,8 +171,9 @@ def test_four_rank_multigrid_solve(orc, tmp_path):
         print("four ranks:", g["info"]["iterations"], "iterations,", cpi)
         # multiplicative cycle (form 2, default): two more fine-level exchanges (the smoother's products) and, with three level-1
         # smoothing steps, two more level-1 exchanges than the additive cycle's six -- for about half its iterations
-        # round 4: the product of the pre-smoothing pass is restricted unsummed (the level-1 exchange completes it): nine
-        assert 8.9 < cpi["exchanges"] < 9.3 and 2.9 < cpi["allreduces"] < 3.2, cpi
+        # round 4: the product of the pre-smoothing pass is restricted unsummed (the level-1 exchange completes it): nine; the last
+        # product of the level-1 pre-smoothing travels with the first one of the post-smoothing: eight
+        assert 7.9 < cpi["exchanges"] < 8.3 and 2.9 < cpi["allreduces"] < 3.2, cpi
 
 
 @pytest.mark.timeout(600)

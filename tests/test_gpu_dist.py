@@ -24,6 +24,7 @@ TRACTION = (20.0, 0.0, 200.0)
 def _worker(rank, world, port, out, precond):
     if precond == "mg-unfused":     # the cycle's end and the inner products as separate kernels (the rounds-1-3 sequence)
         os.environ["FCVM_DIST_FUSED_LO"] = "0"
+        os.environ["FCVM_DIST_MERGE_L1"] = "0"      # ... and every level-1 product exchanged on its own
         precond = "mg"
     os.environ["FCVM_PRECOND"] = precond
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
