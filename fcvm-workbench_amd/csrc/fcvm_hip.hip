@@ -1701,14 +1701,14 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
         if (sig ? launch_assemble_sym<true>(c, disp, sig, pgp, mc, grav, glv_grav, modf, xgp, lo)
                 : launch_assemble_sym<false>(c, disp, nullptr, nullptr, mc, grav, glv_grav, modf, xgp, lo))
             return 1;
-        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, s, ws.part_vol, ws.nitems, c->d_out8);
+        hipLaunchKernelGGL(k_sum_final_wide, dim3(1), dim3(1024), 0, s, ws.part_vol, ws.nitems, c->d_out8);
         HCHK(hipGetLastError());
         c->sell_valid = false;
     } else if (use_lds) {  // quarter slices accumulated in LDS, written once (fcvm_assemble_lds.hip.h)
         if (sig ? launch_assemble_lds<true>(c, disp, sig, pgp, mc, grav, glv_grav, modf, xgp, c->d_part_vol, 0)
                 : launch_assemble_lds<false>(c, disp, nullptr, nullptr, mc, grav, glv_grav, modf, xgp, c->d_part_vol, 0))
             return 1;
-        hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, s, c->d_part_vol, 4 * c->pat.nslices, c->d_out8);
+        hipLaunchKernelGGL(k_sum_final_wide, dim3(1), dim3(1024), 0, s, c->d_part_vol, 4 * c->pat.nslices, c->d_out8);
     } else {  // one lane per matrix row, global read-modify-writes, no atomics, bitwise reproducible
         if (sig)
             hipLaunchKernelGGL(k_assemble_rows<true>, rgrid, block, 0, s, nslots, c->d_rownode, c->d_nptr, c->d_nel, c->d_el, c->d_coord,

@@ -899,6 +899,13 @@ __global__ __launch_bounds__(256) void k_sum_final(const double *__restrict__ pa
     double v = sum_partials(part, n, sh);
     if (threadIdx.x == 0) *out = v;
 }
+// the same with 1024 threads, for long lists (the volume partials of the assembly: one per work item, 90 k at 1 M tet10 -- 149 us
+// with 256 threads in a kernel trace, on the critical path behind every assembly)
+__global__ __launch_bounds__(1024) void k_sum_final_wide(const double *__restrict__ part, int64_t n, double *__restrict__ out) {
+    __shared__ double sh[16];
+    double v = sum_partials(part, n, sh);
+    if (threadIdx.x == 0) *out = v;
+}
 // k <= 16 inner products x_j . y in one pass over y (the Newton driver's projection / Gram / Riks scalars: one launch and one
 // host synchronisation instead of k).  Same grid, same per-thread order and the same two-stage sums as k_dot_partial /
 // k_sum_final, so every result is bitwise what fcvm_vec_dot returns for that pair.
