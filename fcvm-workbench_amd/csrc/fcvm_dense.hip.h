@@ -273,6 +273,16 @@ __global__ __launch_bounds__(256) void k_sym_pad(int64_t n, int64_t np, const do
     dst[r * ldd + c] = v;
 }
 
+// dense matrix from 6 x 6 blocks: A[6 row[sl] + k][6 col[sl] + l] = B[sl][k][l] (every block once: plain stores into a zeroed matrix)
+__global__ __launch_bounds__(256) void k_scatter_blocks6(int64_t nslots, const int32_t *__restrict__ row, const int32_t *__restrict__ col,
+                                                         const double *__restrict__ B, double *__restrict__ A, int64_t lda) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= nslots * 36) return;
+    const int64_t sl = t / 36;
+    const int kk = (int)(t - sl * 36), k = kk / 6, l = kk - 6 * k;
+    A[(6 * (int64_t)row[sl] + k) * lda + 6 * (int64_t)col[sl] + l] = B[t];
+}
+
 __global__ __launch_bounds__(256) void k_copy_block(int64_t n, const double *__restrict__ src, int64_t lds, double *__restrict__ dst, int64_t ldd) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= n * n) return;

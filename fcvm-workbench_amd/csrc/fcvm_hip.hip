@@ -245,6 +245,10 @@ struct fcvm_ctx {
     int32_t *d_agg = nullptr, *d_anodes = nullptr;
     int64_t *d_aoff = nullptr, *d_aptr = nullptr;
     double *d_Z = nullptr, *d_A2inv = nullptr, *d_r2 = nullptr, *d_e2 = nullptr;
+    // multi-GPU aggregate level: this rank's blocks of Z^T A1 Z between fcvm_mg_l2_galerkin and fcvm_mg_l2_galerkin_get
+    std::vector<int64_t> gl_sptr;
+    std::vector<int32_t> gl_slot;
+    std::vector<double> gl_B;
     std::vector<hipEvent_t> evpool;
     double *h_pcgS = nullptr;      // pinned copies of the PCG scalars, one per queued chunk (fcvm_mg.inc)
     double *h_pcgS2 = nullptr;     // the same for the two states of fcvm_solve2
@@ -2378,6 +2382,108 @@ int fcvm_mg_sparse_info(fcvm_ctx *c, int64_t out[4]) {
     return 0;
 }
 
+/* ---- aggregate level of a PARTITIONED mesh (fcvm_hip/dist.py DistMG): every rank holds the whole level, bit for bit ----
+ * The host layer numbers the aggregates globally (bins over the global bounding box), forms Z from Gram matrices summed over the ranks
+ * and hands both over with fcvm_mg_set_level2(..., aoff[g] = 6 g, A2inv = NULL).  Then:
+ *   fcvm_mg_l2_galerkin      this rank's share of A2 = Z^T A1 Z as 6 x 6 blocks (k_galerkin_blocks on the rank's level-1 matrix);
+ *                            *nslots = number of blocks
+ *   fcvm_mg_l2_galerkin_get  sptr_g int64[nagg + 1] (blocks of aggregate g: sptr_g[g] .. sptr_g[g + 1]), slot_agg int32[nslots] (column
+ *                            aggregate, ascending within a row), B f64[nslots][36]
+ *   (host layer: union of the ranks' block patterns, ONE all-reduce of the block values -- a few 10 MB, where the dense matrix of
+ *    rounds 1-4 was n2^2 doubles)
+ *   fcvm_mg_l2_finish        from the summed blocks in the global pattern: nsuper == 0 -> dense inverse of the replicated matrix (n2 = 6
+ *                            nagg, applied from its lower triangle by every rank: no gather of the correction); nsuper > 0 -> the sparse
+ *                            level of fcvm_l2s.inc with the caller's super-aggregates (sagg, soff, C as in l2s_finish).
+ * Identical input on every rank gives identical device state, so fcvm_mg_l2_solve returns the same correction everywhere. */
+int fcvm_mg_l2_galerkin(fcvm_ctx *c, int64_t *nslots) {
+    NEED(c && c->mg_topo && c->l2 && nslots, "fcvm_mg_l2_galerkin: fcvm_mg_set_level2 first");
+    HCHK(hipSetDevice(c->device));
+    const int64_t nc = c->nc, nagg = c->nagg;
+    std::vector<int32_t> agg(nc), anodes(nc);
+    std::vector<int64_t> aptr(nagg + 1);
+    HCHK(hipMemcpyAsync(agg.data(), c->d_agg, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, c->stream));
+    HCHK(hipMemcpyAsync(anodes.data(), c->d_anodes, sizeof(int32_t) * nc, hipMemcpyDeviceToHost, c->stream));
+    HCHK(hipMemcpyAsync(aptr.data(), c->d_aptr, sizeof(int64_t) * (nagg + 1), hipMemcpyDeviceToHost, c->stream));
+    HCHK(hipStreamSynchronize(c->stream));
+    int nthr = (int)std::thread::hardware_concurrency();
+    nthr = std::min(std::max(nthr, 1), 16);
+    std::vector<int64_t> eptr;
+    std::vector<int32_t> ent_i, ent_j;
+    std::vector<uint64_t> ent_loc;
+    galerkin_lists(c->pat1, nagg, agg, aptr, anodes, nthr, c->gl_sptr, c->gl_slot, eptr, ent_i, ent_j, ent_loc);
+    if (galerkin_blocks_host(c, nagg, c->gl_sptr, eptr, ent_i, ent_j, ent_loc, c->gl_B)) return 1;
+    *nslots = (int64_t)c->gl_slot.size();
+    return 0;
+}
+
+int fcvm_mg_l2_galerkin_get(fcvm_ctx *c, int64_t *sptr_g, int32_t *slot_agg, double *B) {
+    NEED(c && c->l2 && (int64_t)c->gl_sptr.size() == c->nagg + 1 && sptr_g && slot_agg && B, "fcvm_mg_l2_galerkin_get: fcvm_mg_l2_galerkin first");
+    std::copy(c->gl_sptr.begin(), c->gl_sptr.end(), sptr_g);
+    std::copy(c->gl_slot.begin(), c->gl_slot.end(), slot_agg);
+    std::copy(c->gl_B.begin(), c->gl_B.end(), B);
+    c->gl_sptr = std::vector<int64_t>(); c->gl_slot = std::vector<int32_t>(); c->gl_B = std::vector<double>();
+    return 0;
+}
+
+int fcvm_mg_l2_finish(fcvm_ctx *c, int64_t nagg, const int32_t *arank, int64_t nslots, const int64_t *sptr_g, const int32_t *slot_agg,
+                      const double *B, int64_t nsuper, const int32_t *sagg, const int64_t *soff, const double *C) {
+    NEED(c && c->mg_topo && c->l2 && nagg == c->nagg && c->n2 == 6 * nagg, "fcvm_mg_l2_finish: fcvm_mg_set_level2 with six modes per aggregate first");
+    NEED(arank && nslots > 0 && sptr_g && slot_agg && B && sptr_g[0] == 0 && sptr_g[nagg] == nslots, "fcvm_mg_l2_finish: bad block lists");
+    NEED(nsuper == 0 || (sagg && soff && C && soff[0] == 0), "fcvm_mg_l2_finish: super-aggregates without their tables");
+    HCHK(hipSetDevice(c->device));
+    std::vector<int64_t> vs(sptr_g, sptr_g + nagg + 1);
+    std::vector<int32_t> va(slot_agg, slot_agg + nslots);
+    std::vector<double> vB(B, B + nslots * 36);
+    std::vector<int> vr(nagg);
+    for (int64_t g = 0; g < nagg; g++) {
+        NEED(arank[g] >= 0 && arank[g] <= 6 && vs[g + 1] >= vs[g], "fcvm_mg_l2_finish: bad rank / row pointer");
+        vr[g] = arank[g];
+    }
+    for (int64_t sl = 0; sl < nslots; sl++) NEED(va[sl] >= 0 && va[sl] < nagg, "fcvm_mg_l2_finish: column aggregate out of range");
+    l2s_free(c->l2s);
+    dfree(c->d_A2inv); dfree(c->d_A2invf); dfree(c->d_symv_part);
+    c->l2_has_inverse = false;
+    if (nsuper > 0) {
+        std::vector<int32_t> vsa(sagg, sagg + nagg);
+        std::vector<int64_t> vso(soff, soff + nsuper + 1);
+        std::vector<double> vC(C, C + nagg * 36);
+        for (int64_t S = 0; S < nsuper; S++) NEED(vso[S + 1] >= vso[S] && vso[S + 1] - vso[S] <= 6, "fcvm_mg_l2_finish: at most 6 modes per super-aggregate");
+        return l2s_finish(c, nagg, vs, va, vB, vr, nsuper, vsa, vso, vC);
+    }
+    // dense: the blocks scattered into the n2 x n2 matrix on the device, inverted by every rank (identical input, identical result)
+    if (l2_symmetrise_blocks(nagg, vs, va, vB, vr, nullptr)) return 1;
+    const int64_t n2 = c->n2;
+    hipStream_t s = c->stream;
+    std::vector<int32_t> srow(nslots);
+    for (int64_t g = 0; g < nagg; g++)
+        for (int64_t sl = vs[g]; sl < vs[g + 1]; sl++) srow[sl] = (int32_t)g;
+    double *d_A2raw = nullptr, *d_B = nullptr;
+    int32_t *d_row = nullptr, *d_col = nullptr;
+    auto cleanup = [&]() { dfree(d_A2raw); dfree(d_B); dfree(d_row); dfree(d_col); };
+    if (dalloc(&d_A2raw, n2 * n2) || dalloc(&d_B, nslots * 36) || dalloc(&d_row, nslots) || dalloc(&d_col, nslots)) { cleanup(); return 1; }
+    if (hipMemsetAsync(d_A2raw, 0, sizeof(double) * n2 * n2, s) != hipSuccess ||
+        hipMemcpyAsync(d_B, vB.data(), sizeof(double) * vB.size(), hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d_row, srow.data(), sizeof(int32_t) * nslots, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d_col, va.data(), sizeof(int32_t) * nslots, hipMemcpyHostToDevice, s) != hipSuccess) {
+        cleanup();
+        return fail("fcvm_mg_l2_finish: upload failed");
+    }
+    hipLaunchKernelGGL(k_scatter_blocks6, dim3((unsigned)cdiv(nslots * 36, 256)), dim3(256), 0, s, nslots, d_row, d_col, d_B, d_A2raw, n2);
+    int rc = dalloc(&c->d_A2inv, n2 * n2);
+    if (!rc) rc = spd_inverse_device(c, n2, d_A2raw, c->d_A2inv, 1e-13);
+    if (hipStreamSynchronize(s) != hipSuccess && !rc) rc = fail("fcvm_mg_l2_finish: HIP error");
+    cleanup();
+    if (rc) return 1;
+    const int64_t lda = a2_lda(n2);
+    if (dalloc(&c->d_A2invf, n2 * lda)) return 1;
+    hipLaunchKernelGGL(k_to_f32_padded, dim3((unsigned)cdiv(n2 * lda, 256)), dim3(256), 0, s, n2, lda, c->d_A2inv, c->d_A2invf);
+    HCHK(hipGetLastError());
+    HCHK(hipStreamSynchronize(s));
+    if (symv_prepare(c)) return 1;
+    c->l2_has_inverse = true;
+    return 0;
+}
+
 /* dst = inverse of the symmetric positive definite n x n matrix src (both row-major on the device, may not alias):
  * blocked Cholesky, triangular inverse and X^T X in HIP kernels (fcvm_dense.hip.h) */
 int fcvm_spd_inverse(fcvm_ctx *c, int64_t n, const double *src, double *dst) {
@@ -2565,7 +2671,20 @@ int fcvm_dist_cg_update(fcvm_ctx *c, const double *S_dev, const double *z, const
 }
 
 int fcvm_mg_l2_solve(fcvm_ctx *c, const double *r2, double *e2) {
-    NEED(c && c->l2 && c->l2_has_inverse, "fcvm_mg_l2_solve: no aggregate level with a dense inverse (fcvm_mg_set_level2)");
+    NEED(c && c->l2 && (c->l2_has_inverse || c->l2s.on) && r2 && e2, "fcvm_mg_l2_solve: no aggregate level with an inverse or a sparse cycle "
+                                                                      "(fcvm_mg_set_level2 with an inverse / fcvm_mg_l2_finish)");
+    if (c->l2s.on) {
+        // sparse aggregate level: block-Jacobi Chebyshev sweeps around the dense super-aggregate corrections (l2s_cycle works on
+        // c->d_r2 and leaves the result in its own x)
+        double *own = c->d_r2;
+        c->d_r2 = const_cast<double *>(r2);
+        c->mg_done = nullptr;
+        l2s_cycle(c);
+        c->d_r2 = own;
+        HCHK(hipMemcpyAsync(e2, c->l2s.x, sizeof(double) * 6 * c->l2s.nagg, hipMemcpyDeviceToDevice, c->stream));
+        HCHK(hipGetLastError());
+        return 0;
+    }
     if (c->mg_fp32)
         launch_gemv_f32(c, r2, e2, nullptr);
     else

@@ -739,12 +739,12 @@ class DistMG:
     """The three-level V-cycle of the single-GPU solver (tet10 -> tet4 -> aggregates with rigid-body
     modes) on a partitioned mesh.  Vectors are consistent; every local SpMV is followed by the
     shared-node exchange of its level; restriction weights every node by 1/multiplicity so that the
-    partial sums add up.  The aggregate level's right-hand side and correction are replicated (two small
-    all-reduces per cycle); its dense inverse is distributed by row blocks, so the number of aggregates can grow
-    with the rank count (about 1000 * world^(2/3): each rank streams n2^2 / world matrix entries per cycle)."""
+    partial sums add up.  The aggregate level is replicated: its right-hand side is all-reduced (one small all-reduce
+    per cycle) and every rank computes the same correction from the same operator -- a dense inverse up to 3000
+    aggregates, the sparse level with super-aggregates beyond (see _level2) -- at the one-GPU aggregate size."""
 
     def __init__(self, be, nocoord_local, k0=1, alpha0=4.0, k1s=None, alpha1s=None, target=None, check_every=4, additive=None,
-                 weight=1.0):
+                 weight=1.0, max_dense=None):
         self.be, self.ops, self.part = be, be.ops, be.part
         self.xyz = np.ascontiguousarray(nocoord_local, dtype=np.float64)
         # form of the level-0 part, as on one GPU (csrc/fcvm_mg.inc): 2 = multiplicative V(1,1), one damped block-Jacobi step before
@@ -763,6 +763,7 @@ class DistMG:
         if self.form == 2:
             alpha0 = max(alpha0, 16.0)               # damping of the Jacobi step as in csrc/fcvm_mg.inc (mg_smoother_weight)
         self.k0, self.alpha0, self.k1s, self.alpha1s, self.target = k0, alpha0, k1s, alpha1s, target
+        self.max_dense = max_dense                   # most aggregates with a dense inverse (None: FCVM_MG_MAX_AGGREGATES, 3000)
         self.check_every = check_every
         self.additive, self.weight = self.form == 1, weight
         self.fused = self.form in (1, 2)             # the PCG update x, r and the start of the cycle in one kernel
@@ -878,10 +879,16 @@ class DistMG:
         self.ready = True
 
     def _level2(self):
-        """global aggregates (bins over the global bounding box), raw rigid-body modes about the global
-        aggregate centroids, A2 = sum over ranks of Z^T A1_local Z, replicated regularised inverse"""
-        import scipy.linalg as sla
-        import scipy.sparse as sp
+        """Aggregate level of the partitioned mesh, REPLICATED on every rank (round 5; rounds 1-4 kept a dense n2 x n2 matrix per rank,
+        all-reduced it in 1 GiB slabs and inverted it in full everywhere: 13 GB and 41 x the one-GPU inverse at 8 x 1 M tet10).
+        Aggregates = bins over the GLOBAL bounding box at the one-GPU aggregate size (~72 level-1 nodes at 1 M tet10 per rank) for any rank
+        count; rigid-body modes about the global aggregate centroids, orthonormalised with Gram matrices summed over the ranks; the rank's
+        share of A2 = Z^T A1 Z as 6 x 6 blocks from the device (ops.mg_galerkin_blocks: k_galerkin_blocks on the rank's level-1 matrix);
+        the union of the ranks' block patterns and ONE all-reduce of the block values (288 B per block: ~90 MB at 8 x 1 M tet10); then every
+        rank builds the same level from the same numbers (ops.mg_l2_finish): a dense inverse while the aggregates number at most
+        FCVM_MG_MAX_AGGREGATES (3000), beyond that the sparse level of the one-GPU library (block-Jacobi Chebyshev sweeps on A2 closed by a
+        dense level of super-aggregates, csrc/fcvm_l2s.inc) with the super-aggregates' modes summed over the ranks here.  Per cycle: one
+        all-reduce of r2 (6 doubles per aggregate), the same correction computed by every rank, no gather."""
         be, dev, part = self.be, self.be.device, self.part
         coord, fm = self.ops.mg_coarse_nodes()
         own = self.own1.view(-1, 3)[:, 0].cpu().numpy() > 0.5
@@ -892,11 +899,12 @@ class DistMG:
         lo, hi = lo.cpu().numpy(), hi.cpu().numpy()
         ncg = torch.tensor([float(own.sum())], dtype=torch.float64, device=dev)
         ncg = float(be._allreduce(ncg).item())
-        # aggregates: FCVM_DIST_AGGREGATES x world^(2/3) (n2^2 / world matrix entries per rank and cycle, an n2^2 FP64 all-reduce
-        # and an n2^3 inverse per rank at set-up); round 3: 1000 -> 1700 with the cheaper inverse (2 x 1.0 M tet10: 1462 -> 2479
-        # aggregates, PCG iterations per solve see DESIGN.md "Multi-GPU")
-        per_rank = float(os.environ.get("FCVM_DIST_AGGREGATES", "1700"))
-        target = self.target if self.target else max(16, int(round(ncg / (per_rank * part.world ** (2.0 / 3.0)))))
+        # nodes per aggregate: the rule of the one-GPU solver (device.Context.build_level2) on the MEAN level-1 node count of a rank, so
+        # the aggregate size -- which is what the PCG iteration count follows -- does not grow with the rank count
+        ncr = ncg / part.world
+        target = self.target if self.target else int(os.environ.get("FCVM_MG_TARGET", "0"))
+        if not target:
+            target = max(16, int(min(176, max(-(-int(ncr) // 2600), min(64.0, ncr / 200.0)))))
         ext = np.maximum(hi - lo, 1e-300)
         live = ext > 1e-9 * ext.max()
         h = (np.prod(ext[live]) / max(1.0, ncg / target)) ** (1.0 / max(1, live.sum()))
@@ -908,112 +916,106 @@ class DistMG:
         allk = np.unique(np.concatenate(keys))
         agg = np.searchsorted(allk, key)
         nagg = len(allk)
-        # global centroid / extent of every aggregate (owner-weighted sums)
-        acc = np.zeros((nagg, 5))
-        np.add.at(acc, agg[own], np.concatenate([coord[own], np.ones((own.sum(), 1)), np.zeros((own.sum(), 1))], 1))
-        acc_t = torch.as_tensor(acc, device=dev)
-        be._allreduce(acc_t)
-        acc = acc_t.cpu().numpy()
-        cen = acc[:, :3] / np.maximum(acc[:, 3:4], 1.0)
-        x = coord - cen[agg]
-        sc = np.zeros(nagg)
-        np.maximum.at(sc, agg, np.abs(x).max(1))
-        sc_t = torch.as_tensor(sc, device=dev)
-        be._allreduce(sc_t, dist.ReduceOp.MAX)
-        x = x / np.maximum(sc_t.cpu().numpy(), 1e-300)[agg][:, None]
-        Z = np.zeros((self.nc, 3, 6))
-        Z[:, 0, 0] = Z[:, 1, 1] = Z[:, 2, 2] = 1.0
-        Z[:, 1, 3], Z[:, 2, 3] = -x[:, 2], x[:, 1]
-        Z[:, 0, 4], Z[:, 2, 4] = x[:, 2], -x[:, 0]
-        Z[:, 0, 5], Z[:, 1, 5] = -x[:, 1], x[:, 0]
-        free = np.stack([(fm & 1) == 0, (fm & 2) == 0, (fm & 4) == 0], 1).astype(np.float64)
-        Z *= free[:, :, None]
-        # orthonormalise the six modes of every aggregate over its (global) node set and drop the combinations that
-        # move nothing (a single line / a single node / clamped nodes): Gram matrices summed over the ranks, symmetric
-        # eigen-decomposition, modes scaled by 1/sqrt(eigenvalue); dropped modes become zero columns, whose (empty)
-        # rows of A2 only see the diagonal shift below.  Without this, near-null combinations get 1e10-sized entries
-        # in the inverse, which FP32 storage cannot cancel.
+
+        def modes(cen, sc, of):
+            """raw rigid-body modes [node][component][mode] about cen[of], lengths scaled by sc[of], supported dofs masked"""
+            x = (coord - cen[of]) / np.maximum(sc, 1e-300)[of][:, None]
+            R = np.zeros((self.nc, 3, 6))
+            R[:, 0, 0] = R[:, 1, 1] = R[:, 2, 2] = 1.0
+            R[:, 1, 3], R[:, 2, 3] = -x[:, 2], x[:, 1]
+            R[:, 0, 4], R[:, 2, 4] = x[:, 2], -x[:, 0]
+            R[:, 0, 5], R[:, 1, 5] = -x[:, 1], x[:, 0]
+            free = np.stack([(fm & 1) == 0, (fm & 2) == 0, (fm & 4) == 0], 1).astype(np.float64)
+            return R * free[:, :, None]
+
+        def centroids(of, n):
+            """global centroid and half extent of every group (owner-weighted sums / maxima over the ranks)"""
+            acc = np.zeros((n, 4))
+            np.add.at(acc, of[own], np.concatenate([coord[own], np.ones((own.sum(), 1))], 1))
+            acc_t = torch.as_tensor(acc, device=dev)
+            be._allreduce(acc_t)
+            acc = acc_t.cpu().numpy()
+            cen = acc[:, :3] / np.maximum(acc[:, 3:4], 1.0)
+            sc = np.zeros(n)
+            np.maximum.at(sc, of, np.abs(coord - cen[of]).max(1))
+            sc_t = torch.as_tensor(sc, device=dev)
+            be._allreduce(sc_t, dist.ReduceOp.MAX)
+            return cen, sc_t.cpu().numpy()
+
+        def orthonormal(G):
+            """G [n][6][6] Gram matrices -> T [n][6][6] (columns: kept combinations scaled to unit norm, largest first; dropped ones
+            zero) and the number kept: combinations that move nothing (a single line / node, clamped nodes) go, as in
+            mg_build_level2 (rank_tol 1e-6 on the singular values)"""
+            lam, V = np.linalg.eigh(G)
+            lam, V = lam[:, ::-1], V[:, :, ::-1]
+            keep = lam > 1e-12 * np.maximum(lam[:, :1], 1e-300)
+            return V * (keep / np.sqrt(np.where(keep, lam, 1.0)))[:, None, :], keep.sum(1).astype(np.int32)
+
+        cen, sc = centroids(agg, nagg)
+        R = modes(cen, sc, agg)
         G = np.zeros((nagg, 6, 6))
-        np.add.at(G, agg[own], np.einsum("ncj,nck->njk", Z[own], Z[own]))
+        np.add.at(G, agg[own], np.einsum("ncj,nck->njk", R[own], R[own]))
         G_t = torch.as_tensor(G, device=dev)
         be._allreduce(G_t)
-        lam, V = np.linalg.eigh(G_t.cpu().numpy())
-        keep = lam > 1e-10 * np.maximum(lam.max(axis=1, keepdims=True), 1e-300)
-        T = V * (keep / np.sqrt(np.where(keep, lam, 1.0)))[:, None, :]
-        Z = np.einsum("ncj,njk->nck", Z, T[agg])
+        T, arank = orthonormal(G_t.cpu().numpy())
+        Z = np.einsum("ncj,njk->nck", R, T[agg])
         n2 = 6 * nagg
-        row, col, val = self.ops.mg_coarse_coo()
-        A1 = sp.csr_matrix((val, (row, col)), shape=(3 * self.nc, 3 * self.nc))
-        ii = np.repeat(np.arange(self.nc), 18)
-        cc = np.tile(np.repeat(np.arange(3), 6), self.nc)
-        kk = np.tile(np.arange(6), 3 * self.nc)
-        Zs = sp.csr_matrix((Z.reshape(-1), (3 * ii + cc, 6 * agg[ii] + kk)), shape=(3 * self.nc, n2))
-        A2s = (Zs.T @ (A1 @ Zs)).tocoo()   # sparse: aggregates couple to their neighbours only; densified on the device
-        A2 = torch.zeros(n2, n2, dtype=torch.float64, device=dev)
-        A2.index_put_((torch.as_tensor(A2s.row.astype(np.int64), device=dev), torch.as_tensor(A2s.col.astype(np.int64), device=dev)),
-                      torch.as_tensor(A2s.data, device=dev), accumulate=True)
-        del A2s
-        step = max(1, (1 << 27) // n2)      # row blocks of at most 1 GiB: some transports count bytes in 32 bits
-        for r0 in range(0, n2, step):
-            be._allreduce(A2[r0:r0 + step])
-        A2 = 0.5 * (A2 + A2.T)
-        dmax = float(A2.diagonal().abs().max().item())
-        # every rank factorises the (replicated) matrix on its own device and solves for the rows of the inverse it
-        # applies (the inverse is symmetric: rows = columns), a few thousand right-hand sides at a time.  Ranks never
-        # mix their rows, so differences in rounding between devices cannot make the correction inconsistent.
-        chunk = -(-n2 // part.world)
-        self.row_lo, self.row_hi = min(n2, part.rank * chunk), min(n2, (part.rank + 1) * chunk)
-        ok = torch.ones(1, dtype=torch.float64, device=dev)
-        rows = torch.zeros(self.row_hi - self.row_lo, n2, dtype=torch.float64, device=dev)
-        why = ""
-        try:
-            # raw rigid-body modes: aggregates with collinear / fully clamped nodes have zero-energy combinations, which
-            # the diagonal shift turns into harmless tiny pivots; the shift grows until the factorisation goes through
-            # (identical decisions on every rank: the matrix is replicated and the pivots are a property of the matrix)
-            shift, done = 1e-10 * dmax, False
-            for _ in range(4):
-                A2.diagonal().add_(shift)
-                if hasattr(self.ops, "spd_inverse"):
-                    # the library's own blocked Cholesky / triangular inverse / X^T X kernels (fcvm_spd_inverse): no vendor
-                    # solver library is loaded; the whole inverse is formed, this rank keeps its rows
-                    try:
-                        inv = self.ops.spd_inverse(A2)
-                        rows.copy_(inv[self.row_lo:self.row_hi])
-                        del inv
-                        done = True
-                    except Exception as e:   # not positive definite at this shift
-                        why = repr(e)
-                else:   # CPU tests: LAPACK through torch
-                    L, info = torch.linalg.cholesky_ex(A2)
-                    if int(info.item()) == 0:
-                        for c0 in range(self.row_lo, self.row_hi, 4096):
-                            c1 = min(self.row_hi, c0 + 4096)
-                            E = torch.zeros(n2, c1 - c0, dtype=torch.float64, device=dev)
-                            E[c0:c1] = torch.eye(c1 - c0, dtype=torch.float64, device=dev)
-                            rows[c0 - self.row_lo:c1 - self.row_lo] = torch.cholesky_solve(E, L).T
-                        del L, E
-                        done = True
-                    else:
-                        why = "cholesky_ex info %d" % int(info.item())
-                if done:
+        self.ops.mg_set_level2(nagg, np.ascontiguousarray(agg, np.int32), np.ascontiguousarray(Z.reshape(self.nc, 18)))
+        # this rank's blocks of Z^T A1 Z, the global block pattern, the sum over the ranks
+        sptr_l, cols_l, B_l = self.ops.mg_galerkin_blocks()
+        rows_l = np.repeat(np.arange(nagg, dtype=np.int64), np.diff(sptr_l))
+        keys_l = rows_l * nagg + cols_l.astype(np.int64)
+        every = [None] * part.world
+        dist.all_gather_object(every, keys_l, group=part.group)
+        allb = np.unique(np.concatenate(every))
+        nslots = len(allb)
+        Bg = torch.zeros(nslots, 36, dtype=torch.float64, device=dev)
+        if len(keys_l):
+            Bg.index_copy_(0, torch.as_tensor(np.searchsorted(allb, keys_l), device=dev), torch.as_tensor(B_l.reshape(-1, 36), device=dev))
+        be._allreduce(Bg)
+        Bsum = Bg.cpu().numpy()
+        del Bg
+        sptr_g = np.zeros(nagg + 1, dtype=np.int64)
+        np.add.at(sptr_g, allb // nagg + 1, 1)
+        sptr_g = np.cumsum(sptr_g)
+        slot_agg = (allb % nagg).astype(np.int32)
+        max_dense = self.max_dense if self.max_dense else int(os.environ.get("FCVM_MG_MAX_AGGREGATES", "3000"))
+        sparse = nagg > max_dense and os.environ.get("FCVM_MG_SPARSE", "1") != "0"
+        nsuper, sagg, soff, Cm = 0, None, None, None
+        if sparse:
+            # super-aggregates: bins of f x f x f aggregate bins, at most FCVM_L2S_MAX_SUPER of them (as mg_build_sparse_levels)
+            max_super = int(os.environ.get("FCVM_L2S_MAX_SUPER", str(min(max_dense, 2000))))
+            ab = np.stack([allk // (nb[1] * nb[2]), (allk // nb[2]) % nb[1], allk % nb[2]], 1)
+            for f in range(2, 64):
+                q = ab // f
+                m1, m2 = q[:, 1].max() + 1, q[:, 2].max() + 1
+                u, sagg = np.unique((q[:, 0] * m1 + q[:, 1]) * m2 + q[:, 2], return_inverse=True)
+                nsuper = len(u)
+                if nsuper <= max_super:
                     break
-                shift *= 100.0
-            if not done:
-                raise RuntimeError("no factorisation after the largest diagonal shift (%s)" % why)
-            why = ""
-        except Exception as e:  # keep every rank in step: the failure is agreed on below
-            ok.zero_()
-            why = repr(e)
-        del A2
-        be._allreduce(ok, dist.ReduceOp.MIN)
-        if float(ok.item()) == 0.0:
-            raise RuntimeError("DistMG: aggregate-level inverse failed on some rank (this rank: %s)" % (why or "ok"))
-        self.ops.mg_set_level2(nagg, np.ascontiguousarray(agg, np.int32), np.ascontiguousarray(Z.reshape(self.nc, 18)), rows)
-        del rows
+            sagg = sagg.astype(np.int32)
+            # C_g = Z_g^T R_S: the super-aggregate's rigid-body modes (about ITS centroid, orthonormalised over its level-1 nodes --
+            # Gram matrices and the products with Z summed over the ranks) in the basis of its aggregates
+            sof = sagg[agg].astype(np.int64)
+            cen3, sc3 = centroids(sof, nsuper)
+            R3 = modes(cen3, sc3, sof)
+            GM = np.zeros((nsuper + nagg, 6, 6))
+            np.add.at(GM, sof[own], np.einsum("ncj,nck->njk", R3[own], R3[own]))
+            np.add.at(GM, nsuper + agg[own], np.einsum("nck,ncl->nkl", Z[own], R3[own]))
+            GM_t = torch.as_tensor(GM, device=dev)
+            be._allreduce(GM_t)
+            GM = GM_t.cpu().numpy()
+            T3, r3 = orthonormal(GM[:nsuper])
+            Cm = np.ascontiguousarray(np.einsum("gkl,glm->gkm", GM[nsuper:], T3[sagg]))
+            soff = np.concatenate([[0], np.cumsum(r3)]).astype(np.int64)
+        self.ops.mg_l2_finish(nagg, arank, sptr_g, slot_agg, Bsum, nsuper, sagg, soff, Cm)
         self.nagg, self.n2 = nagg, n2
         self.r2 = TVec(torch.zeros(n2, dtype=torch.float64, device=dev))
         self.e2 = TVec(torch.zeros(n2, dtype=torch.float64, device=dev))
-        self.l2_info = dict(aggregates=nagg, unknowns=n2, target=target, rows=(self.row_lo, self.row_hi), diagonal_shift=shift / dmax)
+        self.l2_info = dict(aggregates=nagg, unknowns=n2, target=target, blocks=nslots, allreduce_bytes=288 * nslots, sparse=bool(sparse),
+                            super_aggregates=int(nsuper), super_unknowns=int(soff[-1]) if sparse else 0)
+        if os.environ.get("FCVM_VERBOSE") and part.rank == 0:
+            print("fcvm dist: aggregate level %s" % self.l2_info, flush=True)
 
     # -- V-cycle ------------------------------------------------------------------------------
     def _spmv(self, level, x, y):
@@ -1071,10 +1073,7 @@ class DistMG:
                 torch.mul(self.rr1.t, self.own1, out=self.t1.t)       # owner-weighted: shared nodes count once
                 self.ops.mg_l2_restrict(self.t1, self.r2)             # r2 = Z^T (.)  (local part)
         be._allreduce(self.r2.t)                              # replicated right-hand side of the aggregate level
-        self.e2.t.zero_()
-        if self.row_hi > self.row_lo:                         # this rank's rows of e2 = A2inv r2 ...
-            self.ops.mg_l2_solve(self.r2, TVec(self.e2.t[self.row_lo:self.row_hi]))
-        be._allreduce(self.e2.t)                              # ... gathered (sum with zeros: bit-identical on every rank)
+        self.ops.mg_l2_solve(self.r2, self.e2)                # the same correction on every rank (replicated level: no gather)
         self.ops.mg_l2_prolong(self.e2, self.d1)
         if merge:
             # first post-smoothing product + the pending one, ONE exchange for both: rr1 -= sum over the ranks of (A1 d + tk1)
@@ -1409,15 +1408,6 @@ class HipLocalOps:
         from ._lib import call
         call("fcvm_dist_pcg_scalars", self.c.h, int(phase), S.data_ptr(), t_in.data_ptr())
 
-    def spd_inverse(self, A):
-        """inverse of the SPD matrix A (torch f64 [n, n] on this rank's device) by the library's dense kernels"""
-        from ._lib import call
-        n = A.shape[0]
-        A = A.contiguous()
-        out = torch.empty_like(A)
-        call("fcvm_spd_inverse", self.c.h, n, A.data_ptr(), out.data_ptr())
-        return out
-
     def wdot(self, w, x, y, out):
         """out[0] = sum w x y (torch tensors on this rank's device)"""
         from ._lib import call
@@ -1441,13 +1431,6 @@ class HipLocalOps:
         coord, fm = np.empty((nc, 3)), np.empty(nc, np.uint8)
         call("fcvm_mg_coarse_nodes", self.c.h, coord.ctypes.data, fm.ctypes.data)
         return coord, fm
-
-    def mg_coarse_coo(self):
-        from ._lib import call
-        nnz = 9 * self.c.precond_info()["coarse_nnz_blocks"]
-        r, c, v = np.empty(nnz, np.int64), np.empty(nnz, np.int64), np.empty(nnz)
-        call("fcvm_mg_coarse_to_coo", self.c.h, r.ctypes.data, c.ctypes.data, v.ctypes.data)
-        return r, c, v
 
     def mg_spmv(self, level, x, y):
         from ._lib import call
@@ -1530,25 +1513,42 @@ class HipLocalOps:
         from ._lib import call
         call("fcvm_spmv_dot", self.c.h, x.ptr, y.ptr, out.data_ptr())
 
-    def mg_set_level2(self, nagg, agg, Z, rows):
-        """rows: this rank's row block [m, 6 nagg] of the aggregate-level inverse (torch f64 on the device);
-        kept in FP32 with rows padded to a multiple of 4 for fcvm_gemv_f32"""
+    def mg_set_level2(self, nagg, agg, Z):
+        """transfer operators of the aggregate level: global aggregate of every level-1 node, Z [nc][3][6] (six slots per aggregate)"""
         from ._lib import call
         aoff = 6 * np.arange(nagg + 1, dtype=np.int64)
         call("fcvm_mg_set_level2", self.c.h, nagg, 6 * nagg, agg.ctypes.data, aoff.ctypes.data, Z.ctypes.data, None, 3, 8.0)
-        m, n = rows.shape
-        self.l2_lda = (n + 3) // 4 * 4
-        self.l2_rows = torch.zeros(max(m, 1), self.l2_lda, dtype=torch.float32, device=rows.device)
-        self.l2_rows[:m, :n] = rows.to(torch.float32)
-        self.l2_m, self.l2_n = m, n
+
+    def mg_galerkin_blocks(self):
+        """this rank's 6 x 6 blocks of Z^T A1 Z (block-CSR over the global aggregates): (row pointer [nagg + 1], column aggregate, values)"""
+        import ctypes as C
+        from ._lib import call
+        n = C.c_int64(0)
+        call("fcvm_mg_l2_galerkin", self.c.h, C.byref(n))
+        nagg = self.c.precond_info()["l2_aggregates"]
+        sptr, cols, B = np.empty(nagg + 1, np.int64), np.empty(max(n.value, 1), np.int32), np.empty(max(n.value, 1) * 36)
+        call("fcvm_mg_l2_galerkin_get", self.c.h, sptr.ctypes.data, cols.ctypes.data, B.ctypes.data)
+        return sptr, cols[:n.value], B[:n.value * 36]
+
+    def mg_l2_finish(self, nagg, arank, sptr_g, slot_agg, B, nsuper, sagg, soff, Cm):
+        """the replicated level from the summed blocks (fcvm_mg_l2_finish): dense inverse (nsuper = 0) or sparse level + super-aggregates"""
+        from ._lib import call
+        arank, sptr_g, slot_agg = (np.ascontiguousarray(arank, np.int32), np.ascontiguousarray(sptr_g, np.int64),
+                                   np.ascontiguousarray(slot_agg, np.int32))
+        B = np.ascontiguousarray(B, np.float64)
+        if nsuper:
+            sagg, soff, Cm = np.ascontiguousarray(sagg, np.int32), np.ascontiguousarray(soff, np.int64), np.ascontiguousarray(Cm, np.float64)
+        call("fcvm_mg_l2_finish", self.c.h, int(nagg), arank.ctypes.data, len(slot_agg), sptr_g.ctypes.data, slot_agg.ctypes.data, B.ctypes.data,
+             int(nsuper), sagg.ctypes.data if nsuper else None, soff.ctypes.data if nsuper else None, Cm.ctypes.data if nsuper else None)
 
     def mg_l2_restrict(self, r1, r2):
         from ._lib import call
         call("fcvm_mg_l2_restrict", self.c.h, r1.ptr, r2.ptr)
 
-    def mg_l2_solve(self, r2, e_rows):
+    def mg_l2_solve(self, r2, e2):
+        """e2 = M2^-1 r2 on the replicated aggregate level (dense inverse from its lower triangle, or one cycle of the sparse level)"""
         from ._lib import call
-        call("fcvm_gemv_f32", self.c.h, self.l2_m, self.l2_n, self.l2_lda, self.l2_rows.data_ptr(), r2.ptr, e_rows.ptr)
+        call("fcvm_mg_l2_solve", self.c.h, r2.ptr, e2.ptr)
 
     def mg_l2_prolong(self, e2, d1):
         from ._lib import call

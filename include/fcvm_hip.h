@@ -257,6 +257,23 @@ int fcvm_mg_build_level2(fcvm_ctx *c, int64_t target, int k1s, double alpha1s, i
  * dense level of super-aggregates (bins of 2 x 2 x 2 aggregates x rigid-body modes).  out[0] = 1 if that path is in use,
  * out[1] = blocks of A2, out[2] = super-aggregates, out[3] = unknowns of the dense top level. */
 int fcvm_mg_sparse_info(fcvm_ctx *c, int64_t out[4]);
+/* Aggregate level of a PARTITIONED mesh (north_star: elements range-partitioned over the GPUs of a node; no reference counterpart --
+ * fcVM.py:1121-1135 factorises once on one process).  Every rank keeps the WHOLE level, bit for bit, so its correction needs no gather:
+ * the host layer (fcvm_hip/dist.py, DistMG._level2) numbers the aggregates globally, forms Z from Gram matrices summed over the ranks and
+ * calls fcvm_mg_set_level2(..., aoff[g] = 6 g, A2inv = NULL); then
+ *   fcvm_mg_l2_galerkin      this rank's share of A2 = Z^T A1 Z as 6 x 6 blocks, formed on the device; *nslots = their number
+ *   fcvm_mg_l2_galerkin_get  sptr_g int64[nagg+1], slot_agg int32[nslots] (column aggregates, ascending within a row), B f64[nslots][36]
+ *   (host layer: union of the ranks' block patterns and ONE all-reduce of the block values)
+ *   fcvm_mg_l2_finish        the summed blocks in the global pattern -> nsuper == 0: dense inverse of the replicated matrix (n2 = 6 nagg,
+ *                            applied from its lower triangle); nsuper > 0: the sparse level (block-Jacobi Chebyshev sweeps) closed by a dense
+ *                            level of the caller's super-aggregates: sagg int32[nagg], soff int64[nsuper+1] (first mode of each), C
+ *                            f64[nagg][6][6] (the super-aggregate's modes in the basis of the aggregate, [k][m]); arank int32[nagg]: modes
+ *                            kept per aggregate (the others are zero columns of Z and get a unit diagonal).
+ * fcvm_mg_l2_solve then returns e2 = M2^-1 r2 for the replicated r2 on every rank. */
+int fcvm_mg_l2_galerkin(fcvm_ctx *c, int64_t *nslots);
+int fcvm_mg_l2_galerkin_get(fcvm_ctx *c, int64_t *sptr_g, int32_t *slot_agg, double *B);
+int fcvm_mg_l2_finish(fcvm_ctx *c, int64_t nagg, const int32_t *arank, int64_t nslots, const int64_t *sptr_g, const int32_t *slot_agg,
+                      const double *B, int64_t nsuper, const int32_t *sagg, const int64_t *soff, const double *C);
 /* dst = inverse of the SPD n x n matrix src (row-major, device pointers, no aliasing) */
 int fcvm_spd_inverse(fcvm_ctx *c, int64_t n, const double *src, double *dst);
 
@@ -348,7 +365,8 @@ int fcvm_mg_l2_restrict_weighted(fcvm_ctx *c, const double *r1, const double *wg
 /*   fcvm_mg_l2_restrict_diff: r2 = Z^T (wgt * r1 - sub): the level-1 residual whose last product (sub: this rank's UNSUMMED A1 d)
  *     has not been exchanged -- the all-reduce of r2 completes the sum over the ranks */
 int fcvm_mg_l2_restrict_diff(fcvm_ctx *c, const double *r1, const double *wgt, const double *sub, double *r2);
-/* aggregate level after fcvm_mg_set_level2: r2 = Z^T r1 (f64[n2]), e2 = A2inv r2, d1 = Z e2 */
+/* aggregate level after fcvm_mg_set_level2 / fcvm_mg_l2_finish: r2 = Z^T r1 (f64[n2]), e2 = A2inv r2 (dense inverse) or one cycle of the
+ * sparse level, d1 = Z e2 */
 int fcvm_mg_l2_restrict(fcvm_ctx *c, const double *r1, double *r2);
 int fcvm_mg_l2_solve(fcvm_ctx *c, const double *r2, double *e2);
 int fcvm_mg_l2_prolong(fcvm_ctx *c, const double *e2, double *d1);

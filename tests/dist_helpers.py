@@ -124,11 +124,6 @@ class OracleLocalOps:
         f = (1.0 - self.free1).reshape(-1, 3).astype(np.uint8)
         return self.xyz[self.c2f], (f[:, 0] | (f[:, 1] << 1) | (f[:, 2] << 2)).astype(np.uint8)
 
-    def mg_coarse_coo(self):
-        self._hier()
-        m = self.A1.tocoo()
-        return m.row.astype(np.int64), m.col.astype(np.int64), m.data
-
     def _A(self, level):
         self._hier()
         return self.K if level == 0 else self.A1
@@ -191,19 +186,106 @@ class OracleLocalOps:
         r.set(rn)
         z0.set(weight * self._dinv(0, rn))
 
-    def mg_set_level2(self, nagg, agg, Z, rows):
+    def mg_set_level2(self, nagg, agg, Z):
         nc = len(agg)
         ii = np.repeat(np.arange(nc), 18)
         cc = np.tile(np.repeat(np.arange(3), 6), nc)
         kk = np.tile(np.arange(6), 3 * nc)
         self.Z2 = sp.csr_matrix((Z.reshape(-1), (3 * ii + cc, 6 * agg[ii].astype(np.int64) + kk)), shape=(3 * nc, 6 * nagg))
-        self.A2rows = rows.cpu().numpy().copy()   # this rank's row block of the aggregate-level inverse
+        self.nagg = nagg
+
+    def mg_galerkin_blocks(self):
+        """this rank's share of Z^T A1 Z as 6 x 6 blocks over the global aggregates (HIP path: k_galerkin_blocks)"""
+        self._hier()
+        nagg = self.nagg
+        A2 = (self.Z2.T @ (self.A1 @ self.Z2)).tocoo()
+        # the block pattern follows the aggregate graph of A1 (not the numerical non-zeros, as the device kernel's lists do)
+        G = sp.csr_matrix((np.ones(self.Z2.nnz), (self.Z2.tocoo().row // 3, self.Z2.tocoo().col // 6)), shape=(self.A1.shape[0] // 3, nagg))
+        A1g = sp.csr_matrix((np.ones(self.A1.nnz), (self.A1.tocoo().row // 3, self.A1.tocoo().col // 3)), shape=(G.shape[0], G.shape[0]))
+        pat = (G.T @ A1g @ G).tocoo()
+        keys = np.unique(pat.row.astype(np.int64) * nagg + pat.col)
+        B = np.zeros((len(keys), 36))
+        pos = np.searchsorted(keys, (A2.row // 6).astype(np.int64) * nagg + A2.col // 6)
+        np.add.at(B, (pos, (A2.row % 6) * 6 + A2.col % 6), A2.data)
+        sptr = np.zeros(nagg + 1, np.int64)
+        np.add.at(sptr, keys // nagg + 1, 1)
+        return np.cumsum(sptr), (keys % nagg).astype(np.int32), B.reshape(-1)
+
+    def mg_l2_finish(self, nagg, arank, sptr_g, slot_agg, B, nsuper, sagg, soff, Cm):
+        """numpy restatement of fcvm_mg_l2_finish: the replicated level from the summed blocks -- dense inverse, or the sparse cycle of
+        csrc/fcvm_l2s.inc (block-Jacobi Chebyshev sweeps around dense super-aggregate corrections)"""
+        from fcvm_hip.dist import _Cheb
+        rows = np.repeat(np.arange(nagg), np.diff(sptr_g))
+        Bb = B.reshape(-1, 6, 6)
+        r = (6 * rows[:, None, None] + np.arange(6)[None, :, None]) + np.zeros((1, 1, 6), np.int64)
+        c = (6 * slot_agg.astype(np.int64)[:, None, None] + np.arange(6)[None, None, :]) + np.zeros((1, 6, 1), np.int64)
+        A2 = sp.csr_matrix((Bb.reshape(-1), (r.reshape(-1), c.reshape(-1))), shape=(6 * nagg, 6 * nagg))
+        A2 = (0.5 * (A2 + A2.T)).tolil()
+        for g in range(nagg):
+            for k in range(int(arank[g]), 6):
+                A2[6 * g + k, 6 * g + k] = 1.0
+        A2 = A2.tocsr()
+        self.l2s = None
+        if not nsuper:
+            Ad = A2.toarray()
+            self.A2inv = np.linalg.inv(Ad + 1e-13 * np.trace(Ad) / len(Ad) * np.eye(len(Ad)))
+            return
+        dinv = np.stack([np.linalg.inv(A2[6 * g:6 * g + 6, 6 * g:6 * g + 6].toarray()) for g in range(nagg)])
+        n3 = int(soff[-1])
+        rr, cc, vv = [], [], []
+        for g in range(nagg):
+            S = int(sagg[g])
+            for m in range(int(soff[S + 1] - soff[S])):
+                for k in range(6):
+                    rr.append(6 * g + k); cc.append(int(soff[S]) + m); vv.append(Cm[g, k, m])
+        C = sp.csr_matrix((vv, (rr, cc)), shape=(6 * nagg, n3))
+        A3 = (C.T @ A2 @ C).toarray()
+        A3inv = np.linalg.inv(A3 + 1e-13 * np.trace(A3) / n3 * np.eye(n3))
+        apply_dinv = lambda v: np.einsum("gkl,gl->gk", dinv, v.reshape(-1, 6)).reshape(-1)  # noqa: E731
+        x = np.random.default_rng(5).standard_normal(6 * nagg)
+        lam = 0.0
+        for _ in range(100):
+            y = apply_dinv(A2 @ x)
+            lam = np.linalg.norm(y) / np.linalg.norm(x)
+            x = y / np.linalg.norm(y)
+        self.l2s = dict(A2=A2, dinv=apply_dinv, C=C, A3inv=A3inv, ch=_Cheb(1.15 * lam, 100.0, 8), k=8, ncoarse=2)
+
+    def _l2s_cycle(self, b):
+        L = self.l2s
+        A2, dinv, ch, k = L["A2"], L["dinv"], L["ch"], L["k"]
+        st = dict(x=np.zeros_like(b), r=b.copy(), d=ch.c0 * dinv(b))
+
+        def step(cdd, cdr, update, add):
+            t = A2 @ st["d"]
+            st["x"] += st["d"]
+            st["r"] -= t
+            if update:
+                st["d"] = cdd * st["d"] + cdr * dinv(st["r"])
+                if add:
+                    st["x"] += st["d"]
+
+        def coarse():
+            st["d"] = L["C"] @ (L["A3inv"] @ (L["C"].T @ st["r"]))
+        for j in range(1, k):
+            step(ch.cdd[j], ch.cdr[j], True, False)
+        step(0.0, 0.0, False, False)
+        coarse()
+        for _ in range(1, L["ncoarse"]):
+            step(0.0, ch.c0, True, False)
+            for j in range(1, k):
+                step(ch.cdd[j], ch.cdr[j], True, False)
+            step(0.0, 0.0, False, False)
+            coarse()
+        step(0.0, ch.c0, True, k == 1)
+        for j in range(1, k):
+            step(ch.cdd[j], ch.cdr[j], True, j == k - 1)
+        return st["x"]
 
     def mg_l2_restrict(self, r1, r2):
         r2.set(self.Z2.T @ r1.get())
 
-    def mg_l2_solve(self, r2, e_rows):
-        e_rows.set(self.A2rows @ r2.get())
+    def mg_l2_solve(self, r2, e2):
+        e2.set(self._l2s_cycle(r2.get()) if self.l2s is not None else self.A2inv @ r2.get())
 
     def mg_l2_prolong(self, e2, d1):
         d1.set(self.Z2 @ e2.get())

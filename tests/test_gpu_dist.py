@@ -77,7 +77,7 @@ def test_two_ranks_on_one_gpu_match_single_gpu(tmp_path, precond):
     assert np.abs(allp - np.sort(ref["peeq"])).max() < 1e-8 * ref["peeq"].max()
 
 
-def _worker_emb(rank, world, port, out):
+def _worker_emb(rank, world, port, out, level2):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -97,7 +97,9 @@ def _worker_emb(rank, world, port, out):
         fix_loc = {int(d): case["fix"][int(g)] for d, g in zip(ld, gd[here])}
         ops = HipLocalOps(part, xyz_loc, case["material"], fix_loc, 0, element_offset=lo)
         be = DistBackend(part, ops, torch.device("cuda", 0))
-        be.enable_multigrid(xyz_loc)
+        # "sparse": the aggregate level a mesh of more than 3000 aggregates gets (block-Jacobi Chebyshev sweeps on the replicated
+        # block matrix, dense level of super-aggregates) forced onto this small mesh
+        be.enable_multigrid(xyz_loc, **(dict(target=16, max_dense=12) if level2 == "sparse" else {}))
         model = DistModel(part, be, xyz_loc, case["material"], fix_loc, Loads(), external_loads)
         ctl = dict(case["ctl"], nstep=8)
         res = calc_disp(model, ctl, rtol=1e-11, maxit=4000)
@@ -105,7 +107,8 @@ def _worker_emb(rank, world, port, out):
         for s, ix in part.shared.items():
             nshare[ix] += 1
         payload = dict(gnodes=part.gnodes, disp=res["displacements"], lout=res["lout"], un=res["un"], crip=res["crip"],
-                       max_sharing=int(nshare.max()) + 1, pcg=res["stats"]["pcg_iterations"], solves=res["stats"]["solves"])
+                       max_sharing=int(nshare.max()) + 1, pcg=res["stats"]["pcg_iterations"], solves=res["stats"]["solves"],
+                       l2=be.mg.l2_info, lib=ops.c.precond_info()["level2"])
         got = [None] * world
         dist.all_gather_object(got, payload)
         if rank == 0:
@@ -114,15 +117,20 @@ def _worker_emb(rank, world, port, out):
         dist.destroy_process_group()
 
 
-def test_three_ranks_unstructured_partition(tmp_path):
+@pytest.mark.parametrize("level2", ["dense", "sparse"])
+def test_three_ranks_unstructured_partition(tmp_path, level2):
     """Element-range partition of an UNSTRUCTURED mesh (the reference's Embankment model refined once,
     5,272 tet10) over three ranks: ragged interfaces, nodes held by all three ranks, distributed
-    three-level multigrid -- against the single-GPU analysis."""
+    three-level multigrid with the REPLICATED aggregate level (blocks of Z^T A1 Z from k_galerkin_blocks on every rank, summed
+    in the global block pattern; dense inverse or the sparse level under super-aggregates) -- against the single-GPU analysis."""
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "r.pt")
-    spawn_sharing_gpu(_worker_emb, (3, port, out), 3)
+    spawn_sharing_gpu(_worker_emb, (3, port, out, level2), 3)
     got = torch.load(out, weights_only=False)
+    assert all(g["l2"] == got[0]["l2"] for g in got) and got[0]["l2"]["sparse"] == (level2 == "sparse"), [g["l2"] for g in got]
+    assert ("sparse" in got[0]["lib"]) == (level2 == "sparse"), got[0]["lib"]
+    print("three ranks (%s):" % level2, got[0]["l2"], got[0]["pcg"] / got[0]["solves"], "PCG iterations per solve")
     from fcvm_hip import examples
     from fcvm_hip.loads import Loads
     from fcvm_hip.solver import run_analysis
