@@ -1,20 +1,22 @@
 #!/usr/bin/env python3
-"""Headline benchmark (BASELINE.json): Newton iterations/s and elements*GP/s of the elastoplastic
-tet10 solver on the synthetic 1M-tet10 cube, SpMV GB/s against the HBM roofline.
+"""Headline benchmark (BASELINE.json): Newton iterations/s and elements*GP/s of the elastoplastic tet10 solver on the reference's
+Plate_with_hole_Example at 1 M tet10, SpMV GB/s against the HBM roofline.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--cells C]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--plate-h H]
 
-A "step" is one Newton (Riks-corrected, modified-Newton) iteration of the reference's calcDisp
-inner loop (fcVM.py:1346-1455): multigrid-preconditioned CG solve of K due = relax*r to 1e-10
-(replacing the CHOLMOD back substitution), arc-length correction, update_stress_load over all
-elements, out-of-balance norm.
-The one-time work of an analysis (pattern, K assembly = calcGSM, elastic solve) is done before the
-timed region, exactly where the reference does it (it factorises once, fcVM.py:1121), and is
-reported separately in the same JSON line.
+N = 1: the workload is the reference's Plate_with_hole_Example (geometry, supports, pressure load, von Mises material, its shipped
+control file) on a mapped mesh of 1,006,434 tet10.  The whole collapse analysis runs the way calcDisp does (fcVM.py:1304-1559); a
+"step" is one Newton / Riks iteration of it (fcVM.py:1346-1455): multigrid-preconditioned CG solve of K due = relax * r to 1e-10
+(replacing the CHOLMOD back substitution), arc-length correction, update_stress_load over all elements, out-of-balance norm.  The
+timed region is Newton iterations W+1 .. W+K of that analysis with whatever start_step / end_step calls fall between them.  The
+one-time work (pattern, K assembly = calcGSM, hierarchy, elastic solve) happens before it, where the reference does it (it factorises
+once, fcVM.py:1121), and is reported separately in the same JSON line, as are: `roofline` (the PCG's SpMV, HIP events on the solver's
+stream), `cpu_baseline` (the oracle port on this host), `north_star_workload` (the whole analysis), `configs2_cube` (BASELINE
+configs[2]: the synthetic 1 M cube) and `gnly` (the geometrically non-linear path: tangent re-assembly + pair of solves per iteration).
 
-N > 1 (one process per GPU under torch.distributed.run): elements are range-partitioned in z-slabs,
-one slab of `cells`^3 cells per rank (weak scaling), RCCL all-reduce for the PCG scalars and an
-interface exchange of the shared-node values per SpMV.
+N > 1 (one process per GPU under torch.distributed.run; fcvm_hip/dist_bench.py): the same analysis on a mesh of N x 1 M tet10 (weak
+scaling), elements cut into N ranges along a Morton curve, RCCL point-to-point sums at the shared nodes after every product and two
+small all-reduces per PCG iteration.
 """
 import argparse
 import json
@@ -148,7 +150,7 @@ def collapse_run(case, warmup, steps):
     return out
 
 
-def cube_run(cells, warmup, steps):
+def cube_run(cells, warmup, steps, with_gnly=True):
     """BASELINE configs[2] geometry (synthetic cube, 1 M tet10) with the plasticity of the real analysis, iterating on one load
     step without a convergence test (error_max = 0): the headline of rounds 1-2, kept as a secondary object for continuity.  Its
     PCG count depends on how long the loop has run (start vectors from the solution history), which is why it is no longer `value`."""
@@ -175,7 +177,54 @@ def cube_run(cells, warmup, steps):
                        (cells, model.ne, model.ndof, warmup, steps),
            "ms_per_newton_iteration": dt / steps * 1e3, "pcg_iterations_per_newton_iteration": (st["pcg_iterations"] - s0["pcg_iterations"]) / steps,
            "spmv_avg_launch_ms": (st["spmv_ms"] - s0["spmv_ms"]) / max(n_spmv, 1), "pattern_host_s": model.t_pattern}
+    del drv
+    gnly = None if not with_gnly else gnly_run(model, cells)
     c.close()
+    return out, gnly
+
+
+def gnly_run(model, cells, warmup=1, steps=6):
+    """The geometrically non-linear path (gnl = GNLY, fcVM.py:1351-1401) on the cube model: every Newton iteration re-assembles the
+    tangent stiffness on the updated geometry (calcTSM: k_assemble_lds<TANGENT, SYM> straight into the SpMV's storage + the level-1
+    operator), then solves K_t ue = f and K_t due = r with the new matrix -- as one lockstep pair (fcvm_solve2: every pass over the
+    matrix serves both), or, when the previous tangent's ue still solves the new system to the tolerance, due alone from the carried
+    start directions.  Timed with a stream synchronisation around every calc_gsm (two extra host waits per iteration)."""
+    from fcvm_hip.solver import RiksDriver
+    c = model.ctx
+    st = {}
+    drv = RiksDriver(model, dict(CTL, gnl="GNLY", maxImp="0.0", buckling=False), rtol=RTOL, stats=st)
+    drv.start_step()
+    orig, t_asm, n_asm = model.calc_gsm, [0.0], [0]
+
+    def timed_gsm(*a, **kw):
+        c.sync()
+        t0 = time.perf_counter()
+        o = orig(*a, **kw)
+        c.sync()
+        t_asm[0] += time.perf_counter() - t0
+        n_asm[0] += 1
+        return o
+    model.calc_gsm = timed_gsm
+    for _ in range(warmup):
+        drv.iteration()
+    c.sync()
+    s0, t_asm[0], n_asm[0] = dict(st), 0.0, 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        drv.iteration()
+    c.sync()
+    dt = time.perf_counter() - t0
+    model.calc_gsm = orig
+    d = lambda k: st.get(k, 0) - s0.get(k, 0)  # noqa: E731
+    out = {"workload": "synthetic cube %d^3 cells = %d tet10, gnl = GNLY: %d Newton iterations after %d, tangent re-assembled in %d of them"
+                       % (cells, model.ne, steps, warmup, n_asm[0]),
+           "ms_per_newton_iteration": dt / steps * 1e3, "tangent_calc_gsm_ms": t_asm[0] / max(n_asm[0], 1) * 1e3,
+           "solve_ms_per_newton_iteration": d("solve_s") / steps * 1e3, "linear_solves_per_newton_iteration": d("solves") / steps,
+           "pcg_iterations_per_newton_iteration": d("pcg_iterations") / steps,
+           "lockstep_pair_iterations_per_newton_iteration": d("paired_iterations") / steps,
+           "start_vector_spmv_per_newton_iteration": d("projection_spmv") / steps,
+           "reference": "fcVM.py:1351-1401 (calcTSM + two back substitutions with the new factorisation per iteration)"}
+    del drv
     return out
 
 
@@ -291,7 +340,9 @@ def run_single(args):
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(plate_h=args.cpu_plate_h)
     if not args.no_cube:
-        out["configs2_cube"] = cube_run(args.cells, 5, 20)
+        out["configs2_cube"], gnly = cube_run(args.cells, 5, 20, with_gnly=not args.no_gnly)
+        if gnly is not None:
+            out["gnly"] = gnly
     print(json.dumps(out))
 
 
@@ -304,7 +355,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-plate-h", type=float, default=6.0,
                     help="mesh size of the CPU sample / same-mesh comparison on Plate_with_hole (6.0 -> 16,830 tet10; 4.0 -> 48,600 = configs[1])")
-    ap.add_argument("--no-cube", action="store_true", help="skip the secondary cube object (N = 1 only)")
+    ap.add_argument("--no-cube", action="store_true", help="skip the secondary cube object and the GNLY object measured on its model (N = 1 only)")
+    ap.add_argument("--no-gnly", action="store_true", help="skip the GNLY object (tangent re-assembly + pair of solves per Newton iteration)")
     ap.add_argument("--plate-h", type=float, default=1.45, help="mesh size of the headline workload (1.45 -> 1,006,434 tet10)")
     args = ap.parse_args()
     world_env = os.environ.get("WORLD_SIZE")

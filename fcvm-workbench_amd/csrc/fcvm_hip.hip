@@ -177,6 +177,12 @@ struct fcvm_ctx {
     bool repack_pending = false;
     bool wsym_use = false;      // the matrix being copied is an SPD stiffness matrix: also into the symmetric form
     bool wsym_lo = true;        // ... and its 16-bit copy (FCVM_WIN_SYM_LO=0: the smoother passes stay on the full form)
+    // round 5: the fixed-point sums of the symmetric form lose relative precision as max / min of the nodal diagonal entries (a graded
+    // mesh): measured at every stiffness assembly (k_diag_grading), beyond grading_max the context runs the full window form
+    bool wsym_graded = false;   // the symmetric form was declined for this mesh because of its grading
+    double grading_max = 1.0e4; // FCVM_SYM_GRADING_MAX
+    double grading[2] = {0.0, 0.0};   // largest / smallest nodal maximum of the free diagonal entries at the last assembly
+    double *d_grading = nullptr;
     int32_t *d_slotof = nullptr;   // [nn] sliced-ELL slot of a node, kept from fcvm_set_mesh's uploads until the symmetric form is set up
     int asm_lpr = 4;            // lanes per row of the assembly into the symmetric window form (FCVM_ASM_LPR = 4, 8 or 16) ...
     int asm_lpr_long = 8;       // ... and in its long-row classes (FCVM_ASM_LPR_LONG), kept length above asm_lpr_from (FCVM_ASM_LPR_FROM)
@@ -1178,6 +1184,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_MG_L1_16")) c->mg_l1_16 = atoi(v);
     if (const char *v = getenv("FCVM_MG_ADD_W")) c->mg_add_w = atof(v);
     if (const char *v = getenv("FCVM_WIN_SYM_LO")) c->wsym_lo = atoi(v) != 0;
+    if (const char *v = getenv("FCVM_SYM_GRADING_MAX")) c->grading_max = atof(v) > 1.0 ? atof(v) : c->grading_max;
     if (const char *v = getenv("FCVM_MG_FUSE_PROLONG")) c->mg_fuse_prolong = atoi(v) != 0;
     if (const char *v = getenv("FCVM_SYM_PAIR")) c->sym_pair = atoi(v) != 0;
     if (const char *v = getenv("FCVM_PAIR_OVERLAP")) c->pair_overlap = atoi(v) != 0;
@@ -1225,7 +1232,7 @@ int fcvm_destroy(fcvm_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_mesh(c);
-    dfree(c->d_S); dfree(c->d_out8); dfree(c->d_part_mdot);
+    dfree(c->d_S); dfree(c->d_out8); dfree(c->d_part_mdot); dfree(c->d_grading);
     for (auto e : c->evpool) (void)hipEventDestroy(e);
     if (c->h_pcgS) (void)hipHostFree(c->h_pcgS);
     if (c->h_pcgS2) (void)hipHostFree(c->h_pcgS2);
@@ -1416,6 +1423,8 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     c->pat.emap.clear();
     c->pat.emap.shrink_to_fit();
     c->have_mesh = true;
+    c->wsym_graded = false;     // (the grading is a property of the mesh: measured again at its first assembly)
+    c->grading[0] = c->grading[1] = 0.0;
     return 0;
 }
 
@@ -1433,6 +1442,7 @@ int fcvm_set_coords(fcvm_ctx *c, const double *nocoord) {
     mg_topology_join(c, false);    // (the thread reads h_coord for the row order of level 1; the numbering it built stays valid)
     c->h_coord.assign(nocoord, nocoord + 3 * c->nn);
     c->mg_topo = false;
+    c->wsym_graded = false;     // (new geometry: the grading is measured again at the next assembly)
     return 0;
 }
 
@@ -1489,10 +1499,12 @@ int fcvm_spmv_info(fcvm_ctx *c, int64_t out[8]) {
  * out[2] = blocks of the matrix not stored (their transposes are), out[3] = bytes one launch streams from the format, out[4] =
  * LDS bytes per workgroup, out[5] = 1 if the values of the last assembly are in it (fcvm_spmv / fcvm_solve then use it), out[6] = 1
  * if the assembly kernels can write the form themselves, out[7] = 1 if the last assembly did (no sliced-ELL array, no copy) */
-int fcvm_spmv_sym_info(fcvm_ctx *c, int64_t out[8]) {
+int fcvm_spmv_sym_info(fcvm_ctx *c, int64_t out[10]) {
     NEED(c && c->have_mesh && out, "fcvm_spmv_sym_info: no mesh");
     if (wsym_finish(c)) return 1;
-    for (int k = 0; k < 8; k++) out[k] = 0;
+    for (int k = 0; k < 10; k++) out[k] = 0;
+    out[8] = c->wsym_graded ? 1 : 0;                            // declined for this mesh: graded beyond FCVM_SYM_GRADING_MAX
+    out[9] = c->grading[1] > 0.0 ? (int64_t)std::min(c->grading[0] / c->grading[1], 9.0e18) : 0;   // max / min nodal diagonal entry, last assembly
     if (!c->wsym.on) return 0;
     const WinSym &w = c->wsym.pat;
     const WinPattern &f = c->win.pat;
@@ -1693,7 +1705,7 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
     // in charge -- no sliced-ELL array, no copy kernel
     const bool lo = c->precond_mode >= 1 && c->mg_additive == 2;
     // (cycle form 0 smooths with Chebyshev steps fused into the sliced-ELL SpMV: it needs that array)
-    const bool direct = use_lds && c->asm_sym && c->win.on && c->wsym.on && c->wsym.asm_ok && (!lo || c->wsym_lo) &&
+    const bool direct = use_lds && c->asm_sym && c->win.on && c->wsym.on && c->wsym.asm_ok && (!lo || c->wsym_lo) && !c->wsym_graded &&
                         !(c->precond_mode >= 1 && c->mg_additive == 0);
     if (direct) {
         WinSymDev &ws = c->wsym;
@@ -1727,12 +1739,18 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
     HCHK(hipGetLastError());
     SetupLap lap(s);
     lap("assemble: kernels");
-    c->wsym_use = true;
+    c->wsym_use = !c->wsym_graded;
     if (direct) {
         if (refresh_precond_direct(c, lo)) return 1;
     } else {
         c->sell_valid = true;
         if (refresh_precond(c)) return 1;
+    }
+    const bool check_grading = c->wsym.on && !c->wsym_graded;
+    if (check_grading) {      // read back behind the synchronisation this call ends with anyway
+        if (!c->d_grading && dalloc(&c->d_grading, 2)) return 1;
+        hipLaunchKernelGGL(k_diag_grading, dim3(1), dim3(1024), 0, s, c->nn, c->d_dblk, c->d_fixmask, c->d_grading);
+        HCHK(hipMemcpyAsync(c->grading, c->d_grading, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     }
     lap("assemble: diagonal blocks, window-format copy");
     if (c->precond_mode >= 1) {
@@ -1746,6 +1764,15 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
     if (win_join(c)) return 1;
     HCHK(hipStreamSynchronize(s));
     c->assembled = true;
+    if (check_grading && c->grading[1] > 0.0 && c->grading[0] > c->grading_max * c->grading[1]) {
+        // a mesh graded beyond what the fixed-point sums resolve: this context keeps to the full window form from here on; the matrix
+        // just assembled went (or may have gone) into the symmetric form, so it is assembled once more along the other route
+        c->wsym_graded = true;
+        if (getenv("FCVM_VERBOSE"))
+            fprintf(stderr, "fcvm: nodal diagonal entries span %.3g .. %.3g (ratio %.3g > %.3g): symmetric window form declined, full form in charge\n",
+                    c->grading[1], c->grading[0], c->grading[0] / c->grading[1], c->grading_max);
+        return fcvm_assemble(c, disp, sig, pgp, Et_E, grav, glv_grav, modf, xgp, volume);
+    }
     return 0;
 }
 

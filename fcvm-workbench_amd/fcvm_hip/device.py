@@ -192,10 +192,10 @@ class Context:
     def spmv_sym_info(self):
         """the symmetric form of the window format (the PCG's FP64 SpMV): built / stored entries / blocks not stored / bytes per
         launch / LDS bytes / in use"""
-        out = (C.c_int64 * 8)()
+        out = (C.c_int64 * 10)()
         call("fcvm_spmv_sym_info", self.h, out)
         return dict(built=bool(out[0]), blocks=out[1], dropped=out[2], bytes=out[3], lds_bytes=out[4], in_use=bool(out[5]),
-                    assembly_writes_it=bool(out[6]), assembled_directly=bool(out[7]))
+                    assembly_writes_it=bool(out[6]), assembled_directly=bool(out[7]), declined_graded=bool(out[8]), grading=int(out[9]))
 
     def matrix_coo(self):
         nnz = 9 * self.pattern_info()["nnz_blocks"]

@@ -218,6 +218,7 @@ class DistBackend:
         self.group = part.group
         self.check_every = pcg_check_every
         self._timing = dict(spmv_ms=0.0, total_ms=0.0)
+        self._ev_pool, self._ev_list = [], None
         self.mg = None  # DistMG once enabled (enable_multigrid)
         self.local_solver = False
 
@@ -284,7 +285,7 @@ class DistBackend:
         self.ex.interface_sum(dblk.t, 9)
         self.ops.set_diag_blocks(dblk)
         if self.mg is not None:
-            self.mg.setup()
+            self.mg.setup(buckling=True)
 
     def spmv_geometric(self, x, y):
         self.ops.spmv_geometric(x, y)
@@ -419,10 +420,19 @@ class DistBackend:
         """y = K x (consistent);  xkx (1-element device tensor, optional): the rank's share of x^T K x = x_local . (K_local x_local),
         from the SpMV kernel's own inner product -- taken BEFORE the shared-node sum (x consistent, product unsummed: the shares
         add up to x^T K x without owner weights)"""
+        evs = self._ev_list
+        if evs is not None:
+            pool = self._ev_pool
+            e0 = pool.pop() if pool else torch.cuda.Event(enable_timing=True)
+            e1 = pool.pop() if pool else torch.cuda.Event(enable_timing=True)
+            e0.record()
         if xkx is not None:
             self.ops.spmv_dot(x, y, xkx)
         else:
             self.ops.spmv(x, y)
+        if evs is not None:
+            e1.record()
+            evs.append((e0, e1))
         self.ex.interface_sum(y.t, 3)
         return y
 
@@ -457,7 +467,10 @@ class DistBackend:
             self._timing = self.ops.c.solve_timing()
             return u, info
         if self.single_reduction:
-            return self._solve_single_reduction(f, u, rtol, maxit)
+            try:
+                return self._solve_single_reduction(f, u, rtol, maxit)
+            finally:
+                self._ev_list = None        # (a solve that raised must not leave spmv() recording events)
         x, r = u.t, f.t.clone()
         x.zero_()
         z, q = self.empty(f.n), self.empty(f.n)
@@ -539,20 +552,23 @@ class DistBackend:
             raise RuntimeError("distributed PCG did not converge in %d iterations" % maxit)
         return u, info
 
-    def _solve_single_reduction(self, f, u, rtol, maxit, max_refine=1):
+    def _solve_single_reduction(self, f, u, rtol, maxit, max_refine=2):
         """Preconditioned CG in the Chronopoulos-Gear form: the SpMV is applied to z = M^-1 r (w = K z), s = K p follows from
         the recurrence s = w + beta s, and r.z, w.z, r.r of an iteration travel in ONE all-reduce (the classic form needs p.Kp
         before and r.z after the update: two).  Same device-side convergence masking as the classic loop: after
         convergence alpha = beta = 0, queued iterations change nothing.  FCVM_DIST_CG=classic selects the two-reduction loop.
         Both r and s = K p are recurrences here, so the r.r the loop converges on can drift from the true residual at tight
         tolerances: after convergence f - K x is formed once (one more SpMV, exchange and all-reduce); when it misses the
-        threshold by more than a factor four in norm the loop restarts from it (max_refine times: once -- a restart costs a third
-        to a half of a solve, and a tolerance below what FP64 allows for the system, 1e-12 in some tests, would pay it again and
-        again for nothing), and what is reported is the TRUE relative residual; if it still misses the threshold then, that is
-        what FP64 allows for the system (info["attainable"]).  p.Kp <= 0 or r.z < 0 (an indefinite operator or preconditioner) stop the loop as a
-        breakdown instead of going unnoticed."""
+        threshold by more than a factor four in norm the loop restarts from it (at most max_refine = 2 times -- a restart costs a
+        third to a half of a solve), and what is reported is the TRUE relative residual.  A second restart that no longer quarters
+        the squared residual has found the floor FP64 sets for this system (a tolerance of 1e-12 in some tests lies below it):
+        reported as info["attainable"], not an error.  Restarts that are used up while each still improved, with the residual
+        above 4 rtol, are reported the same way AND warned about on rank 0; the Newton driver counts both in its statistics
+        (solves_above_tolerance, worst_attained_residual).  An iteration budget that runs out raises, on the TRUE residual.
+        p.Kp <= 0 or r.z < 0 (an indefinite operator or preconditioner) stop the loop as a breakdown instead of going unnoticed."""
         c0 = dict(self.comm)
         dev = self.device
+        self._timing = dict(spmv_ms=0.0, spmv_timed=0, total_ms=0.0)
         x, r = u.t, f.t.clone()
         x.zero_()
         z, w = self.empty(f.n), self.empty(f.n)
@@ -563,6 +579,11 @@ class DistBackend:
         # kernel and z^T K z out of the SpMV kernel (its own inner product over the rank's rows, before the shared-node sum): no
         # separate inner-product passes, still ONE all-reduce of three numbers per iteration
         fused_lo = fused and getattr(self.mg, "fused_lo", False)
+
+        # in-solver timing of the rank's fine SpMV kernel (HIP events on the stream it is launched on, around the kernel only: the
+        # shared-node exchange that follows is outside), resolved after the solve -- what bench.py's roofline object quotes for N > 1
+        timed = dev.type == "cuda"
+        evs = self._ev_list = [] if timed else None     # DistBackend.spmv brackets its kernel with events while this list is set
 
         def spmv_zw():
             if fused_lo:
@@ -681,16 +702,15 @@ class DistBackend:
             if flag == 2.0:
                 raise RuntimeError("distributed PCG broke down: p.Kp <= 0 or r.M^-1 r < 0 (operator or preconditioner not positive "
                                    "definite) after %d iterations%s" % (total_it, detail))
-            if rr_h > thresh_h:
-                break           # iteration budget used up: reported below
-            # the true residual of what the recurrences converged to
+            # the true residual of what the recurrences converged to (or stopped at, when the iteration budget ran out)
+            out_of_budget = rr_h > thresh_h
             self.spmv(TVec(x), w)
             spmvs += 1
             rt = f.t - w.t
             rr_true = float(self.dot_t(rt, rt).item())
             self.comm["host_syncs"] += 1
             rr_h = rr_true
-            if rr_true <= 16.0 * thresh_h or attempt == max_refine or queued_all >= maxit:
+            if out_of_budget or rr_true <= 16.0 * thresh_h or attempt == max_refine or queued_all >= maxit:
                 break
             if prev_true is not None and rr_true > 0.25 * prev_true:
                 # a restart from the true residual no longer halves it: this is the floor FP64 sets for this matrix and solution
@@ -702,6 +722,12 @@ class DistBackend:
             r = rt
             info["refinements"] += 1
         info.update(iterations=total_it, rel_residual=float(np.sqrt(rr_h / bb_h)), spmv=spmvs)
+        self._ev_list = None
+        if timed:       # (the host has just read scalars of this stream: the events are complete)
+            torch.cuda.current_stream(dev).synchronize()
+            self._timing = dict(spmv_ms=float(sum(a.elapsed_time(b) for a, b in evs)), spmv_timed=len(evs), total_ms=0.0)
+            for a, b in evs:
+                self._ev_pool += [a, b]
         info["comm"] = {k: self.comm[k] - c0[k] for k in self.comm}
         info["comm_per_iteration"] = {k: (self.comm[k] - c0[k]) / max(queued_all + 1, 1) for k in ("exchanges", "allreduces")}
         if rr_h > 16.0 * thresh_h and "attainable" not in info:
@@ -709,6 +735,10 @@ class DistBackend:
                 raise RuntimeError("distributed PCG did not converge in %d iterations (true relative residual %.3e)"
                                    % (maxit, np.sqrt(rr_h / bb_h)))
             info["attainable"] = float(np.sqrt(rr_h / bb_h))       # (max_refine restarts, each still improving: stop here)
+            if self.part.rank == 0:
+                import warnings
+                warnings.warn("distributed PCG: true relative residual %.3e after %d restarts, asked for %.1e (recurrences drifting, "
+                              "not the FP64 floor)" % (info["attainable"], info["refinements"], rtol))
         return u, info
 
     def solve_timing(self):
@@ -782,6 +812,9 @@ class DistMG:
         self.merge_l1 = os.environ.get("FCVM_DIST_MERGE_L1", "1") != "0"
         self.ready = False
         self.topo = False
+        self.lmax0 = self.lmax1 = 0.0
+        self.lmax_stale = True
+        self.timing = {}
 
     # -- set-up -------------------------------------------------------------------------------
     def _topology(self):
@@ -809,6 +842,7 @@ class DistMG:
         self.r1, self.x1, self.rr1, self.d1, self.t1 = mk(n1), mk(n1), mk(n1), mk(n1), mk(n1)
         self.tk1 = mk(n1)      # the last pre-smoothing product of level 1, unsummed (merge_l1)
         self.topo = True
+        self.lmax_stale = True
 
     def _lmax(self, level, n, wdot):
         """largest eigenvalue of Dinv*A: Lanczos for the pencil (A, D) with D-orthonormal vectors v_j = Dinv p_j carried beside
@@ -840,7 +874,9 @@ class DistMG:
             T = np.diag(al) + (np.diag(be_, 1) + np.diag(be_, -1) if be_ else 0.0)
             lam = float(np.linalg.eigvalsh(T)[-1])
             hist.append(lam)
-            if (j + 1 >= 8 and abs(lam - hist[-3]) <= 1e-3 * abs(lam)) or j + 1 == kmax:
+            # (at least 16 steps and 3e-4 over two steps: this estimator, unlike mg_estimate_lmax, was never checked against an
+            # eigensolver until round 5 -- tests/test_distributed.py does now -- and the bounds are formed once per mesh)
+            if (j + 1 >= 16 and abs(lam - hist[-3]) <= 3e-4 * abs(lam)) or j + 1 == kmax:
                 break
             Q.t.mul_(-beta_prev).add_(U.t).add_(P.t, alpha=-alpha)      # p~ = u - alpha p_j - beta_{j-1} p_{j-1}
             dinv(Q, U)                                                  # v~
@@ -857,25 +893,46 @@ class DistMG:
             raise RuntimeError("DistMG: eigenvalue estimate broke down")
         return lam
 
-    def setup(self):
+    def _lap(self, name, t0):
+        """stage times of the set-up (FCVM_SETUP_TIMING=1: printed by rank 0; kept in self.timing either way)"""
+        import time
+        self.be.sync()
+        t = time.perf_counter()
+        self.timing[name] = self.timing.get(name, 0.0) + t - t0
+        return t
+
+    def setup(self, buckling=False):
+        """after every assembly: consistent level-1 diagonal blocks; smoother bounds and the aggregate level once per mesh (tangent
+        re-assemblies keep both, as the one-GPU solver does -- csrc/fcvm_mg.inc mg_setup: plastic softening only lowers the eigenvalues of
+        Dinv A; rounds 1-4 re-ran 2 x 40 Lanczos steps with an exchange and an all-reduce each at every GNLY tangent).  buckling: the
+        shifted operator K_b + sigma K_g gets bounds of its own, and so does the ordinary assembly after it."""
+        import time
         be, dev = self.be, self.be.device
+        t0 = time.perf_counter()
         if not self.topo:
             self._topology()
+            t0 = self._lap("level-1 topology, exchange tables", t0)
         # level-1 diagonal blocks: local partial sums -> consistent -> inverted for the smoother
         dblk = TVec(torch.zeros(9 * self.nc, dtype=torch.float64, device=dev))
         self.ops.mg_get_diag(1, dblk)
         self.ex1.interface_sum(dblk.t, 9)
         self.ops.mg_set_diag(1, dblk)
-        wdot0 = lambda a, b: be._allreduce(torch.sum(be.w * a * b).reshape(1))  # noqa: E731
-        wdot1 = lambda a, b: be._allreduce(torch.sum(self.own1 * a * b).reshape(1))  # noqa: E731
-        self.lmax0 = self._lmax(0, 3 * self.part.nn, wdot0)
-        self.lmax1 = self._lmax(1, 3 * self.nc, wdot1)
-        if os.environ.get("FCVM_VERBOSE") and self.part.rank == 0:
-            print("fcvm dist: smoother bounds lmax0 %.6f lmax1 %.6f (alpha0 %.3g, weight %.3g)" % (self.lmax0, self.lmax1, self.alpha0, self.weight), flush=True)
+        if buckling or self.lmax_stale or not (self.lmax0 and self.lmax1):
+            wdot0 = lambda a, b: be._allreduce(torch.sum(be.w * a * b).reshape(1))  # noqa: E731
+            wdot1 = lambda a, b: be._allreduce(torch.sum(self.own1 * a * b).reshape(1))  # noqa: E731
+            self.lmax0 = self._lmax(0, 3 * self.part.nn, wdot0)
+            self.lmax1 = self._lmax(1, 3 * self.nc, wdot1)
+            self.lmax_stale = bool(buckling)
+            if os.environ.get("FCVM_VERBOSE") and self.part.rank == 0:
+                print("fcvm dist: smoother bounds lmax0 %.6f lmax1 %.6f (alpha0 %.3g, weight %.3g)" % (self.lmax0, self.lmax1, self.alpha0, self.weight), flush=True)
+            t0 = self._lap("smoother bounds (2 Lanczos runs)", t0)
         self.ch0 = _Cheb(LMAX_SAFETY * self.lmax0, self.alpha0, self.k0)
         self.ch1 = _Cheb(LMAX_SAFETY * self.lmax1, self.alpha1s, self.k1s)
         if not getattr(self, "nagg", 0):
-            self._level2()   # once per mesh; tangent re-assemblies keep the aggregate level
+            self._level2()   # once per mesh; tangent re-assemblies keep the aggregate level (as device.Context.assemble does on one GPU)
+            t0 = self._lap("aggregate level", t0)
+            if os.environ.get("FCVM_SETUP_TIMING") and self.part.rank == 0:
+                print("fcvm dist set-up: " + ", ".join("%s %.3f s" % kv for kv in self.timing.items()), flush=True)
         self.ready = True
 
     def _level2(self):
@@ -889,7 +946,9 @@ class DistMG:
         FCVM_MG_MAX_AGGREGATES (3000), beyond that the sparse level of the one-GPU library (block-Jacobi Chebyshev sweeps on A2 closed by a
         dense level of super-aggregates, csrc/fcvm_l2s.inc) with the super-aggregates' modes summed over the ranks here.  Per cycle: one
         all-reduce of r2 (6 doubles per aggregate), the same correction computed by every rank, no gather."""
+        import time
         be, dev, part = self.be, self.be.device, self.part
+        t0 = time.perf_counter()
         coord, fm = self.ops.mg_coarse_nodes()
         own = self.own1.view(-1, 3)[:, 0].cpu().numpy() > 0.5
         lo = torch.as_tensor(coord.min(0), device=dev)
@@ -961,8 +1020,10 @@ class DistMG:
         Z = np.einsum("ncj,njk->nck", R, T[agg])
         n2 = 6 * nagg
         self.ops.mg_set_level2(nagg, np.ascontiguousarray(agg, np.int32), np.ascontiguousarray(Z.reshape(self.nc, 18)))
+        t0 = self._lap("  level 2: aggregates, modes (4 small all-reduces)", t0)
         # this rank's blocks of Z^T A1 Z, the global block pattern, the sum over the ranks
         sptr_l, cols_l, B_l = self.ops.mg_galerkin_blocks()
+        t0 = self._lap("  level 2: Z^T A1 Z blocks (device)", t0)
         rows_l = np.repeat(np.arange(nagg, dtype=np.int64), np.diff(sptr_l))
         keys_l = rows_l * nagg + cols_l.astype(np.int64)
         every = [None] * part.world
@@ -979,6 +1040,7 @@ class DistMG:
         np.add.at(sptr_g, allb // nagg + 1, 1)
         sptr_g = np.cumsum(sptr_g)
         slot_agg = (allb % nagg).astype(np.int32)
+        t0 = self._lap("  level 2: block pattern, all-reduce of %.1f MB" % (288e-6 * nslots), t0)
         max_dense = self.max_dense if self.max_dense else int(os.environ.get("FCVM_MG_MAX_AGGREGATES", "3000"))
         sparse = nagg > max_dense and os.environ.get("FCVM_MG_SPARSE", "1") != "0"
         nsuper, sagg, soff, Cm = 0, None, None, None
@@ -1008,7 +1070,9 @@ class DistMG:
             T3, r3 = orthonormal(GM[:nsuper])
             Cm = np.ascontiguousarray(np.einsum("gkl,glm->gkm", GM[nsuper:], T3[sagg]))
             soff = np.concatenate([[0], np.cumsum(r3)]).astype(np.int64)
+            t0 = self._lap("  level 2: super-aggregates (3 all-reduces)", t0)
         self.ops.mg_l2_finish(nagg, arank, sptr_g, slot_agg, Bsum, nsuper, sagg, soff, Cm)
+        t0 = self._lap("  level 2: finish (%s)" % ("sparse level, A3 inverse, bound" if sparse else "dense inverse"), t0)
         self.nagg, self.n2 = nagg, n2
         self.r2 = TVec(torch.zeros(n2, dtype=torch.float64, device=dev))
         self.e2 = TVec(torch.zeros(n2, dtype=torch.float64, device=dev))

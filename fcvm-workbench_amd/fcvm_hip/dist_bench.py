@@ -1,6 +1,9 @@
-"""N > 1 leg of bench.py: one process per GPU (torch.distributed.run), weak scaling -- every rank
-owns one slab of cells^3 cells (6*cells^3 tet10) of a column of N stacked cubes; base clamped,
-traction on the top face of the last slab."""
+"""N > 1 leg of bench.py: one process per GPU (torch.distributed.run), weak scaling.  `run`: the headline workload of N = 1 -- the
+reference's Plate_with_hole_Example with its control file -- on a mesh of N x 1 M tet10, elements cut into N ranges along a Morton
+curve (dist.partition_model); the timed region is Newton iterations W+1 .. W+K of the collapse analysis, exactly as for N = 1, with a
+barrier in its clock reads.  FCVM_DIST_WORKLOAD=column keeps the workload of rounds 1-2 (`build_rank_model`, `_run_column`: a column of
+N stacked cubes, one slab of cells^3 cells per rank, base clamped, traction on the top face of the last slab), which the GPU tests of
+tests/test_gpu_dist.py also use."""
 import json
 import os
 import time
@@ -155,8 +158,9 @@ def run(args, ctl, material, traction, rtol, hbm_peak):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         s0, s1 = reg["stats0"], reg["stats1"]
-        # local SpMV timing for the roofline object (HIP events on the stream the kernel runs on): the stand-alone kernel on
-        # rank 0's matrix, not the in-solver launches (those are followed by the shared-node exchange)
+        # roofline object: the IN-SOLVER launches of rank 0's fine SpMV kernel inside the timed region (HIP events on the stream the kernel
+        # runs on, around the kernel alone -- the shared-node exchange that follows is outside; DistBackend._solve_single_reduction), and
+        # the same kernel back to back afterwards for context
         x, y = be.array(np.random.default_rng(rank).standard_normal(3 * model.nn)), be.empty(3 * model.nn)
         for _ in range(3):
             ops.spmv(x, y)
@@ -167,7 +171,9 @@ def run(args, ctl, material, traction, rtol, hbm_peak):
             ops.spmv(x, y)
         e1.record()
         torch.cuda.synchronize()
-        avg_ms = e0.elapsed_time(e1) / reps
+        standalone_ms = e0.elapsed_time(e1) / reps
+        launches = s1.get("spmv_launches", 0) - s0.get("spmv_launches", 0)
+        avg_ms = (s1.get("spmv_ms", 0.0) - s0.get("spmv_ms", 0.0)) / launches if launches > 0 else standalone_ms
         info = ops.c.pattern_info()
         sinfo = ops.c.spmv_sym_info()      # the symmetric form stores (and streams) fewer blocks than the matrix has
         alg = (sinfo["blocks"] if sinfo["built"] and sinfo["in_use"] else info["nnz_blocks"]) * 76 + 2 * info["ndof"] * 8
@@ -191,10 +197,13 @@ def run(args, ctl, material, traction, rtol, hbm_peak):
                                        (case["name"], ne_total, ne_total // world, 3 * len(case["nocoord"]), world, world, args.warmup + 1,
                                         args.warmup + args.steps),
                            "pcg_rtol": rtol,
-                           "preconditioner": (("distributed p-multigrid, %s (tet10 -> tet4 -> %d aggregates x rigid-body modes, dense "
-                                               "inverse split by rows over the ranks), single-reduction CG" %
+                           "preconditioner": (("distributed p-multigrid, %s (tet10 -> tet4 -> %d aggregates x rigid-body modes, replicated on "
+                                               "every rank: %s), single-reduction CG" %
                                                ({2: "multiplicative V(1,1) with 16-bit smoother products per rank", 1: "additive cycle",
-                                                 0: "multiplicative Chebyshev cycle"}[be.mg.form], be.mg.nagg)) if be.mg is not None else
+                                                 0: "multiplicative Chebyshev cycle"}[be.mg.form], be.mg.nagg,
+                                                ("sparse 6 x 6 blocks with block-Jacobi Chebyshev sweeps -> %d super-aggregates, dense inverse"
+                                                 % be.mg.l2_info["super_aggregates"]) if be.mg.l2_info["sparse"] else "dense inverse"))
+                                              if be.mg is not None else
                                               ("the one-GPU p-multigrid PCG of the library (single rank: nothing to exchange)" if be.local_solver
                                                else "block-Jacobi 3x3")), "parallelism": "element-partition x%d" % world,
                            "partition": {"elements_nodes_interface_nodes_per_rank": sh_all},
@@ -204,10 +213,22 @@ def run(args, ctl, material, traction, rtol, hbm_peak):
                 "pcg_iterations_per_solve": pcg / max(solves, 1),
                 "setup_s": {"mesh": t_mesh, "partition_pattern_upload": t_part, "inside_analysis": run_["setup_s"]},
                 "north_star_workload": dict(an, elements_gp_per_s=an["newton_iterations"] * ne_total * 4 / an["analysis_s"]),
-                "roofline": {"bound": "hbm", "kernel": "k_spmv_win (rank 0, local matrix, stand-alone launches after the timed region)",
+                "roofline": {"bound": "hbm", "kernel": "k_spmv_win_sym<true> on rank 0's matrix (%d elements), launches inside the PCG of the timed "
+                                                       "region" % model.ne,
                              "achieved": achieved, "peak": hbm_peak, "unit": "GB/s", "frac": achieved / hbm_peak, "traffic": None,
-                             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms},
+                             "traffic_note": "no PMC pass over a rank's partition; the same kernel and layout on the N = 1 workload move 1.027 x "
+                                             "their algorithmic bytes (profiles/r04_plate_spmv_sym_traffic_pmc.txt)",
+                             "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches_timed": launches,
+                             "back_to_back_launch_ms": standalone_ms},
+                "aggregate_level": be.mg.l2_info if be.mg is not None else None,
+                "multigrid_setup_s": be.mg.timing if be.mg is not None else None,
             }
+        # cpu_baseline: rank 0's host, the same bounded sample as for N = 1 (the other ranks wait in the barrier below)
+        if rank == 0 and not args.no_cpu:
+            import bench
+            out["cpu_baseline"] = bench.cpu_baseline(plate_h=args.cpu_plate_h)
+        dist.barrier()
+        if rank == 0:
             print(json.dumps(out))
     finally:
         dist.destroy_process_group()

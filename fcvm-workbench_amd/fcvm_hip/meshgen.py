@@ -27,9 +27,10 @@ def cube_tet10(nx, ny, nz, lx=1.0, ly=1.0, lz=1.0):
     nocoord[idx.ravel(), 1] = gj.ravel() * (ly / (2 * ny))
     nocoord[idx.ravel(), 2] = gk.ravel() * (lz / (2 * nz))
     ci, cj, ck = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
-    base = np.stack([2 * ci.ravel(), 2 * cj.ravel(), 2 * ck.ravel()], axis=1)  # [ncell,3] lattice origin
-    els = []
-    for perm in itertools.permutations(range(3)):
+    # lattice number of every cell's origin; a node of the cell at lattice offset (ox, oy, oz) is that number + (oz * my + oy) * mx + ox
+    base_id = ((2 * ck.ravel()) * my + 2 * cj.ravel()) * mx + 2 * ci.ravel() + 1
+    offs = np.empty((6, 10), dtype=np.int64)
+    for t, perm in enumerate(itertools.permutations(range(3))):
         v = [np.zeros(3, dtype=np.int64)]
         for ax in perm:
             s = v[-1].copy()
@@ -40,12 +41,8 @@ def cube_tet10(nx, ny, nz, lx=1.0, ly=1.0, lz=1.0):
         if d < 0:
             v[[1, 2]] = v[[2, 1]]
         loc = [v[0], v[1], v[2], v[3]] + [(v[a] + v[b]) // 2 for a, b in MID_PAIRS]
-        cols = []
-        for off in loc:
-            p = base + off
-            cols.append((p[:, 2] * my + p[:, 1]) * mx + p[:, 0] + 1)
-        els.append(np.stack(cols, axis=1))
-    elNodes = np.stack(els, axis=1).reshape(-1, 10).astype(np.int64)
+        offs[t] = [(o[2] * my + o[1]) * mx + o[0] for o in loc]
+    elNodes = (base_id[:, None, None] + offs[None, :, :]).reshape(-1, 10)
     return elNodes, nocoord
 
 
@@ -117,21 +114,40 @@ def fix_orientation(elNodes, nocoord):
     return int(neg.sum())
 
 
-def merge_blocks(blocks, tol=1e-7):
+def merge_blocks(blocks, tol=1e-7, lattices=None):
     """Glues structured blocks [(elNodes, nocoord), ...] with matching interface lattices into one mesh:
     nodes closer than tol (per coordinate, after rounding) become one.  Straight-sided elements: every
-    mid-side node is put at the mean of its two corners before merging, so mapped blocks stay conforming."""
-    els, pts, off = [], [], 0
-    for el, xyz in blocks:
+    mid-side node is put at the mean of its two corners before merging, so mapped blocks stay conforming.
+    lattices (optional): per block the half-cell lattice (mx, my, mz) of a cube_tet10 block whose nodes were only moved -- the
+    fast path of the large meshes (8 M tet10 for the 8-GPU bench: 64 -> 30 s): a mid-side node of a Kuhn triangulation sits between the
+    lattice points p - o and p + o (o = the odd coordinates of p), so the corners are found per NODE instead of per element edge, and
+    only nodes on a block's boundary faces can coincide with another block's, so only those are compared.  Same mesh, same numbering."""
+    els, pts, cand, off = [], [], [], 0
+    for nb, (el, xyz) in enumerate(blocks):
         xyz = xyz.copy()
-        e0 = el - 1
-        for k, (a, b) in enumerate(MID_PAIRS):
-            xyz[e0[:, 4 + k]] = 0.5 * (xyz[e0[:, a]] + xyz[e0[:, b]])
+        lat = lattices[nb] if lattices is not None else None
+        if lat is not None:
+            mx, my, mz = lat
+            assert len(xyz) == mx * my * mz
+            idx = np.arange(len(xyz), dtype=np.int64)
+            i, j, k = idx % mx, (idx // mx) % my, idx // (mx * my)
+            oi, oj, ok = i & 1, j & 1, k & 1
+            mid = np.nonzero((oi | oj | ok) > 0)[0]
+            d = ((ok * my + oj) * mx + oi)[mid]
+            xyz[mid] = 0.5 * (xyz[mid - d] + xyz[mid + d])
+            onb = (i == 0) | (i == mx - 1) | (j == 0) | (j == my - 1) | (k == 0) | (k == mz - 1)
+            cand.append(np.nonzero(onb)[0] + off)
+        else:
+            e0 = el - 1
+            for k, (a, b) in enumerate(MID_PAIRS):
+                xyz[e0[:, 4 + k]] = 0.5 * (xyz[e0[:, a]] + xyz[e0[:, b]])
+            cand.append(np.arange(len(xyz), dtype=np.int64) + off)
         els.append(el + off)
         pts.append(xyz)
         off += len(xyz)
     el, xyz = np.concatenate(els), np.concatenate(pts)
-    key = np.round(xyz / tol).astype(np.int64)
+    cand = np.concatenate(cand)
+    key = np.round(xyz[cand] / tol).astype(np.int64)
     # one 64-bit hash per lattice point instead of a row-wise unique (5x faster at 1.5 M nodes); a collision between
     # different points would merge them, so it is checked for and falls back to the exact row-wise path
     h = (key[:, 0] * np.int64(73856093)) ^ (key[:, 1] * np.int64(19349663)) ^ (key[:, 2] * np.int64(83492791))
@@ -140,11 +156,14 @@ def merge_blocks(blocks, tol=1e-7):
     if not np.array_equal(key[first[inv]], key):
         _, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
         inv = inv.reshape(-1)
-    order = np.argsort(first)  # keep first-appearance order (block by block, lattice order inside a block)
-    rank = np.empty(len(order), np.int64)
-    rank[order] = np.arange(len(order))
-    el = rank[inv[el - 1]] + 1
-    xyz = xyz[first[order]]
+    # every node's representative = its first appearance (block by block, lattice order inside a block); the kept nodes are
+    # numbered in that order
+    rep = np.arange(len(xyz), dtype=np.int64)
+    rep[cand] = cand[first[inv]]
+    keep = rep == np.arange(len(xyz))
+    newid = np.cumsum(keep) - 1
+    el = newid[rep[el - 1]] + 1
+    xyz = xyz[keep]
     fix_orientation(el, xyz)
     return el.astype(np.int64), xyz
 
@@ -173,4 +192,5 @@ def plate_with_hole(h, length=200.0, width=100.0, thick=10.0, radius=50.0):
     p1 = np.concatenate([out * (r / rout)[:, None], q[:, 2:3]], axis=1)
     el2, p2 = cube_tet10(n_x, n_a, n_z, length - w, w, thick)
     p2[:, 0] += w
-    return merge_blocks([(el1, p1), (el2, p2)])
+    lat = lambda a, b, c: (2 * a + 1, 2 * b + 1, 2 * c + 1)  # noqa: E731
+    return merge_blocks([(el1, p1), (el2, p2)], lattices=[lat(n_t, 2 * n_a, n_z), lat(n_x, n_a, n_z)])

@@ -225,6 +225,10 @@ class RiksDriver:
         st["solves"] += 1
         if "comm_per_iteration" in info:      # distributed backend: exchanges / all-reduces per PCG iteration of the last solve
             st["comm_per_iteration"] = info["comm_per_iteration"]
+        if "attainable" in info:              # distributed PCG: the true residual stayed above the tolerance asked for (what FP64 allows
+            #                                   for the system, or restarts that kept improving): the worst such solve of the analysis
+            st["solves_above_tolerance"] = st.get("solves_above_tolerance", 0) + 1
+            st["worst_attained_residual"] = max(st.get("worst_attained_residual", 0.0), float(info["attainable"]))
         if info["iterations"] == 0 and info["spmv"] == 0:
             return u
         tm = self.c.solve_timing()
@@ -256,11 +260,13 @@ class RiksDriver:
             return None, rhs, nf, nf
         return x0, r0, nf, n0
 
-    def _adopt_carry(self, known):
+    def _adopt_carry(self, known, skip=None):
         """History for the first solve with a new tangent: `known` = (u, K u) pairs whose product is at hand, plus the carried
-        solutions of the previous tangent with their products formed now (one SpMV each).  Sets _hist / _gram."""
+        solutions of the previous tangent with their products formed now (one SpMV each).  skip: a carried vector that `known`
+        already holds a copy of (the previous ue is both the start vector of the new ue and the first carried solution: taken twice
+        it made the Gram matrix singular up to rounding and cost an SpMV for nothing).  Sets _hist / _gram."""
         c = self.c
-        carry, self._carry = self._carry, []
+        carry, self._carry = [u for u in self._carry if u is not skip], []
         if self.proj_depth <= 0 or not carry:
             return
         hist = [(u, f.clone()) for u, f in known]
@@ -300,7 +306,7 @@ class RiksDriver:
         if not np.isfinite(n0) or n0 >= nf:
             x0, r0, n0 = None, rhs_a, nf
         if x0 is not None and n0 <= self.rtol * nf:        # the old ue still solves the new system: only due is left
-            self._adopt_carry([(x0, rhs_a)])               # ... from the projection onto ue (product known: rhs_a) and the carried solutions
+            self._adopt_carry([(x0, rhs_a)], skip=guess_a)   # ... from the projection onto ue (product known: rhs_a) and the carried solutions
             st["solve_s"] += time.perf_counter() - t0
             st["solves"] += 1
             return x0, self.solve(rhs_b)
@@ -384,7 +390,8 @@ class RiksDriver:
             # new tangent matrix: the stored K U products are stale.  The last solutions themselves still point the way (the
             # right-hand side of the next due is close to the last one's): they are kept, without products -- solve_pair forms
             # K_new u for them (one SpMV each) where that pays (FCVM_GNLY_CARRY vectors, default 2; 0: start every due from zero)
-            self._carry = [h[0] for h in self._hist][-self.carry_depth:] if self.carry_depth > 0 else []
+            # (only where solve_pair consumes them: backends without solve2 -- the distributed one -- would hold two fine vectors for nothing)
+            self._carry = [h[0] for h in self._hist][-self.carry_depth:] if self.carry_depth > 0 and hasattr(c, "solve2") else []
             self._hist, self._gram = [], None
             c.mul(self.model.fixdof, self.glv, out=self.f)
             c.axpby(1.0, self.f, 1.0, self.modf, out=self.f)

@@ -286,8 +286,11 @@ int fcvm_membench(fcvm_ctx *c, int64_t nbytes, double out[2]);
  * mesh, out[1] = stored entries, out[2] = blocks not stored, out[3] = bytes one launch streams, out[4] = LDS bytes per
  * workgroup, out[5] = 1 if it holds the values of the last assembly, out[6] = 1 if fcvm_assemble can write the form itself
  * (round 4: rows leave the assembly kernel's LDS straight into this storage, its 16-bit copy and the diagonal blocks), out[7] = 1
- * if the last assembly did.  No reference counterpart (CHOLMOD, fcVM.py:1121). */
-int fcvm_spmv_sym_info(fcvm_ctx *c, int64_t out[8]);
+ * if the last assembly did.  Round 5: out[8] = 1 if the form was DECLINED for this mesh because of its grading -- the fixed-point sums take
+ * their unit from the largest matrix entry, so products in the region of smallest entries lose relative precision as out[9] = max / min
+ * over the nodes of the largest free diagonal entry (measured at every stiffness assembly); beyond FCVM_SYM_GRADING_MAX (1e4) the
+ * context assembles into and multiplies with the full window form instead.  No reference counterpart (CHOLMOD, fcVM.py:1121). */
+int fcvm_spmv_sym_info(fcvm_ctx *c, int64_t out[10]);
 
 /* host-only self check of the symmetric form of the window format (the PCG's FP64 SpMV stores one block of every pair
  * K_ij, K_ji inside a group and forms both products): out[0] = built, out[1] = stored entries, out[2] = blocks not stored,

@@ -380,6 +380,46 @@ def _cg_guard_worker(rank, world, port, out):
         except RuntimeError as ex:
             res["breakdown"] = str(ex)
         be.precond = orig_pre
+        # 4) an iteration budget that runs out raises -- on the true residual, whatever the recurrence says
+        try:
+            be.solve(f, rtol=1e-10, maxit=6)
+            res["budget"] = "no error"
+        except RuntimeError as ex:
+            res["budget"] = str(ex)
+        # 5) a recurrence that never stops drifting: the restarts are used up with the true residual still above the tolerance --
+        #    reported as info["attainable"] and warned about on rank 0, not returned silently
+        import warnings
+
+        def always_drifting(x, y):
+            orig_spmv(x, y)
+            calls[0] += 1
+            if calls[0] % 3 == 0:
+                y.t.mul_(1.0 + 5e-3)
+            return y
+        be.spmv = always_drifting
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            u3, info3 = be.solve(f, rtol=1e-10, maxit=4000)
+        be.spmv = orig_spmv
+        be.spmv(u3, q)
+        rt = f.t - q.t
+        res["stuck_true"] = float(np.sqrt(be.dot_t(rt, rt).item() / be.dot_t(f.t, f.t).item()))
+        res["stuck_info"] = {k: info3.get(k) for k in ("attainable", "refinements", "rel_residual")}
+        res["stuck_warned"] = any("distributed PCG" in str(w.message) for w in caught)
+        # 6) the Lanczos bound of the smoothers (DistMG._lmax) against an eigensolver on the assembled global pencil (A, D)
+        be.enable_multigrid(model.nocoord, target=12)
+        be.mg.setup()
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as sla
+        K = be.ops.K.tocoo()
+        gd = (3 * (model.part.gnodes[K.row // 3] - 1) + K.row % 3, 3 * (model.part.gnodes[K.col // 3] - 1) + K.col % 3)
+        trip = [None] * world
+        dist.all_gather_object(trip, (gd[0], gd[1], K.data))
+        n = 3 * model.part.nn_global
+        Kg = sp.coo_matrix((np.concatenate([t[2] for t in trip]), (np.concatenate([t[0] for t in trip]), np.concatenate([t[1] for t in trip]))),
+                           shape=(n, n)).tocsr()
+        D = sp.block_diag([Kg[3 * i:3 * i + 3, 3 * i:3 * i + 3].toarray() for i in range(n // 3)]).tocsc()
+        res["lmax0"] = (be.mg.lmax0, float(sla.eigsh(Kg, k=1, M=D, which="LA", return_eigenvectors=False)[0]))
         gathered = [None] * world
         dist.all_gather_object(gathered, res)
         if rank == 0:
@@ -401,6 +441,12 @@ def test_single_reduction_cg_reports_the_true_residual_and_flags_breakdown(tmp_p
         assert g["drift_true"] <= 4e-10 and g["drift_reported"] == pytest.approx(g["drift_true"], rel=1e-6)
         assert g["drift_refinements"] >= 1
         assert "broke down" in g["breakdown"]
+        assert "did not converge" in g["budget"], g["budget"]
+        si = g["stuck_info"]
+        assert si["attainable"] is not None and si["attainable"] == pytest.approx(g["stuck_true"], rel=1e-6) and g["stuck_true"] > 4e-10, (si, g["stuck_true"])
+        est, exact = g["lmax0"]
+        assert 0.98 * exact <= est <= 1.0000001 * exact, (est, exact)      # from below, within the 1.02 margin of the smoother bounds
+    assert torch.load(out, weights_only=False)[0]["stuck_warned"]
 
 
 def _shared_case_worker(rank, world, port, out, fail):

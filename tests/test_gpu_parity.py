@@ -295,6 +295,59 @@ def test_pcg_solve_matches_direct(orc):
     assert rel(z, np.concatenate(blocks)) < 1e-10
 
 
+def _graded_shell(n_t, n_a, ratio, ang=0.7):
+    """A sector of a thick spherical shell, radii 1 .. ratio in geometric progression (n_t cells), n_a x n_a cells across a patch of `ang`
+    radians: cells that shrink ISOTROPICALLY towards the inner face -- element size, and with it the stiffness entries, span 1 : ratio
+    (a cube lattice graded per axis makes slivers whose entries span the SQUARE of the size ratio).  Outer face clamped, traction on the
+    inner face; straight-sided elements (mid-side nodes put back at the edge midpoints by merge_blocks)."""
+    from fcvm_hip import meshgen
+    el, q = meshgen.cube_tet10(n_t, n_a, n_a, 1.0, 1.0, 1.0)
+    d = np.stack([np.tan((q[:, 1] - 0.5) * ang), np.tan((q[:, 2] - 0.5) * ang), np.ones(len(q))], 1)
+    xyz = (ratio ** q[:, 0] / np.linalg.norm(d, axis=1))[:, None] * d
+    el, xyz = meshgen.merge_blocks([(el, xyz)], lattices=[(2 * n_t + 1, 2 * n_a + 1, 2 * n_a + 1)])
+    fix = {3 * int(nd) + k: 0.0 for nd in np.where(np.abs(q[:, 0] - 1.0) < 1e-12)[0] for k in range(3)}
+    on = np.abs(q[:, 0]) < 1e-12
+    faces = []
+    for f in meshgen.TET_FACES:
+        nd = el[:, list(f)]
+        faces.append(nd[on[nd[:, 0] - 1] & on[nd[:, 1] - 1] & on[nd[:, 2] - 1]])
+    faces = np.concatenate(faces)
+    return dict(elNodes=el, nocoord=xyz, fix=fix, ufaces=faces, uloads=np.tile([1.0, 0.5, 8.0], (len(faces), 1)),
+                material=np.array([210000.0, 0.3, 7.8e-6]))
+
+
+@pytest.mark.parametrize("ratio,n_t,declined", [(1.0e3, 40, False), (1.0e5, 66, True)], ids=["graded-1e3", "graded-1e5"])
+def test_fixed_point_symmetric_form_on_graded_meshes(ratio, n_t, declined):
+    """The symmetric window form adds its transposed products in 64-bit fixed point with ONE unit per group taken from the largest
+    matrix entry (fcvm_spmv_win.hip.h): on a graded mesh the products in the region of smallest entries lose relative precision as
+    max / min of the nodal diagonal entries.  Round 5: fcvm_assemble measures that ratio (k_diag_grading) and declines the form
+    beyond FCVM_SYM_GRADING_MAX = 1e4.  A shell sector graded 1 : 1e3 in element size (nodal diagonal entries 1 : 7.6e3) keeps the form
+    and still solves to 1e-11 with a TRUE residual at that level; graded 1 : 1e5 (7.6e5) the context falls back to the full window form
+    (fcvm_spmv_sym_info says so) and solves as well."""
+    case = _graded_shell(n_t, 4, ratio)
+    m = make_model(case)
+    c = m.ctx
+    glv, modf, _, _ = m.calc_gsm((0, 0, -9.81))
+    si, wi = c.spmv_sym_info(), c.spmv_info()
+    assert wi["window_format"] and si["built"], (wi, si)
+    assert si["declined_graded"] == declined and si["in_use"] == (not declined), si
+    assert (5e3 < si["grading"] < 1e4) if not declined else si["grading"] > 1e5, si
+    f = c.mul(m.fixdof, glv)
+    c.axpby(1.0, f, 1.0, modf, out=f)
+    u, info = c.solve(f, rtol=1e-11, maxit=5000)
+    K = gpu_matrix(m).tocsr()       # (read back from the form that is in charge)
+    fh, uh = f.get(), u.get()
+    true_res = np.linalg.norm(fh - K @ uh) / np.linalg.norm(fh)
+    assert info["rel_residual"] <= 1e-11 and true_res < 4e-11, (info, true_res)
+    # the product itself, entry by entry against the host's (rows of the smallest elements included: relative to each ROW's scale)
+    x = np.random.default_rng(2).standard_normal(m.ndof)
+    y, yh = c.spmv(c.array(x), c.empty(m.ndof)).get(), K @ x
+    rowscale = np.asarray(abs(K).sum(axis=1)).reshape(-1)
+    assert (np.abs(y - yh) / rowscale).max() < (1e-12 if not declined else 1e-14)
+    u_ref = spla.spsolve(K.tocsc(), fh)
+    assert rel(uh, u_ref) < 1e-6          # (conditioning of a 1 : 1e3 .. 1e5 graded mesh, not the solver, sets this)
+
+
 @pytest.mark.parametrize("mode", ["bj", "mg"])
 def test_both_preconditioners_solve_the_embankment_system(embankment, mode):
     """unstructured Gmsh mesh, nu = 0.45: block-Jacobi and p-multigrid PCG reach the same solution"""
