@@ -365,14 +365,25 @@ def main():
         # torch.distributed.run) BEFORE anything in this process touches the GPU, and pass their exit code on
         import socket
         import subprocess
-        import torch
-        have = torch.cuda.device_count()   # counting devices does not initialise HIP
-        if have < args.gpus and os.environ.get("FCVM_DIST_SHARE_GPU") != "1":   # (rehearsal: all ranks on GPU 0 over gloo)
-            raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) visible" % (args.gpus, have))
+        if os.environ.get("FCVM_DIST_SHARE_GPU") != "1":   # (rehearsal with all ranks on GPU 0 over gloo: this process stays off the GPU
+            #                                                   altogether -- a GPU box admits six processes on its card, ranks included)
+            import torch
+            have = torch.cuda.device_count()   # counting devices does not initialise HIP
+            if have < args.gpus:
+                raise SystemExit("bench.py: --gpus %d but only %d HIP device(s) visible" % (args.gpus, have))
         sk = socket.socket()
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
         sk.close()
+        if os.environ.get("FCVM_DIST_SHARE_GPU") == "1":
+            # rehearsal: the ranks as plain children with the launcher's environment (torch.distributed.run itself opens the GPU, which
+            # would be a seventh process on the card next to six ranks)
+            procs = []
+            for r in range(args.gpus):
+                env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+            rcs = [p.wait() for p in procs]
+            raise SystemExit(max(rcs, key=abs))
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))

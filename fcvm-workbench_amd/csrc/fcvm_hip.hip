@@ -1749,7 +1749,9 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
     const bool check_grading = c->wsym.on && !c->wsym_graded;
     if (check_grading) {      // read back behind the synchronisation this call ends with anyway
         if (!c->d_grading && dalloc(&c->d_grading, 2)) return 1;
-        hipLaunchKernelGGL(k_diag_grading, dim3(1), dim3(1024), 0, s, c->nn, c->d_dblk, c->d_fixmask, c->d_grading);
+        const int gb = (int)std::min<int64_t>(std::max<int64_t>(cdiv(c->nn, 1024), 1), 1024);     // (d_part_misc holds 2048 partials)
+        hipLaunchKernelGGL(k_diag_grading_partial, dim3((unsigned)gb), dim3(256), 0, s, c->nn, c->d_dblk, c->d_fixmask, c->d_part_misc);
+        hipLaunchKernelGGL(k_diag_grading_final, dim3(1), dim3(256), 0, s, c->d_part_misc, gb, c->d_grading);
         HCHK(hipMemcpyAsync(c->grading, c->d_grading, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     }
     lap("assemble: diagonal blocks, window-format copy");

@@ -70,12 +70,13 @@ __global__ __launch_bounds__(256) void k_absmax_partial(int64_t n, const double 
 // How strongly is the mesh graded?  Per node the largest |diagonal entry| over its FREE dofs (supported dofs carry a unit-sized diagonal
 // that no product of the solver touches); out[0] = max, out[1] = min (> 0) of that over the nodes.  The fixed-point sums of the symmetric
 // window form take their unit from the GLOBAL maximum, so the transposed products of the region of smallest entries carry a relative
-// error of 2^-54 * out[0] / out[1] (see k_spmv_win_sym): fcvm_assemble declines the form beyond FCVM_SYM_GRADING_MAX (1e4).  One block.
-__global__ __launch_bounds__(1024) void k_diag_grading(int64_t nn, const double *__restrict__ dblk, const uint8_t *__restrict__ fixmask,
-                                                       double *__restrict__ out) {
-    __shared__ double shmax[16], shmin[16];
+// error of 2^-54 * out[0] / out[1] (see k_spmv_win_sym): fcvm_assemble declines the form beyond FCVM_SYM_GRADING_MAX (1e4).
+// k_diag_grading_partial: part[2 b], part[2 b + 1] = maximum, minimum of block b; k_diag_grading_final (one block) reduces them.
+__global__ __launch_bounds__(256) void k_diag_grading_partial(int64_t nn, const double *__restrict__ dblk, const uint8_t *__restrict__ fixmask,
+                                                              double *__restrict__ part) {
+    __shared__ double shmax[4], shmin[4];
     double vmax = 0.0, vmin = 1.0e300;
-    for (int64_t i = threadIdx.x; i < nn; i += 1024) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nn; i += (int64_t)gridDim.x * 256) {
         const uint8_t fm = fixmask[i];
         double m = 0.0;
 #pragma unroll
@@ -88,9 +89,21 @@ __global__ __launch_bounds__(1024) void k_diag_grading(int64_t nn, const double 
     if ((threadIdx.x & 63) == 0) { shmax[threadIdx.x >> 6] = vmax; shmin[threadIdx.x >> 6] = vmin; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 1; k < 16; k++) { vmax = fmax(vmax, shmax[k]); vmin = fmin(vmin, shmin[k]); }
-        out[0] = vmax;
-        out[1] = vmin;
+        part[2 * blockIdx.x] = fmax(fmax(shmax[0], shmax[1]), fmax(shmax[2], shmax[3]));
+        part[2 * blockIdx.x + 1] = fmin(fmin(shmin[0], shmin[1]), fmin(shmin[2], shmin[3]));
+    }
+}
+__global__ __launch_bounds__(256) void k_diag_grading_final(const double *__restrict__ part, int nb, double *__restrict__ out) {
+    __shared__ double shmax[4], shmin[4];
+    double vmax = 0.0, vmin = 1.0e300;
+    for (int i = threadIdx.x; i < nb; i += 256) { vmax = fmax(vmax, part[2 * i]); vmin = fmin(vmin, part[2 * i + 1]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { vmax = fmax(vmax, __shfl_down(vmax, o, 64)); vmin = fmin(vmin, __shfl_down(vmin, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { shmax[threadIdx.x >> 6] = vmax; shmin[threadIdx.x >> 6] = vmin; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = fmax(fmax(shmax[0], shmax[1]), fmax(shmax[2], shmax[3]));
+        out[1] = fmin(fmin(shmin[0], shmin[1]), fmin(shmin[2], shmin[3]));
     }
 }
 __global__ __launch_bounds__(256) void k_lo_scale(const double *__restrict__ part, int64_t n, double *__restrict__ out) {

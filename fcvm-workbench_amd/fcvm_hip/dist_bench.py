@@ -220,6 +220,10 @@ def run(args, ctl, material, traction, rtol, hbm_peak):
                                              "their algorithmic bytes (profiles/r04_plate_spmv_sym_traffic_pmc.txt)",
                              "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches_timed": launches,
                              "back_to_back_launch_ms": standalone_ms},
+                # HIP memory in use on rank 0's device at the end (all ranks' when they share the GPU in a rehearsal) / the peak torch saw
+                "device_memory_GB": {"in_use_on_device": (torch.cuda.mem_get_info(dev_index)[1] - torch.cuda.mem_get_info(dev_index)[0]) / 1e9,
+                                     "ranks_on_this_device": world if share_gpu else 1,
+                                     "torch_peak_this_rank": torch.cuda.max_memory_allocated(dev_index) / 1e9},
                 "aggregate_level": be.mg.l2_info if be.mg is not None else None,
                 "multigrid_setup_s": be.mg.timing if be.mg is not None else None,
             }
