@@ -244,6 +244,7 @@ def run_single(args):
     info = c.pattern_info()
     ndof, ne = info["ndof"], model.ne
     label = precond_label(c)      # (before the block-Jacobi detour below: the label reads the state of the cycle that ran)
+    placement = c.placement_info()
     # one-time work of an analysis, timed on its own after the run: the bare assembly (calcGSM on the GPU), and assembly + hierarchy
     t_pat = model.t_pattern
     model.calc_gsm((0.0, 0.0, 0.0), want_x=False)
@@ -310,7 +311,10 @@ def run_single(args):
                      "route": ("k_assemble_lds<SYM>: rows leave LDS straight into the SpMV's storage (symmetric window form, its 16-bit copy, "
                                "diagonal blocks)" if sinfo.get("assembled_directly") else "sliced-ELL array + copy into the SpMV's storage")},
         "setup_s": {"mesh": t_mesh, "pattern_and_upload": run["pattern_and_upload_s"], "pattern_host": t_pat,
-                    "assembly_plus_preconditioner_hierarchy": t_asm_setup},
+                    "assembly_plus_preconditioner_hierarchy": t_asm_setup,
+                    # once per mesh, inside the first assembly: the PCG's result vector and the symmetric form's value array timed against fresh
+                    # allocations on the assembled matrix, the fastest kept (ms of the SpMV with the first / the kept allocation, ms spent)
+                    "placement_tuning": placement},
         "roofline": {"bound": "hbm",
                      "kernel": (("k_spmv_win_sym<true> (window-format 3x3-block SpMV on the symmetric form: one block per pair K_ij, K_ji inside a "
                                  "group, transposed products through LDS in 64-bit fixed point; x staged in LDS, + p.Ap partials)") if sym else

@@ -168,6 +168,14 @@ struct fcvm_ctx {
     int level1_overlap = 1;         // FCVM_LEVEL1_OVERLAP=0: the level-1 operator of a tangent refresh after the fine assembly, on the main stream
     hipStream_t level1_stream = nullptr;
     hipEvent_t level1_fork = nullptr, level1_done = nullptr;
+    // round 5: where the driver puts an allocation decides 10-15 % of the time of a kernel that streams it or scatters its results into it
+    // (the same binary, box and matrix: 0.335 or 0.385 ms for the FP64 SpMV -- profiles/r05_spmv_slow_box.txt); after the first stiffness
+    // assembly of a mesh the PCG's result vector q and the value array of the symmetric form are each timed against fresh allocations
+    // and the fastest is kept (tune_sym_placement; FCVM_TUNE_PLACEMENT = candidates per array, 1 = off)
+    int tune_tries = 3;
+    bool placement_tuned = false;
+    double tune_info[6] = {0, 0, 0, 0, 0, 0};   // tuned, q first / best [ms], value array first / best [ms], time spent [ms]
+    int pcg_events = 1;             // FCVM_PCG_EVENTS=0: no HIP events around the PCG's SpMV launches (no in-solver SpMV timing; experiment of round 5)
     int pair_overlap = 1;           // FCVM_PAIR_OVERLAP=0: the coarse parts of a pair of solves one after the other on the main stream
     hipStream_t pair_stream = nullptr;
     hipEvent_t pair_fork = nullptr, pair_done = nullptr;
@@ -1021,6 +1029,99 @@ static int tune_matrix_placement(fcvm_ctx *c) {
     return 0;
 }
 
+// Round 5: placement of the two arrays the PCG's FP64 SpMV is sensitive to, decided by measurement on the ASSEMBLED matrix (round 4 timed
+// candidate value arrays filled with zeros and found nothing that carried over: zeros skip the transposed products).  What the experiments
+// of this round showed (profiles/r05_spmv_slow_box.txt): on one box, with one binary, the kernel takes 0.335 or 0.385 ms depending on the
+// model instance -- not the clocks, the power, the temperature, the instruction mix, the occupancy, the address translation or what runs
+// before it, but (a) which allocation its scattered 8-byte result stores go to (the solver's own q: +0.04 ms in the first context of a
+// process, none in twelve other vectors) and (b) which allocation holds the values.  So: the result vector first (34 MB candidates), then
+// the value array (candidates filled by a device copy), five timed launches each on the solver's stream, the fastest kept.
+static int tune_sym_placement(fcvm_ctx *c) {
+    c->placement_tuned = true;
+    if (c->tune_tries < 2 || !(c->win.on && c->wsym.on && c->wsym.valid) || c->wsym.pat.nblocks * 72 < ((int64_t)256 << 20)) return 0;   // < 256 MB: caches hide it
+    hipStream_t s = c->stream;
+    WinSymDev &ws = c->wsym;
+    const int64_t n = 3 * c->nn, nb = ws.pat.nblocks;
+    const bool verbose = getenv("FCVM_VERBOSE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    hipEvent_t e0, e1;
+    HCHK(hipEventCreate(&e0));
+    HCHK(hipEventCreate(&e1));
+    int which = 0;      // 0: the FP64 SpMV; 1 / 2: the 16-bit passes with epilogue 1 / 2
+    auto time_kernel = [&](float *out) -> int {
+        auto launch = [&]() {
+            if (which == 0) launch_spmv_win(c, true, c->d_p, c->d_q, nullptr);
+            else if (which == 1) launch_spmv_win_lo<1>(c, c->d_md, c->d_r, c->d_mr, 0.3, nullptr, nullptr, nullptr);
+            else launch_spmv_win_lo<2>(c, c->d_md, c->d_r, c->d_z, 0.3, nullptr, nullptr, nullptr);
+        };
+        for (int k = 0; k < 2; k++) launch();
+        HCHK(hipEventRecord(e0, s));
+        for (int k = 0; k < 5; k++) launch();
+        HCHK(hipEventRecord(e1, s));
+        HCHK(hipEventSynchronize(e1));
+        HCHK(hipEventElapsedTime(out, e0, e1));
+        *out /= 5;
+        HCHK(hipGetLastError());
+        return 0;
+    };
+    // one array: the current allocation against tune_tries - 1 fresh ones (filled by a device copy when the kernel reads it); the fastest is
+    // kept -- a fresh one only for a gain beyond the noise of the measurement.  first / best: times with the first and the kept allocation.
+    auto tune = [&](const char *name, void **slot, size_t bytes, bool copy, double *first, double *best_ms) -> int {
+        std::vector<void *> cand{*slot};
+        std::vector<float> ms(1, 0.f);
+        void *orig = *slot;
+        if (time_kernel(&ms[0])) return 1;
+        for (int t = 1; t < c->tune_tries; t++) {
+            void *v = nullptr;
+            if (hipMalloc(&v, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+            if (copy && hipMemcpyAsync(v, orig, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) { (void)hipFree(v); *slot = orig; return fail("tune_sym_placement: device copy"); }
+            *slot = v;
+            float tm = 0.f;
+            if (time_kernel(&tm)) return 1;
+            cand.push_back(v);
+            ms.push_back(tm);
+        }
+        size_t best = 0;
+        for (size_t i = 1; i < cand.size(); i++)
+            if (ms[i] < 0.985f * ms[best]) best = i;
+        HCHK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < cand.size(); i++)
+            if (i != best) (void)hipFree(cand[i]);
+        *slot = cand[best];
+        if (first) *first = ms[0];
+        if (best_ms) *best_ms = ms[best];
+        if (verbose) {
+            fprintf(stderr, "fcvm: placement of %s:", name);
+            for (size_t i = 0; i < ms.size(); i++) fprintf(stderr, " %.4f%s", ms[i], i == best ? "*" : "");
+            fprintf(stderr, " ms\n");
+        }
+        return 0;
+    };
+    const dim3 gv((unsigned)cdiv(n, 256)), blk(256);
+    hipLaunchKernelGGL(k_lcg_vector, gv, blk, 0, s, n, c->d_p);     // a dense x: every transposed product is formed
+    int rc = tune("the FP64 SpMV's result vector (q)", (void **)&c->d_q, sizeof(double) * n, false, &c->tune_info[1], &c->tune_info[2]);
+    // the arrays the kernels STREAM: in every run of round 5 a fresh allocation was as good as the first one or worse (0.375 against 0.339 ms
+    // for the value array, twice) -- two candidates of 2.1 GB each cost 25 of the tuning's 36 ms for nothing: only on request
+    const bool arrays = getenv("FCVM_TUNE_PLACEMENT_ARRAYS") && atoi(getenv("FCVM_TUNE_PLACEMENT_ARRAYS")) != 0;
+    c->tune_info[3] = c->tune_info[4] = c->tune_info[2];
+    if (!rc && arrays) rc = tune("the symmetric form's value array", (void **)&ws.vals, sizeof(double) * 9 * nb, true, &c->tune_info[3], &c->tune_info[4]);
+    if (!rc && arrays) rc = tune("the symmetric form's column array", (void **)&ws.cols, sizeof(uint32_t) * nb, true, nullptr, &c->tune_info[4]);
+    if (!rc && ws.lo_valid && ws.lo8 && c->win.part_lo && c->d_md && c->d_mr && c->d_dinv6f) {   // the two 16-bit smoother passes of the cycle
+        hipLaunchKernelGGL(k_lcg_vector, gv, blk, 0, s, n, c->d_md);
+        hipLaunchKernelGGL(k_lcg_vector, gv, blk, 0, s, n, c->d_r);
+        which = 1;
+        rc = tune("the first 16-bit pass's result vector", (void **)&c->d_mr, sizeof(double) * n, false, nullptr, nullptr);
+        if (!rc && arrays) rc = tune("the 16-bit copy's value array", (void **)&ws.lo8, sizeof(short8) * nb, true, nullptr, nullptr);
+        which = 2;
+        if (!rc) rc = tune("the second 16-bit pass's result vector (z)", (void **)&c->d_z, sizeof(double) * n, false, nullptr, nullptr);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    c->tune_info[0] = 1.0;
+    c->tune_info[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return rc;
+}
+
 // slice-length classes of k_assemble_lds (blocks of the longest row): a quarter slice needs asm_lds_bytes() of LDS
 static const int64_t ASM_LEN_LIMIT[fcvm_ctx::ASM_BUCKETS] = {19, 27, 41, 65, 82, 98, 133};   // 28 / 37 / 54 / 81 / 100 / 119 / 160 KiB: 5 / 4 / 3 / 2 / 1 / 1 / 1 per CU
 
@@ -1188,6 +1289,8 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_MG_FUSE_PROLONG")) c->mg_fuse_prolong = atoi(v) != 0;
     if (const char *v = getenv("FCVM_SYM_PAIR")) c->sym_pair = atoi(v) != 0;
     if (const char *v = getenv("FCVM_PAIR_OVERLAP")) c->pair_overlap = atoi(v) != 0;
+    if (const char *v = getenv("FCVM_PCG_EVENTS")) c->pcg_events = atoi(v) != 0;
+    if (const char *v = getenv("FCVM_TUNE_PLACEMENT")) c->tune_tries = std::min(8, std::max(1, atoi(v)));
     if (const char *v = getenv("FCVM_ASSEMBLE_SYM")) c->asm_sym = atoi(v);
     if (const char *v = getenv("FCVM_ASM_NT")) c->asm_nt = atoi(v);
     if (const char *v = getenv("FCVM_ASM_LPR")) { const int l = atoi(v); if (l == 4 || l == 8 || l == 16) c->asm_lpr = l; }
@@ -1196,6 +1299,11 @@ int fcvm_create(int device, fcvm_ctx **out) {
     HCHK(hipStreamCreateWithFlags(&c->own, hipStreamNonBlocking));
     c->stream = c->own;
     if (dalloc(&c->d_S, S_COUNT) || dalloc(&c->d_out8, 16)) return 1;
+    {   // group -> workgroup map of the symmetric-form kernels (win_group_of_block): chunks of 16 groups per XCD unless FCVM_WIN_GMAP says otherwise
+        int mode = 16;
+        if (const char *v = getenv("FCVM_WIN_GMAP")) mode = std::min(4096, std::max(0, atoi(v)));
+        HCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_win_gmap), &mode, sizeof(int)));
+    }
     *out = c;
     return 0;
 }
@@ -1425,6 +1533,8 @@ int fcvm_set_mesh(fcvm_ctx *c, int64_t ne, int64_t nn, const int64_t *elNodes, c
     c->have_mesh = true;
     c->wsym_graded = false;     // (the grading is a property of the mesh: measured again at its first assembly)
     c->grading[0] = c->grading[1] = 0.0;
+    c->placement_tuned = false;
+    for (double &v : c->tune_info) v = 0.0;
     return 0;
 }
 
@@ -1499,6 +1609,33 @@ int fcvm_spmv_info(fcvm_ctx *c, int64_t out[8]) {
  * out[2] = blocks of the matrix not stored (their transposes are), out[3] = bytes one launch streams from the format, out[4] =
  * LDS bytes per workgroup, out[5] = 1 if the values of the last assembly are in it (fcvm_spmv / fcvm_solve then use it), out[6] = 1
  * if the assembly kernels can write the form themselves, out[7] = 1 if the last assembly did (no sliced-ELL array, no copy) */
+/* group -> workgroup map of the symmetric-form kernels on this context's device (see win_group_of_block): 0 = an eighth of the groups per
+ * XCD, 1 = identity, C >= 2 = chunks of C groups per XCD.  A device-wide switch (a __device__ variable): all contexts of the process on that
+ * device follow it. */
+int fcvm_set_group_map(fcvm_ctx *c, int mode) {
+    NEED(c && mode >= 0 && mode <= 4096, "fcvm_set_group_map: mode 0, 1 or a chunk length up to 4096");
+    HCHK(hipSetDevice(c->device));
+    HCHK(hipStreamSynchronize(c->stream));
+    HCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_win_gmap), &mode, sizeof(int)));
+    return 0;
+}
+
+/* what tune_sym_placement measured for this mesh: out[0] = 1 if it ran, out[1] / out[2] = SpMV time [ms] with the result vector first
+ * allocated / kept, out[3] / out[4] = with the value array first allocated / kept, out[5] = milliseconds the tuning took */
+int fcvm_placement_info(fcvm_ctx *c, double out[6]) {
+    NEED(c && out, "fcvm_placement_info: bad arguments");
+    for (int k = 0; k < 6; k++) out[k] = c->tune_info[k];
+    return 0;
+}
+
+/* experiment hook (round 5): device addresses of the PCG's own vectors r, z, p, q and of the partial buffer of its SpMV */
+int fcvm_debug_pcg_vectors(fcvm_ctx *c, uint64_t out[5]) {
+    NEED(c && c->have_mesh && out, "fcvm_debug_pcg_vectors: no mesh");
+    out[0] = (uint64_t)(uintptr_t)c->d_r; out[1] = (uint64_t)(uintptr_t)c->d_z; out[2] = (uint64_t)(uintptr_t)c->d_p;
+    out[3] = (uint64_t)(uintptr_t)c->d_q; out[4] = (uint64_t)(uintptr_t)c->d_part_spmv;
+    return 0;
+}
+
 int fcvm_spmv_sym_info(fcvm_ctx *c, int64_t out[10]) {
     NEED(c && c->have_mesh && out, "fcvm_spmv_sym_info: no mesh");
     if (wsym_finish(c)) return 1;
@@ -1766,6 +1903,9 @@ int fcvm_assemble(fcvm_ctx *c, const double *disp, const double *sig, const uint
     if (win_join(c)) return 1;
     HCHK(hipStreamSynchronize(s));
     c->assembled = true;
+    if (!c->placement_tuned && c->wsym.on && c->wsym.valid && !(check_grading && c->grading[1] > 0.0 && c->grading[0] > c->grading_max * c->grading[1]) &&
+        tune_sym_placement(c))
+        return 1;
     if (check_grading && c->grading[1] > 0.0 && c->grading[0] > c->grading_max * c->grading[1]) {
         // a mesh graded beyond what the fixed-point sums resolve: this context keeps to the full window form from here on; the matrix
         // just assembled went (or may have gone) into the symmetric form, so it is assembled once more along the other route

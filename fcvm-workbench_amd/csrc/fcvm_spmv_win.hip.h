@@ -15,6 +15,37 @@
 
 namespace fcvm {
 
+// Experiment of round 5 (FCVM_SPMV_TOUCH_KB): one load per `stride` bytes of an array from every workgroup -- 16 workgroups land on all eight
+// XCDs, so each XCD's address translation caches hold the array's pages when the kernel that streams it starts.
+__global__ __launch_bounds__(256) void k_touch_pages(const char *__restrict__ base, int64_t bytes, int64_t stride, int *__restrict__ sink) {
+    int acc = 0;
+    for (int64_t o = (int64_t)threadIdx.x * stride; o < bytes; o += 256 * stride) acc += __builtin_nontemporal_load((const int *)(base + o));
+    if (acc == 0x7fffffff) *sink = acc;
+}
+
+// Which group of the window format a workgroup takes.  Workgroups go to the eight XCDs round-robin (blockIdx & 7); neighbouring groups share
+// window nodes, so an XCD should work on neighbouring groups (its L2 then serves the second reader of a node's x).  mode 0 (rounds 2-4): every
+// XCD walks one contiguous eighth of the groups -- eight streams through the value array, each an eighth of the array apart;
+// mode 1: group = block (neighbours on different XCDs, one moving front); mode C >= 2: chunks of C consecutive groups per XCD, the eight XCDs
+// side by side inside a super-chunk of 8 C groups -- one moving front of 8 C groups with the L2 sharing inside the chunks.  Round 5
+// (tools/sessions/gmap_probe_r05.py, profiles/r05_spmv_slow_box.txt: four model instances in one process, every mode on each): C = 16 is
+// 2-4 % faster than mode 0 for the FP64 SpMV and the 16-bit passes in every instance (0.3644 / 0.3418 / 0.3387 / 0.3348 against 0.3817 /
+// 0.3548 / 0.3550 / 0.3418 ms back to back), identity and C = 4 / 64 in between: the default.  The results do not depend on the map (a group's
+// numbers are formed by its own workgroup).  Per device: fcvm_set_group_map / FCVM_WIN_GMAP.
+__device__ int g_win_gmap = 16;
+__device__ __forceinline__ int64_t win_group_of_block(int64_t b, int64_t ngroups) {
+    const int mode = g_win_gmap;
+    if (mode == 1) return b;
+    if (mode >= 2) {
+        const int64_t C = mode, full = (ngroups / (8 * C)) * (8 * C);
+        if (b >= full) return b;
+        const int64_t xcd = b & 7, k = b >> 3;
+        return (k / C) * (8 * C) + xcd * C + (k % C);
+    }
+    const int64_t q = ngroups >> 3, r8 = ngroups & 7, xcd = b & 7;
+    return (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+}
+
 
 // position of component c of lane's block inside a block row of n lanes (9 * n doubles).  v2 = 0: nine runs of n doubles;
 // v2 = 1: components (0,1), (2,3), (4,5), (6,7) as n double2's each (one 16-byte load per lane), component 8 as n doubles
@@ -1135,9 +1166,17 @@ __device__ __forceinline__ void win_fma_sym(const WinSlotS &t, bool active, cons
                 const double t1 = __builtin_fma(t.v[7], o2, __builtin_fma(t.v[4], o1, t.v[1] * o0));
                 const double t2 = __builtin_fma(t.v[8], o2, __builtin_fma(t.v[5], o1, t.v[2] * o0));
                 unsigned long long *ya = yacc + 3 * NRHS * ts + 3 * r;
+#if defined(FCVM_AB_PLAIN_LDS)      // (timing experiments only, wrong results: plain LDS stores instead of the 64-bit atomic adds ...)
+                ya[0] = fixed62(t0, sh[r]); ya[1] = fixed62(t1, sh[r]); ya[2] = fixed62(t2, sh[r]);
+#elif defined(FCVM_AB_NO_FIXED)     // (... the atomic adds without the fixed-point conversion in front of them)
+                atomicAdd(ya, (unsigned long long)__double_as_longlong(t0));
+                atomicAdd(ya + 1, (unsigned long long)__double_as_longlong(t1));
+                atomicAdd(ya + 2, (unsigned long long)__double_as_longlong(t2));
+#else
                 atomicAdd(ya, fixed62(t0, sh[r]));
                 atomicAdd(ya + 1, fixed62(t1, sh[r]));
                 atomicAdd(ya + 2, fixed62(t2, sh[r]));
+#endif
             }
     }
 }
@@ -1185,8 +1224,7 @@ __global__ __launch_bounds__(64 * WAVES, NRHS == 1 ? FCVM_SYM_MINWAVES : 2) void
         if (all_done) return;
     }
     const int64_t b = blockIdx.x;
-    const int64_t q = ngroups >> 3, r8 = ngroups & 7, xcd = b & 7;
-    const int64_t g = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+    const int64_t g = win_group_of_block(b, ngroups);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wig = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t wave = g * WAVES + wig, row = wave * 64 + lane;
@@ -1451,8 +1489,7 @@ __global__ __launch_bounds__(64 * WAVES, NRHS == 1 ? FCVM_LOSYM_MINWAVES : 4) vo
     const bool fuse = NRHS == 1 && EPI == 2 && pf.e1 != nullptr;
     const int e0 = (int)lo_scale[0];      // matrix exponent: block exponents are stored absolutely (WinLoTailS)
     const int64_t b = blockIdx.x;
-    const int64_t q = ngroups >> 3, rr8 = ngroups & 7, xcd = b & 7;
-    const int64_t g = (xcd < rr8 ? xcd * (q + 1) : rr8 * (q + 1) + (xcd - rr8) * q) + (b >> 3);
+    const int64_t g = win_group_of_block(b, ngroups);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wig = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t wave = g * WAVES + wig, row = wave * 64 + lane;

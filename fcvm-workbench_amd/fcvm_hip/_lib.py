@@ -64,6 +64,9 @@ SIGNATURES = {
     "fcvm_host_window_sym_check": [_i64, _i64, _vp, _vp, _pi64],
     "fcvm_finish_setup": [_vp],
     "fcvm_spmv_sym_info": [_vp, _pi64],
+    "fcvm_set_group_map": [_vp, _int],
+    "fcvm_debug_pcg_vectors": [_vp, _vp],
+    "fcvm_placement_info": [_vp, _pf64],
     "fcvm_spmv_info": [_vp, _pi64],
     "fcvm_mem_info": [_vp, _pi64],
     "fcvm_mg_sparse_info": [_vp, _pi64],

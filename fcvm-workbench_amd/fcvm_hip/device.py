@@ -197,6 +197,12 @@ class Context:
         return dict(built=bool(out[0]), blocks=out[1], dropped=out[2], bytes=out[3], lds_bytes=out[4], in_use=bool(out[5]),
                     assembly_writes_it=bool(out[6]), assembled_directly=bool(out[7]), declined_graded=bool(out[8]), grading=int(out[9]))
 
+    def placement_info(self):
+        """what the placement tuning of the first assembly measured (fcvm_placement_info)"""
+        o = (C.c_double * 6)()
+        call("fcvm_placement_info", self.h, o)
+        return dict(tuned=bool(o[0]), result_vector_ms=(o[1], o[2]), value_array_ms=(o[3], o[4]), spent_ms=o[5])
+
     def matrix_coo(self):
         nnz = 9 * self.pattern_info()["nnz_blocks"]
         r, c, v = np.empty(nnz, np.int64), np.empty(nnz, np.int64), np.empty(nnz, np.float64)

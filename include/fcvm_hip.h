@@ -291,6 +291,19 @@ int fcvm_membench(fcvm_ctx *c, int64_t nbytes, double out[2]);
  * over the nodes of the largest free diagonal entry (measured at every stiffness assembly); beyond FCVM_SYM_GRADING_MAX (1e4) the
  * context assembles into and multiplies with the full window form instead.  No reference counterpart (CHOLMOD, fcVM.py:1121). */
 int fcvm_spmv_sym_info(fcvm_ctx *c, int64_t out[10]);
+/* Which group of the window format a workgroup of the symmetric-form kernels takes (workgroups go to the eight XCDs round-robin): mode 0 = every
+ * XCD walks one contiguous eighth of the groups (rounds 2-4), 1 = group = workgroup, C >= 2 = chunks of C consecutive groups per XCD inside
+ * super-chunks of 8 C groups (one moving front through the value array instead of eight streams an eighth of it apart; L2 sharing of window
+ * nodes kept inside the chunks; default C = 16).  Device-wide.  FCVM_WIN_GMAP sets it when a context is created. */
+int fcvm_set_group_map(fcvm_ctx *c, int mode);
+/* Placement tuning (round 5; no reference counterpart): where the driver puts an allocation decides 10-15 % of the time of the kernel that
+ * streams it or scatters its results into it.  After the first stiffness assembly of a mesh the PCG's result vector and the value array of the
+ * 16-bit passes' result vectors (and, with FCVM_TUNE_PLACEMENT_ARRAYS=1, the value / column arrays they stream) are each timed against
+ * FCVM_TUNE_PLACEMENT - 1 (default 2) fresh allocations on the assembled matrix and the fastest is kept.  out[0] = 1 if it ran, out[1] / out[2] = SpMV time [ms] with the result vector first allocated / kept, out[3] / out[4] = with the value
+ * array first allocated / kept, out[5] = milliseconds the tuning took. */
+int fcvm_placement_info(fcvm_ctx *c, double out[6]);
+/* experiment hook: device addresses of the PCG's own vectors r, z, p, q and of its SpMV's partial buffer (placement studies) */
+int fcvm_debug_pcg_vectors(fcvm_ctx *c, uint64_t out[5]);
 
 /* host-only self check of the symmetric form of the window format (the PCG's FP64 SpMV stores one block of every pair
  * K_ij, K_ji inside a group and forms both products): out[0] = built, out[1] = stored entries, out[2] = blocks not stored,

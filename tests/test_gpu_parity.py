@@ -1,6 +1,8 @@
 """HIP path (through the C-ABI of libfcvm_hip.so) against the CPU oracle and the reference's
 golden result files.  FP64 throughout; tolerances are relative to the field's max magnitude (and, where rel_each is used, entry by entry):
 1e-11 for single kernels (only summation order differs), 1e-6 (north_star) for whole analyses."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -1345,6 +1347,54 @@ def test_reruns_are_bitwise_identical():
     for k in ("lout", "un", "displacements", "stresses", "peeq", "tet10stress"):
         assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
     assert a["stats"]["pcg_iterations"] == b["stats"]["pcg_iterations"]
+
+
+def test_group_map_and_placement_tuning_do_not_change_a_number():
+    """Round 5: (a) the order in which the workgroups of the symmetric-form kernels take the groups of the window format (fcvm_set_group_map:
+    an eighth of the groups per XCD / identity / chunks of C groups per XCD, default 16) is a scheduling choice -- product, inner-product
+    partials and 16-bit pass are bitwise the same under every map, also where the group count is no multiple of 8 C; (b) the placement
+    tuning of the first assembly (fcvm_placement_info: the PCG's result vectors timed against fresh allocations on the assembled matrix)
+    moves buffers, not numbers: a context with FCVM_TUNE_PLACEMENT=1 (off) solves to the same bits."""
+    import ctypes as C
+    from fcvm_hip._lib import call
+    case = small_case(9, prescribed=False)          # 4374 tet10 / 6859 nodes: 14 groups, not a multiple of 8
+    m = make_model(case)
+    c = m.ctx
+    glv, modf, _, _ = m.calc_gsm((0, 0, -9.81))
+    si = c.spmv_sym_info()
+    assert si["built"] and si["in_use"], si
+    x = c.array(np.random.default_rng(4).standard_normal(m.ndof))
+    f = c.mul(m.fixdof, glv)
+    c.axpby(1.0, f, 1.0, modf, out=f)
+    ref = None
+    for mode in (16, 0, 1, 2, 3, 64):
+        call("fcvm_set_group_map", c.h, mode)
+        y = c.spmv(x, c.empty(m.ndof)).get()
+        z = c.spmv_lo(x, c.empty(m.ndof)).get()
+        out = c.empty(8)
+        yd = c.empty(m.ndof)
+        call("fcvm_spmv_dot", c.h, x.ptr, yd.ptr, out.ptr)
+        u, info = c.solve(f, rtol=1e-11)
+        got = (y, z, yd.get(), out.get()[:1], u.get(), info["iterations"])
+        if ref is None:
+            ref = got
+        else:
+            for a, b in zip(ref[:5], got[:5]):
+                assert np.array_equal(a, b), mode
+            assert got[5] == ref[5]
+    call("fcvm_set_group_map", c.h, 16)
+    pi = c.placement_info()
+    assert not pi["tuned"]                          # (a matrix this small lives in the caches: nothing to tune)
+    os.environ["FCVM_TUNE_PLACEMENT"] = "1"
+    try:
+        m2 = make_model(case)
+    finally:
+        del os.environ["FCVM_TUNE_PLACEMENT"]
+    glv2, modf2, _, _ = m2.calc_gsm((0, 0, -9.81))
+    f2 = m2.ctx.mul(m2.fixdof, glv2)
+    m2.ctx.axpby(1.0, f2, 1.0, modf2, out=f2)
+    u2, info2 = m2.ctx.solve(f2, rtol=1e-11)
+    assert np.array_equal(u2.get(), ref[4]) and info2["iterations"] == ref[5]
 
 
 def test_fused_inner_products_are_bitwise_the_single_ones():
