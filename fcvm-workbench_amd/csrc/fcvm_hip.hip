@@ -87,6 +87,11 @@ struct WinSymDev {
     int64_t asm_count[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0, 0}, asm_first[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0, 0}, asm_off[ASM_BUCKETS] = {0, 0, 0, 0, 0, 0, 0};
     double *part_vol = nullptr;     // [items] volume partials
     int64_t nitems = 0;
+    // multi-GPU layer (fcvm_set_interface_nodes): the groups that hold a row of a node shared with another rank, and the others -- the three
+    // fine-level passes launch the first list, hand the shared entries to the exchange, and launch the second while the messages travel
+    int32_t *glist_b = nullptr, *glist_i = nullptr;
+    int64_t n_gb = 0, n_gi = 0;
+    bool split = false;
 };
 
 struct L2sDev {   // device state of the sparse aggregate level (owned by fcvm_ctx)
@@ -410,21 +415,32 @@ static int symv_prepare(fcvm_ctx *c) {
     const int64_t nt = cdiv(c->n2, SYMV_T);
     return dalloc(&c->d_symv_part, nt * nt * SYMV_T);
 }
-static void launch_spmv_win(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done) {
+// part (multi-GPU layer): 0 = all groups; 1 = the groups with rows of interface nodes only; 2 = the others only.  Storage forms without the
+// lists (no symmetric form, or no interface nodes set) do everything in part 1 and nothing in part 2: the same result, no overlap.
+static void launch_spmv_win(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done, int part = 0) {
     const WinDev &w = c->win;
     if (c->wsym.on && c->wsym.valid) {   // symmetric form: 0.70 x the blocks, transposed products through LDS in fixed point
         const WinSymDev &ws = c->wsym;
-        const SymVecs<1> V{{x}, {y}, {dot ? c->d_part_spmv : (double *)nullptr}, {done}};
+        SymVecs<1> V{{x}, {y}, {dot ? c->d_part_spmv : (double *)nullptr}, {done}};
+        int64_t grid = w.pat.ngroups;
+        if (part && ws.split) {
+            V.glist = part == 1 ? ws.glist_b : ws.glist_i;
+            grid = part == 1 ? ws.n_gb : ws.n_gi;
+            if (grid == 0) return;
+        } else if (part == 2) {
+            return;
+        }
         if (dot)
-            hipLaunchKernelGGL((k_spmv_win_sym<true, WIN_WAVES, 1>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), ws.lds, c->stream,
+            hipLaunchKernelGGL((k_spmv_win_sym<true, WIN_WAVES, 1>), dim3((unsigned)grid), dim3(64 * WIN_WAVES), ws.lds, c->stream,
                                w.pat.ngroups, w.pat.wmax, ws.pat.xmax, w.gptr, ws.gextra, w.wlist, ws.woff, ws.rowlen, ws.rownode, ws.seg, ws.own,
                                ws.cols, ws.vals, w.lo_scale, V);
         else
-            hipLaunchKernelGGL((k_spmv_win_sym<false, WIN_WAVES, 1>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), ws.lds, c->stream,
+            hipLaunchKernelGGL((k_spmv_win_sym<false, WIN_WAVES, 1>), dim3((unsigned)grid), dim3(64 * WIN_WAVES), ws.lds, c->stream,
                                w.pat.ngroups, w.pat.wmax, ws.pat.xmax, w.gptr, ws.gextra, w.wlist, ws.woff, ws.rowlen, ws.rownode, ws.seg, ws.own,
                                ws.cols, ws.vals, w.lo_scale, V);
         return;
     }
+    if (part == 2) return;
     if (w.pat.waves == 4) {   // meshes whose 512-row windows do not fit the LDS: groups of 256 rows
         if (dot) launch_spmv_win_t<true, 4, true>(c, w, x, y, done);
         else launch_spmv_win_t<false, 4, true>(c, w, x, y, done);
@@ -438,11 +454,12 @@ static void launch_spmv_win(fcvm_ctx *c, bool dot, const double *x, double *y, c
 }
 // p.Ap partials the fine SpMV leaves: one per group of the window format, one per workgroup of the sliced-ELL kernel
 static inline int64_t spmv_partials(const fcvm_ctx *c) { return c->win.on ? c->win.pat.ngroups : c->nb_spmv; }
-static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done) {
+static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const double *done, int part = 0) {
     if (c->win.on) {   // window format: x through LDS (the p.Ap partials beyond the group count stay zero)
-        launch_spmv_win(c, dot, x, y, done);
+        launch_spmv_win(c, dot, x, y, done, part);
         return;
     }
+    if (part == 2) return;
     if (dot) launch_spmv_t<true>(c, fine_view(c), x, y, c->d_part_spmv, done);
     else launch_spmv_t<false>(c, fine_view(c), x, y, nullptr, done);
 }
@@ -450,18 +467,27 @@ static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const
 // smoother passes of the multiplicative cycle on the 16-bit copy (EPI 1: out = r - K~ x; EPI 2: out = x + c0 Dinv (r - K~ x) + partials)
 template <int EPI>
 static void launch_spmv_win_lo(fcvm_ctx *c, const double *x, const double *r, double *out, double c0, const double *done, double *part = nullptr,
-                               const double *fuse_e1 = nullptr) {
+                               const double *fuse_e1 = nullptr, int gpart = 0) {
     const WinDev &w = c->win;
     if (!part) part = w.part_lo;
     if (c->wsym.on && c->wsym.lo_valid) {      // symmetric form of the 16-bit copy
         const WinSymDev &ws = c->wsym;
         const ProlongFuse pf{c->d_pa, c->d_pb, c->d_fixmask, fuse_e1};      // (fuse_e1: x + P e1 is formed while x is staged, EPI 2 only)
-        const LoSymVecs<1> V{{x}, {r}, {out}, {part}, {done}};
-        hipLaunchKernelGGL((k_spmv_win_lo_sym<EPI, WIN_WAVES, 1>), dim3((unsigned)w.pat.ngroups), dim3(64 * WIN_WAVES), ws.lds_lo, c->stream, w.pat.ngroups,
+        LoSymVecs<1> V{{x}, {r}, {out}, {part}, {done}};
+        int64_t grid = w.pat.ngroups;
+        if (gpart && ws.split) {       // (gpart: the boundary-groups-first split of the multi-GPU layer, as launch_spmv_win's part)
+            V.glist = gpart == 1 ? ws.glist_b : ws.glist_i;
+            grid = gpart == 1 ? ws.n_gb : ws.n_gi;
+            if (grid == 0) return;
+        } else if (gpart == 2) {
+            return;
+        }
+        hipLaunchKernelGGL((k_spmv_win_lo_sym<EPI, WIN_WAVES, 1>), dim3((unsigned)grid), dim3(64 * WIN_WAVES), ws.lds_lo, c->stream, w.pat.ngroups,
                            w.pat.wmax, ws.pat.xmax, w.gptr, ws.gextra, w.wlist, ws.woff, ws.rowlen, ws.rownode, ws.seg, ws.own, ws.lo8,
                            (const WinLoTail *)ws.lo2, w.lo_scale, V, c0, (const float *)c->d_dinv6f, pf);
         return;
     }
+    if (gpart == 2) return;
     if (w.pat.waves == 4)
         hipLaunchKernelGGL((k_spmv_win_lo<EPI, 4>), dim3((unsigned)w.pat.ngroups), dim3(256), w.lds / 2, c->stream, w.pat.ngroups, w.pat.wmax, w.gptr,
                            w.gextra, w.wlist, w.woff, w.rowlen, w.rownode, w.seg, w.lo8, w.lo2, w.lo_scale, x, r, out, c0,
@@ -555,6 +581,9 @@ static void wsym_free(WinSymDev &w) {
     dfree(w.woff); dfree(w.rownode); dfree(w.srcslot); dfree(w.gextra); dfree(w.seg); dfree(w.cols); dfree(w.rowlen); dfree(w.own);
     dfree(w.jell); dfree(w.vals); dfree(w.lo8); dfree(w.lo2);
     dfree(w.emap); dfree(w.diagk); dfree(w.jfirst); dfree(w.rowoff); dfree(w.nextseg); dfree(w.asm_items); dfree(w.part_vol);
+    dfree(w.glist_b); dfree(w.glist_i);
+    w.n_gb = w.n_gi = 0;
+    w.split = false;
     w.asm_ok = false;
     w.nitems = 0;
     w.on = w.valid = w.lo_valid = false;
@@ -2762,6 +2791,65 @@ int fcvm_dist_post_smooth(fcvm_ctx *c, const double *x2, const double *b, const 
     return 0;
 }
 
+/* Multi-GPU layer: the local nodes shared with other ranks (0-based, any order).  The groups of the window format that hold a row of such a node
+ * form the first of two launch lists, the rest the second: fcvm_spmv_dot_part / fcvm_spmv_lo_part(part = 1) compute every shared entry, the
+ * caller hands them to the exchange, and part = 2 computes the interior while the messages travel.  Both parts together are bitwise the unsplit
+ * launch (a group's numbers are formed by its own workgroup).  n = 0 removes the lists.  Needs the symmetric window form; without it part 1
+ * does everything and part 2 nothing.  out[0] / out[1] (optional): groups in the first / second list. */
+int fcvm_set_interface_nodes(fcvm_ctx *c, int64_t n, const int64_t *nodes, int64_t out[2]) {
+    NEED(c && c->have_mesh && n >= 0 && (n == 0 || nodes), "fcvm_set_interface_nodes: no mesh / bad arguments");
+    if (wsym_finish(c)) return 1;
+    WinSymDev &ws = c->wsym;
+    HCHK(hipStreamSynchronize(c->stream));
+    dfree(ws.glist_b); dfree(ws.glist_i);
+    ws.n_gb = ws.n_gi = 0;
+    ws.split = false;
+    if (out) out[0] = out[1] = 0;
+    if (n == 0 || !ws.on) return 0;
+    std::vector<uint8_t> shared(c->nn, 0);
+    for (int64_t i = 0; i < n; i++) {
+        NEED(nodes[i] >= 0 && nodes[i] < c->nn, "fcvm_set_interface_nodes: node out of range");
+        shared[nodes[i]] = 1;
+    }
+    const int64_t ng = c->win.pat.ngroups, rows_per_group = 64 * (int64_t)ws.pat.waves, nrows = ws.pat.nwaves * SLICE;
+    std::vector<int32_t> rownode(nrows);
+    HCHK(hipMemcpy(rownode.data(), ws.rownode, sizeof(int32_t) * nrows, hipMemcpyDeviceToHost));
+    std::vector<int32_t> gb, gi;
+    for (int64_t g = 0; g < ng; g++) {
+        bool b = false;
+        for (int64_t r = g * rows_per_group; r < std::min((g + 1) * rows_per_group, nrows) && !b; r++)
+            b = rownode[r] >= 0 && shared[rownode[r]];
+        (b ? gb : gi).push_back((int32_t)g);
+    }
+    if (dalloc(&ws.glist_b, (int64_t)gb.size()) || dalloc(&ws.glist_i, (int64_t)gi.size())) return 1;
+    if (!gb.empty()) HCHK(hipMemcpy(ws.glist_b, gb.data(), sizeof(int32_t) * gb.size(), hipMemcpyHostToDevice));
+    if (!gi.empty()) HCHK(hipMemcpy(ws.glist_i, gi.data(), sizeof(int32_t) * gi.size(), hipMemcpyHostToDevice));
+    ws.n_gb = (int64_t)gb.size(); ws.n_gi = (int64_t)gi.size();
+    ws.split = true;
+    if (out) { out[0] = ws.n_gb; out[1] = ws.n_gi; }
+    return 0;
+}
+
+/* y = K_local x over the groups of `part` (0 all, 1 boundary groups, 2 interior groups) and, after part 0 or 2, xy_dev[0] = x . y over the local rows */
+int fcvm_spmv_dot_part(fcvm_ctx *c, const double *x, double *y, double *xy_dev, int part) {
+    NEED(c && c->have_mesh && xy_dev && part >= 0 && part <= 2, "fcvm_spmv_dot_part: no mesh / bad part");
+    NEED(x != y && aligned16(x) && aligned16(y), "fcvm_spmv_dot_part: x and y must be distinct 16-byte aligned device vectors");
+    launch_spmv(c, true, x, y, nullptr, part);
+    if (part != 1) hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, c->stream, c->d_part_spmv, spmv_partials(c), xy_dev);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+/* y = K~ x (16-bit copy) over the groups of `part`, as fcvm_spmv_dot_part */
+int fcvm_spmv_lo_part(fcvm_ctx *c, const double *x, double *y, int part) {
+    NEED(c && c->have_mesh && part >= 0 && part <= 2, "fcvm_spmv_lo_part: no mesh / bad part");
+    NEED(x && y && x != y && aligned16(x) && aligned16(y), "fcvm_spmv_lo_part: x and y must be distinct 16-byte aligned device vectors");
+    if (mg_use_lo(c)) launch_spmv_win_lo<0>(c, x, nullptr, y, 0.0, nullptr, nullptr, nullptr, part);
+    else launch_spmv(c, false, x, y, nullptr, part);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
 int fcvm_spmv_dot(fcvm_ctx *c, const double *x, double *y, double *xy_dev) {
     NEED(c && c->have_mesh && xy_dev, "fcvm_spmv_dot: no mesh");
     NEED(x != y, "fcvm_spmv_dot: x and y must not alias");
@@ -2890,6 +2978,47 @@ int fcvm_unpack_sum(fcvm_ctx *c, int64_t nshared, const int64_t *node, const int
     NEED(c && nshared >= 0 && ncomp > 0, "fcvm_unpack_sum: bad arguments");
     if (nshared == 0) return 0;
     hipLaunchKernelGGL(k_unpack_sum, dim3((unsigned)cdiv(nshared * ncomp, 256)), dim3(256), 0, c->stream, nshared, node, eptr, src, ncomp, v, recv);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+/* Multi-GPU layer, level 1 of the cycle on the library's current kernels (round 5; rounds 1-4 ran the FP32 sliced-ELL product and a separate
+ * smoother-step kernel per pass): one pass of the Chebyshev smoother on this rank's 16-bit copy of the tet4 matrix (k_spmv_l1_i16) with the step
+ * as epilogue -- t = A1_local din (+ t2: a pending product of this rank);  r -= t;  x += din;  dout = cdd din + cdr Dinv r (update_d);
+ * x += dout (add_dout) -- for every row EXCEPT those of nodes flagged in defer (u8 per level-1 node: shared with another rank), whose raw
+ * product goes to t_out and whose step fcvm_unpack_sum_cheb applies after the exchange has summed the ranks' parts.  dout != din. */
+int fcvm_mg_l1_pass(fcvm_ctx *c, const double *din, double *dout, double *x, double *r, const double *t2, double *t_out, const uint8_t *defer,
+                    double cdd, double cdr, int update_d, int add_dout) {
+    NEED(c && c->mg_topo && din && dout && din != dout && x && r, "fcvm_mg_l1_pass: no multigrid hierarchy / null or aliased vectors");
+    NEED((defer == nullptr) == (t_out == nullptr), "fcvm_mg_l1_pass: defer and t_out go together");
+    MatView A = coarse_view(c);
+    NEED(A.A16 && c->d_dinv1_6f, "fcvm_mg_l1_pass: needs the 16-bit copy of the level-1 matrix (FCVM_MG_L1_16=1)");
+    ChebEpi epi{c->d_dinv1, x, r, dout, cdd, cdr, update_d ? 1 : 0, add_dout ? 1 : 0, c->d_dinv1_6f};
+    epi.defer = defer; epi.t_out = t_out; epi.t2 = t2;
+    launch_spmv_cheb(c, A, din, nullptr, epi);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+/* raw product of the level-1 16-bit copy: y = A1_local x (the last pre-smoothing product, which stays unsummed) */
+int fcvm_mg_l1_spmv(fcvm_ctx *c, const double *x, double *y) {
+    NEED(c && c->mg_topo && x && y && x != y, "fcvm_mg_l1_spmv: no multigrid hierarchy / null or aliased vectors");
+    MatView A = coarse_view(c);
+    NEED(A.A16, "fcvm_mg_l1_spmv: needs the 16-bit copy of the level-1 matrix (FCVM_MG_L1_16=1)");
+    hipLaunchKernelGGL((k_spmv_l1_i16<0, false>), dim3((unsigned)A.nslices), dim3(64), 0, c->stream, A.nslices, A.rp16, A.A16, A.B16, A.C16,
+                       A.scale16, A.rownode, x, y, (const double *)nullptr, ChebEpi{});
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+/* the shared-node sum of fcvm_unpack_sum (three components, level-1 nodes) fused with the smoother step fcvm_mg_l1_pass deferred */
+int fcvm_unpack_sum_cheb(fcvm_ctx *c, int64_t nshared, const int64_t *node, const int64_t *eptr, const int64_t *src, const double *traw,
+                         const double *recv, const double *din, double *dout, double *x, double *r, double cdd, double cdr, int update_d,
+                         int add_dout) {
+    NEED(c && c->mg_topo && c->d_dinv1_6f && nshared >= 0, "fcvm_unpack_sum_cheb: no multigrid hierarchy");
+    if (nshared == 0) return 0;
+    hipLaunchKernelGGL(k_unpack_sum_cheb, dim3((unsigned)cdiv(nshared, 256)), dim3(256), 0, c->stream, nshared, node, eptr, src, traw, recv,
+                       (const float *)c->d_dinv1_6f, din, dout, x, r, cdd, cdr, update_d ? 1 : 0, add_dout ? 1 : 0);
     HCHK(hipGetLastError());
     return 0;
 }

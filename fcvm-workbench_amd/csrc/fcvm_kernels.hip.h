@@ -654,6 +654,12 @@ struct ChebEpi {
     double cdd, cdr;
     int update_d, add_dout;
     const float *dinv6 = nullptr;   // optional: the six distinct entries of every inverse diagonal block in FP32 (24 B instead of 72 B)
+    // multi-GPU layer (k_spmv_l1_i16 only): rows of nodes shared with other ranks hold a PART of the product -- their step waits for the
+    // exchange: the raw product goes to t_out and the row is left alone (k_unpack_sum_cheb finishes it); t2: a second, pending product
+    // (this rank's part) added to this one at every row -- the last pre-smoothing product that rides on the first post-smoothing exchange
+    const uint8_t *defer = nullptr;
+    double *t_out = nullptr;
+    const double *t2 = nullptr;
 };
 __device__ __forceinline__ void apply_dinv(const double *d, double r0, double r1, double r2, double &z0, double &z1, double &z2);
 

@@ -744,6 +744,41 @@ __global__ __launch_bounds__(256) void k_unpack_sum(int64_t nshared, const int64
     v[nd * ncomp + c] = acc;
 }
 
+// The shared-node sum of k_unpack_sum (3 components) followed by the Chebyshev smoother step of that node -- the rows k_spmv_l1_i16 deferred
+// (ChebEpi::defer): t = sum over the ranks of their products;  r -= t;  x += d;  if (update_d) { dout = cdd d + cdr Dinv r; if (add_dout) x += dout }.
+// Every sharer adds the same numbers in the same order and steps with the same arithmetic: the consistent vectors stay bit-identical.
+// thread = interface node.
+__global__ __launch_bounds__(256) void k_unpack_sum_cheb(int64_t nshared, const int64_t *__restrict__ node, const int64_t *__restrict__ eptr,
+                                                         const int64_t *__restrict__ src, const double *__restrict__ traw,
+                                                         const double *__restrict__ recv, const float *__restrict__ dinv6,
+                                                         const double *__restrict__ din, double *__restrict__ dout, double *__restrict__ x,
+                                                         double *__restrict__ r, double cdd, double cdr, int update_d, int add_dout) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= nshared) return;
+    const int64_t nd = node[k], o = 3 * nd;
+    double t[3] = {0.0, 0.0, 0.0};
+    for (int64_t e = eptr[k]; e < eptr[k + 1]; e++) {
+        const int64_t sidx = src[e];
+        const double *p = sidx < 0 ? traw + o : recv + 3 * sidx;
+        t[0] += p[0]; t[1] += p[1]; t[2] += p[2];
+    }
+    const double d0 = din[o], d1 = din[o + 1], d2 = din[o + 2];
+    const double r0 = r[o] - t[0], r1 = r[o + 1] - t[1], r2 = r[o + 2] - t[2];
+    r[o] = r0; r[o + 1] = r1; r[o + 2] = r2;
+    double a0 = d0, a1 = d1, a2 = d2;
+    if (update_d) {
+        const float2 *q = (const float2 *)(dinv6 + 6 * nd);
+        const float2 v0 = q[0], v1 = q[1], v2 = q[2];   // xx xy | xz yy | yz zz
+        const double z0 = (double)v0.x * r0 + (double)v0.y * r1 + (double)v1.x * r2;
+        const double z1 = (double)v0.y * r0 + (double)v1.y * r1 + (double)v2.x * r2;
+        const double z2 = (double)v1.x * r0 + (double)v2.x * r1 + (double)v2.y * r2;
+        const double n0 = cdd * d0 + cdr * z0, n1 = cdd * d1 + cdr * z1, n2 = cdd * d2 + cdr * z2;
+        dout[o] = n0; dout[o + 1] = n1; dout[o + 2] = n2;
+        if (add_dout) { a0 += n0; a1 += n1; a2 += n2; }
+    }
+    x[o] += a0; x[o + 1] += a1; x[o + 2] += a2;
+}
+
 __global__ __launch_bounds__(256) void k_add_if(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ o,
                                                 const double *__restrict__ done) {
     if (done && *done != 0.0) return;

@@ -977,10 +977,15 @@ __global__ __launch_bounds__(64) void k_spmv_l1_i16(int64_t nslices, const int64
         at += 64;
     }
     const double is = scale[1];
-    const double t0 = is * (double)(y0 + z0 + u0 + w0), t1 = is * (double)(y1 + z1 + u1 + w1), t2 = is * (double)(y2 + z2 + u2 + w2);
+    double t0 = is * (double)(y0 + z0 + u0 + w0), t1 = is * (double)(y1 + z1 + u1 + w1), t2 = is * (double)(y2 + z2 + u2 + w2);
     if (node < 0) return;
     if (EPI == 0) {
         y[o] = t0; y[o + 1] = t1; y[o + 2] = t2;
+        return;
+    }
+    if (epi.t2) { t0 += epi.t2[o]; t1 += epi.t2[o + 1]; t2 += epi.t2[o + 2]; }
+    if (epi.defer && epi.defer[node]) {      // a node other ranks hold too: its step needs the sum of the ranks' products (k_unpack_sum_cheb)
+        epi.t_out[o] = t0; epi.t_out[o + 1] = t1; epi.t_out[o + 2] = t2;
         return;
     }
     const double r0 = e0 - t0, r1 = e1 - t1, r2 = e2 - t2;
@@ -1188,6 +1193,8 @@ struct SymVecs {
     double *y[NRHS];
     double *partial[NRHS];
     const double *done[NRHS];
+    const int32_t *glist = nullptr;   // launch over a SUBSET of the groups (grid = its length): workgroup b takes group glist[b] -- the multi-GPU layer's
+                                      // boundary-groups-first split (fcvm_set_interface_nodes); null: all groups through win_group_of_block
 };
 
 // LDS: x of the window [3 NRHS wmax], partial results of later segments [3 NRHS xseg], fixed-point accumulators [3 NRHS * 64 * WAVES].
@@ -1224,7 +1231,7 @@ __global__ __launch_bounds__(64 * WAVES, NRHS == 1 ? FCVM_SYM_MINWAVES : 2) void
         if (all_done) return;
     }
     const int64_t b = blockIdx.x;
-    const int64_t g = win_group_of_block(b, ngroups);
+    const int64_t g = V.glist ? (int64_t)V.glist[b] : win_group_of_block(b, ngroups);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wig = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t wave = g * WAVES + wig, row = wave * 64 + lane;
@@ -1432,6 +1439,7 @@ struct LoSymVecs {
     double *out[NRHS];
     double *partial[NRHS];
     const double *done[NRHS];
+    const int32_t *glist = nullptr;   // as SymVecs::glist
 };
 // one vector's share of the epilogue (one function for every NRHS: the same arithmetic in the same order)
 template <int EPI>
@@ -1489,7 +1497,7 @@ __global__ __launch_bounds__(64 * WAVES, NRHS == 1 ? FCVM_LOSYM_MINWAVES : 4) vo
     const bool fuse = NRHS == 1 && EPI == 2 && pf.e1 != nullptr;
     const int e0 = (int)lo_scale[0];      // matrix exponent: block exponents are stored absolutely (WinLoTailS)
     const int64_t b = blockIdx.x;
-    const int64_t g = win_group_of_block(b, ngroups);
+    const int64_t g = V.glist ? (int64_t)V.glist[b] : win_group_of_block(b, ngroups);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wig = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t wave = g * WAVES + wig, row = wave * 64 + lane;

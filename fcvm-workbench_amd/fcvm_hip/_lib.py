@@ -67,6 +67,12 @@ SIGNATURES = {
     "fcvm_set_group_map": [_vp, _int],
     "fcvm_debug_pcg_vectors": [_vp, _vp],
     "fcvm_placement_info": [_vp, _pf64],
+    "fcvm_mg_l1_pass": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _int, _int],
+    "fcvm_mg_l1_spmv": [_vp, _vp, _vp],
+    "fcvm_unpack_sum_cheb": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _int, _int],
+    "fcvm_set_interface_nodes": [_vp, _i64, _vp, _pi64],
+    "fcvm_spmv_dot_part": [_vp, _vp, _vp, _vp, _int],
+    "fcvm_spmv_lo_part": [_vp, _vp, _vp, _int],
     "fcvm_spmv_info": [_vp, _pi64],
     "fcvm_mem_info": [_vp, _pi64],
     "fcvm_mg_sparse_info": [_vp, _pi64],

@@ -152,19 +152,22 @@ class Exchanger:
             srcmat[m, k] = np.asarray(src, dtype=np.int64)[np.asarray(eptr[:-1])[m] + k]
         self.srcmat = torch.as_tensor(srcmat, device=device)
 
-    def interface_sum(self, t, ncomp):
-        """t: flat tensor [nn*ncomp]; in place."""
+    def begin(self, t, ncomp):
+        """First half of interface_sum: pack the shared entries of t and post the sends / receives.  Returns a handle for end(), or None
+        when there is nothing to exchange.  Between begin and end the caller may launch work that does not touch the shared entries of t
+        (the interior groups of a fine-level pass: fcvm_spmv_dot_part(part = 2)) -- with RCCL the messages then travel on the
+        communicator's own stream beside it."""
         p = self.part
         if self.count is not None:
             self.count["exchanges"] += 1
         if p.world == 1 or not self.ranks:
-            return t
+            return None
         # gloo has no GPU point-to-point: stage through the host there (CPU tests / shared-GPU rehearsal);
         # with nccl (= RCCL) the buffers go GPU to GPU over xGMI
         stage = t.is_cuda and dist.get_backend(p.group) == "gloo"
         key = (ncomp, t.dtype, t.device, stage)
         cached = self._bufs.get(key)
-        if cached is None:     # send / receive buffers are allocated once per vector shape and reused: an exchange happens ten times
+        if cached is None:     # send / receive buffers are allocated once per vector shape and reused: an exchange happens eight times
                                # per PCG iteration and its host-side cost is on the critical path.  (The P2POp list is rebuilt every
                                # time: cached ops keep the process group alive past destroy_process_group and a rank aborted at exit.)
             send = torch.empty(self.rows * ncomp, dtype=t.dtype, device=t.device)
@@ -183,9 +186,23 @@ class Exchanger:
             send.copy_(t.view(self.nn, ncomp).index_select(0, self.idx_all).reshape(-1))
         if stage:
             sbuf.copy_(send)
-        for w in dist.batch_isend_irecv(ops):
+        return (t, ncomp, stage, rbuf, dist.batch_isend_irecv(ops))
+
+    def end(self, handle, finish=None):
+        """Second half of interface_sum: wait for the messages and add the received rows per interface node in the fixed order.
+        finish(recv): a caller's kernel that does the sum itself together with what follows it (DistMG: the smoother step of the level-1
+        interface rows, fcvm_unpack_sum_cheb); without neighbours it is called with None."""
+        if handle is None:
+            if finish is not None:
+                finish(None)
+            return
+        t, ncomp, stage, rbuf, works = handle
+        for w in works:
             w.wait()
         recv = rbuf.to(t.device) if stage else rbuf
+        if finish is not None:
+            finish(recv)
+            return
         if self.ops is not None and t.is_cuda:
             self.ops.unpack_sum(self.inodes, self.eptr, self.src, ncomp, t, recv)
         else:
@@ -198,6 +215,10 @@ class Exchanger:
                                    torch.where((col == -1).unsqueeze(1), own, torch.zeros_like(own)))
                 acc = acc + term
             v.index_copy_(0, self.inodes, acc)
+
+    def interface_sum(self, t, ncomp):
+        """t: flat tensor [nn*ncomp]; in place."""
+        self.end(self.begin(t, ncomp))
         return t
 
 
@@ -219,6 +240,13 @@ class DistBackend:
         self.check_every = pcg_check_every
         self._timing = dict(spmv_ms=0.0, total_ms=0.0)
         self._ev_pool, self._ev_list = [], None
+        # boundary-groups-first split of the fine-level passes (round 5): the local kernels get the shared nodes once (set_interface_nodes) and
+        # launch the groups that hold them first; FCVM_DIST_SPLIT=0: unsplit launches, exchange after the whole pass
+        self.split = False
+        if hasattr(ops, "set_interface_nodes") and part.world > 1 and os.environ.get("FCVM_DIST_SPLIT", "1") != "0":
+            shared_nodes = np.unique(np.concatenate([np.asarray(ix, dtype=np.int64) for ix in part.shared.values()])) if part.shared else np.zeros(0, np.int64)
+            self.split_groups = ops.set_interface_nodes(shared_nodes)
+            self.split = self.split_groups[0] > 0 and self.split_groups[1] > 0
         self.mg = None  # DistMG once enabled (enable_multigrid)
         self.local_solver = False
 
@@ -426,6 +454,17 @@ class DistBackend:
             e0 = pool.pop() if pool else torch.cuda.Event(enable_timing=True)
             e1 = pool.pop() if pool else torch.cuda.Event(enable_timing=True)
             e0.record()
+        if xkx is not None and self.split and self.part.world > 1:
+            # boundary groups first: every shared entry of the product is complete after part 1, the messages are posted, and the interior
+            # groups run while they travel (fcvm_spmv_dot_part; both parts together are bitwise the unsplit launch)
+            self.ops.spmv_dot_part(x, y, xkx, 1)
+            h = self.ex.begin(y.t, 3)
+            self.ops.spmv_dot_part(x, y, xkx, 2)
+            if evs is not None:
+                e1.record()
+                evs.append((e0, e1))
+            self.ex.end(h)
+            return y
         if xkx is not None:
             self.ops.spmv_dot(x, y, xkx)
         else:
@@ -841,6 +880,17 @@ class DistMG:
         self.x2, self.z0 = mk(n0), mk(n0)       # form 2: x after the coarse correction; a scratch vector
         self.r1, self.x1, self.rr1, self.d1, self.t1 = mk(n1), mk(n1), mk(n1), mk(n1), mk(n1)
         self.tk1 = mk(n1)      # the last pre-smoothing product of level 1, unsummed (merge_l1)
+        # round 5: level-1 passes on the 16-bit kernel with the smoother step as epilogue (fcvm_mg_l1_pass); the rows of shared corner nodes
+        # are deferred to the kernel that sums their exchanged products.  Needs the fused form-2 cycle and the merged level-1 exchange;
+        # FCVM_DIST_FUSED_L1=0 keeps the round-4 sequence (FP32 sliced-ELL product + step kernel per pass)
+        self.fused_l1 = (self.fused_lo and self.merge_l1 and all(hasattr(self.ops, m) for m in ("mg_l1_pass", "mg_l1_spmv", "unpack_sum_cheb"))
+                         and self.ops.mg_l1_16() and os.environ.get("FCVM_DIST_FUSED_L1", "1") != "0")
+        if self.fused_l1:
+            self.dn1 = mk(n1)
+            defer = np.zeros(self.nc, dtype=np.uint8)
+            if self.ex1.ranks:
+                defer[self.ex1.inodes.cpu().numpy()] = 1
+            self.defer1 = torch.as_tensor(defer, device=dev)
         self.topo = True
         self.lmax_stale = True
 
@@ -1115,6 +1165,9 @@ class DistMG:
             self.ops.mg_restrict_weighted(r, TVec(self.w0), self.r1)
         self.ex1.interface_sum(self.r1.t, 3)
         merge = self.merge_l1
+        if self.fused_l1:
+            self._coarse_fused_l1()
+            return
         if merge:
             # k1s Chebyshev steps from zero, the last one's product A1 d left UNSUMMED in tk1: x is complete, rr1 still lacks it
             ch, k = self.ch1, self.k1s
@@ -1155,6 +1208,42 @@ class DistMG:
         else:
             self._post(1, self.ch1, self.k1s, self.x1, self.rr1, self.d1, self.t1)
 
+    def _l1_pass(self, din, dout, cdd, cdr, update_d, add_dout=False, t2=None):
+        """one level-1 smoother pass on the library's 16-bit kernel with the step as epilogue; the rows of shared corner nodes are finished
+        after the exchange of their raw products by one small kernel that sums and steps (no full-vector step kernel, no separate unpack)"""
+        ex = self.ex1
+        self.ops.mg_l1_pass(din, dout, self.x1, self.rr1, t2, self.t1, self.defer1, cdd, cdr, update_d, add_dout)
+        h = ex.begin(self.t1.t, 3)
+        if ex.ranks:
+            ex.end(h, finish=lambda recv: self.ops.unpack_sum_cheb(ex.inodes, ex.eptr, ex.src, self.t1, recv, din, dout, self.x1, self.rr1,
+                                                                    cdd, cdr, update_d, add_dout))
+        else:
+            ex.end(h)
+
+    def _coarse_fused_l1(self):
+        """level 1 and below from the restricted, exchanged r1 (round 5: on k_spmv_l1_i16 with the Chebyshev step as epilogue -- what the
+        one-GPU cycle runs -- instead of the FP32 sliced-ELL product plus a step kernel per pass).  Same algebra as the merge_l1 branch of
+        _coarse: k1s steps from zero with the last product left unsummed (tk1), aggregate level, k1s steps after it with tk1 riding on the
+        first exchange.  The direction ping-pongs between d1 and dn1 (a pass's rows still gather the old one)."""
+        be, ch, k = self.be, self.ch1, self.k1s
+        self.ops.mg_cheb_init(1, self.r1, self.x1, self.rr1, self.d1, ch.c0)
+        din, dout = self.d1, self.dn1
+        for j in range(1, k):
+            self._l1_pass(din, dout, ch.cdd[j], ch.cdr[j], True)
+            din, dout = dout, din
+        self.ops.mg_l1_spmv(din, self.tk1)                                        # this rank's part of the last product
+        self.ops.mg_cheb_step(1, None, self.x1, self.rr1, din, 0.0, 0.0, False)   # x += d
+        self.ops.mg_l2_restrict_diff(self.rr1, self.own1, self.tk1, self.r2)      # Z^T (own1 * rr1 - tk1): summed by the all-reduce
+        be._allreduce(self.r2.t)                              # replicated right-hand side of the aggregate level
+        self.ops.mg_l2_solve(self.r2, self.e2)                # the same correction on every rank (replicated level: no gather)
+        self.ops.mg_l2_prolong(self.e2, din)                  # the correction as the next direction
+        # absorb it (x += d, r -= A1 d + the pending product), then k - 1 more steps of a fresh sequence and the closing x += d
+        self._l1_pass(din, dout, 0.0, ch.c0, True, add_dout=(k == 1), t2=self.tk1)
+        din, dout = dout, din
+        for j in range(1, k):
+            self._l1_pass(din, dout, ch.cdd[j], ch.cdr[j], True, add_dout=(j == k - 1))
+            din, dout = dout, din
+
     def _cycle_lo(self, b, x):
         """form 2 from x1 = c0 Dinv b in self.d0:  x2 = x1 + P M1^-1 P^T (b - K~ x1);  x = x2 + c0 Dinv (b - K~ x2), K~ = the sum
         over the ranks of the 16-bit copies of their local matrices (one fine-level exchange: the second product's)"""
@@ -1164,8 +1253,14 @@ class DistMG:
             self.ops.mg_restrict_diff(b, TVec(self.w0), self.t0, self.r1)        # P^T (w0 b - K~_local x1), never written out
             self._coarse(None, restricted=True)
             self.ops.mg_prolong_add(self.x1, self.d0, self.x2)
-            self.ops.spmv_lo(self.x2, self.t0)
-            be.ex.interface_sum(self.t0.t, 3)
+            if be.split:       # boundary groups first, interior groups beside the messages (as DistBackend.spmv)
+                self.ops.spmv_lo_part(self.x2, self.t0, 1)
+                h = be.ex.begin(self.t0.t, 3)
+                self.ops.spmv_lo_part(self.x2, self.t0, 2)
+                be.ex.end(h)
+            else:
+                self.ops.spmv_lo(self.x2, self.t0)
+                be.ex.interface_sum(self.t0.t, 3)
             if self.rz_rr is None:
                 self._dots = torch.zeros(3, dtype=torch.float64, device=be.device)
                 self.rz_rr = (self._dots[0:1], self._dots[2:3])
@@ -1576,6 +1671,42 @@ class HipLocalOps:
         """y = K_local x and out[0] = x . y over the local rows (the rank's share of x^T K x for a consistent x)"""
         from ._lib import call
         call("fcvm_spmv_dot", self.c.h, x.ptr, y.ptr, out.data_ptr())
+
+    def mg_l1_16(self):
+        """does the library keep the 16-bit copy of the level-1 matrix (FCVM_MG_L1_16, default on)?"""
+        return os.environ.get("FCVM_MG_L1_16", "1") != "0"
+
+    def mg_l1_pass(self, din, dout, x, r, t2, t_out, defer, cdd, cdr, update_d, add_dout):
+        from ._lib import call
+        call("fcvm_mg_l1_pass", self.c.h, din.ptr, dout.ptr, x.ptr, r.ptr, t2.ptr if t2 is not None else None, t_out.ptr, defer.data_ptr(),
+             float(cdd), float(cdr), 1 if update_d else 0, 1 if add_dout else 0)
+
+    def mg_l1_spmv(self, x, y):
+        from ._lib import call
+        call("fcvm_mg_l1_spmv", self.c.h, x.ptr, y.ptr)
+
+    def unpack_sum_cheb(self, inodes, eptr, src, traw, recv, din, dout, x, r, cdd, cdr, update_d, add_dout):
+        from ._lib import call
+        call("fcvm_unpack_sum_cheb", self.c.h, inodes.numel(), inodes.data_ptr(), eptr.data_ptr(), src.data_ptr(), traw.ptr, recv.data_ptr(),
+             din.ptr, dout.ptr, x.ptr, r.ptr, float(cdd), float(cdr), 1 if update_d else 0, 1 if add_dout else 0)
+
+    def set_interface_nodes(self, nodes):
+        """the local nodes other ranks hold too: the groups of the window format with a row of one of them are launched first by the *_part calls.
+        Returns (boundary groups, interior groups); (0, 0) where the storage form has no lists"""
+        import ctypes as C
+        from ._lib import call
+        nodes = np.ascontiguousarray(nodes, np.int64)
+        out = (C.c_int64 * 2)()
+        call("fcvm_set_interface_nodes", self.c.h, len(nodes), nodes.ctypes.data if len(nodes) else None, out)
+        return int(out[0]), int(out[1])
+
+    def spmv_dot_part(self, x, y, out, part):
+        from ._lib import call
+        call("fcvm_spmv_dot_part", self.c.h, x.ptr, y.ptr, out.data_ptr(), int(part))
+
+    def spmv_lo_part(self, x, y, part):
+        from ._lib import call
+        call("fcvm_spmv_lo_part", self.c.h, x.ptr, y.ptr, int(part))
 
     def mg_set_level2(self, nagg, agg, Z):
         """transfer operators of the aggregate level: global aggregate of every level-1 node, Z [nc][3][6] (six slots per aggregate)"""

@@ -296,6 +296,26 @@ int fcvm_spmv_sym_info(fcvm_ctx *c, int64_t out[10]);
  * super-chunks of 8 C groups (one moving front through the value array instead of eight streams an eighth of it apart; L2 sharing of window
  * nodes kept inside the chunks; default C = 16).  Device-wide.  FCVM_WIN_GMAP sets it when a context is created. */
 int fcvm_set_group_map(fcvm_ctx *c, int mode);
+/* Multi-GPU layer, overlap of the shared-node exchange with the interior rows of the three fine-level passes (north_star: "halo displacement
+ * exchange at shared nodes"; no reference counterpart -- fcVM.py is one process).  fcvm_set_interface_nodes: the local nodes (0-based) another rank
+ * holds too; the groups of the window format with a row of such a node form the first launch list, the rest the second (out[0] / out[1]: their
+ * sizes; n = 0: no lists).  fcvm_spmv_dot_part / fcvm_spmv_lo_part(part): 0 = all groups, 1 = the first list (every entry the exchange needs is
+ * complete after it), 2 = the second list (launched after the sends are posted); after part 0 or 2 fcvm_spmv_dot_part also reduces x . y.  Parts
+ * 1 + 2 are bitwise part 0.  Without the symmetric window form part 1 does everything and part 2 nothing. */
+int fcvm_set_interface_nodes(fcvm_ctx *c, int64_t n, const int64_t *nodes, int64_t out[2]);
+int fcvm_spmv_dot_part(fcvm_ctx *c, const double *x, double *y, double *xy_dev, int part);
+int fcvm_spmv_lo_part(fcvm_ctx *c, const double *x, double *y, int part);
+/* Multi-GPU layer, level 1 of the cycle on the library's current kernels (round 5): fcvm_mg_l1_pass = one Chebyshev pass on this rank's 16-bit
+ * copy of the tet4 matrix with the smoother step as epilogue (t = A1_local din (+ t2); r -= t; x += din; dout = cdd din + cdr Dinv r; x += dout
+ * if add_dout) for every row except those of nodes flagged in defer (u8 per level-1 node: held by another rank too) -- their raw product goes to
+ * t_out, the exchange sums the ranks' parts, and fcvm_unpack_sum_cheb (the sum of fcvm_unpack_sum fused with that step) finishes them.
+ * fcvm_mg_l1_spmv: the raw product y = A1_local x of the same copy. */
+int fcvm_mg_l1_pass(fcvm_ctx *c, const double *din, double *dout, double *x, double *r, const double *t2, double *t_out, const uint8_t *defer,
+                    double cdd, double cdr, int update_d, int add_dout);
+int fcvm_mg_l1_spmv(fcvm_ctx *c, const double *x, double *y);
+int fcvm_unpack_sum_cheb(fcvm_ctx *c, int64_t nshared, const int64_t *node, const int64_t *eptr, const int64_t *src, const double *traw,
+                         const double *recv, const double *din, double *dout, double *x, double *r, double cdd, double cdr, int update_d,
+                         int add_dout);
 /* Placement tuning (round 5; no reference counterpart): where the driver puts an allocation decides 10-15 % of the time of the kernel that
  * streams it or scatters its results into it.  After the first stiffness assembly of a mesh the PCG's result vector and the value array of the
  * 16-bit passes' result vectors (and, with FCVM_TUNE_PLACEMENT_ARRAYS=1, the value / column arrays they stream) are each timed against

@@ -1397,6 +1397,51 @@ def test_group_map_and_placement_tuning_do_not_change_a_number():
     assert np.array_equal(u2.get(), ref[4]) and info2["iterations"] == ref[5]
 
 
+def test_boundary_groups_first_is_bitwise_the_unsplit_pass():
+    """Multi-GPU layer, round 5: the three fine-level passes launch the groups of the window format that hold rows of shared nodes first
+    (fcvm_set_interface_nodes, fcvm_spmv_dot_part / fcvm_spmv_lo_part part 1), so that the shared-node exchange can start while the interior
+    groups (part 2) still run.  Here on one GPU: for a made-up interface (the nodes of a plane through the cube, and a scattered set) part 1
+    leaves every interface entry complete, parts 1 + 2 are bitwise the unsplit product -- vector, inner product, 16-bit pass."""
+    import ctypes as C
+    from fcvm_hip import meshgen
+    from fcvm_hip._lib import call
+    case = small_case(12, prescribed=False)         # 10,368 tet10 / 15,625 nodes: ~31 groups
+    m = make_model(case)
+    c = m.ctx
+    m.calc_gsm((0, 0, -9.81))
+    assert c.spmv_sym_info()["in_use"]
+    x = c.array(np.random.default_rng(7).standard_normal(m.ndof))
+    out_ref, out = c.empty(8), c.empty(8)
+    y_ref, z_ref = c.empty(m.ndof), c.empty(m.ndof)
+    call("fcvm_spmv_dot_part", c.h, x.ptr, y_ref.ptr, out_ref.ptr, 0)
+    call("fcvm_spmv_lo_part", c.h, x.ptr, z_ref.ptr, 0)
+    assert np.array_equal(y_ref.get(), c.spmv(x, c.empty(m.ndof)).get()) and np.array_equal(z_ref.get(), c.spmv_lo(x, c.empty(m.ndof)).get())
+    plane = meshgen.nodes_on_plane(case["nocoord"], 0, 5.0)
+    scattered = np.random.default_rng(8).choice(m.nn, 40, replace=False)
+    for nodes in (plane, scattered):
+        nodes = np.ascontiguousarray(nodes, np.int64)
+        o = (C.c_int64 * 2)()
+        call("fcvm_set_interface_nodes", c.h, len(nodes), nodes.ctypes.data, o)
+        assert o[0] > 0 and o[1] > 0 and o[0] + o[1] == c.spmv_info()["groups"], tuple(o)
+        dofs = (3 * nodes[:, None] + np.arange(3)[None, :]).reshape(-1)
+        for name, ref in (("dot", y_ref), ("lo", z_ref)):
+            y = c.array(np.full(m.ndof, np.nan))
+            if name == "dot":
+                call("fcvm_spmv_dot_part", c.h, x.ptr, y.ptr, out.ptr, 1)
+            else:
+                call("fcvm_spmv_lo_part", c.h, x.ptr, y.ptr, 1)
+            yh = y.get()
+            assert np.array_equal(yh[dofs], ref.get()[dofs]), name                  # every shared entry is there after part 1
+            assert np.isnan(yh).any()                                               # ... and the interior is not yet
+            if name == "dot":
+                call("fcvm_spmv_dot_part", c.h, x.ptr, y.ptr, out.ptr, 2)
+                assert np.array_equal(out.get()[:1], out_ref.get()[:1])
+            else:
+                call("fcvm_spmv_lo_part", c.h, x.ptr, y.ptr, 2)
+            assert np.array_equal(y.get(), ref.get()), name
+    call("fcvm_set_interface_nodes", c.h, 0, None, None)
+
+
 def test_fused_inner_products_are_bitwise_the_single_ones():
     """fcvm_vec_mdot (the Newton driver's projection / Gram / Riks scalars in one pass) returns, for every pair, exactly the value
     of fcvm_vec_dot: same grid, same per-thread order, same two-stage sums -- sizes around the block and grid-stride limits,
