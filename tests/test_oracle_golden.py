@@ -66,8 +66,16 @@ def lug_pressure_case(g, meta, orc_or_none=None):
     return fix, g["pfaces"], g["pvals"], meta["inp"]
 
 
-def check_lug_against_reference_files(res, g, tol):
-    """all 61 rows of the reference's .out (two passes of 30 steps), every column, and the f64 fields of its .vtk"""
+def rel_each(a, b, floor=1e-3):
+    """largest ELEMENT-WISE relative difference over the entries of b above floor * max |b|"""
+    a, b = np.asarray(a, float).ravel(), np.asarray(b, float).ravel()
+    m = np.abs(b) > floor * np.abs(b).max()
+    return float((np.abs(a - b)[m] / np.abs(b)[m]).max()) if m.any() else 0.0
+
+
+def check_lug_against_reference_files(res, g, tol, tol_each=None):
+    """all 61 rows of the reference's .out (two passes of 30 steps), every column, and the f64 fields of its .vtk (tol: relative to the
+    field maximum; tol_each: entry by entry over the entries above 1e-3 of it)"""
     tab = g["out_table"]
     assert len(res["lout"]) == len(tab) == 61
     assert np.array_equal(np.asarray(res["crip"]), tab[:, 0].astype(int))
@@ -84,6 +92,12 @@ def check_lug_against_reference_files(res, g, tol):
     assert rel(res["tet10csr"], g["vtk_Critical_Strain_Ratio"]) < tol
     assert rel(res["tet10svm"], g["vtk_von_Mises_Stress"]) < tol
     assert rel(res["tet10triax"], g["vtk_Triaxiality"]) < tol
+    if tol_each is not None:
+        each = {k: rel_each(a, b) for k, a, b in (("displacement", np.asarray(res["displacements"]).reshape(-1, 3), g["vtk_Displacement"]),
+                                                   ("stress", res["tet10stress"], g["vtk_Stress_Tensor"]),
+                                                   ("von Mises", res["tet10svm"], g["vtk_von_Mises_Stress"]),
+                                                   ("peeq", res["tet10peeq"], g["vtk_Equivalent_Plastic_Strain"]))}
+        assert max(each.values()) < tol_each, each
 
 
 def test_lug_pressure_example_out_and_vtk(orc):
