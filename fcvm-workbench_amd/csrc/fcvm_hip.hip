@@ -2624,7 +2624,7 @@ int fcvm_mg_l2_galerkin_get(fcvm_ctx *c, int64_t *sptr_g, int32_t *slot_agg, dou
 }
 
 int fcvm_mg_l2_finish(fcvm_ctx *c, int64_t nagg, const int32_t *arank, int64_t nslots, const int64_t *sptr_g, const int32_t *slot_agg,
-                      const double *B, int64_t nsuper, const int32_t *sagg, const int64_t *soff, const double *C) {
+                      const double *B, int64_t nsuper, const int32_t *sagg, const int64_t *soff, const double *C, int k2, int ncoarse) {
     NEED(c && c->mg_topo && c->l2 && nagg == c->nagg && c->n2 == 6 * nagg, "fcvm_mg_l2_finish: fcvm_mg_set_level2 with six modes per aggregate first");
     NEED(arank && nslots > 0 && sptr_g && slot_agg && B && sptr_g[0] == 0 && sptr_g[nagg] == nslots, "fcvm_mg_l2_finish: bad block lists");
     NEED(nsuper == 0 || (sagg && soff && C && soff[0] == 0), "fcvm_mg_l2_finish: super-aggregates without their tables");
@@ -2646,7 +2646,11 @@ int fcvm_mg_l2_finish(fcvm_ctx *c, int64_t nagg, const int32_t *arank, int64_t n
         std::vector<int64_t> vso(soff, soff + nsuper + 1);
         std::vector<double> vC(C, C + nagg * 36);
         for (int64_t S = 0; S < nsuper; S++) NEED(vso[S + 1] >= vso[S] && vso[S + 1] - vso[S] <= 6, "fcvm_mg_l2_finish: at most 6 modes per super-aggregate");
-        return l2s_finish(c, nagg, vs, va, vB, vr, nsuper, vsa, vso, vC);
+        if (l2s_finish(c, nagg, vs, va, vB, vr, nsuper, vsa, vso, vC)) return 1;
+        // smoothing steps per sweep / super-aggregate corrections per cycle of the caller (0: the library's defaults; the environment still overrides)
+        if (k2 > 0 && !getenv("FCVM_L2S_K")) c->l2s.k2 = k2;
+        if (ncoarse > 0 && !getenv("FCVM_L2S_COARSE")) c->l2s.ncoarse = std::min(4, ncoarse);
+        return 0;
     }
     // dense: the blocks scattered into the n2 x n2 matrix on the device, inverted by every rank (identical input, identical result)
     if (l2_symmetrise_blocks(nagg, vs, va, vB, vr, nullptr)) return 1;

@@ -88,7 +88,7 @@ SIGNATURES = {
     "fcvm_spd_inverse": [_vp, _i64, _vp, _vp],
     "fcvm_mg_l2_galerkin": [_vp, _pi64],
     "fcvm_mg_l2_galerkin_get": [_vp, _vp, _vp, _vp],
-    "fcvm_mg_l2_finish": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp],
+    "fcvm_mg_l2_finish": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _int, _int],
     "fcvm_dist_pcg_scalars": [_vp, C.c_int, _vp, _vp],
     "fcvm_any_u8": [_vp, _i64, _vp, C.POINTER(C.c_int)],
     "fcvm_pack_nodes": [_vp, _i64, _vp, _int, _vp, _vp],

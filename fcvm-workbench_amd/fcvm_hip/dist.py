@@ -1733,8 +1733,10 @@ class HipLocalOps:
         B = np.ascontiguousarray(B, np.float64)
         if nsuper:
             sagg, soff, Cm = np.ascontiguousarray(sagg, np.int32), np.ascontiguousarray(soff, np.int64), np.ascontiguousarray(Cm, np.float64)
+        # sparse form: 2 smoothing steps per sweep, 2 super-aggregate corrections (the one-GPU library's 8 / 2 cost 25 launches per cycle on EVERY
+        # rank; 13 k aggregates of the 6.0 M plate, gpurun_out/r05r: 8 / 2 -> 49 PCG iterations, 4 / 2 -> 54, 2 / 2 -> 49, 2 / 3 -> 48, 1 / 2 -> 55)
         call("fcvm_mg_l2_finish", self.c.h, int(nagg), arank.ctypes.data, len(slot_agg), sptr_g.ctypes.data, slot_agg.ctypes.data, B.ctypes.data,
-             int(nsuper), sagg.ctypes.data if nsuper else None, soff.ctypes.data if nsuper else None, Cm.ctypes.data if nsuper else None)
+             int(nsuper), sagg.ctypes.data if nsuper else None, soff.ctypes.data if nsuper else None, Cm.ctypes.data if nsuper else None, 2, 2)
 
     def mg_l2_restrict(self, r1, r2):
         from ._lib import call

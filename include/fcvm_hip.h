@@ -268,12 +268,14 @@ int fcvm_mg_sparse_info(fcvm_ctx *c, int64_t out[4]);
  *                            applied from its lower triangle); nsuper > 0: the sparse level (block-Jacobi Chebyshev sweeps) closed by a dense
  *                            level of the caller's super-aggregates: sagg int32[nagg], soff int64[nsuper+1] (first mode of each), C
  *                            f64[nagg][6][6] (the super-aggregate's modes in the basis of the aggregate, [k][m]); arank int32[nagg]: modes
- *                            kept per aggregate (the others are zero columns of Z and get a unit diagonal).
+ *                            kept per aggregate (the others are zero columns of Z and get a unit diagonal); k2 / ncoarse: smoothing steps per
+ *                            sweep and super-aggregate corrections per cycle of the sparse form (0: the library's 8 / 2; every rank computes the
+ *                            whole level, so the multi-GPU layer asks for 2 / 2: the same PCG iteration count at 7 instead of 25 launches).
  * fcvm_mg_l2_solve then returns e2 = M2^-1 r2 for the replicated r2 on every rank. */
 int fcvm_mg_l2_galerkin(fcvm_ctx *c, int64_t *nslots);
 int fcvm_mg_l2_galerkin_get(fcvm_ctx *c, int64_t *sptr_g, int32_t *slot_agg, double *B);
 int fcvm_mg_l2_finish(fcvm_ctx *c, int64_t nagg, const int32_t *arank, int64_t nslots, const int64_t *sptr_g, const int32_t *slot_agg,
-                      const double *B, int64_t nsuper, const int32_t *sagg, const int64_t *soff, const double *C);
+                      const double *B, int64_t nsuper, const int32_t *sagg, const int64_t *soff, const double *C, int k2, int ncoarse);
 /* dst = inverse of the SPD n x n matrix src (row-major, device pointers, no aliasing) */
 int fcvm_spd_inverse(fcvm_ctx *c, int64_t n, const double *src, double *dst);
 
