@@ -2977,6 +2977,15 @@ int fcvm_pack_nodes(fcvm_ctx *c, int64_t n, const int64_t *idx, int ncomp, const
     return 0;
 }
 
+/* v[idx[k]][c] += a[k][c], idx distinct (device arrays): see k_scatter_add_nodes */
+int fcvm_scatter_add_nodes(fcvm_ctx *c, int64_t n, const int64_t *idx, int ncomp, const double *a, double *v) {
+    NEED(c && n >= 0 && ncomp > 0 && (n == 0 || (idx && a && v)), "fcvm_scatter_add_nodes: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_scatter_add_nodes, dim3((unsigned)cdiv(n * ncomp, 256)), dim3(256), 0, c->stream, n, idx, ncomp, a, v);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
 int fcvm_unpack_sum(fcvm_ctx *c, int64_t nshared, const int64_t *node, const int64_t *eptr, const int64_t *src, int ncomp, double *v,
                     const double *recv) {
     NEED(c && nshared >= 0 && ncomp > 0, "fcvm_unpack_sum: bad arguments");

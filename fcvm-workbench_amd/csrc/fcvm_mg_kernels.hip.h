@@ -725,6 +725,15 @@ __global__ __launch_bounds__(256) void k_pack_nodes(int64_t n, const int64_t *__
     const int64_t k = t / ncomp, c = t - k * ncomp;
     out[t] = v[idx[k] * ncomp + c];
 }
+// v[idx[k]][c] += a[k][c] for DISTINCT idx: the follower-pressure part of the external load vector, computed on the host for the loaded faces' nodes only
+// (fcVM.py:858-883: pressure follows the deformed geometry in a GNLY analysis) and added on the device
+__global__ __launch_bounds__(256) void k_scatter_add_nodes(int64_t n, const int64_t *__restrict__ idx, int ncomp, const double *__restrict__ a,
+                                                           double *__restrict__ v) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * ncomp) return;
+    const int64_t k = t / ncomp, c = t - k * ncomp;
+    v[idx[k] * ncomp + c] += a[t];
+}
 // v[node[t]][c] = sum over the entries of interface node t, in list order, of (src < 0 ? v[node[t]][c] : recv[src][c]).
 // The lists are sorted by the rank a contribution comes from, the own one standing at the place of the own rank, so that
 // every rank holding the node adds the same numbers in the same order: shared values stay bit-identical on all sharers.

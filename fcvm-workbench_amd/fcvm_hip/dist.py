@@ -1330,6 +1330,7 @@ class DistModel:
         self.loads = loads_local
         self._ext_fn = external_loads_fn
         self._ext = None   # cached external load vector (device, exchanged), as solver.GpuModel; None: build it at the next calc_gsm
+        self._follow = None   # follower pressure (GNLY): (FollowerPressure or None, its node numbers on the device, the static loads)
         self.ne, self.nn = len(part.elNodes), part.nn
         self.ndof = 3 * self.nn
         fixdof, movdof = np.ones(self.ndof), np.zeros(self.ndof)
@@ -1354,14 +1355,34 @@ class DistModel:
         xgp = c.empty(12 * self.ne) if want_x else None
         glv, modf, V = c.assemble(grav, disp=disp, sig=sig, pgp=pgp, Et_E=Et_E, xgp=xgp)
         follower = disp is not None and self.follower_loads
-        if follower or self._ext is None:
-            ext = self._ext_fn(self.nocoord, self.loads, disp.get() if follower else None)
+        if follower:
+            # round 5: the static loads once (exchanged, kept on the device); the pressure from the displacements of this rank's loaded faces'
+            # nodes alone -- gathered on the device, integrated on the host (O(loaded faces)), scattered into a zero vector and summed over the
+            # shared nodes.  Rounds 1-4 took the whole displacement vector to the host at every tangent.  Every rank takes part in the
+            # exchange, loaded or not.
+            if self._follow is None:
+                from .loads import FollowerPressure, split_follower
+                static, _p = split_follower(self.loads)
+                es = c.array(self._ext_fn(self.nocoord, static, None))
+                c.ex.interface_sum(es.t, 3)
+                fp = FollowerPressure(self.nocoord, self.loads) if getattr(self.loads, "has_pressure", False) else None
+                idx = torch.as_tensor(fp.nodes.astype(np.int64), device=c.device) if fp is not None else None
+                self._follow = (fp, idx, es)
+            fp, idx, es = self._follow
+            e = TVec(torch.zeros(3 * self.nn, dtype=torch.float64, device=c.device))
+            if fp is not None and len(fp.nodes):
+                d = disp.t.view(-1, 3).index_select(0, idx).cpu().numpy()
+                f = torch.as_tensor(fp.loads(d), device=c.device)
+                e.t.view(-1, 3).index_add_(0, idx, f)
+            c.ex.interface_sum(e.t, 3)
+            e.t.add_(es.t)
+        elif self._ext is None:
+            ext = self._ext_fn(self.nocoord, self.loads, None)
             # every rank takes part in the exchange, loaded or not (a rank-local "any load?" test would
             # leave the neighbours waiting)
             e = c.array(ext)
             c.ex.interface_sum(e.t, 3)
-            if not follower:
-                self._ext = e          # (the driver resets it when the coordinates change: imperfection, set_coords)
+            self._ext = e          # (the driver resets it when the coordinates change: imperfection, set_coords)
         else:
             e = self._ext
         glv.t.add_(e.t)

@@ -86,3 +86,31 @@ def external_loads(nocoord, loads, disp=None):
             f = (np.abs(xsj) * w)[:, None, None] * shp[None, :, None] * loads.eloads[:, None, :]
             np.add.at(g3, loads.edges - 1, f)
     return glv
+
+
+def split_follower(loads):
+    """(the loads that do not follow the geometry, the pressure faces alone) -- calcTSM re-integrates only the pressure on the deformed
+    geometry (fcVM.py:858-883); everything else is the same vector at every tangent"""
+    static = Loads(vnodes=loads.vnodes, vloads=loads.vloads, ufaces=loads.ufaces, uloads=loads.uloads, edges=loads.edges, eloads=loads.eloads)
+    return static, Loads(pfaces=loads.pfaces, pvals=loads.pvals)
+
+
+class FollowerPressure:
+    """The pressure part of the external load vector on the deformed geometry from the displacements of the loaded faces' nodes ALONE:
+    nodes = their (0-based, sorted, distinct) numbers; loads(x_nodes) -> [len(nodes), 3] nodal forces at those nodes (the face integrals of
+    external_loads restricted to that node set).  The solver gathers disp[nodes] on the device, calls this on the host (O(loaded faces)) and
+    scatters the result back: no full displacement vector leaves the GPU per GNLY tangent."""
+
+    def __init__(self, nocoord, loads):
+        self.nodes = np.unique(loads.pfaces.reshape(-1) - 1)
+        self.faces = np.searchsorted(self.nodes, loads.pfaces - 1)      # local numbering within `nodes`
+        self.pvals = loads.pvals
+        self.x0 = np.ascontiguousarray(np.asarray(nocoord, dtype=np.float64)[self.nodes])
+
+    def loads(self, disp_nodes):
+        x6 = (self.x0 + np.asarray(disp_nodes, dtype=np.float64).reshape(-1, 3))[self.faces]
+        g3 = np.zeros((len(self.nodes), 3))
+        for shp, xsj, xp, w in _face_integrals(x6):
+            f = (self.pvals * np.abs(xsj) * w)[:, None, None] * shp[None, :, None] * xp[:, None, :]
+            np.add.at(g3, self.faces, f)
+        return g3

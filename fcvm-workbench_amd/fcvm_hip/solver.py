@@ -45,6 +45,7 @@ class GpuModel:
         self.movdof = self.ctx.array(movdof)
         self.moving = bool(movdof.max() == 1.0) if len(movdof) else False
         self._ext = None   # device copy of the external load vector (None: not built yet, False: no such loads)
+        self._follow = None   # follower pressure (GNLY): (FollowerPressure, device copy of the static loads or False)
         self.ctx.finish_setup()   # (the symmetric window form was building beside the lines above)
 
     def calc_gsm(self, grav, disp=None, sig=None, pgp=None, Et_E=0.0, want_x=True):
@@ -56,11 +57,28 @@ class GpuModel:
         # surface / edge / vertex loads (host, O(surface)): only pressure follows the deformed geometry (fcVM.py:858-883), so
         # the displacements come back to the host only then; otherwise the load vector is built once and kept on the device
         follower = disp is not None and self.loads.has_pressure
-        if follower or self._ext is None:
-            ext = external_loads(self.nocoord, self.loads, disp.get() if follower else None)
-            ext_d = c.array(ext) if np.any(ext != 0.0) else False
-            if not follower:
-                self._ext = ext_d
+        if follower:
+            # round 5: the static loads once, the pressure from the displacements of the loaded faces' nodes alone (gathered on the device,
+            # integrated on the host, scattered back) -- rounds 1-4 took the whole displacement vector to the host at every tangent
+            if self._follow is None:
+                from ._lib import call     # noqa: F401
+                from .loads import FollowerPressure, split_follower
+                static, _p = split_follower(self.loads)
+                ext = external_loads(self.nocoord, static, None)
+                self._follow = (FollowerPressure(self.nocoord, self.loads), c.array(ext) if np.any(ext != 0.0) else False)
+                self._follow_idx = c.array(self._follow[0].nodes.astype(np.int64), dtype=np.int64)
+                self._follow_buf = c.empty(3 * len(self._follow[0].nodes))
+            from ._lib import call
+            fp, static_d = self._follow
+            n = len(fp.nodes)
+            call("fcvm_pack_nodes", c.h, n, self._follow_idx.ptr, 3, disp.ptr, self._follow_buf.ptr)
+            f = fp.loads(self._follow_buf.get())
+            self._follow_buf.set(f.reshape(-1))
+            call("fcvm_scatter_add_nodes", c.h, n, self._follow_idx.ptr, 3, self._follow_buf.ptr, glv_g.ptr)
+            ext_d = static_d
+        elif self._ext is None:
+            ext = external_loads(self.nocoord, self.loads, None)
+            ext_d = self._ext = c.array(ext) if np.any(ext != 0.0) else False
         else:
             ext_d = self._ext
         if ext_d is not False:
@@ -149,6 +167,7 @@ class RiksDriver:
                 model.nocoord = model.nocoord + imper.reshape(-1, 3)
                 c.set_coords(model.nocoord)
                 model._ext = None   # load integrals follow the geometry
+                model._follow = None
             # back to the ordinary stiffness matrix (on the imperfect geometry, if any) and its elastic solution
             self._hist, self._gram = [], None
             self.glv, self.modf, self.V, self.xgp = model.calc_gsm(self.grav)

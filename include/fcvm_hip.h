@@ -318,6 +318,10 @@ int fcvm_mg_l1_spmv(fcvm_ctx *c, const double *x, double *y);
 int fcvm_unpack_sum_cheb(fcvm_ctx *c, int64_t nshared, const int64_t *node, const int64_t *eptr, const int64_t *src, const double *traw,
                          const double *recv, const double *din, double *dout, double *x, double *r, double cdd, double cdr, int update_d,
                          int add_dout);
+/* v[idx[k]][c] += a[k][c] for distinct idx (int64, device): the follower-pressure part of the external loads (calcTSM, fcVM.py:858-883) is computed on the
+ * host from the displacements of the loaded faces' nodes alone (gathered with fcvm_pack_nodes) and added here -- no full displacement vector crosses PCIe
+ * per GNLY tangent */
+int fcvm_scatter_add_nodes(fcvm_ctx *c, int64_t n, const int64_t *idx, int ncomp, const double *a, double *v);
 /* Placement tuning (round 5; no reference counterpart): where the driver puts an allocation decides 10-15 % of the time of the kernel that
  * streams it or scatters its results into it.  After the first stiffness assembly of a mesh the PCG's result vector and the value array of the
  * 16-bit passes' result vectors (and, with FCVM_TUNE_PLACEMENT_ARRAYS=1, the value / column arrays they stream) are each timed against

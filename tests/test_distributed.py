@@ -321,6 +321,58 @@ def test_crip_of_a_partitioned_model_is_the_callers_gauss_point_index(orc, tmp_p
         assert np.array_equal(g["crip"], ref["crip"])
 
 
+def _follower_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dist_helpers import OracleLocalOps
+        from fcvm_hip import meshgen
+        from fcvm_hip.dist import partition_model
+        from fcvm_hip.loads import Loads
+        case = small_case(3, prescribed=False)
+        side = meshgen.boundary_faces_on_plane(case["elNodes"], case["nocoord"], 0, 10.0)
+        loads = Loads(pfaces=case["ufaces"], pvals=np.full(len(case["ufaces"]), -30.0), ufaces=side, uloads=np.tile([0.0, 6.0, 0.0], (len(side), 1)))
+        model = partition_model(case["elNodes"], case["nocoord"], case["material"], case["fix"], loads, device=torch.device("cpu"), precond="bj",
+                                ops_factory=lambda part, x, m, f, lo: OracleLocalOps(part, x, m, f, element_offset=lo))
+        be = model.ctx
+        dg = 0.05 * np.random.default_rng(1).standard_normal(case["nocoord"].size)          # the same global displacement field on every rank
+        disp = be.array(dg.reshape(-1, 3)[model.part.gnodes - 1].reshape(-1))
+        ne = model.ne
+        sig, pgp = be.array(np.zeros(24 * ne)), be.array(np.zeros(4 * ne, np.uint8), dtype=np.uint8)
+        glv1, *_ = model.calc_gsm((0.0, 0.0, 0.0), disp=disp, sig=sig, pgp=pgp, want_x=False)
+        glv2, *_ = model.calc_gsm((0.0, 0.0, 0.0), disp=disp, sig=sig, pgp=pgp, want_x=False)    # second tangent: the cached static part
+        glv0, *_ = model.calc_gsm((0.0, 0.0, 0.0), want_x=False)                                  # undeformed: the cached full vector
+        gathered = [None] * world
+        dist.all_gather_object(gathered, dict(gnodes=model.part.gnodes, g1=glv1.get(), g2=glv2.get(), g0=glv0.get(), disp=dg))
+        if rank == 0:
+            torch.save(gathered, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_follower_pressure_load_vector(orc, tmp_path):
+    """GNLY tangent of a partitioned model with a pressure load: the pressure is re-integrated on the deformed geometry (fcVM.py:858-883) from the
+    displacements of the loaded faces' nodes alone and summed over the shared nodes, the static loads are cached -- the consistent load vector of
+    every rank equals the oracle's external_loads of the whole model, deformed and undeformed."""
+    from fcvm_hip import meshgen
+    out = str(tmp_path / "fol.pt")
+    mp.spawn(_follower_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=False)
+    case = small_case(3, prescribed=False)
+    side = meshgen.boundary_faces_on_plane(case["elNodes"], case["nocoord"], 0, 10.0)
+    L = orc.Loads(pfaces=case["ufaces"], pvals=np.full(len(case["ufaces"]), -30.0), ufaces=side, uloads=np.tile([0.0, 6.0, 0.0], (len(side), 1)))
+    ref1 = orc.external_loads(case["nocoord"], L, got[0]["disp"]).reshape(-1, 3)
+    ref0 = orc.external_loads(case["nocoord"], L, None).reshape(-1, 3)
+    assert np.abs(ref1 - ref0).max() > 1e-3 * np.abs(ref0).max()          # the deformation does change the pressure load
+    for g in got:
+        idx = g["gnodes"] - 1
+        for key, ref in (("g1", ref1), ("g2", ref1), ("g0", ref0)):
+            assert np.abs(g[key].reshape(-1, 3) - ref[idx]).max() < 1e-12 * np.abs(ref).max(), key
+
+
 def _cg_guard_worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -931,6 +931,33 @@ def test_gnly_updated_lagrange_analysis_matches_oracle(orc):
     assert rel(res["peeq"], o["peeq"]) < 1e-6
 
 
+def test_gnly_follower_pressure_matches_oracle(orc):
+    """gnl == "GNLY" with a PRESSURE load: calcTSM re-integrates the pressure on the deformed geometry at every tangent (fcVM.py:858-883; no shipped
+    result file of the reference exercises it).  GPU against the oracle's restatement of that branch -- and the GPU path takes only the
+    displacements of the loaded faces' nodes to the host (fcvm_pack_nodes / fcvm_scatter_add_nodes, round 5), not the whole vector: pressure on
+    the top face of the cube plus a uniform shear traction on one side (a static load beside the follower one)."""
+    from fcvm_hip import meshgen
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import run_analysis
+    case = small_case(3, prescribed=False)
+    ctl = dict(sig_yield=30.0, grav_x=0.0, grav_y=0.0, grav_z=-9.81, nstep=4, iterat_max=20, error_max=1e-5, relax=1.2,
+               scale_re=2.0, scale_up=1.2, scale_dn=1.2, disp_output="total", ultimate_strain=0.25, Et_E=0.05, target_LF=10.0,
+               csr_option="PEEQ", averaged_option="unaveraged", gnl="GNLY", maxImp="0.0", ev1="1.0", ev2="0.0")
+    top = case["ufaces"]
+    side = meshgen.boundary_faces_on_plane(case["elNodes"], case["nocoord"], 0, 10.0)
+    kw = dict(pfaces=top, pvals=np.full(len(top), -30.0), ufaces=side, uloads=np.tile([0.0, 6.0, 0.0], (len(side), 1)))
+    o = orc.run_analysis(case["elNodes"], case["nocoord"], case["material"], case["fix"], orc.Loads(**kw), ctl)
+    assert o["peeq"].max() > 0 and np.abs(o["displacements"]).max() > 1e-3
+    res = run_analysis(case["elNodes"], case["nocoord"], case["material"], case["fix"], Loads(**kw), ctl, rtol=1e-12)
+    assert res["model"]._follow is not None and res["model"]._follow[1] is not False          # the sparse follower route ran, beside a static part
+    assert len(res["lout"]) == len(o["lout"])
+    assert rel(res["lout"], o["lout"]) < 1e-6 and rel(res["un"], o["un"]) < 1e-6
+    assert rel(res["displacements"], o["displacements"]) < 1e-6
+    assert rel(res["stresses"], o["stresses"]) < 1e-6
+    assert rel(res["peeq"], o["peeq"]) < 1e-6
+    assert rel_each(res["displacements"], o["displacements"]) < 1e-5
+
+
 def test_gnly_start_directions_carried_over_a_tangent_refresh_save_iterations_not_accuracy(monkeypatch):
     """GNLY: the solutions of the previous tangent carried over as start directions (FCVM_GNLY_CARRY, products with the new matrix
     formed by fcvm_spmv2) against starting every first solve with a new tangent from zero: the same analysis (the PCG works on
