@@ -467,13 +467,14 @@ static void launch_spmv(fcvm_ctx *c, bool dot, const double *x, double *y, const
 // smoother passes of the multiplicative cycle on the 16-bit copy (EPI 1: out = r - K~ x; EPI 2: out = x + c0 Dinv (r - K~ x) + partials)
 template <int EPI>
 static void launch_spmv_win_lo(fcvm_ctx *c, const double *x, const double *r, double *out, double c0, const double *done, double *part = nullptr,
-                               const double *fuse_e1 = nullptr, int gpart = 0) {
+                               const double *fuse_e1 = nullptr, int gpart = 0, const double *rw = nullptr) {
     const WinDev &w = c->win;
     if (!part) part = w.part_lo;
     if (c->wsym.on && c->wsym.lo_valid) {      // symmetric form of the 16-bit copy
         const WinSymDev &ws = c->wsym;
         const ProlongFuse pf{c->d_pa, c->d_pb, c->d_fixmask, fuse_e1};      // (fuse_e1: x + P e1 is formed while x is staged, EPI 2 only)
         LoSymVecs<1> V{{x}, {r}, {out}, {part}, {done}};
+        V.rw = rw;
         int64_t grid = w.pat.ngroups;
         if (gpart && ws.split) {       // (gpart: the boundary-groups-first split of the multi-GPU layer, as launch_spmv_win's part)
             V.glist = gpart == 1 ? ws.glist_b : ws.glist_i;
@@ -2840,6 +2841,18 @@ int fcvm_spmv_dot_part(fcvm_ctx *c, const double *x, double *y, double *xy_dev, 
     NEED(x != y && aligned16(x) && aligned16(y), "fcvm_spmv_dot_part: x and y must be distinct 16-byte aligned device vectors");
     launch_spmv(c, true, x, y, nullptr, part);
     if (part != 1) hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(256), 0, c->stream, c->d_part_spmv, spmv_partials(c), xy_dev);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+/* out = w r - K~_local x on the 16-bit copy (w per dof, e.g. 1 / ranks holding the node): the residual after the pre-smoothing step of the multi-GPU
+ * cycle as the epilogue of its smoother pass -- the rank's product stays unsummed (the restriction is linear; the level-1 exchange completes the sum), r
+ * enters once over the ranks.  Needs the symmetric form of the 16-bit copy. */
+int fcvm_spmv_lo_resid(fcvm_ctx *c, const double *x, const double *r, const double *w, double *out) {
+    NEED(c && c->have_mesh && x && r && w && out && x != out, "fcvm_spmv_lo_resid: no mesh / null or aliased vectors");
+    NEED(aligned16(x) && aligned16(out), "fcvm_spmv_lo_resid: device vectors must be 16-byte aligned");
+    NEED(mg_use_lo(c) && c->wsym.on && c->wsym.lo_valid, "fcvm_spmv_lo_resid: needs the symmetric form of the 16-bit copy (cycle form 2)");
+    launch_spmv_win_lo<1>(c, x, r, out, 0.0, nullptr, nullptr, nullptr, 0, w);
     HCHK(hipGetLastError());
     return 0;
 }

@@ -1440,18 +1440,21 @@ struct LoSymVecs {
     double *partial[NRHS];
     const double *done[NRHS];
     const int32_t *glist = nullptr;   // as SymVecs::glist
+    const double *rw = nullptr;       // EPI 1 only: per-dof weights of r -- out = rw r - K~ x (multi-GPU layer: r counted once over the ranks that hold a node)
 };
 // one vector's share of the epilogue (one function for every NRHS: the same arithmetic in the same order)
 template <int EPI>
 __device__ __forceinline__ void win_lo_sym_epilogue(int64_t node, double is, double yd0, double yd1, double yd2, const double *__restrict__ x,
                                                     const double *__restrict__ r, double *__restrict__ out, double c0,
-                                                    const float *__restrict__ dinv6, const ProlongFuse &pf, bool fuse, double &rz, double &rr) {
+                                                    const float *__restrict__ dinv6, const ProlongFuse &pf, bool fuse, double &rz, double &rr,
+                                                    const double *__restrict__ rw = nullptr) {
     const int64_t o = 3 * node;
     if (EPI == 0) {     // plain product out = K~ x (the host-driven cycle of the multi-GPU layer exchanges it before using it)
         out[o] = is * yd0; out[o + 1] = is * yd1; out[o + 2] = is * yd2;
         return;
     }
-    const double r0 = r[o], r1 = r[o + 1], r2 = r[o + 2];
+    double r0 = r[o], r1 = r[o + 1], r2 = r[o + 2];
+    if (EPI == 1 && rw) { const double w = rw[o]; r0 *= w; r1 *= w; r2 *= w; }
     const double t0 = r0 - is * yd0, t1 = r1 - is * yd1, t2 = r2 - is * yd2;
     if (EPI == 1) {
         out[o] = t0; out[o + 1] = t1; out[o + 2] = t2;
@@ -1639,7 +1642,7 @@ __global__ __launch_bounds__(64 * WAVES, NRHS == 1 ? FCVM_LOSYM_MINWAVES : 4) vo
                 yd1 += ldexp((double)(long long)ya[1], -shf[r]);
                 yd2 += ldexp((double)(long long)ya[2], -shf[r]);
             }
-            win_lo_sym_epilogue<EPI>((int64_t)node, lo_scale[1], yd0, yd1, yd2, V.x[r], V.r[r], V.out[r], c0, dinv6, pf, fuse, rz[r], rr[r]);
+            win_lo_sym_epilogue<EPI>((int64_t)node, lo_scale[1], yd0, yd1, yd2, V.x[r], V.r[r], V.out[r], c0, dinv6, pf, fuse, rz[r], rr[r], V.rw);
         }
     }
     if (EPI == 2) {

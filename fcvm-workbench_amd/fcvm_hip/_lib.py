@@ -74,6 +74,7 @@ SIGNATURES = {
     "fcvm_set_interface_nodes": [_vp, _i64, _vp, _pi64],
     "fcvm_spmv_dot_part": [_vp, _vp, _vp, _vp, _int],
     "fcvm_spmv_lo_part": [_vp, _vp, _vp, _int],
+    "fcvm_spmv_lo_resid": [_vp, _vp, _vp, _vp, _vp],
     "fcvm_spmv_info": [_vp, _pi64],
     "fcvm_mem_info": [_vp, _pi64],
     "fcvm_mg_sparse_info": [_vp, _pi64],

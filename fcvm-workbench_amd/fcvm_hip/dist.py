@@ -843,6 +843,7 @@ class DistMG:
                                                                               "pcg_update_xr_z0_f32"))
                          and os.environ.get("FCVM_DIST_FUSED_LO", "1") != "0")
         self.rz_rr = None                            # (r.z, r.r) shares of the last cycle (device, 2 one-element views), fused_lo only
+        self.lo_resid = self.fused_lo and hasattr(be.ops, "spmv_lo_resid") and os.environ.get("FCVM_DIST_LO_RESID", "1") != "0"
         # round 4: the last product of the level-1 pre-smoothing only ever enters (a) the residual the aggregate level restricts --
         # whose sum over the ranks the all-reduce of r2 completes anyway -- and (b) the residual the post-smoothing starts from, where
         # it rides on the exchange of the FIRST post-smoothing product (both are subtracted from the same vector): one shared-node
@@ -1248,9 +1249,19 @@ class DistMG:
         """form 2 from x1 = c0 Dinv b in self.d0:  x2 = x1 + P M1^-1 P^T (b - K~ x1);  x = x2 + c0 Dinv (b - K~ x2), K~ = the sum
         over the ranks of the 16-bit copies of their local matrices (one fine-level exchange: the second product's)"""
         be, c0 = self.be, self.weight * self.ch0.c0
-        self.ops.spmv_lo(self.d0, self.t0)
+        if self.fused_lo and self.lo_resid:
+            # round 5: the residual after pre-smoothing as the epilogue of the smoother pass (one vector for the restriction to read instead of three)
+            try:
+                self.ops.spmv_lo_resid(self.d0, b, TVec(self.w0), self.r0)       # w0 b - K~_local x1
+            except RuntimeError:       # no symmetric form of the 16-bit copy on this rank (small or graded mesh): the three-vector restriction
+                self.lo_resid = False
+        if self.fused_lo and self.lo_resid:
+            self.ops.mg_restrict(self.r0, self.r1)
+        else:
+            self.ops.spmv_lo(self.d0, self.t0)
         if self.fused_lo:
-            self.ops.mg_restrict_diff(b, TVec(self.w0), self.t0, self.r1)        # P^T (w0 b - K~_local x1), never written out
+            if not self.lo_resid:
+                self.ops.mg_restrict_diff(b, TVec(self.w0), self.t0, self.r1)        # P^T (w0 b - K~_local x1), never written out
             self._coarse(None, restricted=True)
             self.ops.mg_prolong_add(self.x1, self.d0, self.x2)
             if be.split:       # boundary groups first, interior groups beside the messages (as DistBackend.spmv)
@@ -1724,6 +1735,11 @@ class HipLocalOps:
     def spmv_dot_part(self, x, y, out, part):
         from ._lib import call
         call("fcvm_spmv_dot_part", self.c.h, x.ptr, y.ptr, out.data_ptr(), int(part))
+
+    def spmv_lo_resid(self, x, r, w, out):
+        """out = w r - K~_local x (16-bit copy): the smoother pass with the weighted residual as epilogue"""
+        from ._lib import call
+        call("fcvm_spmv_lo_resid", self.c.h, x.ptr, r.ptr, w.ptr, out.ptr)
 
     def spmv_lo_part(self, x, y, part):
         from ._lib import call

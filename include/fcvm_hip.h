@@ -307,6 +307,9 @@ int fcvm_set_group_map(fcvm_ctx *c, int mode);
 int fcvm_set_interface_nodes(fcvm_ctx *c, int64_t n, const int64_t *nodes, int64_t out[2]);
 int fcvm_spmv_dot_part(fcvm_ctx *c, const double *x, double *y, double *xy_dev, int part);
 int fcvm_spmv_lo_part(fcvm_ctx *c, const double *x, double *y, int part);
+/* out = w r - K~_local x on the 16-bit copy (w per dof): the residual after the pre-smoothing step of the multi-GPU cycle formed by the smoother pass itself,
+ * the rank's product left unsummed for the restriction (fcvm_mg_restrict) whose level-1 exchange completes the sum */
+int fcvm_spmv_lo_resid(fcvm_ctx *c, const double *x, const double *r, const double *w, double *out);
 /* Multi-GPU layer, level 1 of the cycle on the library's current kernels (round 5): fcvm_mg_l1_pass = one Chebyshev pass on this rank's 16-bit
  * copy of the tet4 matrix with the smoother step as epilogue (t = A1_local din (+ t2); r -= t; x += din; dout = cdd din + cdr Dinv r; x += dout
  * if add_dout) for every row except those of nodes flagged in defer (u8 per level-1 node: held by another rank too) -- their raw product goes to
