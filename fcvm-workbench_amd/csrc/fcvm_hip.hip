@@ -689,6 +689,53 @@ static int wsym_asm_setup(fcvm_ctx *c) {
         nt = std::min(std::max(nt, 1), 32);
         std::vector<std::vector<int32_t>> part(nt * WinSymDev::ASM_BUCKETS);      // per thread (= contiguous range of groups) and class
         std::vector<char> bad(nt, 0);
+        // Round 5 experiment (FCVM_ASM_ITEMS=octet; NOT the default: slower, see below): a work item = whole OCTETS of consecutive lanes of a wave -- the eight lanes whose 16-byte stores
+        // fill one 128-byte line of every value plane of a block row, so a finished item leaves whole lines (rounds 3-4: rows picked by kept length from
+        // all over the group, every store a lone 16 bytes of a line that seven other items complete some time later: 4.02 GB written for 2.83).  The
+        // lanes of a group are sorted by segment length with the kinds clustered (build_window_sym), so an octet's rows are of one kept-length class
+        // but for the seams; octets of later segments alone hold nothing to assemble.  Measured on the 1 M plate (profiles/r05_assembly_items.txt): whole
+        // lines are written (WRITE_SIZE falls), but calc_gsm takes 6.45 / 10.34 ms (elastic / tangent) with the lane order by wave and 7.73 / 12.19 with the
+        // order inside a length, against 5.76 / 9.28 for the items of rounds 3-4 -- seam octets put short rows into the long-row classes (one octet
+        // = one item of eight lanes per row there), and the kernel is bound by its dependent chain per element visit, not by its writes.
+        const bool octets = getenv("FCVM_ASM_ITEMS") && std::string(getenv("FCVM_ASM_ITEMS")) == "octet";
+        if (octets)
+        parallel_for(w.ngroups, nt, [&](int64_t gb, int64_t ge, int t) {
+            std::vector<int32_t> oct[WinSymDev::ASM_BUCKETS];      // per class: the group's octets, eight lane positions each (-1: nothing to assemble)
+            for (int64_t g = gb; g < ge; g++) {
+                for (int b = 0; b < WinSymDev::ASM_BUCKETS; b++) oct[b].clear();
+                for (int64_t at0 = g * R; at0 < (g + 1) * R; at0 += 8) {
+                    int m = 0;
+                    for (int l = 0; l < 8; l++) {
+                        const int64_t at = at0 + l;
+                        if (w.rownode[at] >= 0 && (w.seg[at] & 255u) > 0) m = std::max<int>(m, w.rowtot[at]);
+                    }
+                    if (m == 0) continue;
+                    if (m > ASM_SYM_LIMIT[WinSymDev::ASM_BUCKETS - 1]) { bad[t] = 1; return; }
+                    int b = 0;
+                    while (m > ASM_SYM_LIMIT[b]) b++;
+                    for (int l = 0; l < 8; l++) {
+                        const int64_t at = at0 + l;
+                        oct[b].push_back(w.rownode[at] >= 0 && (w.seg[at] & 255u) > 0 ? (int32_t)at : -1);
+                    }
+                }
+                for (int b = 0; b < WinSymDev::ASM_BUCKETS; b++) {
+                    const int RW = d.asm_rows[b];
+                    std::vector<int32_t> &dst = part[t * WinSymDev::ASM_BUCKETS + b];
+                    const size_t n = oct[b].size();
+                    for (size_t k = 0; k < n; k += RW) {    // (RW = 16: two octets per item, 8: one, 4: half an octet)
+                        const size_t first = dst.size();
+                        for (int l = 0; l < RW; l++) dst.push_back(k + l < n ? oct[b][k + l] : -1);
+                        // the kernel reads the item's group from its FIRST row: a row there (the order of an item's rows is free); an item
+                        // without any row (half an octet of later segments) goes
+                        size_t v = first;
+                        while (v < dst.size() && dst[v] < 0) v++;
+                        if (v == dst.size()) dst.resize(first);
+                        else std::swap(dst[first], dst[v]);
+                    }
+                }
+            }
+        }, 16);
+        else
         parallel_for(w.ngroups, nt, [&](int64_t gb, int64_t ge, int t) {
             std::vector<int32_t> rows;
             for (int64_t g = gb; g < ge; g++) {

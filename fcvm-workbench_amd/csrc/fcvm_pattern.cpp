@@ -537,7 +537,24 @@ bool build_window_sym(const Pattern &p, const WinPattern &w, int nthreads, WinSy
             // sorted over the whole group (uniform lengths inside a wave).  Sorting inside each wave only would keep a wave's rows
             // on one or two sliced-ELL slices and the copy kernel at 2.6 instead of 3.3 ms per assembly, but the 16-bit passes
             // lose 4 % to the ragged block rows (gpurun_out/r03bi, r03bj): the passes run 80 times per Newton iteration
-            std::stable_sort(rows.begin(), rows.end(), [](const VRow &x, const VRow &y) { return x.len > y.len; });
+            // Round 5 experiment (FCVM_SYM_CLUSTER_CUT=1): inside one length the uncut rows come first, then the first segments of cut rows, then their later segments (the kernels
+            // need the lengths descending, nothing more): runs of eight consecutive lanes -- one 128-byte line of every value plane -- then hold
+            // rows of ONE kind, which is what lets the assembly's work items be made of whole lane octets (wsym_asm_setup).  FCVM_SYM_CLUSTER_CUT=0:
+            // the order of rounds 3-4 (cut segments where the full format's lane order left them).
+            // mode 2: the kinds are dealt to the group's waves one after the other (uncut rows, first segments, later segments; lengths descending
+            // inside a kind) and only THEN every wave is sorted by length (the prefix layout wants that per wave, not per group): all but two waves
+            // of a group hold one kind.
+            // Default 0 (rounds 3-4): mode 1 changes no time, mode 2 costs the SpMV 3.5 % (ragged block rows in the seam waves) -- profiles/r05_assembly_items.txt.
+            static const int cluster_cut = getenv("FCVM_SYM_CLUSTER_CUT") ? atoi(getenv("FCVM_SYM_CLUSTER_CUT")) : 0;
+            auto kind = [](const VRow &r) { return (r.seg & 255u) == 1u ? 0 : (r.tt == 0 ? 1 : 2); };
+            if (cluster_cut == 2) {
+                std::stable_sort(rows.begin(), rows.end(), [&](const VRow &x, const VRow &y) { return kind(x) < kind(y) || (kind(x) == kind(y) && x.len > y.len); });
+                for (size_t k0 = 0; k0 < rows.size(); k0 += SLICE)
+                    std::stable_sort(rows.begin() + k0, rows.begin() + std::min(rows.size(), k0 + (size_t)SLICE), [](const VRow &x, const VRow &y) { return x.len > y.len; });
+            } else if (cluster_cut)
+                std::stable_sort(rows.begin(), rows.end(), [&](const VRow &x, const VRow &y) { return x.len > y.len || (x.len == y.len && kind(x) < kind(y)); });
+            else
+                std::stable_sort(rows.begin(), rows.end(), [](const VRow &x, const VRow &y) { return x.len > y.len; });
             chain.clear();
             for (size_t k = 0; k < rows.size(); k++) {
                 const int64_t wave = g * WV + (int64_t)k / SLICE, at = wave * SLICE + (int64_t)k % SLICE;
