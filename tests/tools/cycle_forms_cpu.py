@@ -147,6 +147,15 @@ def main(h):
         def pre(r, z): return unperm(Fw.solve(r[perm]))
         def post(r, z): return z + unperm(Bw.solve((r - K @ z)[perm]))
         return pre, post
+    if os.environ.get("CYCLE_FORMS_COLOURS"):
+        # round 5: Gauss-Seidel BETWEEN colours of whole groups (group = 512 consecutive Morton nodes = a workgroup of the window format; colour = group
+        # number mod ncol), damped Jacobi inside a colour: on the GPU ncol launches of the 16-bit pass over the colour's group list per smoothing step
+        # (the same matrix bytes as one pass), no dependency inside a launch
+        for ncol in (2, 4):
+            for damp in (c0 * lmax / lmax, 0.65, 0.8, 1.0):
+                grp_colour = (np.arange(nn) // 512) % ncol
+                pre, post = gs_pair(grp_colour, damp)
+                variants.append(("group-colour GS, %d colours of 512-node groups, damping %.2f" % (ncol, damp), make_mult(pre, post)))
     if os.environ.get("CYCLE_FORMS_HYBRID"):
         for nclass in (2, 4, 8):
             for damp in (0.8, 0.7):
