@@ -104,6 +104,7 @@ struct L2sDev {   // device state of the sparse aggregate level (owned by fcvm_c
     float *blocks = nullptr, *A3invf = nullptr;
     double *dinv = nullptr, *C = nullptr;
     double *x = nullptr, *r = nullptr, *d = nullptr, *t = nullptr, *r3 = nullptr, *e3 = nullptr;
+    double *symv_part3 = nullptr;   // [nt3][nt3][128] partial results of k_symv_tiles on the super-aggregate inverse (null: k_gemv_f32x4 streams the whole of it)
 };
 
 // Work vectors of the multigrid PCG for a second right-hand side (fcvm_solve2): the cycle's code works on the context's own
@@ -114,6 +115,7 @@ struct MgAlt {
     double *r = nullptr, *z = nullptr, *p = nullptr, *q = nullptr, *S = nullptr, *part_vec = nullptr, *part_spmv = nullptr, *part_lo = nullptr;
     double *md = nullptr, *mr = nullptr, *mt = nullptr, *x1 = nullptr, *rr1 = nullptr, *d1 = nullptr, *t1 = nullptr, *r2 = nullptr, *e2 = nullptr;
     double *sx = nullptr, *sr = nullptr, *sd = nullptr, *st = nullptr, *sr3 = nullptr, *se3 = nullptr;   // sparse aggregate level
+    double *spart3 = nullptr;      // ... and its own partial buffer of the super-aggregate level's k_symv_tiles
     double *symv_part = nullptr;   // its own partial buffer of k_symv_tiles: the two coarse parts of a pair run side by side
     bool symv = false;
 };
@@ -1389,7 +1391,7 @@ static void alt_free(fcvm_ctx *c) {
     MgAlt &a = c->alt;
     dfree(a.r); dfree(a.z); dfree(a.p); dfree(a.q); dfree(a.S); dfree(a.part_vec); dfree(a.part_spmv); dfree(a.part_lo);
     dfree(a.md); dfree(a.mr); dfree(a.mt); dfree(a.x1); dfree(a.rr1); dfree(a.d1); dfree(a.t1); dfree(a.r2); dfree(a.e2);
-    dfree(a.sx); dfree(a.sr); dfree(a.sd); dfree(a.st); dfree(a.sr3); dfree(a.se3); dfree(a.symv_part);
+    dfree(a.sx); dfree(a.sr); dfree(a.sd); dfree(a.st); dfree(a.sr3); dfree(a.se3); dfree(a.symv_part); dfree(a.spart3);
     a = MgAlt();
 }
 

@@ -515,7 +515,8 @@ def test_sparse_aggregate_level_solves_like_the_dense_one(monkeypatch):
     from fcvm_hip.solver import GpuModel
     case = examples.embankment(refine=2)
     res = {}
-    for name, env in (("dense", {}), ("sparse", {"FCVM_MG_MAX_AGGREGATES": "40"})):
+    for name, env in (("dense", {}), ("sparse", {"FCVM_MG_MAX_AGGREGATES": "40"}),
+                      ("sparse, symmetric product", {"FCVM_MG_MAX_AGGREGATES": "40", "FCVM_L2S_SYMV_MIN": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         m = GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"], Loads(), ctx=Context(0))
@@ -536,6 +537,11 @@ def test_sparse_aggregate_level_solves_like_the_dense_one(monkeypatch):
     assert 0 < sp["l3_unknowns"] <= 6 * sp["l3_super_aggregates"]
     assert rel(res["sparse"][0], res["dense"][0]) < 1e-8
     assert res["sparse"][1] <= 1.15 * res["dense"][1] + 5, (res["sparse"][1], res["dense"][1])
+    # the inverse of the super-aggregate level applied from its lower triangle (what levels of 2048 unknowns and more get): the same
+    # preconditioner up to the order of the sums
+    sy = res["sparse, symmetric product"]
+    assert sy[2]["l2_sparse"] and sy[2]["l3_unknowns"] == sp["l3_unknowns"]
+    assert rel(sy[0], res["dense"][0]) < 1e-8 and abs(sy[1] - res["sparse"][1]) <= 2, (sy[1], res["sparse"][1])
 
 
 @pytest.mark.parametrize("mesh", ["plate", "embankment", "cube"])
