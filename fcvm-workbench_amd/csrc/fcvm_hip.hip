@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <functional>
 #include <string>
 #include <thread>
 #include <memory>
@@ -20,6 +21,7 @@
 #include "fcvm_assemble_lds.hip.h"
 #include "fcvm_dense.hip.h"
 #include "fcvm_l2s_kernels.hip.h"
+#include "fcvm_patch_kernels.hip.h"
 #include "fcvm_pattern.h"
 
 using namespace fcvm;
@@ -109,6 +111,23 @@ struct L2sDev {   // device state of the sparse aggregate level (owned by fcvm_c
 
 // Work vectors of the multigrid PCG for a second right-hand side (fcvm_solve2): the cycle's code works on the context's own
 // pointers, so the second state is brought in by swapping pointers between launches (kernel arguments are taken at launch).
+// vertex-patch smoother of the fine level (fcvm_patch_kernels.hip.h, fcvm_patch.inc)
+struct PatchDev {
+    bool on = false;       // tables built for this mesh (FCVM_MG_PATCH, patch sizes within the LDS)
+    bool valid = false;    // the inverses belong to the matrix of the last assembly
+    int64_t npatch = 0, nslots = 0, tri_total = 0, full_total = 0;
+    int maxn = 0, maxtri4 = 0, wpb = 4;
+    size_t lds_apply = 0, lds_invert = 0;
+    uint16_t *posa = nullptr, *posb = nullptr;
+    int64_t *poff = nullptr, *toff = nullptr;
+    float *inv = nullptr;      // packed lower triangles of the patch inverses, FP32
+    double *y = nullptr;       // patch-major result of k_patch_apply: 3 doubles per node slot
+    int *fail = nullptr;
+    double lmax = 0.0;         // largest eigenvalue of S K (Lanczos, once per mesh)
+    int64_t refreshes = 0;
+    double last_refresh_ms = 0.0;
+};
+
 struct MgAlt {
     bool ready = false;
     int64_t nn = 0, nc = 0, n2 = 0, nagg2 = 0, n3 = 0, ngroups = 0;
@@ -116,6 +135,7 @@ struct MgAlt {
     double *md = nullptr, *mr = nullptr, *mt = nullptr, *x1 = nullptr, *rr1 = nullptr, *d1 = nullptr, *t1 = nullptr, *r2 = nullptr, *e2 = nullptr;
     double *sx = nullptr, *sr = nullptr, *sd = nullptr, *st = nullptr, *sr3 = nullptr, *se3 = nullptr;   // sparse aggregate level
     double *spart3 = nullptr;      // ... and its own partial buffer of the super-aggregate level's k_symv_tiles
+    double *py = nullptr;          // ... and of the patch smoother's patch-major result vector
     double *symv_part = nullptr;   // its own partial buffer of k_symv_tiles: the two coarse parts of a pair run side by side
     bool symv = false;
 };
@@ -127,6 +147,7 @@ struct TopoHost {
     int64_t nc = 0;
     std::vector<int32_t> c2f, el4, pa, pb, mids;
     std::vector<int64_t> mptr;
+    std::vector<uint16_t> posa, posb;   // position of a mid-side node in the vertex patches of pa / pb (1 + its index in mids of that corner)
     Pattern pat1;
 };
 
@@ -207,6 +228,12 @@ struct fcvm_ctx {
     bool sell_valid = false;    // d_vals holds the matrix of the last assembly (false after an assembly straight into the symmetric form)
     bool wsym_pending = false;  // the symmetric form's host build may still be running; its device half is done by wsym_finish
     bool sym_pair = true;       // two right-hand sides share one pass over the symmetric form (FCVM_SYM_PAIR=0: the one-vector kernels twice)
+    bool mg_patch = false;         // FCVM_MG_PATCH=1: vertex-patch smoother on the fine level in the place of the block-Jacobi step (needs cycle form 2 on the symmetric window
+                                   // form).  Off: on the 1 M plate it brings 46 -> 44 PCG iterations at 1.13 -> 1.68 ms per iteration -- the aggregate-based coarse solve, not the
+                                   // fine smoother, is what bounds the cycle there (profiles/r05_patch_smoother.txt)
+    PatchDev patch;
+    std::vector<uint16_t> h_posa, h_posb;
+    std::vector<int64_t> h_mptr;
     bool mg_fuse_prolong = false;  // FCVM_MG_FUSE_PROLONG=1: x + P e1 formed while the post-smoothing pass stages x instead of by k_prolong_add
                                    // (measured: 212 us against 177 + 29 -- every window node is staged by 2.9 groups -- so off)
     int spmv_win = 1, win_v2 = 1;   // win_v2: value components in 16-byte pairs (FCVM_WIN_V2=0: nine 8-byte runs)
@@ -404,9 +431,11 @@ static void launch_gemv_f32(fcvm_ctx *c, const double *r2, double *e2, const dou
         hipLaunchKernelGGL(k_symv_tiles, dim3((unsigned)(nt * (nt + 1) / 2)), dim3(256), 0, c->stream, nt, c->n2, lda, c->d_A2invf, r2,
                            c->d_symv_part, done);
         hipLaunchKernelGGL(k_symv_reduce, dim3((unsigned)nt), dim3(2 * SYMV_T), 0, c->stream, nt, c->n2, c->d_symv_part, e2, done);
-        return;
+    } else {
+        hipLaunchKernelGGL(k_gemv_f32x4, dim3((unsigned)cdiv(c->n2, 16)), dim3(256), 0, c->stream, c->n2, c->n2, lda, c->d_A2invf, r2, e2, done);
     }
-    hipLaunchKernelGGL(k_gemv_f32x4, dim3((unsigned)cdiv(c->n2, 16)), dim3(256), 0, c->stream, c->n2, c->n2, lda, c->d_A2invf, r2, e2, done);
+    static const double over = getenv("FCVM_MG_L2_SCALE") ? atof(getenv("FCVM_MG_L2_SCALE")) : 1.0;   // (experiment: over-correction of the unsmoothed aggregation)
+    if (over != 1.0) hipLaunchKernelGGL(k_axpby, dim3((unsigned)cdiv(c->n2, 256)), dim3(256), 0, c->stream, c->n2, over, e2, 0.0, e2, e2);
 }
 // (re)allocates the partial buffer of k_symv_tiles for the current n2, or drops it: small levels (the row kernel is launch-bound
 // there anyway) and FCVM_L2_SYMV=0
@@ -567,6 +596,7 @@ static inline bool mg_fuse_prolong(const fcvm_ctx *c) { return c->wsym.on && c->
 static inline bool mg_use_lo(const fcvm_ctx *c) { return c->mg_additive == 2 && c->win.on && (c->win.lo_valid || (c->wsym.on && c->wsym.lo_valid)); }
 // the form that runs: 2 without the window format (tiny meshes, windows beyond the LDS) becomes the additive form -- the FP64
 // multiplicative form would stream the sliced-ELL matrix three times per iteration there
+static inline bool mg_use_patch(const fcvm_ctx *c) { return mg_use_lo(c) && c->mg_patch && c->patch.on && c->patch.valid && c->wsym.on && c->wsym.lo_valid; }
 static inline int mg_form(const fcvm_ctx *c) { return c->mg_additive == 2 ? (mg_use_lo(c) ? 2 : 1) : c->mg_additive; }
 
 static int dot_common(fcvm_ctx *c, int64_t n, const double *w, const double *x, const double *y, double *result_dev) {
@@ -578,7 +608,15 @@ static int dot_common(fcvm_ctx *c, int64_t n, const double *w, const double *x, 
     return 0;
 }
 static void alt_free(fcvm_ctx *c);
+static void patch_free(fcvm_ctx *c);
+static int patch_build_tables(fcvm_ctx *c);
+static int patch_refresh(fcvm_ctx *c);
+static void patch_apply(fcvm_ctx *c, const double *x, double *y);
+static void patch_smooth_from_zero(fcvm_ctx *c, const double *x, double w, double *out);
+static void patch_smooth_post(fcvm_ctx *c, const double *t, double w, const double *x, const double *r, double *out, double *part, int64_t nb);
+static double mg_patch_weight(const fcvm_ctx *c);
 #include "fcvm_mg.inc"
+#include "fcvm_patch.inc"
 
 static void wsym_free(WinSymDev &w) {
     dfree(w.woff); dfree(w.rownode); dfree(w.srcslot); dfree(w.gextra); dfree(w.seg); dfree(w.cols); dfree(w.rowlen); dfree(w.own);
@@ -1366,6 +1404,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_WIN_SYM_LO")) c->wsym_lo = atoi(v) != 0;
     if (const char *v = getenv("FCVM_SYM_GRADING_MAX")) c->grading_max = atof(v) > 1.0 ? atof(v) : c->grading_max;
     if (const char *v = getenv("FCVM_MG_FUSE_PROLONG")) c->mg_fuse_prolong = atoi(v) != 0;
+    if (const char *v = getenv("FCVM_MG_PATCH")) c->mg_patch = atoi(v) != 0;
     if (const char *v = getenv("FCVM_SYM_PAIR")) c->sym_pair = atoi(v) != 0;
     if (const char *v = getenv("FCVM_PAIR_OVERLAP")) c->pair_overlap = atoi(v) != 0;
     if (const char *v = getenv("FCVM_PCG_EVENTS")) c->pcg_events = atoi(v) != 0;
@@ -1391,7 +1430,7 @@ static void alt_free(fcvm_ctx *c) {
     MgAlt &a = c->alt;
     dfree(a.r); dfree(a.z); dfree(a.p); dfree(a.q); dfree(a.S); dfree(a.part_vec); dfree(a.part_spmv); dfree(a.part_lo);
     dfree(a.md); dfree(a.mr); dfree(a.mt); dfree(a.x1); dfree(a.rr1); dfree(a.d1); dfree(a.t1); dfree(a.r2); dfree(a.e2);
-    dfree(a.sx); dfree(a.sr); dfree(a.sd); dfree(a.st); dfree(a.sr3); dfree(a.se3); dfree(a.symv_part); dfree(a.spart3);
+    dfree(a.sx); dfree(a.sr); dfree(a.sd); dfree(a.st); dfree(a.sr3); dfree(a.se3); dfree(a.symv_part); dfree(a.spart3); dfree(a.py);
     a = MgAlt();
 }
 
@@ -2266,6 +2305,26 @@ int fcvm_precond_info(fcvm_ctx *c, double out[8]) {
     out[0] = c->precond_mode; out[1] = (double)c->nc; out[2] = c->mg_lmax0; out[3] = c->mg_lmax1;
     out[4] = c->mg_topo ? (double)c->pat1.nnzb : 0.0; out[5] = (double)c->mg_spmv0;
     out[6] = c->l2 ? (double)c->nagg : 0.0; out[7] = c->l2 ? (double)c->n2 : 0.0;
+    return 0;
+}
+
+/* vertex-patch smoother of the fine level (round 5; no reference counterpart -- the reference factorises): out[0] = tables built for this
+ * mesh, out[1] = inverses valid for the last assembly (the cycle uses them), out[2] = patches, out[3] = largest patch [unknowns],
+ * out[4] = mean patch [unknowns], out[5] = bytes of the FP32 inverses, out[6] = largest eigenvalue of S K, out[7] = ms of the last refresh */
+int fcvm_patch_info(fcvm_ctx *c, double out[8]) {
+    NEED(c && out, "fcvm_patch_info: bad arguments");
+    const PatchDev &P = c->patch;
+    out[0] = P.on ? 1.0 : 0.0; out[1] = mg_use_patch(c) ? 1.0 : 0.0; out[2] = (double)P.npatch; out[3] = (double)P.maxn;
+    out[4] = P.npatch > 0 ? 3.0 * (double)P.nslots / (double)P.npatch : 0.0; out[5] = 4.0 * (double)P.tri_total; out[6] = P.lmax; out[7] = P.last_refresh_ms;
+    return 0;
+}
+/* test hook: out = S x, the undamped additive Schwarz smoother over the vertex patches of the last assembly (device vectors of 3 nn) */
+int fcvm_debug_patch_apply(fcvm_ctx *c, const double *x, double *out) {
+    NEED(c && c->have_mesh && x && out, "fcvm_debug_patch_apply: bad arguments");
+    NEED(c->patch.on && c->patch.valid, "fcvm_debug_patch_apply: no vertex-patch smoother on this context");
+    c->mg_done = nullptr;
+    patch_smooth_from_zero(c, x, 1.0, out);
+    HCHK(hipGetLastError());
     return 0;
 }
 

@@ -67,6 +67,8 @@ SIGNATURES = {
     "fcvm_set_group_map": [_vp, _int],
     "fcvm_debug_pcg_vectors": [_vp, _vp],
     "fcvm_placement_info": [_vp, _pf64],
+    "fcvm_patch_info": [_vp, _pf64],
+    "fcvm_debug_patch_apply": [_vp, _vp, _vp],
     "fcvm_scatter_add_nodes": [_vp, _i64, _vp, _int, _vp, _vp],
     "fcvm_mg_l1_pass": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _int, _int],
     "fcvm_mg_l1_spmv": [_vp, _vp, _vp],

@@ -203,6 +203,18 @@ class Context:
         call("fcvm_placement_info", self.h, o)
         return dict(tuned=bool(o[0]), result_vector_ms=(o[1], o[2]), value_array_ms=(o[3], o[4]), spent_ms=o[5])
 
+    def patch_info(self):
+        """the vertex-patch smoother of the fine multigrid level (fcvm_patch_info)"""
+        o = (C.c_double * 8)()
+        call("fcvm_patch_info", self.h, o)
+        return dict(built=bool(o[0]), in_use=bool(o[1]), patches=int(o[2]), largest=int(o[3]), mean=o[4], bytes=int(o[5]), lmax=o[6], refresh_ms=o[7])
+
+    def patch_apply(self, x, out=None):
+        """out = S x: the undamped vertex-patch smoother of the last assembly (test hook)"""
+        out = self.empty(x.n) if out is None else out
+        call("fcvm_debug_patch_apply", self.h, x.ptr, out.ptr)
+        return out
+
     def matrix_coo(self):
         nnz = 9 * self.pattern_info()["nnz_blocks"]
         r, c, v = np.empty(nnz, np.int64), np.empty(nnz, np.int64), np.empty(nnz, np.float64)
@@ -319,6 +331,7 @@ class Context:
         call("fcvm_get_mg_cycle", self.h, C.byref(form), C.byref(wgt), C.byref(lo))
         # the form that runs (2 needs the 16-bit copy, i.e. the window format; without it the additive form stands in)
         d["cycle_form"], d["cycle_weight"] = form.value, wgt.value
+        d["patch_smoother"] = self.patch_info()["in_use"]
         sp = (C.c_int64 * 4)()
         call("fcvm_mg_sparse_info", self.h, sp)
         d["l2_sparse"], d["l3_super_aggregates"], d["l3_unknowns"] = bool(sp[0]), int(sp[2]), int(sp[3])

@@ -331,6 +331,16 @@ int fcvm_scatter_add_nodes(fcvm_ctx *c, int64_t n, const int64_t *idx, int ncomp
  * FCVM_TUNE_PLACEMENT - 1 (default 2) fresh allocations on the assembled matrix and the fastest is kept.  out[0] = 1 if it ran, out[1] / out[2] = SpMV time [ms] with the result vector first allocated / kept, out[3] / out[4] = with the value
  * array first allocated / kept, out[5] = milliseconds the tuning took. */
 int fcvm_placement_info(fcvm_ctx *c, double out[6]);
+/* Vertex-patch smoother of the fine multigrid level (round 5; no reference counterpart -- the reference factorises with CHOLMOD,
+ * fcVM.py:1121-1135): additive Schwarz over the patches "corner node + mid-side nodes of its edges" in the place of the damped
+ * block-Jacobi step of cycle form 2; patch matrices cut out of the assembled symmetric window form after every assembly, inverted on
+ * the device, kept as FP32 triangles.  Off by default (FCVM_MG_PATCH=1 switches it on): with the library's aggregate-based coarse solve it
+ * does not pay on large meshes (profiles/r05_patch_smoother.txt).  out[0] = tables built for this mesh, out[1] = the cycle uses
+ * it (inverses valid for the last assembly), out[2] = patches, out[3] = largest patch [unknowns], out[4] = mean patch [unknowns],
+ * out[5] = bytes of the inverses, out[6] = largest eigenvalue of S K (Lanczos), out[7] = milliseconds of the last refresh */
+int fcvm_patch_info(fcvm_ctx *c, double out[8]);
+/* test hook: out = S x (undamped) on device vectors of 3 nn doubles */
+int fcvm_debug_patch_apply(fcvm_ctx *c, const double *x, double *out);
 /* experiment hook: device addresses of the PCG's own vectors r, z, p, q and of its SpMV's partial buffer (placement studies) */
 int fcvm_debug_pcg_vectors(fcvm_ctx *c, uint64_t out[5]);
 
