@@ -320,6 +320,10 @@ static int device_lds_cap(int device) {
 template <class T>
 static int dalloc(T **p, int64_t n) {
     HCHK(hipMalloc((void **)p, (size_t)std::max<int64_t>(n, 1) * sizeof(T)));
+    // FCVM_POISON=1 (debugging): every fresh allocation filled with 0xFF bytes (NaN as a double, -1 as an index) -- a read of memory nothing
+    // wrote, which a fresh process hides behind zero pages, shows at once
+    static const bool poison = getenv("FCVM_POISON") && atoi(getenv("FCVM_POISON")) != 0;
+    if (poison) HCHK(hipMemset((void *)*p, 0xFF, (size_t)std::max<int64_t>(n, 1) * sizeof(T)));
     return 0;
 }
 template <class T>
@@ -1503,6 +1507,7 @@ int fcvm_set_stream(fcvm_ctx *c, void *s, int external) {
 int fcvm_malloc(fcvm_ctx *c, uint64_t bytes, void **dev) {
     HCHK(hipSetDevice(c->device));
     HCHK(hipMalloc(dev, bytes ? bytes : 8));
+    if (getenv("FCVM_POISON") && atoi(getenv("FCVM_POISON")) != 0) HCHK(hipMemset(*dev, 0xFF, bytes ? bytes : 8));   // (see dalloc)
     return 0;
 }
 int fcvm_free(fcvm_ctx *c, void *dev) {

@@ -1615,8 +1615,10 @@ def test_vertex_patch_smoother_is_the_additive_schwarz_operator_and_cuts_the_ite
     ld = Loads(ufaces=case["ufaces"], uloads=case["uloads"]) if name == "plate" else Loads()
     grav = (0.0, 0.0, 0.0) if name == "plate" else (0.0, 0.0, -10.0)
     res = {}
+    monkeypatch.setenv("FCVM_VERBOSE", "1")     # (what the library says about the patches goes into the report of a failure)
     for mode in ("patch", "jacobi"):
         monkeypatch.setenv("FCVM_MG_PATCH", "1" if mode == "patch" else "0")
+        print("leg:", mode, flush=True)
         m = GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"], ld, ctx=Context(0))
         c = m.ctx
         glv, modf, _, _ = m.calc_gsm(grav, want_x=False)
