@@ -613,6 +613,7 @@ static int dot_common(fcvm_ctx *c, int64_t n, const double *w, const double *x, 
 }
 static void alt_free(fcvm_ctx *c);
 static void patch_free(fcvm_ctx *c);
+static int win_join(fcvm_ctx *c);
 static int patch_build_tables(fcvm_ctx *c);
 static int patch_refresh(fcvm_ctx *c);
 static void patch_apply(fcvm_ctx *c, const double *x, double *y);
