@@ -216,8 +216,8 @@ def run(args, ctl, material, traction, rtol, hbm_peak):
                 "roofline": {"bound": "hbm", "kernel": "k_spmv_win_sym<true> on rank 0's matrix (%d elements), launches inside the PCG of the timed "
                                                        "region" % model.ne,
                              "achieved": achieved, "peak": hbm_peak, "unit": "GB/s", "frac": achieved / hbm_peak, "traffic": None,
-                             "traffic_note": "no PMC pass over a rank's partition; the same kernel and layout on the N = 1 workload move 1.027 x "
-                                             "their algorithmic bytes (profiles/r04_plate_spmv_sym_traffic_pmc.txt)",
+                             "traffic_note": "no PMC pass over a rank's partition; the same kernel and layout on the N = 1 workload move 1.039 x "
+                                             "their algorithmic bytes (profiles/r05_plate_spmv_sym_traffic_pmc.txt)",
                              "algorithmic_bytes_per_launch": alg, "avg_launch_ms": avg_ms, "launches_timed": launches,
                              "back_to_back_launch_ms": standalone_ms},
                 # HIP memory in use on rank 0's device at the end (all ranks' when they share the GPU in a rehearsal) / the peak torch saw
