@@ -584,7 +584,10 @@ __global__ __launch_bounds__(256) void k_gemv_f32x4(int64_t m, int64_t n, int64_
         v4f v[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) v[r] = __builtin_nontemporal_load(a[r] + (j >> 2));
-        const double x0 = x[j], x1 = j + 1 < n ? x[j + 1] : 0.0, x2 = j + 2 < n ? x[j + 2] : 0.0, x3 = j + 3 < n ? x[j + 3] : 0.0;
+        // (every x is guarded: lda is a multiple of 32 since round 3, so j runs up to 31 entries past n -- the padding of A is zero there, but
+        // 0 x whatever lies behind the vector is NaN when that happens to be a NaN or an infinity: found in round 5 as a solve that broke down
+        // only late in long test runs, on recycled device memory)
+        const double x0 = j < n ? x[j] : 0.0, x1 = j + 1 < n ? x[j + 1] : 0.0, x2 = j + 2 < n ? x[j + 2] : 0.0, x3 = j + 3 < n ? x[j + 3] : 0.0;
 #pragma unroll
         for (int r = 0; r < 4; r++) acc[r] += (double)v[r].x * x0 + (double)v[r].y * x1 + (double)v[r].z * x2 + (double)v[r].w * x3;
     }

@@ -1642,10 +1642,50 @@ def test_vertex_patch_smoother_is_the_additive_schwarz_operator_and_cuts_the_ite
             a, b = c.dot(xd, My), c.dot(yd, Mx)
             # (symmetric up to the FP32 roundings of the 16-bit passes' staged vectors)
             assert c.dot(xd, Mx) > 0.0 and c.dot(yd, My) > 0.0 and abs(a - b) <= 1e-6 * np.sqrt(c.dot(xd, Mx) * c.dot(yd, My))
-        u, info = c.solve(f, rtol=1e-10)
+        print("before the solve:", c.precond_info(), c.spmv_sym_info(), "norm f", c.norm(f), flush=True)
+        try:
+            u, info = c.solve(f, rtol=1e-10)
+        except Exception:
+            # (round 5: this solve failed inside whole-suite runs only -- say where the first non-finite number is)
+            def bad(v):
+                a = v.get()
+                return "%d of %d entries not finite, first at %s" % ((~np.isfinite(a)).sum(), a.size, np.where(~np.isfinite(a))[0][:5])
+            print("f:", bad(f), "| K f:", bad(c.spmv(f, c.empty(m.ndof))), "| K~ f:", bad(c.spmv_lo(f, c.empty(m.ndof))),
+                  "| M^-1 f:", bad(c.mg_apply(f, c.empty(m.ndof))), "| diagonal blocks:", bad(c.get_diag_blocks()), flush=True)
+            for it in (1, 2, 3, 5, 8):
+                try:
+                    u2, i2 = c.solve(f, rtol=1e-10, maxit=it)
+                except Exception as e:
+                    print("maxit", it, "->", str(e)[-160:], flush=True)
+            raise
         r = c.axpby(1.0, f, -1.0, c.spmv(u, c.empty(m.ndof)))
         assert c.norm(r) <= 5e-10 * c.norm(f)
         res[mode] = (u.get(), info["iterations"])
         c.close()
     assert rel(res["patch"][0], res["jacobi"][0]) < 1e-7
     assert res["patch"][1] <= 0.9 * res["jacobi"][1], (res["patch"][1], res["jacobi"][1])
+
+
+def test_dense_inverse_product_does_not_read_behind_its_vector():
+    """Round 5 bug: k_gemv_f32x4 (the aggregate level's product where the level has fewer than 2048 unknowns) multiplied the zero padding of
+    its rows (lda = a multiple of 32 since round 3) with whatever lay BEHIND the vector -- 0 x NaN = NaN, a solve that broke down only on
+    recycled device memory late in long runs.  Here: the vector is the head of a longer buffer whose tail is NaN and infinity."""
+    import ctypes as C
+    from fcvm_hip._lib import call
+    from fcvm_hip.device import Context
+    c = Context(0)
+    rng = np.random.default_rng(11)
+    for n in (385, 7, 64, 100):
+        lda = (n + 31) // 32 * 32
+        A = np.zeros((n, lda), np.float32)
+        A[:, :n] = rng.standard_normal((n, n)).astype(np.float32)
+        xb = np.full(n + 40, np.nan)
+        xb[n + 1::2] = np.inf
+        xb[:n] = rng.standard_normal(n)
+        dA = c.array(A.view(np.float32).reshape(-1), dtype=np.float32)
+        dx, dy = c.array(xb), c.empty(n)
+        call("fcvm_gemv_f32", c.h, C.c_int64(n), C.c_int64(n), C.c_int64(lda), dA.ptr, dx.ptr, dy.ptr)
+        got = dy.get()
+        want = A[:, :n].astype(np.float64) @ xb[:n]
+        assert np.isfinite(got).all() and rel(got, want) < 1e-12, (n, got[:4], want[:4])
+    c.close()
