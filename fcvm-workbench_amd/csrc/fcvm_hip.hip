@@ -12,6 +12,7 @@
 #include <functional>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <memory>
 #include <vector>
 
@@ -319,11 +320,17 @@ static int device_lds_cap(int device) {
 }
 template <class T>
 static int dalloc(T **p, int64_t n) {
-    HCHK(hipMalloc((void **)p, (size_t)std::max<int64_t>(n, 1) * sizeof(T)));
     // FCVM_POISON=1 (debugging): every fresh allocation filled with 0xFF bytes (NaN as a double, -1 as an index) -- a read of memory nothing
-    // wrote, which a fresh process hides behind zero pages, shows at once
+    // wrote, which a fresh process hides behind zero pages, shows at once; floating-point arrays get 512 poisoned bytes BEHIND them as well
+    // (the read behind a vector that k_gemv_f32x4 multiplied with zero padding, round 5, was invisible to an exactly sized poisoned array)
     static const bool poison = getenv("FCVM_POISON") && atoi(getenv("FCVM_POISON")) != 0;
-    if (poison) HCHK(hipMemset((void *)*p, 0xFF, (size_t)std::max<int64_t>(n, 1) * sizeof(T)));
+    const size_t bytes = (size_t)std::max<int64_t>(n, 1) * sizeof(T), tail = (poison && std::is_floating_point<T>::value) ? 512 : 0;
+    HCHK(hipMalloc((void **)p, bytes + tail));
+    if (poison) {      // (hipMemset runs on the null stream and does not wait for the host: without the synchronisation it can land on top of what a
+                       // context's own non-blocking stream writes into the array next)
+        HCHK(hipMemset((void *)*p, 0xFF, bytes + tail));
+        HCHK(hipDeviceSynchronize());
+    }
     return 0;
 }
 template <class T>
@@ -1507,8 +1514,12 @@ int fcvm_set_stream(fcvm_ctx *c, void *s, int external) {
 }
 int fcvm_malloc(fcvm_ctx *c, uint64_t bytes, void **dev) {
     HCHK(hipSetDevice(c->device));
-    HCHK(hipMalloc(dev, bytes ? bytes : 8));
-    if (getenv("FCVM_POISON") && atoi(getenv("FCVM_POISON")) != 0) HCHK(hipMemset(*dev, 0xFF, bytes ? bytes : 8));   // (see dalloc)
+    const bool poison = getenv("FCVM_POISON") && atoi(getenv("FCVM_POISON")) != 0;      // (see dalloc)
+    HCHK(hipMalloc(dev, (bytes ? bytes : 8) + (poison ? 512 : 0)));
+    if (poison) {
+        HCHK(hipMemset(*dev, 0xFF, (bytes ? bytes : 8) + 512));
+        HCHK(hipDeviceSynchronize());
+    }
     return 0;
 }
 int fcvm_free(fcvm_ctx *c, void *dev) {
@@ -2085,7 +2096,7 @@ int fcvm_update_peeq_csr(fcvm_ctx *c, const double *sig_test, const double *sig_
     double *pmaxc = c->d_part_misc, *pmaxp = c->d_part_misc + nb;
     hipLaunchKernelGGL(k_peeq_csr, dim3((unsigned)nb), dim3(256), 0, c->stream, ngp, sig_test, sig_new, sig_yield, peeq,
                        csr, triax, pressure, sigmises, ecr, mc.G, mc.H, mc.Et, alpha, pmaxc, c->d_pidx, pmaxp);
-    hipLaunchKernelGGL(k_peeq_csr_final, dim3(1), dim3(256), 0, c->stream, nb, pmaxc, c->d_pidx, pmaxp, pressure,
+    hipLaunchKernelGGL(k_peeq_csr_final, dim3(1), dim3(256), 0, c->stream, nb, ngp, pmaxc, c->d_pidx, pmaxp, pressure,
                        sigmises, triax, ecr, peeq, c->d_out8);
     HCHK(hipGetLastError());
     HCHK(hipMemcpyAsync(out, c->d_out8, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));

@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_peeq_csr(int64_t ngp, const double *__r
     }
 }
 
-__global__ __launch_bounds__(256) void k_peeq_csr_final(int64_t nb, const double *__restrict__ pmaxc,
+__global__ __launch_bounds__(256) void k_peeq_csr_final(int64_t nb, int64_t ngp, const double *__restrict__ pmaxc,
                                                         const long long *__restrict__ pidx, const double *__restrict__ pmaxp,
                                                         const double *__restrict__ pressure, const double *__restrict__ sigmises,
                                                         const double *__restrict__ triax, const double *__restrict__ ecr,
@@ -1053,8 +1053,15 @@ __global__ __launch_bounds__(256) void k_peeq_csr_final(int64_t nb, const double
     }
     if (threadIdx.x == 0) {
         long long i = shi[0];
-        out[0] = (double)i; out[1] = shc[0]; out[2] = shp[0];
-        out[3] = pressure[i]; out[4] = sigmises[i]; out[5] = triax[i]; out[6] = ecr[i]; out[7] = peeq[i];
+        out[1] = shc[0]; out[2] = shp[0];
+        // a state that is NaN throughout (a diverged analysis) leaves no index: report it as such instead of reading at 2^63 - 1 (round 5)
+        if (i < 0 || i >= ngp) {
+            const double nan = __builtin_nan("");
+            out[0] = -1.0; out[1] = nan; out[3] = nan; out[4] = nan; out[5] = nan; out[6] = nan; out[7] = nan;
+        } else {
+            out[0] = (double)i;
+            out[3] = pressure[i]; out[4] = sigmises[i]; out[5] = triax[i]; out[6] = ecr[i]; out[7] = peeq[i];
+        }
     }
 }
 
