@@ -135,6 +135,7 @@ struct MgAlt {
     double *r = nullptr, *z = nullptr, *p = nullptr, *q = nullptr, *S = nullptr, *part_vec = nullptr, *part_spmv = nullptr, *part_lo = nullptr;
     double *md = nullptr, *mr = nullptr, *mt = nullptr, *x1 = nullptr, *rr1 = nullptr, *d1 = nullptr, *t1 = nullptr, *r2 = nullptr, *e2 = nullptr;
     double *sx = nullptr, *sr = nullptr, *sd = nullptr, *st = nullptr, *sr3 = nullptr, *se3 = nullptr;   // sparse aggregate level
+    float *d1_32 = nullptr, *t1_32 = nullptr;   // FP32 twins of d1 / t1 (gathers of k_spmv_l1_i16)
     double *spart3 = nullptr;      // ... and its own partial buffer of the super-aggregate level's k_symv_tiles
     double *py = nullptr;          // ... and of the patch smoother's patch-major result vector
     double *symv_part = nullptr;   // its own partial buffer of k_symv_tiles: the two coarse parts of a pair run side by side
@@ -235,6 +236,8 @@ struct fcvm_ctx {
     PatchDev patch;
     std::vector<uint16_t> h_posa, h_posb;
     std::vector<int64_t> h_mptr;
+    bool mg_l1_x32 = true;         // FCVM_L1_X32=0: the level-1 passes gather from the FP64 direction vector as in rounds 3-4 (bitwise the same numbers)
+    float *d_d1_32 = nullptr, *d_t1_32 = nullptr;   // FP32 twins of d_d1 / d_t1, one 16-byte record per node
     bool mg_fuse_prolong = false;  // FCVM_MG_FUSE_PROLONG=1: x + P e1 formed while the post-smoothing pass stages x instead of by k_prolong_add
                                    // (measured: 212 us against 177 + 29 -- every window node is staged by 2.9 groups -- so off)
     int spmv_win = 1, win_v2 = 1;   // win_v2: value components in 16-byte pairs (FCVM_WIN_V2=0: nine 8-byte runs)
@@ -412,7 +415,21 @@ static void launch_spmv_t(fcvm_ctx *c, const MatView &m, const double *x, double
     else FCVM_SPMV_LAUNCH(DOT, true, 4, double2, 0, m.vals, ChebEpi{});
 }
 // SpMV t = A d fused with a Chebyshev smoother step on the same rows (see ChebEpi); nothing is written but epi's vectors
-static void launch_spmv_cheb(fcvm_ctx *c, const MatView &m, const double *x, const double *done, const ChebEpi &epi) {
+// FP32 twin of a level-1 direction vector of this context (null: none -- a caller's own vector)
+static inline float *l1_twin(const fcvm_ctx *c, const double *v) {
+    if (!c->mg_l1_x32 || !v) return nullptr;
+    return v == c->d_d1 ? c->d_d1_32 : (v == c->d_t1 ? c->d_t1_32 : nullptr);
+}
+static void launch_spmv_cheb(fcvm_ctx *c, const MatView &m, const double *x, const double *done, const ChebEpi &epi_in) {
+    ChebEpi epi = epi_in;
+    if (m.A16 && m.A16 == c->d_l1A) {
+        epi.dout32 = epi.update_d ? l1_twin(c, epi.dout) : nullptr;
+        if (const float *x32 = l1_twin(c, x)) {      // round 5: the gathers read the FP32 twin the producer of x wrote beside it
+            hipLaunchKernelGGL((k_spmv_l1_i16<1, false, true>), dim3((unsigned)m.nslices), dim3(64), 0, c->stream, m.nslices, m.rp16, m.A16, m.B16, m.C16,
+                               m.scale16, m.rownode, x, (double *)nullptr, done, epi, (const f4v *)x32);
+            return;
+        }
+    }
     if (m.A16) {   // level 1 on its 16-bit copy: 24 instead of 40 bytes per block
         // plain loads by default: the level-1 matrix (tens of MB) is read six times per V-cycle and stays in the memory-side cache
         // between those passes (1 M plate: 24.1 -> 21.2 us per pass, gpurun_out/r03ag); FCVM_L1_NT=1: nontemporal loads
@@ -1417,6 +1434,7 @@ int fcvm_create(int device, fcvm_ctx **out) {
     if (const char *v = getenv("FCVM_SYM_GRADING_MAX")) c->grading_max = atof(v) > 1.0 ? atof(v) : c->grading_max;
     if (const char *v = getenv("FCVM_MG_FUSE_PROLONG")) c->mg_fuse_prolong = atoi(v) != 0;
     if (const char *v = getenv("FCVM_MG_PATCH")) c->mg_patch = atoi(v) != 0;
+    if (const char *v = getenv("FCVM_L1_X32")) c->mg_l1_x32 = atoi(v) != 0;
     if (const char *v = getenv("FCVM_SYM_PAIR")) c->sym_pair = atoi(v) != 0;
     if (const char *v = getenv("FCVM_PAIR_OVERLAP")) c->pair_overlap = atoi(v) != 0;
     if (const char *v = getenv("FCVM_PCG_EVENTS")) c->pcg_events = atoi(v) != 0;
@@ -1442,7 +1460,7 @@ static void alt_free(fcvm_ctx *c) {
     MgAlt &a = c->alt;
     dfree(a.r); dfree(a.z); dfree(a.p); dfree(a.q); dfree(a.S); dfree(a.part_vec); dfree(a.part_spmv); dfree(a.part_lo);
     dfree(a.md); dfree(a.mr); dfree(a.mt); dfree(a.x1); dfree(a.rr1); dfree(a.d1); dfree(a.t1); dfree(a.r2); dfree(a.e2);
-    dfree(a.sx); dfree(a.sr); dfree(a.sd); dfree(a.st); dfree(a.sr3); dfree(a.se3); dfree(a.symv_part); dfree(a.spart3); dfree(a.py);
+    dfree(a.sx); dfree(a.sr); dfree(a.sd); dfree(a.st); dfree(a.sr3); dfree(a.se3); dfree(a.symv_part); dfree(a.spart3); dfree(a.py); dfree(a.d1_32); dfree(a.t1_32);
     a = MgAlt();
 }
 

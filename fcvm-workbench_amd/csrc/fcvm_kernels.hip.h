@@ -660,6 +660,8 @@ struct ChebEpi {
     const uint8_t *defer = nullptr;
     double *t_out = nullptr;
     const double *t2 = nullptr;
+    // round 5 (k_spmv_l1_i16 only): FP32 twin of dout, one 16-byte record (x, y, z, 0) per node -- the next pass gathers from it
+    float *dout32 = nullptr;
 };
 __device__ __forceinline__ void apply_dinv(const double *d, double r0, double r1, double r2, double &z0, double &z1, double &z2);
 

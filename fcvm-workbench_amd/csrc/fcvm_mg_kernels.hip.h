@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_restrict_init(int64_t nc, const int32_t
                                                        const int32_t *__restrict__ mids, const uint8_t *__restrict__ fixmask0,
                                                        const double *__restrict__ r0, const double *__restrict__ dinv1, double c0,
                                                        double *__restrict__ x1, double *__restrict__ r1, double *__restrict__ d1,
-                                                       const double *__restrict__ done) {
+                                                       const double *__restrict__ done, float *__restrict__ d32 = nullptr) {
     if (done && *done != 0.0) return;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int64_t c = t >> 2;
@@ -236,6 +236,7 @@ __global__ __launch_bounds__(256) void k_restrict_init(int64_t nc, const int32_t
     x1[3 * c] = 0.0; x1[3 * c + 1] = 0.0; x1[3 * c + 2] = 0.0;
     r1[3 * c] = a0; r1[3 * c + 1] = a1; r1[3 * c + 2] = a2;
     d1[3 * c] = c0 * z0; d1[3 * c + 1] = c0 * z1; d1[3 * c + 2] = c0 * z2;
+    if (d32) { d32[4 * c] = (float)(c0 * z0); d32[4 * c + 1] = (float)(c0 * z1); d32[4 * c + 2] = (float)(c0 * z2); d32[4 * c + 3] = 0.f; }   // FP32 twin for the gathers of k_spmv_l1_i16
 }
 
 // d0 = M0 P M1 e1 : fine corner nodes copy, mid-side nodes average their two edge ends
@@ -705,7 +706,8 @@ __global__ __launch_bounds__(256) void k_to_f32_padded(int64_t n, int64_t lda, c
 
 // d1[3i+c] = sum_k Z[i][c][k] * e2[aoff[agg[i]]+k]
 __global__ __launch_bounds__(256) void k_l2_prolong(int64_t nc, const int32_t *__restrict__ agg, const int64_t *__restrict__ aoff,
-                                                    const double *__restrict__ Z, const double *__restrict__ e2, double *__restrict__ d1, const double *__restrict__ done) {
+                                                    const double *__restrict__ Z, const double *__restrict__ e2, double *__restrict__ d1, const double *__restrict__ done,
+                                                    float *__restrict__ d32 = nullptr) {
     if (done && *done != 0.0) return;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nc) return;
@@ -717,6 +719,7 @@ __global__ __launch_bounds__(256) void k_l2_prolong(int64_t nc, const int32_t *_
         v0 += z[k] * e; v1 += z[6 + k] * e; v2 += z[12 + k] * e;
     }
     d1[3 * i] = v0; d1[3 * i + 1] = v1; d1[3 * i + 2] = v2;
+    if (d32) { d32[4 * i] = (float)v0; d32[4 * i + 1] = (float)v1; d32[4 * i + 2] = (float)v2; d32[4 * i + 3] = 0.f; }
 }
 
 // ---- shared-node exchange of the element partition (multi-GPU): pack / fixed-order sum ----------------

@@ -921,6 +921,25 @@ __device__ __forceinline__ void l1_gather(const double *__restrict__ x, int node
     const double sv = xa[o ? 0 : 2];
     a0 = (float)(o ? sv : wv.x) * sc; a1 = (float)(o ? wv.x : wv.y) * sc; a2 = (float)(o ? wv.y : sv) * sc;
 }
+// the same from an FP32 twin of x with one 16-byte record per node (x, y, z, unused) -- round 5: one load and one cache line per gathered node instead of
+// two loads over 24 bytes (the pass is bound by its gathers: 70 MB of matrix stream in 10.6 us, the pass took 24.5); the values are the roundings
+// l1_gather forms itself, so the products are bitwise the same.  The twin is written by whoever writes the vector (k_restrict_init, k_l2_prolong, the
+// epilogue of the previous pass).
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void l1_gather32(const f4v *__restrict__ x32, int node, float sc, float &a0, float &a1, float &a2) {
+    const f4v v = x32[node];
+    a0 = v.x * sc; a1 = v.y * sc; a2 = v.z * sc;
+}
+__device__ __forceinline__ void l1_fma32(const L1Rec &t, const f4v *__restrict__ x32, float &y0, float &y1, float &y2) {
+    const int e0 = (int)(signed char)(t.c[1] & 0xff), e1 = (int)(signed char)((t.c[1] >> 8) & 0xff);
+    const float s0 = __builtin_bit_cast(float, (127 + (e0 < -126 ? -126 : e0)) << 23), s1 = __builtin_bit_cast(float, (127 + (e1 < -126 ? -126 : e1)) << 23);
+    float a0, a1, a2, b0, b1, b2;
+    l1_gather32(x32, t.c[2], s0, a0, a1, a2);
+    l1_gather32(x32, t.c[3], s1, b0, b1, b2);
+    y0 += win_dot3(lo16(t.a[0]), hi16(t.a[0]), lo16(t.a[1]), a0, a1, a2) + win_dot3(hi16(t.b[0]), lo16(t.b[1]), hi16(t.b[1]), b0, b1, b2);
+    y1 += win_dot3(hi16(t.a[1]), lo16(t.a[2]), hi16(t.a[2]), a0, a1, a2) + win_dot3(lo16(t.b[2]), hi16(t.b[2]), lo16(t.b[3]), b0, b1, b2);
+    y2 += win_dot3(lo16(t.a[3]), hi16(t.a[3]), lo16(t.b[0]), a0, a1, a2) + win_dot3(hi16(t.b[3]), lo16(t.c[0]), hi16(t.c[0]), b0, b1, b2);
+}
 __device__ __forceinline__ void l1_fma(const L1Rec &t, const double *__restrict__ x, float &y0, float &y1, float &y2) {
     const int e0 = (int)(signed char)(t.c[1] & 0xff), e1 = (int)(signed char)((t.c[1] >> 8) & 0xff);
     const float s0 = __builtin_bit_cast(float, (127 + (e0 < -126 ? -126 : e0)) << 23), s1 = __builtin_bit_cast(float, (127 + (e1 < -126 ? -126 : e1)) << 23);
@@ -934,12 +953,12 @@ __device__ __forceinline__ void l1_fma(const L1Rec &t, const double *__restrict_
 
 // SpMV t = A1 d on the 16-bit copy with the Chebyshev smoother step of the row's node as epilogue (ChebEpi, as k_spmv<EPI = 1>);
 // EPI 0: y = A1 x.  One wavefront per slice, one row per lane, four records in flight.
-template <int EPI, bool NT = true>
+template <int EPI, bool NT = true, bool X32 = false>
 __global__ __launch_bounds__(64) void k_spmv_l1_i16(int64_t nslices, const int64_t *__restrict__ rp, const int4v *__restrict__ A,
                                                     const int4v *__restrict__ B, const int4v *__restrict__ C,
                                                     const double *__restrict__ scale, const int32_t *__restrict__ rownode,
                                                     const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ done,
-                                                    ChebEpi epi) {
+                                                    ChebEpi epi, const f4v *__restrict__ x32 = nullptr) {
     if (done && *done != 0.0) return;
     const int64_t b = blockIdx.x, nb = nslices;
     const int64_t q = nb >> 3, r = nb & 7, xcd = b & 7;
@@ -965,15 +984,23 @@ __global__ __launch_bounds__(64) void k_spmv_l1_i16(int64_t nslices, const int64
     L1Rec ra, rb, rc, rd;
     for (; p + 4 <= P; p += 4) {
         l1_load<NT>(ra, A, B, C, at); l1_load<NT>(rb, A, B, C, at + 64); l1_load<NT>(rc, A, B, C, at + 128); l1_load<NT>(rd, A, B, C, at + 192);
+        if (X32) {
+            l1_fma32(ra, x32, y0, y1, y2);
+            l1_fma32(rb, x32, z0, z1, z2);
+            l1_fma32(rc, x32, u0, u1, u2);
+            l1_fma32(rd, x32, w0, w1, w2);
+        } else {
         l1_fma(ra, x, y0, y1, y2);
         l1_fma(rb, x, z0, z1, z2);
         l1_fma(rc, x, u0, u1, u2);
         l1_fma(rd, x, w0, w1, w2);
+        }
         at += 256;
     }
     for (; p < P; p++) {
         l1_load<NT>(ra, A, B, C, at);
-        l1_fma(ra, x, y0, y1, y2);
+        if (X32) l1_fma32(ra, x32, y0, y1, y2);
+        else l1_fma(ra, x, y0, y1, y2);
         at += 64;
     }
     const double is = scale[1];
@@ -1003,6 +1030,7 @@ __global__ __launch_bounds__(64) void k_spmv_l1_i16(int64_t nslices, const int64
         }
         const double n0 = epi.cdd * d0 + epi.cdr * zz0, n1 = epi.cdd * d1 + epi.cdr * zz1, n2 = epi.cdd * d2 + epi.cdr * zz2;
         epi.dout[o] = n0; epi.dout[o + 1] = n1; epi.dout[o + 2] = n2;
+        if (epi.dout32) ((f4v *)epi.dout32)[node] = f4v{(float)n0, (float)n1, (float)n2, 0.f};
         if (epi.add_dout) { a0 += n0; a1 += n1; a2 += n2; }
     }
     epi.x[o] += a0; epi.x[o + 1] += a1; epi.x[o + 2] += a2;

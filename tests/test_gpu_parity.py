@@ -1689,3 +1689,31 @@ def test_dense_inverse_product_does_not_read_behind_its_vector():
         want = A[:, :n].astype(np.float64) @ xb[:n]
         assert np.isfinite(got).all() and rel(got, want) < 1e-12, (n, got[:4], want[:4])
     c.close()
+
+
+def test_level1_fp32_twin_gathers_are_bitwise_the_fp64_gathers(monkeypatch):
+    """Round 5: the level-1 passes of the cycle (k_spmv_l1_i16) gather their input from an FP32 twin of the direction vector -- one 16-byte
+    record per node, written by whoever writes the vector -- instead of converting the FP64 vector entry by entry: the same roundings, so a
+    solve is bitwise the one with FCVM_L1_X32=0.  Single solves and the lockstep pair (second state: its own twins)."""
+    from fcvm_hip import examples
+    from fcvm_hip.device import Context
+    from fcvm_hip.loads import Loads
+    from fcvm_hip.solver import GpuModel
+    case = examples.plate_with_hole(5.0)
+    res = {}
+    for x32 in ("1", "0"):
+        monkeypatch.setenv("FCVM_L1_X32", x32)
+        m = GpuModel(case["elNodes"], case["nocoord"], case["material"], case["fix"], Loads(ufaces=case["ufaces"], uloads=case["uloads"]), ctx=Context(0))
+        c = m.ctx
+        glv, modf, _, _ = m.calc_gsm((0.0, 0.0, 0.0), want_x=False)
+        f = c.axpby(1.0, c.mul(m.fixdof, glv), 1.0, modf)
+        g = c.array(np.random.default_rng(3).standard_normal(m.ndof) * m.fixdof_h)
+        u, info = c.solve(f, rtol=1e-10)
+        ua, ub, _ia, _ib = c.solve2(f, g, rtol=(1e-10, 1e-9))
+        res[x32] = (u.get(), info["iterations"], ua.get(), ub.get())
+        assert c.precond_info()["l2_aggregates"] > 0
+        c.close()
+    assert res["1"][1] == res["0"][1]
+    for k in (0, 2, 3):
+        assert np.array_equal(res["1"][k], res["0"][k])
+    assert np.array_equal(res["1"][0], res["1"][2])        # (and the pair's first vector is the single solve, as before)
