@@ -825,6 +825,10 @@ class DistMG:
             self.form = 1 if additive else 2
         else:
             self.form = 1 if additive else 0
+        if k1s is None and os.environ.get("FCVM_DIST_K1S"):
+            # round 5: two steps per side are SIX exchange points per PCG iteration instead of eight (each level-1 product is one); what that costs
+            # in iterations is in profiles/r05_dist_rehearsal_final_build.txt, what an exchange costs on xGMI has never been measured
+            k1s = max(1, int(os.environ["FCVM_DIST_K1S"]))
         if k1s is None:
             k1s = 3 if self.form == 2 else 2         # the multiplicative cycle leaves the level-1 solve as the weakest part
         if alpha1s is None:
