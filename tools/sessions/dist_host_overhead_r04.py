@@ -10,7 +10,9 @@ from fcvm_hip import examples
 from fcvm_hip.dist import partition_model
 from fcvm_hip.loads import Loads
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-dist.init_process_group("gloo", rank=0, world_size=1)
+dist.init_process_group(os.environ.get("FCVM_DIST_BACKEND", "gloo"), rank=0, world_size=1)      # (nccl = RCCL: the collectives of the layer on one rank)
+if dist.get_backend() == "nccl":
+    torch.cuda.set_device(0)
 case = examples.plate_with_hole(float(os.environ.get("PLATE_H", "1.45")))
 torch.cuda.set_device(0)
 for force in os.environ.get("FORCE_MODES", "0,1").split(","):
