@@ -128,6 +128,14 @@ class Exchanger:
             self.offs[s] = (rows, rows + len(shared[s]))
             rows += len(shared[s])
         self.rows = rows
+        # round 5: the exchange as ONE collective -- all_to_all_single with the rows per rank as split sizes (0 for ranks that share nothing): the send
+        # buffer is already laid out by ascending neighbour rank, the receive buffer comes back in the same layout.  Over RCCL a batch of point-to-point
+        # operations costs ~45 us of host time per exchange (building the P2POps 7, batch_isend_irecv 36), the collective 13
+        # (tools/sessions/rccl_p2p_self_r05.py) -- with eight exchange points per PCG iteration the host was about to become the bottleneck.
+        # FCVM_DIST_EXCHANGE=p2p: the batched isend / irecv of rounds 1-4.  A collective has to be entered by EVERY rank of the group, also by one
+        # that shares nothing at this level.
+        self.alltoall = os.environ.get("FCVM_DIST_EXCHANGE", "alltoall") != "p2p" and part.world > 1
+        self.split_rows = [(self.offs[r][1] - self.offs[r][0]) if r in self.offs else 0 for r in range(part.world)]
         if not self.ranks:
             return
         idx_all = np.concatenate([np.asarray(shared[s], dtype=np.int64) for s in self.ranks])
@@ -160,11 +168,15 @@ class Exchanger:
         p = self.part
         if self.count is not None:
             self.count["exchanges"] += 1
-        if p.world == 1 or not self.ranks:
+        if p.world == 1 or (not self.ranks and not self.alltoall):
             return None
         # gloo has no GPU point-to-point: stage through the host there (CPU tests / shared-GPU rehearsal);
         # with nccl (= RCCL) the buffers go GPU to GPU over xGMI
         stage = t.is_cuda and dist.get_backend(p.group) == "gloo"
+        if self.alltoall and not self.ranks:       # nothing shared at this level: an empty contribution to the collective
+            e = torch.empty(0, dtype=t.dtype, device="cpu" if stage else t.device)
+            z = [0] * p.world
+            return (t, ncomp, stage, None, [dist.all_to_all_single(e, e.clone(), output_split_sizes=z, input_split_sizes=z, group=p.group, async_op=True)])
         key = (ncomp, t.dtype, t.device, stage)
         cached = self._bufs.get(key)
         if cached is None:     # send / receive buffers are allocated once per vector shape and reused: an exchange happens eight times
@@ -175,17 +187,20 @@ class Exchanger:
             rbuf = torch.empty_like(sbuf)
             cached = self._bufs[key] = (send, sbuf, rbuf)
         send, sbuf, rbuf = cached
-        ops = []
-        for s in self.ranks:
-            a, b = self.offs[s]
-            ops.append(dist.P2POp(dist.isend, sbuf[a * ncomp:b * ncomp], s, group=p.group))
-            ops.append(dist.P2POp(dist.irecv, rbuf[a * ncomp:b * ncomp], s, group=p.group))
         if self.ops is not None and t.is_cuda:
             self.ops.pack(self.idx_all, ncomp, t, send)
         else:
             send.copy_(t.view(self.nn, ncomp).index_select(0, self.idx_all).reshape(-1))
         if stage:
             sbuf.copy_(send)
+        if self.alltoall:
+            splits = [r * ncomp for r in self.split_rows]
+            return (t, ncomp, stage, rbuf, [dist.all_to_all_single(rbuf, sbuf, output_split_sizes=splits, input_split_sizes=splits, group=p.group, async_op=True)])
+        ops = []
+        for s in self.ranks:
+            a, b = self.offs[s]
+            ops.append(dist.P2POp(dist.isend, sbuf[a * ncomp:b * ncomp], s, group=p.group))
+            ops.append(dist.P2POp(dist.irecv, rbuf[a * ncomp:b * ncomp], s, group=p.group))
         return (t, ncomp, stage, rbuf, dist.batch_isend_irecv(ops))
 
     def end(self, handle, finish=None):
@@ -199,6 +214,10 @@ class Exchanger:
         t, ncomp, stage, rbuf, works = handle
         for w in works:
             w.wait()
+        if rbuf is None:           # (the empty contribution of a rank that shares nothing at this level)
+            if finish is not None:
+                finish(None)
+            return
         recv = rbuf.to(t.device) if stage else rbuf
         if finish is not None:
             finish(recv)
