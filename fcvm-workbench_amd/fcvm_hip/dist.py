@@ -131,7 +131,8 @@ class Exchanger:
         # round 5: the exchange as ONE collective -- all_to_all_single with the rows per rank as split sizes (0 for ranks that share nothing): the send
         # buffer is already laid out by ascending neighbour rank, the receive buffer comes back in the same layout.  Over RCCL a batch of point-to-point
         # operations costs ~45 us of host time per exchange (building the P2POps 7, batch_isend_irecv 36), the collective 13
-        # (tools/sessions/rccl_p2p_self_r05.py) -- with eight exchange points per PCG iteration the host was about to become the bottleneck.
+        # (tools/sessions/rccl_p2p_self_r05.py); eight exchange points per PCG iteration are 0.35 ms of host time the one way and 0.1 ms the other,
+        # beside 0.2 ms of sequencing and 1.1-1.2 ms of device time per iteration.
         # FCVM_DIST_EXCHANGE=p2p: the batched isend / irecv of rounds 1-4.  A collective has to be entered by EVERY rank of the group, also by one
         # that shares nothing at this level.
         self.alltoall = os.environ.get("FCVM_DIST_EXCHANGE", "alltoall") != "p2p" and part.world > 1
