@@ -236,6 +236,8 @@ struct fcvm_ctx {
     PatchDev patch;
     std::vector<uint16_t> h_posa, h_posb;
     std::vector<int64_t> h_mptr;
+    int32_t *d_l1_sb = nullptr, *d_l1_si = nullptr;   // multi-GPU layer: level-1 slices with a row of a shared node / the others (fcvm_mg_l1_set_interface)
+    int64_t n_l1_sb = 0, n_l1_si = 0;
     bool mg_l1_x32 = true;         // FCVM_L1_X32=0: the level-1 passes gather from the FP64 direction vector as in rounds 3-4 (bitwise the same numbers)
     float *d_d1_32 = nullptr, *d_t1_32 = nullptr;   // FP32 twins of d_d1 / d_t1, one 16-byte record per node
     bool mg_fuse_prolong = false;  // FCVM_MG_FUSE_PROLONG=1: x + P e1 formed while the post-smoothing pass stages x instead of by k_prolong_add
@@ -3165,6 +3167,58 @@ int fcvm_mg_l1_pass(fcvm_ctx *c, const double *din, double *dout, double *x, dou
     ChebEpi epi{c->d_dinv1, x, r, dout, cdd, cdr, update_d ? 1 : 0, add_dout ? 1 : 0, c->d_dinv1_6f};
     epi.defer = defer; epi.t_out = t_out; epi.t2 = t2;
     launch_spmv_cheb(c, A, din, nullptr, epi);
+    HCHK(hipGetLastError());
+    return 0;
+}
+
+/* Boundary slices first for the level-1 passes (round 5, as fcvm_set_interface_nodes for the fine passes): nodes = the level-1 (corner) nodes, 0-based
+ * in the level-1 numbering, that another rank holds too.  fcvm_mg_l1_pass_part(part = 1) then covers the slices of the 16-bit copy with a row of one of
+ * them -- their raw products are complete and can be exchanged -- and part = 2 the others, beside the exchange; parts 1 + 2 are bitwise the unsplit pass
+ * (every row is formed by the same lane either way).  out[0] / out[1] = slices in the two lists.  n = 0 drops the lists. */
+int fcvm_mg_l1_set_interface(fcvm_ctx *c, int64_t n, const int64_t *nodes, int64_t out[2]) {
+    NEED(c && c->mg_topo && n >= 0 && (n == 0 || nodes), "fcvm_mg_l1_set_interface: no multigrid hierarchy / bad arguments");
+    HCHK(hipStreamSynchronize(c->stream));
+    dfree(c->d_l1_sb); dfree(c->d_l1_si);
+    c->n_l1_sb = c->n_l1_si = 0;
+    if (out) out[0] = out[1] = 0;
+    if (n == 0) return 0;
+    std::vector<uint8_t> shared(c->nc, 0);
+    for (int64_t i = 0; i < n; i++) {
+        NEED(nodes[i] >= 0 && nodes[i] < c->nc, "fcvm_mg_l1_set_interface: node out of range");
+        shared[nodes[i]] = 1;
+    }
+    const int64_t ns = c->pat1.nslices;
+    std::vector<int32_t> rownode(ns * SLICE);
+    HCHK(hipMemcpy(rownode.data(), c->d_rownode1, sizeof(int32_t) * ns * SLICE, hipMemcpyDeviceToHost));
+    std::vector<int32_t> sb, si;
+    for (int64_t s = 0; s < ns; s++) {
+        bool b = false;
+        for (int64_t r = s * SLICE; r < (s + 1) * SLICE && !b; r++) b = rownode[r] >= 0 && shared[rownode[r]];
+        (b ? sb : si).push_back((int32_t)s);
+    }
+    if (dalloc(&c->d_l1_sb, (int64_t)sb.size()) || dalloc(&c->d_l1_si, (int64_t)si.size())) return 1;
+    if (!sb.empty()) HCHK(hipMemcpy(c->d_l1_sb, sb.data(), sizeof(int32_t) * sb.size(), hipMemcpyHostToDevice));
+    if (!si.empty()) HCHK(hipMemcpy(c->d_l1_si, si.data(), sizeof(int32_t) * si.size(), hipMemcpyHostToDevice));
+    c->n_l1_sb = (int64_t)sb.size(); c->n_l1_si = (int64_t)si.size();
+    if (out) { out[0] = c->n_l1_sb; out[1] = c->n_l1_si; }
+    return 0;
+}
+/* fcvm_mg_l1_pass over the slices of `part` (0: all, as fcvm_mg_l1_pass; 1: the slices with rows of shared nodes; 2: the others) */
+int fcvm_mg_l1_pass_part(fcvm_ctx *c, const double *din, double *dout, double *x, double *r, const double *t2, double *t_out, const uint8_t *defer,
+                         double cdd, double cdr, int update_d, int add_dout, int part) {
+    if (part == 0) return fcvm_mg_l1_pass(c, din, dout, x, r, t2, t_out, defer, cdd, cdr, update_d, add_dout);
+    NEED(c && c->mg_topo && din && dout && din != dout && x && r && (part == 1 || part == 2), "fcvm_mg_l1_pass_part: no multigrid hierarchy / bad arguments");
+    NEED((defer == nullptr) == (t_out == nullptr), "fcvm_mg_l1_pass_part: defer and t_out go together");
+    NEED(c->d_l1_sb || c->d_l1_si, "fcvm_mg_l1_pass_part: no slice lists (fcvm_mg_l1_set_interface)");
+    MatView A = coarse_view(c);
+    NEED(A.A16 && c->d_dinv1_6f, "fcvm_mg_l1_pass_part: needs the 16-bit copy of the level-1 matrix (FCVM_MG_L1_16=1)");
+    ChebEpi epi{c->d_dinv1, x, r, dout, cdd, cdr, update_d ? 1 : 0, add_dout ? 1 : 0, c->d_dinv1_6f};
+    epi.defer = defer; epi.t_out = t_out; epi.t2 = t2;
+    const int64_t n = part == 1 ? c->n_l1_sb : c->n_l1_si;
+    const int32_t *list = part == 1 ? c->d_l1_sb : c->d_l1_si;
+    if (n > 0)
+        hipLaunchKernelGGL((k_spmv_l1_i16<1, false>), dim3((unsigned)n), dim3(64), 0, c->stream, A.nslices, A.rp16, A.A16, A.B16, A.C16, A.scale16, A.rownode, din,
+                           (double *)nullptr, (const double *)nullptr, epi, (const f4v *)nullptr, list);
     HCHK(hipGetLastError());
     return 0;
 }

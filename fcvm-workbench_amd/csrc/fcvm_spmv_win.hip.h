@@ -958,11 +958,12 @@ __global__ __launch_bounds__(64) void k_spmv_l1_i16(int64_t nslices, const int64
                                                     const int4v *__restrict__ B, const int4v *__restrict__ C,
                                                     const double *__restrict__ scale, const int32_t *__restrict__ rownode,
                                                     const double *__restrict__ x, double *__restrict__ y, const double *__restrict__ done,
-                                                    ChebEpi epi, const f4v *__restrict__ x32 = nullptr) {
+                                                    ChebEpi epi, const f4v *__restrict__ x32 = nullptr, const int32_t *__restrict__ slist = nullptr) {
     if (done && *done != 0.0) return;
     const int64_t b = blockIdx.x, nb = nslices;
     const int64_t q = nb >> 3, r = nb & 7, xcd = b & 7;
-    const int64_t s = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    // slist (multi-GPU layer): the slices this launch covers -- those with a row of a node shared with another rank first, the rest beside the exchange
+    const int64_t s = slist ? (int64_t)slist[b] : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     const int lane = threadIdx.x;
     const int64_t p0 = rp[s], P = rp[s + 1] - p0;
     // the epilogue's operands do not depend on the products: their loads are issued before the record loop, not after it (the

@@ -916,6 +916,14 @@ class DistMG:
             if self.ex1.ranks:
                 defer[self.ex1.inodes.cpu().numpy()] = 1
             self.defer1 = torch.as_tensor(defer, device=dev)
+            # boundary slices first (round 5): the slices of the 16-bit copy with a row of a shared corner node are launched before the exchange of the
+            # raw products is posted, the others beside it; FCVM_DIST_L1_SPLIT=0: one launch, exchange after it
+            self.l1_split = False
+            if (self.ex1.ranks and hasattr(self.ops, "mg_l1_set_interface") and self.part.world > 1
+                    and os.environ.get("FCVM_DIST_L1_SPLIT", "1") != "0"):
+                nb, ni = self.ops.mg_l1_set_interface(self.ex1.inodes.cpu().numpy())
+                self.l1_split = nb > 0 and ni > 0
+                self.l1_split_slices = (nb, ni)
         self.topo = True
         self.lmax_stale = True
 
@@ -1237,8 +1245,13 @@ class DistMG:
         """one level-1 smoother pass on the library's 16-bit kernel with the step as epilogue; the rows of shared corner nodes are finished
         after the exchange of their raw products by one small kernel that sums and steps (no full-vector step kernel, no separate unpack)"""
         ex = self.ex1
-        self.ops.mg_l1_pass(din, dout, self.x1, self.rr1, t2, self.t1, self.defer1, cdd, cdr, update_d, add_dout)
-        h = ex.begin(self.t1.t, 3)
+        if getattr(self, "l1_split", False):
+            self.ops.mg_l1_pass(din, dout, self.x1, self.rr1, t2, self.t1, self.defer1, cdd, cdr, update_d, add_dout, part=1)
+            h = ex.begin(self.t1.t, 3)          # the shared rows' products are complete: pack and post while the interior slices run
+            self.ops.mg_l1_pass(din, dout, self.x1, self.rr1, t2, self.t1, self.defer1, cdd, cdr, update_d, add_dout, part=2)
+        else:
+            self.ops.mg_l1_pass(din, dout, self.x1, self.rr1, t2, self.t1, self.defer1, cdd, cdr, update_d, add_dout)
+            h = ex.begin(self.t1.t, 3)
         if ex.ranks:
             ex.end(h, finish=lambda recv: self.ops.unpack_sum_cheb(ex.inodes, ex.eptr, ex.src, self.t1, recv, din, dout, self.x1, self.rr1,
                                                                     cdd, cdr, update_d, add_dout))
@@ -1732,10 +1745,20 @@ class HipLocalOps:
         """does the library keep the 16-bit copy of the level-1 matrix (FCVM_MG_L1_16, default on)?"""
         return os.environ.get("FCVM_MG_L1_16", "1") != "0"
 
-    def mg_l1_pass(self, din, dout, x, r, t2, t_out, defer, cdd, cdr, update_d, add_dout):
+    def mg_l1_pass(self, din, dout, x, r, t2, t_out, defer, cdd, cdr, update_d, add_dout, part=0):
         from ._lib import call
-        call("fcvm_mg_l1_pass", self.c.h, din.ptr, dout.ptr, x.ptr, r.ptr, t2.ptr if t2 is not None else None, t_out.ptr, defer.data_ptr(),
-             float(cdd), float(cdr), 1 if update_d else 0, 1 if add_dout else 0)
+        call("fcvm_mg_l1_pass_part", self.c.h, din.ptr, dout.ptr, x.ptr, r.ptr, t2.ptr if t2 is not None else None, t_out.ptr, defer.data_ptr(),
+             float(cdd), float(cdr), 1 if update_d else 0, 1 if add_dout else 0, int(part))
+
+    def mg_l1_set_interface(self, nodes):
+        """the level-1 nodes other ranks hold too (level-1 numbering): mg_l1_pass(part = 1) launches the slices with a row of one of them, part = 2
+        the others.  Returns (boundary slices, interior slices)"""
+        import ctypes as C
+        from ._lib import call
+        nodes = np.ascontiguousarray(nodes, np.int64)
+        out = (C.c_int64 * 2)()
+        call("fcvm_mg_l1_set_interface", self.c.h, len(nodes), nodes.ctypes.data if len(nodes) else None, out)
+        return int(out[0]), int(out[1])
 
     def mg_l1_spmv(self, x, y):
         from ._lib import call

@@ -317,6 +317,13 @@ int fcvm_spmv_lo_resid(fcvm_ctx *c, const double *x, const double *r, const doub
  * fcvm_mg_l1_spmv: the raw product y = A1_local x of the same copy. */
 int fcvm_mg_l1_pass(fcvm_ctx *c, const double *din, double *dout, double *x, double *r, const double *t2, double *t_out, const uint8_t *defer,
                     double cdd, double cdr, int update_d, int add_dout);
+/* Boundary slices first for the level-1 passes (round 5; no reference counterpart): fcvm_mg_l1_set_interface gives the library the level-1 (corner)
+ * nodes, 0-based in the level-1 numbering, that another rank holds too; fcvm_mg_l1_pass_part(part = 1) covers the slices with a row of one of them,
+ * part = 2 the others (beside the exchange of the raw products), part = 0 everything; parts 1 + 2 are bitwise the unsplit pass.  out[0] / out[1] =
+ * slices in the two lists; n = 0 drops them. */
+int fcvm_mg_l1_set_interface(fcvm_ctx *c, int64_t n, const int64_t *nodes, int64_t out[2]);
+int fcvm_mg_l1_pass_part(fcvm_ctx *c, const double *din, double *dout, double *x, double *r, const double *t2, double *t_out, const uint8_t *defer,
+                         double cdd, double cdr, int update_d, int add_dout, int part);
 int fcvm_mg_l1_spmv(fcvm_ctx *c, const double *x, double *y);
 int fcvm_unpack_sum_cheb(fcvm_ctx *c, int64_t nshared, const int64_t *node, const int64_t *eptr, const int64_t *src, const double *traw,
                          const double *recv, const double *din, double *dout, double *x, double *r, double cdd, double cdr, int update_d,

@@ -1717,3 +1717,42 @@ def test_level1_fp32_twin_gathers_are_bitwise_the_fp64_gathers(monkeypatch):
     for k in (0, 2, 3):
         assert np.array_equal(res["1"][k], res["0"][k])
     assert np.array_equal(res["1"][0], res["1"][2])        # (and the pair's first vector is the single solve, as before)
+
+
+def test_level1_boundary_slices_first_is_bitwise_the_unsplit_pass():
+    """Multi-GPU layer, round 5: a level-1 smoother pass (k_spmv_l1_i16 with the Chebyshev step as epilogue, rows of shared corner nodes deferred)
+    launches the slices with a row of a shared node first (fcvm_mg_l1_set_interface, fcvm_mg_l1_pass_part part 1), so that the exchange of their raw
+    products runs beside the other slices (part 2).  Here on one GPU with a made-up interface: after part 1 every deferred raw product is there,
+    after part 2 all five vectors are bitwise those of the unsplit pass."""
+    import ctypes as C
+    from fcvm_hip._lib import call
+    case = small_case(12, prescribed=False)
+    m = make_model(case)
+    c = m.ctx
+    m.calc_gsm((0, 0, -9.81))
+    nc = c.precond_info()["coarse_nodes"]
+    assert nc > 1500
+    rng = np.random.default_rng(21)
+    shared = np.sort(rng.choice(nc, 60, replace=False)).astype(np.int64)
+    defer_h = np.zeros(nc, np.uint8); defer_h[shared] = 1
+    defer = c.array(defer_h, dtype=np.uint8)
+    din_h, x_h, r_h, t2_h = (rng.standard_normal(3 * nc) for _ in range(4))
+    o = (C.c_int64 * 2)()
+    call("fcvm_mg_l1_set_interface", c.h, len(shared), shared.ctypes.data, o)
+    assert o[0] > 0 and o[1] > 0
+    def run(parts):
+        din, dout, x, r, t2 = c.array(din_h), c.array(np.full(3 * nc, np.nan)), c.array(x_h), c.array(r_h), c.array(t2_h)
+        t_out = c.array(np.full(3 * nc, np.nan))
+        snaps = []
+        for part in parts:
+            call("fcvm_mg_l1_pass_part", c.h, din.ptr, dout.ptr, x.ptr, r.ptr, t2.ptr, t_out.ptr, defer.ptr, C.c_double(0.3), C.c_double(0.7), 1, 1, part)
+            snaps.append(t_out.get())
+        return [v.get() for v in (dout, x, r, t_out)], snaps
+    ref, _ = run([0])
+    got, snaps = run([1, 2])
+    dofs = (3 * shared[:, None] + np.arange(3)[None, :]).reshape(-1)
+    assert np.array_equal(snaps[0][dofs], ref[3][dofs])                        # every deferred raw product is there after part 1
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert np.isnan(ref[0][dofs]).all() and np.isfinite(np.delete(ref[0], dofs)).all()   # (deferred rows are left to fcvm_unpack_sum_cheb)
+    call("fcvm_mg_l1_set_interface", c.h, 0, None, None)
