@@ -238,6 +238,8 @@ struct fcvm_ctx {
     std::vector<int64_t> h_mptr;
     int32_t *d_l1_sb = nullptr, *d_l1_si = nullptr;   // multi-GPU layer: level-1 slices with a row of a shared node / the others (fcvm_mg_l1_set_interface)
     int64_t n_l1_sb = 0, n_l1_si = 0;
+    int32_t *d_l1_nb = nullptr, *d_l1_ni = nullptr;   // ... and the shared level-1 nodes themselves / the others (fcvm_mg_restrict_part)
+    int64_t n_l1_nb = 0, n_l1_ni = 0;
     bool mg_l1_x32 = true;         // FCVM_L1_X32=0: the level-1 passes gather from the FP64 direction vector as in rounds 3-4 (bitwise the same numbers)
     float *d_d1_32 = nullptr, *d_t1_32 = nullptr;   // FP32 twins of d_d1 / d_t1, one 16-byte record per node
     bool mg_fuse_prolong = false;  // FCVM_MG_FUSE_PROLONG=1: x + P e1 formed while the post-smoothing pass stages x instead of by k_prolong_add
@@ -3178,8 +3180,8 @@ int fcvm_mg_l1_pass(fcvm_ctx *c, const double *din, double *dout, double *x, dou
 int fcvm_mg_l1_set_interface(fcvm_ctx *c, int64_t n, const int64_t *nodes, int64_t out[2]) {
     NEED(c && c->mg_topo && n >= 0 && (n == 0 || nodes), "fcvm_mg_l1_set_interface: no multigrid hierarchy / bad arguments");
     HCHK(hipStreamSynchronize(c->stream));
-    dfree(c->d_l1_sb); dfree(c->d_l1_si);
-    c->n_l1_sb = c->n_l1_si = 0;
+    dfree(c->d_l1_sb); dfree(c->d_l1_si); dfree(c->d_l1_nb); dfree(c->d_l1_ni);
+    c->n_l1_sb = c->n_l1_si = c->n_l1_nb = c->n_l1_ni = 0;
     if (out) out[0] = out[1] = 0;
     if (n == 0) return 0;
     std::vector<uint8_t> shared(c->nc, 0);
@@ -3200,7 +3202,25 @@ int fcvm_mg_l1_set_interface(fcvm_ctx *c, int64_t n, const int64_t *nodes, int64
     if (!sb.empty()) HCHK(hipMemcpy(c->d_l1_sb, sb.data(), sizeof(int32_t) * sb.size(), hipMemcpyHostToDevice));
     if (!si.empty()) HCHK(hipMemcpy(c->d_l1_si, si.data(), sizeof(int32_t) * si.size(), hipMemcpyHostToDevice));
     c->n_l1_sb = (int64_t)sb.size(); c->n_l1_si = (int64_t)si.size();
+    std::vector<int32_t> nb, ni;
+    for (int64_t i = 0; i < c->nc; i++) (shared[i] ? nb : ni).push_back((int32_t)i);
+    if (dalloc(&c->d_l1_nb, (int64_t)nb.size()) || dalloc(&c->d_l1_ni, (int64_t)ni.size())) return 1;
+    if (!nb.empty()) HCHK(hipMemcpy(c->d_l1_nb, nb.data(), sizeof(int32_t) * nb.size(), hipMemcpyHostToDevice));
+    if (!ni.empty()) HCHK(hipMemcpy(c->d_l1_ni, ni.data(), sizeof(int32_t) * ni.size(), hipMemcpyHostToDevice));
+    c->n_l1_nb = (int64_t)nb.size(); c->n_l1_ni = (int64_t)ni.size();
     if (out) { out[0] = c->n_l1_sb; out[1] = c->n_l1_si; }
+    return 0;
+}
+/* r1 = P^T r0 for the level-1 nodes of `part` (0: all, as fcvm_mg_restrict; 1: the nodes given to fcvm_mg_l1_set_interface; 2: the others): the restricted
+ * residual of the shared corner nodes can be exchanged while the rest is still being restricted */
+int fcvm_mg_restrict_part(fcvm_ctx *c, const double *r0, double *r1, int part) {
+    if (part == 0) return fcvm_mg_restrict(c, r0, r1);
+    NEED(c && c->mg_topo && (part == 1 || part == 2) && (c->d_l1_nb || c->d_l1_ni), "fcvm_mg_restrict_part: no multigrid hierarchy / no node lists (fcvm_mg_l1_set_interface)");
+    const int64_t n = part == 1 ? c->n_l1_nb : c->n_l1_ni;
+    if (n > 0)
+        hipLaunchKernelGGL(k_restrict, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, c->stream, n, c->d_c2f, c->d_mptr, c->d_mids, c->d_fixmask, r0, r1,
+                           (const double *)nullptr, (const double *)nullptr, part == 1 ? c->d_l1_nb : c->d_l1_ni);
+    HCHK(hipGetLastError());
     return 0;
 }
 /* fcvm_mg_l1_pass over the slices of `part` (0: all, as fcvm_mg_l1_pass; 1: the slices with rows of shared nodes; 2: the others) */

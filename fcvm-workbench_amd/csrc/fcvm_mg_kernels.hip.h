@@ -145,10 +145,11 @@ __global__ __launch_bounds__(256) void k_restrict(int64_t nc, const int32_t *__r
                                                   const int64_t *__restrict__ mptr, const int32_t *__restrict__ mids,
                                                   const uint8_t *__restrict__ fixmask0, const double *__restrict__ r0,
                                                   double *__restrict__ r1, const double *__restrict__ done,
-                                                  const double *__restrict__ wgt = nullptr) {
+                                                  const double *__restrict__ wgt = nullptr, const int32_t *__restrict__ nlist = nullptr) {
     if (done && *done != 0.0) return;
     int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= nc) return;
+    if (nlist) c = nlist[c];       // (multi-GPU layer: nc entries of a node list -- the shared corner nodes first, the others beside their exchange)
     const int64_t f = c2f[c];
     const int fm = fixmask0[f];
     double a0 = r0[3 * f], a1 = r0[3 * f + 1], a2 = r0[3 * f + 2];

@@ -73,6 +73,7 @@ SIGNATURES = {
     "fcvm_mg_l1_pass": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _int, _int],
     "fcvm_mg_l1_pass_part": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _int, _int, _int],
     "fcvm_mg_l1_set_interface": [_vp, _i64, _vp, _pi64],
+    "fcvm_mg_restrict_part": [_vp, _vp, _vp, _int],
     "fcvm_mg_l1_spmv": [_vp, _vp, _vp],
     "fcvm_unpack_sum_cheb": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f64, _f64, _int, _int],
     "fcvm_set_interface_nodes": [_vp, _i64, _vp, _pi64],

@@ -1185,7 +1185,7 @@ class DistMG:
             else:
                 self.ops.mg_cheb_step(level, None, x, r, d, 0.0, 0.0, False)
 
-    def _coarse(self, r, partial=False, restricted=False):
+    def _coarse(self, r, partial=False, restricted=False, summed=False):
         """x1 = M1^-1 P^T (w0 r): weighted restriction of a consistent fine vector, level-1 / aggregate cycle.
         partial: r is already a per-rank PART of the fine vector (its sum over the ranks is the vector): restricted as it stands,
         the level-1 exchange then completes fine and coarse sums at once.  restricted: self.r1 already holds the rank's part."""
@@ -1196,7 +1196,8 @@ class DistMG:
             self.ops.mg_restrict(r, self.r1)
         else:
             self.ops.mg_restrict_weighted(r, TVec(self.w0), self.r1)
-        self.ex1.interface_sum(self.r1.t, 3)
+        if not summed:       # (summed: the caller restricted the shared corner nodes first and ran the exchange beside the rest)
+            self.ex1.interface_sum(self.r1.t, 3)
         merge = self.merge_l1
         if self.fused_l1:
             self._coarse_fused_l1()
@@ -1292,14 +1293,22 @@ class DistMG:
                 self.ops.spmv_lo_resid(self.d0, b, TVec(self.w0), self.r0)       # w0 b - K~_local x1
             except RuntimeError:       # no symmetric form of the 16-bit copy on this rank (small or graded mesh): the three-vector restriction
                 self.lo_resid = False
+        summed = False
         if self.fused_lo and self.lo_resid:
-            self.ops.mg_restrict(self.r0, self.r1)
+            if getattr(self, "l1_split", False):      # shared corner nodes first, their exchange beside the restriction of the others
+                self.ops.mg_restrict(self.r0, self.r1, part=1)
+                h = self.ex1.begin(self.r1.t, 3)
+                self.ops.mg_restrict(self.r0, self.r1, part=2)
+                self.ex1.end(h)
+                summed = True
+            else:
+                self.ops.mg_restrict(self.r0, self.r1)
         else:
             self.ops.spmv_lo(self.d0, self.t0)
         if self.fused_lo:
             if not self.lo_resid:
                 self.ops.mg_restrict_diff(b, TVec(self.w0), self.t0, self.r1)        # P^T (w0 b - K~_local x1), never written out
-            self._coarse(None, restricted=True)
+            self._coarse(None, restricted=True, summed=summed)
             self.ops.mg_prolong_add(self.x1, self.d0, self.x2)
             if be.split:       # boundary groups first, interior groups beside the messages (as DistBackend.spmv)
                 self.ops.spmv_lo_part(self.x2, self.t0, 1)
@@ -1686,9 +1695,9 @@ class HipLocalOps:
         call("fcvm_mg_cheb_step", self.c.h, level, t.ptr if t is not None else None, x.ptr, r.ptr, d.ptr, float(cdd),
              float(cdr), 1 if update_d else 0)
 
-    def mg_restrict(self, r0, r1):
+    def mg_restrict(self, r0, r1, part=0):
         from ._lib import call
-        call("fcvm_mg_restrict", self.c.h, r0.ptr, r1.ptr)
+        call("fcvm_mg_restrict_part", self.c.h, r0.ptr, r1.ptr, int(part))
 
     def mg_restrict_weighted(self, r0, w, r1):
         from ._lib import call

@@ -322,6 +322,8 @@ int fcvm_mg_l1_pass(fcvm_ctx *c, const double *din, double *dout, double *x, dou
  * part = 2 the others (beside the exchange of the raw products), part = 0 everything; parts 1 + 2 are bitwise the unsplit pass.  out[0] / out[1] =
  * slices in the two lists; n = 0 drops them. */
 int fcvm_mg_l1_set_interface(fcvm_ctx *c, int64_t n, const int64_t *nodes, int64_t out[2]);
+/* r1 = P^T r0 (fcvm_mg_restrict) for the level-1 nodes of `part`: 1 = the nodes given to fcvm_mg_l1_set_interface, 2 = the others, 0 = all */
+int fcvm_mg_restrict_part(fcvm_ctx *c, const double *r0, double *r1, int part);
 int fcvm_mg_l1_pass_part(fcvm_ctx *c, const double *din, double *dout, double *x, double *r, const double *t2, double *t_out, const uint8_t *defer,
                          double cdd, double cdr, int update_d, int add_dout, int part);
 int fcvm_mg_l1_spmv(fcvm_ctx *c, const double *x, double *y);

@@ -1755,4 +1755,13 @@ def test_level1_boundary_slices_first_is_bitwise_the_unsplit_pass():
     for a, b in zip(got, ref):
         assert np.array_equal(a, b, equal_nan=True)
     assert np.isnan(ref[0][dofs]).all() and np.isfinite(np.delete(ref[0], dofs)).all()   # (deferred rows are left to fcvm_unpack_sum_cheb)
+    # the restriction in the same two parts: the shared corner nodes' entries first (their exchange runs beside the rest)
+    r0 = c.array(rng.standard_normal(m.ndof))
+    r1_ref, r1 = c.empty(3 * nc), c.array(np.full(3 * nc, np.nan))
+    call("fcvm_mg_restrict_part", c.h, r0.ptr, r1_ref.ptr, 0)
+    call("fcvm_mg_restrict_part", c.h, r0.ptr, r1.ptr, 1)
+    h = r1.get()
+    assert np.array_equal(h[dofs], r1_ref.get()[dofs]) and np.isnan(np.delete(h, dofs)).all()
+    call("fcvm_mg_restrict_part", c.h, r0.ptr, r1.ptr, 2)
+    assert np.array_equal(r1.get(), r1_ref.get())
     call("fcvm_mg_l1_set_interface", c.h, 0, None, None)
