@@ -553,3 +553,57 @@ def test_shared_bench_mesh_uses_a_private_directory_and_reports_a_failed_build(t
         else:
             assert g["ok"] and g["ne"] == len(c["elNodes"]) and g["nfix"] == len(c["fix"]) and g["name"] == "tiny" and g["nstep"] == 3
             assert g["checksum"] == float(np.asarray(c["nocoord"]).sum())
+
+
+def _exchanger_worker(rank, world, port, out, mode):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["FCVM_DIST_EXCHANGE"] = mode
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+        from fcvm_hip.dist import Exchanger
+        # four local nodes per rank; ranks 0 and 1 share two of them (in different local positions), rank 1 and 3 one, rank 2 shares NOTHING --
+        # with the exchange as a collective it still has to enter every exchange, or the others would wait for it forever
+        shared = {0: {1: [1, 3]}, 1: {0: [0, 2], 3: [3]}, 2: {}, 3: {1: [0]}}[rank]
+        part = SimpleNamespace(rank=rank, world=world, group=dist.group.WORLD, nn=4,
+                               shared={s: np.asarray(ix, dtype=np.int64) for s, ix in shared.items()})
+        ex = Exchanger(part, torch.device("cpu"))
+        assert ex.alltoall == (mode == "alltoall")
+        res = []
+        for ncomp in (3, 1):
+            t = torch.arange(4 * ncomp, dtype=torch.float64) + 100.0 * (rank + 1)
+            ex.interface_sum(t, ncomp)
+            res.append(t.clone())
+        h = ex.begin(torch.zeros(12, dtype=torch.float64) + rank, 3)      # the two-phase form with a finishing callback
+        seen = []
+        ex.end(h, finish=lambda recv: seen.append(None if recv is None else recv.clone()))
+        got = [None] * world
+        dist.all_gather_object(got, dict(res=res, seen=seen))
+        if rank == 0:
+            torch.save(got, out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["alltoall", "p2p"])
+def test_exchanger_with_a_rank_that_shares_nothing(tmp_path, mode):
+    """Round 5: the shared-node exchange is ONE collective (all_to_all_single with the rows per rank as split sizes) instead of a batch of
+    isend / irecv -- a collective has to be entered by every rank, also by one without neighbours (all split sizes zero).  Four ranks, one of
+    them isolated: the sums at shared nodes are those of the point-to-point form, the isolated rank's vectors come back untouched, nobody hangs."""
+    out = str(tmp_path / "ex.pt")
+    mp.spawn(_exchanger_worker, args=(4, _free_port(), out, mode), nprocs=4, join=True)
+    got = torch.load(out, weights_only=False)
+    base = lambda r, nc: torch.arange(4 * nc, dtype=torch.float64) + 100.0 * (r + 1)       # noqa: E731
+    for k, nc in enumerate((3, 1)):
+        v = [base(r, nc).view(4, nc).clone() for r in range(4)]
+        exp = [x.clone() for x in v]
+        # rank 0 nodes [1, 3] <-> rank 1 nodes [0, 2]; rank 1 node 3 <-> rank 3 node 0
+        for a, b in ((1, 0), (3, 2)):
+            s = v[0][a] + v[1][b]
+            exp[0][a] = s; exp[1][b] = s
+        s = v[1][3] + v[3][0]
+        exp[1][3] = s; exp[3][0] = s
+        for r in range(4):
+            assert torch.equal(got[r]["res"][k].view(4, nc), exp[r]), (mode, r, nc)
+    assert got[2]["seen"] == [None] and all(g["seen"][0] is not None for r, g in enumerate(got) if r != 2)
