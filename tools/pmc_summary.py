@@ -25,7 +25,7 @@ for grp in sorted(os.listdir(root)):
     for (k, grid), cs in sorted(acc.items(), key=lambda kv: -kv[0][1]):
         if not any(s in k for s in ("k_spmv", "k_stream_read", "k_assemble", "k_update_stress", "k_gather_qin", "k_repack")):
             continue
-        if "k_spmv" in k and grid < 500000:
+        if "k_spmv" in k and grid < 500000 and "k_spmv_l1" not in k:      # (the level-1 16-bit pass: 2900 one-wave workgroups)
             continue
         n = len(next(iter(cs.values())))
         print("%-72s grid %9d  n=%d" % (k, grid, n))
