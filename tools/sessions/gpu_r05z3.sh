@@ -1,4 +1,4 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05z3; mkdir -p $O
 cd $R
-TAG=l1_wpb bash tools/sessions/gpu_r05x.sh "FCVM_L1_WPB=1" "FCVM_L1_WPB=2" "FCVM_L1_WPB=4" "FCVM_L1_WPB=1" "FCVM_L1_WPB=2" "FCVM_L1_WPB=4"
+timeout -k 10 200 python3 tools/sessions/l1_pass_parts_r05.py 2>&1 | grep -v "^fcvm" | tail -3 | tee $O/l1_parts.txt
